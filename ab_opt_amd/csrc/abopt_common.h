@@ -1,0 +1,121 @@
+// Shared device helpers for the gfx950 kernels: SO(3)/frame algebra with the reference's exact
+// epsilons, wave64 reductions, Philox4x32-10.  Written for CDNA4 only (wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/abopt.h"
+
+#define ABOPT_WAVE 64
+
+namespace abopt {
+
+// ---------------------------------------------------------------- host-side error plumbing
+void set_error(const char* fmt, ...);
+#define ABOPT_CHECK_ARG(cond, ...) do { if (!(cond)) { ::abopt::set_error(__VA_ARGS__); return ABOPT_EINVAL; } } while (0)
+#define ABOPT_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    ::abopt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return ABOPT_EHIP; } } while (0)
+#define ABOPT_LAUNCH_CHECK() ABOPT_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- 3x3 helpers (row-major float[9])
+struct Mat3 { float m[9]; };
+struct Vec3 { float x, y, z; };
+
+__device__ __forceinline__ Mat3 matmul3(const Mat3& a, const Mat3& b) {
+    Mat3 c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            c.m[i * 3 + j] = a.m[i * 3 + 0] * b.m[0 * 3 + j] + a.m[i * 3 + 1] * b.m[1 * 3 + j] + a.m[i * 3 + 2] * b.m[2 * 3 + j];
+    return c;
+}
+
+// exp map, reference so3.py:33-57.  The 'skew' layout there is rows (0,z,-y),(-z,0,x),(y,-x,0).
+__device__ __forceinline__ Mat3 so3_exp(float x, float y, float z) {
+    Mat3 S = {{0.f, z, -y, -z, 0.f, x, y, -x, 0.f}};
+    float th = sqrtf(x * x + y * y + z * z);
+    float b = (sinf(th) + 1e-8f) / (th + 1e-8f);
+    float c = (1.f - cosf(th) + 1e-8f) / (th * th + 2e-8f);
+    Mat3 S2 = matmul3(S, S);
+    Mat3 R;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R.m[i] = ((i == 0 || i == 4 || i == 8) ? 1.f : 0.f) + b * S.m[i] + c * S2.m[i];
+    return R;
+}
+
+// log map, reference so3.py:10-30,60-63.  min_cos = -0.999 when the reference runs with autograd on.
+__device__ __forceinline__ Vec3 so3_log(const Mat3& R, bool grad_mode) {
+    float tr = R.m[0] + R.m[4] + R.m[8];
+    float cmin = grad_mode ? -0.999f : -1.0f;
+    float ct = fmaxf((tr - 1.f) / 2.f, cmin);
+    float st = sqrtf(1.f - ct * ct);
+    float th = acosf(ct);
+    float coef = (th + 1e-8f) / (2.f * st + 2e-8f);
+    Vec3 w;
+    w.x = coef * (R.m[1 * 3 + 2] - R.m[2 * 3 + 1]);
+    w.y = coef * (R.m[2 * 3 + 0] - R.m[0 * 3 + 2]);
+    w.z = coef * (R.m[0 * 3 + 1] - R.m[1 * 3 + 0]);
+    return w;
+}
+
+// (1 + b i + c j + d k) -> R, reference geometry.py:215-233.
+__device__ __forceinline__ Mat3 quat1ijk_to_rot(float qb, float qc, float qd) {
+    float s = sqrtf(1.f + qb * qb + qc * qc + qd * qd);
+    float a = 1.f / s, b = qb / s, c = qc / s, d = qd / s;
+    Mat3 o = {{a * a + b * b - c * c - d * d, 2 * b * c - 2 * a * d, 2 * b * d + 2 * a * c,
+               2 * b * c + 2 * a * d, a * a - b * b + c * c - d * d, 2 * c * d - 2 * a * b,
+               2 * b * d - 2 * a * c, 2 * c * d + 2 * a * b, a * a - b * b - c * c + d * d}};
+    return o;
+}
+
+// general quaternion (real first) -> R with normalisation, reference geometry.py:148-175.
+__device__ __forceinline__ Mat3 quat_to_rot(float r, float i, float j, float k) {
+    float n = fmaxf(sqrtf(r * r + i * i + j * j + k * k), 1e-12f);
+    r /= n; i /= n; j /= n; k /= n;
+    float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    Mat3 o = {{1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+               two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+               two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)}};
+    return o;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 (Salmon et al. 2011)
+struct Philox {
+    uint32_t key0, key1;
+    __device__ __forceinline__ Philox(uint64_t seed) : key0((uint32_t)seed), key1((uint32_t)(seed >> 32)) {}
+    __device__ __forceinline__ uint4 operator()(uint64_t ctr_lo, uint64_t ctr_hi) const {
+        uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+        uint32_t k0 = key0, k1 = key1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+            uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+            uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        return make_uint4(c0, c1, c2, c3);
+    }
+};
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }           // [0,1)
+__device__ __forceinline__ float u01_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); } // (0,1)
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    float r = sqrtf(-2.0f * logf(u01_open(a)));
+    float ph = 6.283185307179586f * u01(b);
+    n0 = r * cosf(ph);
+    n1 = r * sinf(ph);
+}
+
+}  // namespace abopt

@@ -1,0 +1,241 @@
+// C-ABI entry points that orchestrate kernel launches (declared in include/abopt.h).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "abopt_common.h"
+#include "kernels.h"
+
+namespace abopt {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// bump allocator over the caller's workspace, 256-byte aligned carves
+struct Carver {
+    char* base; size_t cap, off = 0; bool ok = true;
+    Carver(void* p, size_t n) : base((char*)p), cap(n) {}
+    float* f(size_t nfloat) {
+        const size_t bytes = (nfloat * sizeof(float) + 255) & ~(size_t)255;
+        if (base && off + bytes > cap) { ok = false; return nullptr; }
+        float* r = base ? (float*)(base + off) : nullptr;
+        off += bytes;
+        return r;
+    }
+};
+
+constexpr int F = 128, C = 64, FI = F + 4;
+
+struct GaScratch { float *proj, *feat, *u, *y, *h1, *h2; };
+static GaScratch carve_ga(Carver& cv, int64_t M) {
+    GaScratch s;
+    s.proj = cv.f((size_t)M * ABOPT_NODE_PROJ);
+    s.feat = cv.f((size_t)M * ABOPT_IPA_FEAT);
+    s.u = cv.f((size_t)M * F);
+    s.y = cv.f((size_t)M * F);
+    s.h1 = cv.f((size_t)M * F);
+    s.h2 = cv.f((size_t)M * F);
+    return s;
+}
+
+static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, const float* x, const float* z, const uint8_t* mask,
+                    float* x_out, int N, int L, const abopt_ga_debug* dbg, const GaScratch& s, hipStream_t st) {
+    const int64_t M = (int64_t)N * L;
+    int rc;
+    // node projections: q|k|v|qp|kp|vp in one GEMM, then points to the global frame
+    if ((rc = launch_linear(x, F, w->w_node, F, nullptr, s.proj, ABOPT_NODE_PROJ, (int)M, ABOPT_NODE_PROJ, F, false, st))) return rc;
+    if ((rc = launch_points_to_global(s.proj, R, t, M, st))) return rc;
+    float* feat = (dbg && dbg->feat) ? dbg->feat : s.feat;
+    if ((rc = launch_ipa_core(s.proj, z, mask, R, t, w->w_pair_bias, w->spatial_coef, feat,
+                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, N, L, st))) return rc;
+    // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
+    if ((rc = launch_linear(feat, ABOPT_IPA_FEAT, w->w_out, ABOPT_IPA_FEAT, w->b_out, s.u, F, (int)M, F, ABOPT_IPA_FEAT, false, st))) return rc;
+    if ((rc = launch_residual_layernorm(x, s.u, mask, w->ln1_gamma, w->ln1_beta, s.y, M, st))) return rc;
+    if ((rc = launch_linear(s.y, F, w->w_mlp0, F, w->b_mlp0, s.h1, F, (int)M, F, F, true, st))) return rc;
+    if ((rc = launch_linear(s.h1, F, w->w_mlp1, F, w->b_mlp1, s.h2, F, (int)M, F, F, true, st))) return rc;
+    if ((rc = launch_linear(s.h2, F, w->w_mlp2, F, w->b_mlp2, s.h1, F, (int)M, F, F, false, st))) return rc;
+    if ((rc = launch_residual_layernorm(s.y, s.h1, nullptr, w->ln2_gamma, w->ln2_beta, x_out, M, st))) return rc;
+    return ABOPT_OK;
+}
+
+static int check_ga_weights(const abopt_ga_weights* w) {
+    ABOPT_CHECK_ARG(w && w->w_node && w->w_pair_bias && w->spatial_coef && w->w_out && w->b_out && w->ln1_gamma && w->ln1_beta &&
+                    w->w_mlp0 && w->b_mlp0 && w->w_mlp1 && w->b_mlp1 && w->w_mlp2 && w->b_mlp2 && w->ln2_gamma && w->ln2_beta,
+                    "GABlock weights: NULL pointer");
+    return ABOPT_OK;
+}
+
+}  // namespace abopt
+
+using namespace abopt;
+
+extern "C" int abopt_abi_version(void) { return ABOPT_ABI_VERSION; }
+extern "C" const char* abopt_last_error(void) { return g_err; }
+
+extern "C" int abopt_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len) {
+    int dev = 0;
+    ABOPT_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    ABOPT_HIP(hipGetDeviceProperties(&prop, dev));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (arch && arch_len > 0) { strncpy(arch, prop.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    return ABOPT_OK;
+}
+
+extern "C" int abopt_so3_exp(const float* w, float* R, int64_t n, abopt_stream stream) {
+    ABOPT_CHECK_ARG(w && R && n >= 0, "so3_exp: bad arguments");
+    return launch_so3_exp(w, R, n, (hipStream_t)stream);
+}
+extern "C" int abopt_so3_log(const float* R, float* w, int64_t n, int grad_mode, abopt_stream stream) {
+    ABOPT_CHECK_ARG(w && R && n >= 0, "so3_log: bad arguments");
+    return launch_so3_log(R, w, n, grad_mode, (hipStream_t)stream);
+}
+
+extern "C" size_t abopt_ga_workspace_bytes(int N, int L, int Fd, int Cd) {
+    (void)Fd; (void)Cd;
+    Carver cv(nullptr, 0);
+    const int64_t M = (int64_t)N * L;
+    carve_ga(cv, M);
+    cv.f((size_t)M * F);   // ping-pong buffer for the encoder
+    return cv.off;
+}
+
+static int check_dims(int N, int L, int Fd, int Cd) {
+    ABOPT_CHECK_ARG(N >= 0 && L >= 0, "negative batch dims N=%d L=%d", N, L);
+    if (Fd != F || Cd != C) { set_error("this build supports res_feat_dim=128, pair_feat_dim=64 only (got %d, %d)", Fd, Cd); return ABOPT_EUNSUPPORTED; }
+    ABOPT_CHECK_ARG((int64_t)N * L < (1ll << 31) / 64, "N*L too large");
+    return ABOPT_OK;
+}
+
+extern "C" int abopt_ga_block_forward(const abopt_ga_weights* w, const float* R, const float* t, const float* x, const float* z,
+                                      const uint8_t* mask, float* x_out, int N, int L, int Fd, int Cd, const abopt_ga_debug* dbg,
+                                      void* ws, size_t ws_bytes, abopt_stream stream) {
+    int rc;
+    if ((rc = check_dims(N, L, Fd, Cd))) return rc;
+    if ((rc = check_ga_weights(w))) return rc;
+    ABOPT_CHECK_ARG(R && t && x && z && mask && x_out && ws, "ga_block_forward: NULL argument");
+    Carver cv(ws, ws_bytes);
+    GaScratch s = carve_ga(cv, (int64_t)N * L);
+    if (!cv.ok) { set_error("ga_block_forward: workspace too small (%zu bytes given)", ws_bytes); return ABOPT_EWORKSPACE; }
+    return ga_block(w, R, t, x, z, mask, x_out, N, L, dbg, s, (hipStream_t)stream);
+}
+
+static int ga_encoder(const abopt_ga_weights* blocks, int num_layers, const float* R, const float* t, const float* x, const float* z,
+                      const uint8_t* mask, float* x_out, int N, int L, const GaScratch& s, float* pong, hipStream_t st) {
+    // ga.py:190-193: the same R, t, z feed every block.  Ping-pong so the last block writes x_out.
+    const float* cur = x;
+    for (int i = 0; i < num_layers; ++i) {
+        float* dst = ((num_layers - 1 - i) % 2 == 0) ? x_out : pong;
+        int rc = ga_block(&blocks[i], R, t, cur, z, mask, dst, N, L, nullptr, s, st);
+        if (rc) return rc;
+        cur = dst;
+    }
+    if (num_layers == 0) ABOPT_HIP(hipMemcpyAsync(x_out, x, (size_t)N * L * F * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return ABOPT_OK;
+}
+
+extern "C" int abopt_ga_encoder_forward(const abopt_ga_weights* blocks, int num_layers, const float* R, const float* t, const float* x,
+                                        const float* z, const uint8_t* mask, float* x_out, int N, int L, int Fd, int Cd,
+                                        void* ws, size_t ws_bytes, abopt_stream stream) {
+    int rc;
+    if ((rc = check_dims(N, L, Fd, Cd))) return rc;
+    ABOPT_CHECK_ARG(blocks && num_layers >= 0, "ga_encoder_forward: bad block list");
+    for (int i = 0; i < num_layers; ++i) if ((rc = check_ga_weights(&blocks[i]))) return rc;
+    ABOPT_CHECK_ARG(R && t && x && z && mask && x_out && ws, "ga_encoder_forward: NULL argument");
+    ABOPT_CHECK_ARG(x != x_out, "ga_encoder_forward: x_out must not alias x");
+    Carver cv(ws, ws_bytes);
+    const int64_t M = (int64_t)N * L;
+    GaScratch s = carve_ga(cv, M);
+    float* pong = cv.f((size_t)M * F);
+    if (!cv.ok) { set_error("ga_encoder_forward: workspace too small (%zu bytes given)", ws_bytes); return ABOPT_EWORKSPACE; }
+    return ga_encoder(blocks, num_layers, R, t, x, z, mask, x_out, N, L, s, pong, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------- EpsilonNet
+namespace {
+struct EpsScratch { GaScratch ga; float *pong, *R, *cat, *x0, *xe, *infeat, *infeat_ln, *hh1, *hh2, *out3, *pr1, *pr2, *pr3; };
+EpsScratch carve_eps(Carver& cv, int64_t M, int num_bins) {
+    EpsScratch e;
+    e.ga = carve_ga(cv, M);
+    e.pong = cv.f((size_t)M * F);
+    e.R = cv.f((size_t)M * 9);
+    e.cat = cv.f((size_t)M * 2 * F);
+    e.x0 = cv.f((size_t)M * F);
+    e.xe = cv.f((size_t)M * F);
+    e.infeat = cv.f((size_t)M * FI);
+    e.infeat_ln = cv.f((size_t)M * FI);
+    e.hh1 = cv.f((size_t)M * 3 * F);
+    e.hh2 = cv.f((size_t)M * 3 * F);
+    e.out3 = cv.f((size_t)M * 32);
+    e.pr1 = cv.f((size_t)M * F);
+    e.pr2 = cv.f((size_t)M * F);
+    e.pr3 = cv.f((size_t)M * (size_t)(num_bins > 0 ? num_bins : 1));
+    return e;
+}
+}  // namespace
+
+extern "C" size_t abopt_eps_workspace_bytes(int N, int L, int Fd, int Cd) {
+    (void)Fd; (void)Cd;
+    Carver cv(nullptr, 0);
+    carve_eps(cv, (int64_t)N * L, 64);
+    return cv.off;
+}
+
+extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_t, const float* p_t, const int64_t* s_t,
+                                     const float* res_feat, const float* pair_feat, const float* beta,
+                                     const uint8_t* mask_generate, const uint8_t* mask_res,
+                                     float* v_next, float* R_next, float* eps_pos, float* c_denoised, float* prmsd_logits,
+                                     int N, int L, int Fd, int Cd, int grad_mode, void* ws, size_t ws_bytes, abopt_stream stream) {
+    int rc;
+    if ((rc = check_dims(N, L, Fd, Cd))) return rc;
+    ABOPT_CHECK_ARG(w && w->seq_embed && w->w_mix0 && w->b_mix0 && w->w_mix1 && w->b_mix1 && w->blocks && w->w_head1 && w->b_head1 &&
+                    w->w_crd2 && w->b_crd2 && w->w_crd3 && w->b_crd3 && w->w_rot2 && w->b_rot2 && w->w_rot3 && w->b_rot3 &&
+                    w->w_seq2 && w->b_seq2 && w->w_seq3 && w->b_seq3, "eps_net_forward: NULL weight pointer");
+    for (int i = 0; i < w->num_layers; ++i) if ((rc = check_ga_weights(&w->blocks[i]))) return rc;
+    ABOPT_CHECK_ARG(v_t && p_t && s_t && res_feat && pair_feat && beta && mask_generate && mask_res && v_next && R_next && eps_pos && c_denoised && ws,
+                    "eps_net_forward: NULL argument");
+    const bool has_prmsd = w->w_prmsd1 != nullptr;
+    ABOPT_CHECK_ARG(!has_prmsd || (prmsd_logits && w->prmsd_ln_gamma && w->prmsd_ln_beta && w->b_prmsd1 && w->w_prmsd2 && w->b_prmsd2 &&
+                                   w->w_prmsd3 && w->b_prmsd3 && w->num_bins > 0 && w->num_bins <= 64), "eps_net_forward: incomplete prmsd head");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t M = (int64_t)N * L;
+    if (M == 0) return ABOPT_OK;
+    Carver cv(ws, ws_bytes);
+    EpsScratch e = carve_eps(cv, M, 64);
+    if (!cv.ok) { set_error("eps_net_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, abopt_eps_workspace_bytes(N, L, Fd, Cd)); return ABOPT_EWORKSPACE; }
+
+    // dpm_full.py:86  R = exp(v_t)
+    if ((rc = launch_so3_exp(v_t, e.R, M, st))) return rc;
+    // dpm_full.py:89  res_feat_mixer([res_feat | Embedding(s_t)])
+    if ((rc = launch_embed_concat(res_feat, s_t, w->seq_embed, e.cat, M, st))) return rc;
+    if ((rc = launch_linear(e.cat, 2 * F, w->w_mix0, 2 * F, w->b_mix0, e.x0, F, (int)M, F, 2 * F, true, st))) return rc;
+    if ((rc = launch_linear(e.x0, F, w->w_mix1, F, w->b_mix1, e.cat, F, (int)M, F, F, false, st))) return rc;   // reuse cat[:, :F] as x (ld = F)
+    // dpm_full.py:90  encoder
+    if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st))) return rc;
+    // dpm_full.py:92-93 time features
+    if ((rc = launch_build_infeat(e.xe, beta, e.infeat, w->prmsd_ln_gamma, w->prmsd_ln_beta, has_prmsd ? e.infeat_ln : nullptr, N, L, st))) return rc;
+    // three heads, first layers fused (shared input): [M,132] x [384,132]^T
+    if ((rc = launch_linear(e.infeat, FI, w->w_head1, FI, w->b_head1, e.hh1, 3 * F, (int)M, 3 * F, FI, true, st))) return rc;
+    if ((rc = launch_linear(e.hh1 + 0 * F, 3 * F, w->w_crd2, F, w->b_crd2, e.hh2 + 0 * F, 3 * F, (int)M, F, F, true, st))) return rc;
+    if ((rc = launch_linear(e.hh1 + 1 * F, 3 * F, w->w_rot2, F, w->b_rot2, e.hh2 + 1 * F, 3 * F, (int)M, F, F, true, st))) return rc;
+    if ((rc = launch_linear(e.hh1 + 2 * F, 3 * F, w->w_seq2, F, w->b_seq2, e.hh2 + 2 * F, 3 * F, (int)M, F, F, true, st))) return rc;
+    // third layers into out3 [M,32]: cols 0..2 crd, 4..6 rot, 8..27 seq logits
+    if ((rc = launch_linear(e.hh2 + 0 * F, 3 * F, w->w_crd3, F, w->b_crd3, e.out3 + 0, 32, (int)M, 3, F, false, st))) return rc;
+    if ((rc = launch_linear(e.hh2 + 1 * F, 3 * F, w->w_rot3, F, w->b_rot3, e.out3 + 4, 32, (int)M, 3, F, false, st))) return rc;
+    if ((rc = launch_linear(e.hh2 + 2 * F, 3 * F, w->w_seq3, F, w->b_seq3, e.out3 + 8, 32, (int)M, ABOPT_AA, F, false, st))) return rc;
+    if ((rc = launch_heads_epilogue(e.R, v_t, e.out3 + 0, e.out3 + 4, e.out3 + 8, 32, 32, mask_generate, v_next, R_next, eps_pos, c_denoised,
+                                    M, grad_mode, st))) return rc;
+    if (has_prmsd) {
+        // PerResiduePredictor (nn.py:179-188) then mean over L (dpm_full.py:109-110)
+        if ((rc = launch_linear(e.infeat_ln, FI, w->w_prmsd1, FI, w->b_prmsd1, e.pr1, F, (int)M, F, FI, true, st))) return rc;
+        if ((rc = launch_linear(e.pr1, F, w->w_prmsd2, F, w->b_prmsd2, e.pr2, F, (int)M, F, F, true, st))) return rc;
+        if ((rc = launch_linear(e.pr2, F, w->w_prmsd3, F, w->b_prmsd3, e.pr3, w->num_bins, (int)M, w->num_bins, F, false, st))) return rc;
+        if ((rc = launch_mean_over_L(e.pr3, prmsd_logits, N, L, w->num_bins, st))) return rc;
+    }
+    return ABOPT_OK;
+}

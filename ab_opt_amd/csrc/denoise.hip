@@ -1,0 +1,269 @@
+// Per-step diffusion transitions and sampler initialisation for CDNA4.
+//
+// Replaces (reference AbDock/src/, identical maths in AbDesign/diffab/):
+//   PositionTransition.pred_noise_from_start / denoise      modules/diffusion/transition.py:42-50, 80-101
+//   RotationTransition.denoise                              modules/diffusion/transition.py:146-160
+//   ApproxAngularDistribution.sample, random_normal_so3     modules/common/so3.py:111-146
+//   AminoacidCategoricalTransition.posterior/denoise/_sample modules/diffusion/transition.py:166-245
+//   pRMSDCa.compute_prmsd, calc_perplexity                  modules/common/prmsd.py:31-47, modules/diffusion/dpm_full.py:380-399
+//   FullDPM.sample initial state                            modules/diffusion/dpm_full.py:255-269
+//   calc_per_rmsd / rank_commoness score                    tools/runner/design_for_testset.py:556-589
+// The reference gathers an (N*L, 8192) histogram copy per step and calls multinomial on it (240 ms at
+// N=4, L=256 on CPU); here one 8191-entry CDF row is binary-searched per residue.
+#include "abopt_common.h"
+#include "kernels.h"
+
+namespace abopt {
+
+constexpr int KAA = ABOPT_AA;
+constexpr float PI_F = 3.14159265358979323846f;
+
+__device__ __forceinline__ float torch_linspace(float a, float b, int steps, int i) {
+    // at::linspace: symmetric evaluation around the midpoint
+    const float step = (b - a) / (float)(steps - 1);
+    return (i < steps / 2) ? a + step * (float)i : b - step * (float)(steps - 1 - i);
+}
+
+// one workgroup per sample n; threads stride over residues; block-reduce the two per-sample scalars.
+__global__ __launch_bounds__(256) void denoise_step_kernel(abopt_step_params sp, abopt_step_noise nz, uint64_t seed, uint64_t offset,
+                                                           const float* __restrict__ v_t, const float* __restrict__ p_t,
+                                                           const int64_t* __restrict__ s_t, const float* __restrict__ v_net,
+                                                           const float* __restrict__ p_net, const float* __restrict__ c_net,
+                                                           const float* __restrict__ prmsd_logits, const uint8_t* __restrict__ mask_generate,
+                                                           const float* __restrict__ igX, const float* __restrict__ igCdf, int bins, int num_bins,
+                                                           float* __restrict__ v_next, float* __restrict__ p_next, int64_t* __restrict__ s_next,
+                                                           float* __restrict__ prmsd, float* __restrict__ ppl, float* __restrict__ post_out,
+                                                           int L, int ppl_masked) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const bool injected = nz.axis != nullptr;
+    const Philox rng(seed);
+    float ppl_num = 0.f, ppl_den = 0.f;
+
+    for (int l = tid; l < L; l += 256) {
+        const int64_t i = (int64_t)n * L + l;
+        const bool gen = mask_generate[i] != 0;
+        // ---- draws
+        float ax, ay, az, ubin, gss, zx, zy, zz, useq;
+        int64_t bin = 0;
+        if (injected) {
+            ax = nz.axis[i * 3]; ay = nz.axis[i * 3 + 1]; az = nz.axis[i * 3 + 2];
+            bin = nz.bin[i]; ubin = nz.ubin[i]; gss = nz.gauss[i];
+            zx = nz.z[i * 3]; zy = nz.z[i * 3 + 1]; zz = nz.z[i * 3 + 2];
+            useq = 0.f;
+        } else {
+            const uint64_t ctr = offset + (uint64_t)i;
+            const uint4 r0 = rng(ctr, ((uint64_t)sp.t << 8) | 0u), r1 = rng(ctr, ((uint64_t)sp.t << 8) | 1u), r2 = rng(ctr, ((uint64_t)sp.t << 8) | 2u);
+            float d0;
+            box_muller(r0.x, r0.y, ax, ay);
+            box_muller(r0.z, r0.w, az, gss);
+            box_muller(r1.x, r1.y, zx, zy);
+            box_muller(r1.z, r1.w, zz, d0);
+            ubin = u01(r2.x); useq = u01(r2.y);
+            const float ub = u01(r2.z);
+            // inverse CDF over bins-1 histogram cells == multinomial(Y[t, :-1]) (so3.py:122)
+            int lo = 0, hi = bins - 2;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (igCdf[mid] > ub) hi = mid; else lo = mid + 1; }
+            bin = lo;
+        }
+        // ---- rotation (transition.py:146-160)
+        const float vx = v_t[i * 3], vy = v_t[i * 3 + 1], vz = v_t[i * 3 + 2];
+        float nvx = vx, nvy = vy, nvz = vz;
+        {
+            const float nrm = fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-12f);
+            const float hist = igX[bin] + ubin * (igX[bin + 1] - igX[bin]);
+            const float gau = fmodf(fabsf(sp.igso3_std * 2.f + gss * sp.igso3_std), PI_F);
+            const float th = sp.igso3_gaussian ? gau : hist;
+            float ex = ax / nrm * th, ey = ay / nrm * th, ez = az / nrm * th;
+            if (!(sp.t > 1)) { ex = 0.f; ey = 0.f; ez = 0.f; }
+            const Mat3 E = so3_exp(ex, ey, ez);
+            const Mat3 Rn = matmul3(E, so3_exp(v_net[i * 3], v_net[i * 3 + 1], v_net[i * 3 + 2]));
+            const Vec3 w = so3_log(Rn, false);
+            if (gen) { nvx = w.x; nvy = w.y; nvz = w.z; }
+        }
+        // ---- position (transition.py:42-50, 80-101); state is kept in Angstrom like the reference traj
+        const float pa[3] = {p_t[i * 3], p_t[i * 3 + 1], p_t[i * 3 + 2]};
+        const float zn[3] = {zx, zy, zz};
+        float pn[3], pt[3];
+        {
+            const float c0 = 1.0f / sqrtf(sp.alpha_clamped + 1e-8f);
+            const float c1 = (1.f - sp.alpha_clamped) / sqrtf(1.f - sp.alpha_bar + 1e-8f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                pt[k] = (pa[k] - sp.position_mean[k]) / sp.position_scale;
+                const float pnet = p_net[i * 3 + k];
+                float eps = pnet;
+                if (sp.pred_x0) eps = gen ? (sp.sqrt_recip_abar * pt[k] - pnet) / sp.sqrt_recipm1_abar : pt[k];
+                const float zk = (sp.t > 1) ? zn[k] : 0.f;
+                const float nx = c0 * (pt[k] - c1 * eps) + sp.sigma * zk;
+                pn[k] = gen ? nx : pt[k];
+            }
+        }
+        if (!sp.sample_structure) { nvx = vx; nvy = vy; nvz = vz; pn[0] = pt[0]; pn[1] = pt[1]; pn[2] = pt[2]; }
+        v_next[i * 3] = nvx; v_next[i * 3 + 1] = nvy; v_next[i * 3 + 2] = nvz;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p_next[i * 3 + k] = pn[k] * sp.position_scale + sp.position_mean[k];
+
+        // ---- sequence (transition.py:202-245): NOTE alpha_bar_t multiplies both factors (reference quirk)
+        const int64_t st = s_t[i];
+        const bool st_ok = st >= 0 && st < KAA;
+        float post[KAA], tot = 0.f;
+        const float ab = sp.alpha_bar, unif = (1.f - ab) / (float)KAA;
+#pragma unroll
+        for (int k = 0; k < KAA; ++k) {
+            const float ct = (st_ok && st == k) ? 1.f : 0.f;
+            post[k] = ((ab * ct) + unif) * ((ab * c_net[i * KAA + k]) + unif);
+            tot += post[k];
+        }
+        float pmax = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KAA; ++k) {
+            const float ct = (st_ok && st == k) ? 1.f : 0.f;
+            post[k] = gen ? post[k] / (tot + 1e-8f) : ct;
+            pmax = fmaxf(pmax, post[k]);
+            if (post_out) post_out[i * KAA + k] = post[k];
+        }
+        int64_t sn;
+        if (injected) sn = nz.s_next[i];
+        else {
+            float cum = 0.f, total = 0.f;
+#pragma unroll
+            for (int k = 0; k < KAA; ++k) total += post[k] + 1e-8f;
+            const float target = useq * total;
+            sn = KAA - 1;
+            for (int k = 0; k < KAA; ++k) { cum += post[k] + 1e-8f; if (cum > target) { sn = k; break; } }
+        }
+        s_next[i] = sp.sample_sequence ? sn : st;
+        // perplexity term: max softmax(post) (dpm_full.py:392-396)
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < KAA; ++k) se += expf(post[k] - pmax);
+        const float w = (!ppl_masked || gen) ? 1.f : 0.f;
+        ppl_num += (1.f / se) * w;
+        ppl_den += w;
+    }
+
+    // ---- per-sample scalars
+    __shared__ float red[2][4];
+    ppl_num = wave_sum(ppl_num); ppl_den = wave_sum(ppl_den);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = ppl_num; red[1][tid >> 6] = ppl_den; }
+    __syncthreads();
+    if (tid == 0) {
+        if (ppl) ppl[n] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        if (prmsd && prmsd_logits) {
+            float mx = -INFINITY;
+            for (int b = 0; b < num_bins; ++b) mx = fmaxf(mx, prmsd_logits[(int64_t)n * num_bins + b]);
+            float sm = 0.f;
+            for (int b = 0; b < num_bins; ++b) sm += expf(prmsd_logits[(int64_t)n * num_bins + b] - mx);
+            float acc = 0.f;
+            for (int b = 0; b < num_bins; ++b)
+                acc += (expf(prmsd_logits[(int64_t)n * num_bins + b] - mx) / sm) * torch_linspace(sp.dist_min, sp.dist_max, num_bins, b);
+            prmsd[n] = acc;
+        }
+    }
+}
+
+// FullDPM.sample init (dpm_full.py:255-269)
+__global__ __launch_bounds__(256) void sample_init_kernel(const float* __restrict__ v, const float* __restrict__ p, const int64_t* __restrict__ s,
+                                                          const uint8_t* __restrict__ mask_generate, const float* __restrict__ q4,
+                                                          const float* __restrict__ pn, const int64_t* __restrict__ sr, uint64_t seed, uint64_t offset,
+                                                          float scale, float m0, float m1, float m2, int sample_structure, int sample_sequence,
+                                                          float* __restrict__ v_init, float* __restrict__ p_init, int64_t* __restrict__ s_init, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const bool gen = mask_generate[i] != 0;
+    const float mean[3] = {m0, m1, m2};
+    float q[4], g[3];
+    int64_t srand_;
+    if (q4) {
+        q[0] = q4[i * 4]; q[1] = q4[i * 4 + 1]; q[2] = q4[i * 4 + 2]; q[3] = q4[i * 4 + 3];
+        g[0] = pn[i * 3]; g[1] = pn[i * 3 + 1]; g[2] = pn[i * 3 + 2];
+        srand_ = sr ? sr[i] : 0;
+    } else {
+        const Philox rng(seed);
+        const uint4 r0 = rng(offset + (uint64_t)i, 0xFFFF00ull), r1 = rng(offset + (uint64_t)i, 0xFFFF01ull);
+        float d0;
+        box_muller(r0.x, r0.y, q[0], q[1]);
+        box_muller(r0.z, r0.w, q[2], q[3]);
+        box_muller(r1.x, r1.y, g[0], g[1]);
+        box_muller(r1.z, r1.w, g[2], d0);
+        const Philox rng2(seed ^ 0x5bd1e995ull);
+        srand_ = (int64_t)(rng2(offset + (uint64_t)i, 0xFFFF02ull).x % 19u);     // randint_like(low=0, high=19): TYR never drawn
+    }
+    // random_uniform_so3: F.normalize then quaternion_to_rotation_matrix (which normalises again), so3.py:66-68
+    const float nq = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+    const Vec3 w = so3_log(quat_to_rot(q[0] / nq, q[1] / nq, q[2] / nq, q[3] / nq), false);
+    const float wr[3] = {w.x, w.y, w.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float pnorm = (p[i * 3 + k] - mean[k]) / scale;
+        const bool rnd = gen && sample_structure;
+        v_init[i * 3 + k] = rnd ? wr[k] : v[i * 3 + k];
+        p_init[i * 3 + k] = (rnd ? g[k] : pnorm) * scale + mean[k];
+    }
+    s_init[i] = (gen && sample_sequence) ? srand_ : s[i];
+}
+
+// score[b] = sum_b' sqrt(mean_n |x_b - x_b'|^2) / (B - 1)   (design_for_testset.py:556-563,586-588)
+__global__ __launch_bounds__(256) void commonness_kernel(const float* __restrict__ x, float* __restrict__ score, int B, int n) {
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ float part[4];
+    float tot = 0.f;
+    for (int o = wave; o < B; o += 4) {
+        float s = 0.f;
+        for (int k = lane; k < n * 3; k += 64) { const float d = x[((int64_t)b * n) * 3 + k] - x[((int64_t)o * n) * 3 + k]; s = fmaf(d, d, s); }
+        s = wave_sum(s);
+        tot += sqrtf(s / (float)n);
+    }
+    if (lane == 0) part[wave] = tot;
+    __syncthreads();
+    if (tid == 0) score[b] = (part[0] + part[1] + part[2] + part[3]) / (float)(B - 1);
+}
+
+}  // namespace abopt
+
+using namespace abopt;
+
+extern "C" int abopt_denoise_step(const abopt_step_params* sp, const abopt_step_noise* noise, uint64_t seed, uint64_t offset,
+                                  const float* v_t, const float* p_t, const int64_t* s_t,
+                                  const float* v_net, const float* p_net, const float* c_net, const float* prmsd_logits,
+                                  const uint8_t* mask_generate, const float* igso3_X, const float* igso3_cdf, int igso3_bins, int num_bins,
+                                  float* v_next, float* p_next, int64_t* s_next, float* prmsd, float* perplexity,
+                                  float* post_out, int N, int L, abopt_stream stream) {
+    ABOPT_CHECK_ARG(sp && v_t && p_t && s_t && v_net && p_net && c_net && mask_generate && v_next && p_next && s_next, "denoise_step: NULL argument");
+    ABOPT_CHECK_ARG(igso3_X && igso3_bins >= 2, "denoise_step: IGSO(3) histogram row missing");
+    abopt_step_noise nz = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (noise && noise->axis) {
+        ABOPT_CHECK_ARG(noise->bin && noise->ubin && noise->gauss && noise->z && noise->s_next, "denoise_step: injected noise must provide all six draws");
+        nz = *noise;
+    } else {
+        ABOPT_CHECK_ARG(igso3_cdf, "denoise_step: device RNG path needs the CDF row");
+    }
+    if (N == 0 || L == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(denoise_step_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, *sp, nz, seed, offset, v_t, p_t, s_t, v_net, p_net, c_net,
+                       prmsd_logits, mask_generate, igso3_X, igso3_cdf, igso3_bins, num_bins, v_next, p_next, s_next, prmsd, perplexity, post_out,
+                       L, sp->ppl_masked);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+extern "C" int abopt_sample_init(const float* v, const float* p, const int64_t* s, const uint8_t* mask_generate,
+                                 const float* q4, const float* pn, const int64_t* sr, uint64_t seed, uint64_t offset,
+                                 float position_scale, const float* position_mean, int sample_structure, int sample_sequence,
+                                 float* v_init, float* p_init, int64_t* s_init, int N, int L, abopt_stream stream) {
+    ABOPT_CHECK_ARG(v && p && s && mask_generate && v_init && p_init && s_init && position_mean, "sample_init: NULL argument");
+    ABOPT_CHECK_ARG((q4 == nullptr) == (pn == nullptr), "sample_init: q4 and pn must be given together");
+    const int64_t rows = (int64_t)N * L;
+    if (rows == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(sample_init_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, p, s, mask_generate, q4, pn, sr,
+                       seed, offset, position_scale, position_mean[0], position_mean[1], position_mean[2], sample_structure, sample_sequence,
+                       v_init, p_init, s_init, rows);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+extern "C" int abopt_commonness_score(const float* structs, float* score, int B, int n, abopt_stream stream) {
+    ABOPT_CHECK_ARG(structs && score && B >= 2 && n >= 1, "commonness_score: bad arguments (B=%d n=%d)", B, n);
+    hipLaunchKernelGGL(commonness_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, structs, score, B, n);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}

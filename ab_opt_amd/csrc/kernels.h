@@ -1,0 +1,37 @@
+// Internal launch interface between the translation units of libabopt_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace abopt {
+
+// gemm.hip ------------------------------------------------------------------------------------
+int launch_linear(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
+                  int M, int N, int K, bool relu, hipStream_t st);
+
+// ipa.hip -------------------------------------------------------------------------------------
+// proj [N*L, 2016] holds q|k|v|qp|kp|vp with the three point sets already in the global frame.
+int launch_points_to_global(float* proj, const float* R, const float* t, int64_t rows, hipStream_t st);
+int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
+                    const float* w_pair_bias, const float* spatial_coef, float* feat,
+                    float* dbg_logits, float* dbg_alpha, int N, int L, hipStream_t st);
+
+// rows.hip ------------------------------------------------------------------------------------
+int launch_so3_exp(const float* w, float* R, int64_t n, hipStream_t st);
+int launch_so3_log(const float* R, float* w, int64_t n, int grad_mode, hipStream_t st);
+// y = LN(x + (mask ? u : 0)); mask may be NULL (no masking). F == 128.
+int launch_residual_layernorm(const float* x, const float* u, const uint8_t* mask, const float* gamma, const float* beta,
+                              float* y, int64_t rows, hipStream_t st);
+// cat[row] = [res_feat[row] | embed[s_t[row]]], F == 128
+int launch_embed_concat(const float* res_feat, const int64_t* s_t, const float* embed, float* cat, int64_t rows, hipStream_t st);
+// infeat[row, 0:128] = x, [128:131] = beta, sin beta, cos beta, [131] = 0 ; optional LN'd copy for the prmsd head
+int launch_build_infeat(const float* x, const float* beta, float* infeat, const float* ln_gamma, const float* ln_beta,
+                        float* infeat_ln, int N, int L, hipStream_t st);
+// heads epilogue: dpm_full.py:92-107
+int launch_heads_epilogue(const float* R, const float* v_t, const float* eps_crd, const float* eps_rot, const float* seq_logits,
+                          int ld3, int ldseq, const uint8_t* mask_generate, float* v_next, float* R_next, float* eps_pos, float* c_den,
+                          int64_t rows, int grad_mode, hipStream_t st);
+// out[n, b] = mean_l in[n, l, b]
+int launch_mean_over_L(const float* in, float* out, int N, int L, int B, hipStream_t st);
+
+}  // namespace abopt

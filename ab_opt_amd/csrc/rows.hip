@@ -1,0 +1,197 @@
+// Per-residue ("row") kernels around the dense projections: SO(3) maps, fused residual+LayerNorm,
+// the EpsilonNet prologue (sequence-embedding gather + concat, time features) and its geometric epilogue.
+// Reference: AbDock/src/modules/common/{so3.py,layers.py:109-155}, AbDock/src/modules/diffusion/dpm_full.py:85-112.
+#include "abopt_common.h"
+#include "kernels.h"
+
+namespace abopt {
+
+constexpr int F = 128;
+
+__global__ void so3_exp_kernel(const float* __restrict__ w, float* __restrict__ R, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Mat3 m = so3_exp(w[i * 3], w[i * 3 + 1], w[i * 3 + 2]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[i * 9 + k] = m.m[k];
+}
+
+__global__ void so3_log_kernel(const float* __restrict__ R, float* __restrict__ w, int64_t n, int grad_mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Mat3 m;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m.m[k] = R[i * 9 + k];
+    const Vec3 v = so3_log(m, grad_mode != 0);
+    w[i * 3] = v.x; w[i * 3 + 1] = v.y; w[i * 3 + 2] = v.z;
+}
+
+int launch_so3_exp(const float* w, float* R, int64_t n, hipStream_t st) {
+    if (n == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(so3_exp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, R, n);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+int launch_so3_log(const float* R, float* w, int64_t n, int grad_mode, hipStream_t st) {
+    if (n == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(so3_log_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, R, w, n, grad_mode);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+// y = LN(x + (mask ? u : 0)) with the reference's LayerNorm (biased variance, sqrt(var + 1e-10)): one wave per
+// row, two features per lane (F = 128).  ga.py:175-177.
+__global__ __launch_bounds__(256) void residual_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                                 const uint8_t* __restrict__ mask, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ y, int64_t rows) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const bool keep = mask ? (mask[row] != 0) : true;
+    const float2 xv = reinterpret_cast<const float2*>(x + row * F)[lane];
+    float2 uv = reinterpret_cast<const float2*>(u + row * F)[lane];
+    if (!keep) uv = make_float2(0.f, 0.f);
+    const float a = xv.x + uv.x, b = xv.y + uv.y;
+    const float mean = wave_sum(a + b) * (1.f / F);
+    const float da = a - mean, db = b - mean;
+    const float var = wave_sum(da * da + db * db) * (1.f / F);
+    const float sd = sqrtf(var + 1e-10f);
+    const float2 g = reinterpret_cast<const float2*>(gamma)[lane], bt = reinterpret_cast<const float2*>(beta)[lane];
+    reinterpret_cast<float2*>(y + row * F)[lane] = make_float2(da / sd * g.x + bt.x, db / sd * g.y + bt.y);
+}
+
+int launch_residual_layernorm(const float* x, const float* u, const uint8_t* mask, const float* gamma, const float* beta,
+                              float* y, int64_t rows, hipStream_t st) {
+    if (rows == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(residual_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, u, mask, gamma, beta, y, rows);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+// cat = [res_feat | Embedding(s_t)]  (dpm_full.py:89)
+__global__ __launch_bounds__(256) void embed_concat_kernel(const float* __restrict__ res_feat, const int64_t* __restrict__ s_t,
+                                                           const float* __restrict__ embed, float* __restrict__ cat, int64_t rows) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t s = s_t[row];
+    const float2 a = reinterpret_cast<const float2*>(res_feat + row * F)[lane];
+    const float2 b = reinterpret_cast<const float2*>(embed + s * F)[lane];
+    reinterpret_cast<float2*>(cat + row * 2 * F)[lane] = a;
+    reinterpret_cast<float2*>(cat + row * 2 * F + F)[lane] = b;
+}
+
+int launch_embed_concat(const float* res_feat, const int64_t* s_t, const float* embed, float* cat, int64_t rows, hipStream_t st) {
+    if (rows == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(embed_concat_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, res_feat, s_t, embed, cat, rows);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+// in_feat = [x | beta, sin beta, cos beta | 0] (dpm_full.py:92-93), K padded 131 -> 132; optionally also its
+// LayerNorm over the 131 real features for the prmsd head (nn.py:179-180).
+constexpr int FI = F + 4;
+__global__ __launch_bounds__(256) void build_infeat_kernel(const float* __restrict__ x, const float* __restrict__ beta,
+                                                           float* __restrict__ infeat, const float* __restrict__ ln_gamma,
+                                                           const float* __restrict__ ln_beta, float* __restrict__ infeat_ln, int N, int L) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)N * L) return;
+    const int lane = threadIdx.x & 63;
+    const float b = beta[row / L];
+    const float2 xv = reinterpret_cast<const float2*>(x + row * F)[lane];
+    const float e0 = b, e1 = sinf(b), e2 = cosf(b);
+    float* o = infeat + row * FI;
+    reinterpret_cast<float2*>(o)[lane] = xv;
+    if (lane == 0) { o[F] = e0; o[F + 1] = e1; o[F + 2] = e2; o[F + 3] = 0.f; }
+    if (infeat_ln) {
+        constexpr float inv = 1.f / (F + 3);
+        const float mean = (wave_sum(xv.x + xv.y) + e0 + e1 + e2) * inv;
+        const float da = xv.x - mean, db = xv.y - mean, d0 = e0 - mean, d1 = e1 - mean, d2 = e2 - mean;
+        const float var = (wave_sum(da * da + db * db) + d0 * d0 + d1 * d1 + d2 * d2) * inv;
+        const float sd = sqrtf(var + 1e-10f);
+        float* ol = infeat_ln + row * FI;
+        const float2 g = reinterpret_cast<const float2*>(ln_gamma)[lane], bt = reinterpret_cast<const float2*>(ln_beta)[lane];
+        reinterpret_cast<float2*>(ol)[lane] = make_float2(da / sd * g.x + bt.x, db / sd * g.y + bt.y);
+        if (lane == 0) {
+            ol[F] = d0 / sd * ln_gamma[F] + ln_beta[F];
+            ol[F + 1] = d1 / sd * ln_gamma[F + 1] + ln_beta[F + 1];
+            ol[F + 2] = d2 / sd * ln_gamma[F + 2] + ln_beta[F + 2];
+            ol[F + 3] = 0.f;
+        }
+    }
+}
+
+int launch_build_infeat(const float* x, const float* beta, float* infeat, const float* ln_gamma, const float* ln_beta,
+                        float* infeat_ln, int N, int L, hipStream_t st) {
+    const int64_t rows = (int64_t)N * L;
+    if (rows == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(build_infeat_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, beta, infeat, ln_gamma, ln_beta, infeat_ln, N, L);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+// Geometric epilogue of the three heads (dpm_full.py:95-107): eps_pos = gen ? R eps_crd : 0;
+// R_next = R * U(eps_rot); v_next = gen ? log(R_next) : v_t; c = softmax(seq logits).
+__global__ __launch_bounds__(256) void heads_epilogue_kernel(const float* __restrict__ R, const float* __restrict__ v_t,
+                                                             const float* __restrict__ eps_crd, const float* __restrict__ eps_rot,
+                                                             const float* __restrict__ seq_logits, int ld3, int ldseq,
+                                                             const uint8_t* __restrict__ mask_generate, float* __restrict__ v_next,
+                                                             float* __restrict__ R_next, float* __restrict__ eps_pos,
+                                                             float* __restrict__ c_den, int64_t rows, int grad_mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const bool gen = mask_generate[i] != 0;
+    Mat3 Rm;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rm.m[k] = R[i * 9 + k];
+    const float cx = eps_crd[i * ld3], cy = eps_crd[i * ld3 + 1], cz = eps_crd[i * ld3 + 2];
+    // apply_rotation_to_vector = R p + 0 (geometry.py:116-117)
+    eps_pos[i * 3 + 0] = gen ? (Rm.m[0] * cx + Rm.m[1] * cy + Rm.m[2] * cz + 0.f) : 0.f;
+    eps_pos[i * 3 + 1] = gen ? (Rm.m[3] * cx + Rm.m[4] * cy + Rm.m[5] * cz + 0.f) : 0.f;
+    eps_pos[i * 3 + 2] = gen ? (Rm.m[6] * cx + Rm.m[7] * cy + Rm.m[8] * cz + 0.f) : 0.f;
+    const Mat3 U = quat1ijk_to_rot(eps_rot[i * ld3], eps_rot[i * ld3 + 1], eps_rot[i * ld3 + 2]);
+    const Mat3 Rn = matmul3(Rm, U);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R_next[i * 9 + k] = Rn.m[k];
+    const Vec3 w = so3_log(Rn, grad_mode != 0);
+    v_next[i * 3 + 0] = gen ? w.x : v_t[i * 3 + 0];
+    v_next[i * 3 + 1] = gen ? w.y : v_t[i * 3 + 1];
+    v_next[i * 3 + 2] = gen ? w.z : v_t[i * 3 + 2];
+    float lgt[ABOPT_AA], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < ABOPT_AA; ++k) { lgt[k] = seq_logits[i * ldseq + k]; mx = fmaxf(mx, lgt[k]); }
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < ABOPT_AA; ++k) { lgt[k] = expf(lgt[k] - mx); sm += lgt[k]; }
+#pragma unroll
+    for (int k = 0; k < ABOPT_AA; ++k) c_den[i * ABOPT_AA + k] = lgt[k] / sm;
+}
+
+int launch_heads_epilogue(const float* R, const float* v_t, const float* eps_crd, const float* eps_rot, const float* seq_logits,
+                          int ld3, int ldseq, const uint8_t* mask_generate, float* v_next, float* R_next, float* eps_pos, float* c_den,
+                          int64_t rows, int grad_mode, hipStream_t st) {
+    if (rows == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(heads_epilogue_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, R, v_t, eps_crd, eps_rot, seq_logits,
+                       ld3, ldseq, mask_generate, v_next, R_next, eps_pos, c_den, rows, grad_mode);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+// prmsd_logits.mean(dim=1) over ALL L rows incl. padding (dpm_full.py:110).
+__global__ void mean_over_L_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int B) {
+    const int n = blockIdx.x, b = threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += in[((int64_t)n * L + l) * B + b];
+    out[(int64_t)n * B + b] = s / (float)L;
+}
+
+int launch_mean_over_L(const float* in, float* out, int N, int L, int B, hipStream_t st) {
+    if (N == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(B <= 1024, "mean_over_L: B=%d too large", B);
+    hipLaunchKernelGGL(mean_over_L_kernel, dim3(N), dim3(((B + 63) / 64) * 64), 0, st, in, out, L, B);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+}  // namespace abopt

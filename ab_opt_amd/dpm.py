@@ -1,0 +1,166 @@
+"""FullDPM: the diffusion driver over the HIP denoiser (host-side loop, device-side everything else).
+
+Mirrors AbDock/src/modules/diffusion/dpm_full.py:115-367 (`FullDPM`) and
+AbDesign/diffab/modules/diffusion/dpm_full.py:105-319 (no prmsd head / obj).  Differences that are
+deliberate and MI355X-first:
+  * the loop never leaves the device: states live in a preallocated (T+1)-slot trajectory and are
+    copied to the host once, after the last step (the reference does a D2H of every state per step,
+    dpm_full.py:300);
+  * noise comes from a counter-based Philox stream inside the transition kernel, or is injected
+    (`noise=`) to replay a recorded reference run.
+"""
+import functools
+import torch
+import torch.nn as nn
+
+from . import hip
+from .modules import (EpsilonNet, RotationTransition, PositionTransition, AminoacidCategoricalTransition, pRMSDCa)
+
+
+class FullDPM(nn.Module):
+
+    def __init__(self, res_feat_dim, pair_feat_dim, num_steps, eps_net_opt={}, trans_rot_opt={}, trans_pos_opt={},
+                 trans_seq_opt={}, position_mean=[0.0, 0.0, 0.0], position_scale=[10.0], obj='pred_noise',
+                 num_bins=20, dist_min=0.5, dist_max=19.5, _abdesign=False):
+        super().__init__()
+        self.abdock = not _abdesign
+        self.register_buffer('position_mean', torch.FloatTensor(position_mean).view(1, 1, -1))
+        self.register_buffer('position_scale', torch.FloatTensor(position_scale).view(1, 1, -1))
+        self.register_buffer('_dummy', torch.empty([0, ]))
+        self.eps_net = EpsilonNet(res_feat_dim, pair_feat_dim, **eps_net_opt, no_bins=num_bins if self.abdock else None)
+        self.num_steps = num_steps
+        self.trans_rot = RotationTransition(num_steps, **trans_rot_opt)
+        self.trans_pos = PositionTransition(num_steps, **trans_pos_opt)
+        self.trans_seq = AminoacidCategoricalTransition(num_steps, **trans_seq_opt)
+        self.obj = obj if self.abdock else 'pred_noise'
+        assert self.obj in ['pred_x0', 'pred_noise']
+        self.num_bins, self.dist_min, self.dist_max = num_bins, dist_min, dist_max
+        if self.abdock:
+            self.prmsd = pRMSDCa(num_bins, dist_min=dist_min, dist_max=dist_max)
+        self._host_sched = None
+
+    # ------------------------------------------------------------------ helpers
+    def _normalize_position(self, p):
+        return (p - self.position_mean) / self.position_scale
+
+    def _unnormalize_position(self, p_norm):
+        return p_norm * self.position_scale + self.position_mean
+
+    def _sched_host(self):
+        """Schedule scalars as python floats (one D2H at first use; the buffers never change after init)."""
+        vs = self.trans_pos.var_sched
+        key = (vs.betas.data_ptr(), vs.betas._version)
+        if self._host_sched is None or self._host_sched[0] != key:
+            g = lambda b: b.detach().cpu().tolist()
+            inv = self.trans_rot.angular_distrib_inv
+            self._host_sched = (key, dict(
+                betas=g(vs.betas), alphas=g(vs.alphas), alpha_bars=g(vs.alpha_bars), sigmas=g(vs.sigmas),
+                sr=g(vs.sqrt_recip_alphas_cumprod), srm1=g(vs.sqrt_recipm1_alphas_cumprod),
+                std=g(inv.stddevs), approx=g(inv.approx_flag), scale=float(self.position_scale.flatten()[0]),
+                mean=g(self.position_mean.flatten())))
+        return self._host_sched[1]
+
+    def _step_params(self, t, sample_structure, sample_sequence, ppl_masked):
+        h = self._sched_host()
+        sp = hip.StepParams()
+        sp.t = t
+        sp.alpha_clamped = max(h['alphas'][t], h['alphas'][-2])
+        sp.alpha_bar, sp.sigma = h['alpha_bars'][t], h['sigmas'][t]
+        sp.sqrt_recip_abar, sp.sqrt_recipm1_abar = h['sr'][t], h['srm1'][t]
+        sp.igso3_std, sp.igso3_gaussian = h['std'][t], int(h['approx'][t])
+        sp.position_scale = h['scale']
+        for k in range(3):
+            sp.position_mean[k] = h['mean'][k]
+        sp.pred_x0 = int(self.abdock and self.obj == 'pred_x0')
+        sp.sample_structure, sp.sample_sequence = int(sample_structure), int(sample_sequence)
+        sp.dist_min, sp.dist_max = float(self.dist_min), float(self.dist_max)
+        sp.ppl_masked = int(ppl_masked)
+        return sp
+
+    @staticmethod
+    def _new_seed():
+        return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+    # ------------------------------------------------------------------ sampling
+    def _run(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
+             ppl_masked, noise, seed, rng_offset, pbar, keep_on_device=False):
+        """Denoise from step t_start down to 0.  state = (v, p_angstrom, s) on device."""
+        dev = res_feat.device
+        N, L = mask_res.shape
+        T0 = t_start
+        f32 = dict(dtype=torch.float32, device=dev)
+        tv = torch.empty(T0 + 1, N, L, 3, **f32)
+        tp = torch.empty(T0 + 1, N, L, 3, **f32)
+        ts = torch.empty(T0 + 1, N, L, dtype=torch.int64, device=dev)
+        tv[T0], tp[T0], ts[T0] = state
+        tpr = torch.zeros(T0 + 1, N, **f32) if self.abdock else None
+        tpp = torch.zeros(T0 + 1, N, **f32) if self.abdock else None
+
+        res_feat, pair_feat = res_feat.contiguous().float(), pair_feat.contiguous().float()
+        mask_generate, mask_res = mask_generate.contiguous(), mask_res.contiguous()
+        ew = self.eps_net.packed()
+        h = self._sched_host()
+        inv = self.trans_rot.angular_distrib_inv
+        X, cdf = inv.X, (inv.cdf() if noise is None else None)
+        betas = self.trans_pos.var_sched.betas
+        net = dict(v_next=torch.empty(N, L, 3, **f32), R_next=torch.empty(N, L, 3, 3, **f32), eps_pos=torch.empty(N, L, 3, **f32),
+                   c=torch.empty(N, L, 20, **f32), prmsd_logits=torch.empty(N, self.num_bins, **f32) if self.abdock else None)
+        p_norm = torch.empty(N, L, 3, **f32)
+        scale, mean = self.position_scale, self.position_mean
+        it = range(T0, 0, -1)
+        if pbar:
+            from tqdm.auto import tqdm
+            it = tqdm(it, total=T0, desc='Sampling')
+        for t in it:
+            # dpm_full.py:276: p_t = normalize(traj[t].p)
+            torch.div(torch.sub(tp[t], mean), scale, out=p_norm)
+            beta = betas[t].expand([N]).contiguous()
+            hip.eps_net_forward(ew, tv[t], p_norm, ts[t], res_feat, pair_feat, beta, mask_generate, mask_res,
+                                self.abdock, self.num_bins, False, out=net)
+            sp = self._step_params(t, sample_structure, sample_sequence, ppl_masked)
+            out = dict(v=tv[t - 1], p=tp[t - 1], s=ts[t - 1])
+            if self.abdock:
+                out.update(prmsd=tpr[t - 1], ppl=tpp[t - 1])
+            hip.denoise_step(sp, noise[t] if noise is not None else None, seed, rng_offset,
+                             tv[t], tp[t], ts[t], net['v_next'], net['eps_pos'], net['c'], net['prmsd_logits'], mask_generate,
+                             X[t], cdf[t] if cdf is not None else None, self.num_bins, out)
+        return tv, tp, ts, tpr, tpp
+
+    def _to_traj(self, T0, tv, tp, ts, tpr, tpp, first_extra):
+        """Reference layout: dict t -> [v, p, s(, prmsd, ppl)], t>0 on the host, t=0 on the device."""
+        hv, hp, hs = tv[1:].cpu(), tp[1:].cpu(), ts[1:].cpu()       # one bulk D2H each
+        traj = {}
+        if self.abdock:
+            hpr, hpp = tpr.cpu(), tpp.cpu()
+        for t in range(T0, 0, -1):
+            e = [hv[t - 1], hp[t - 1], hs[t - 1]]
+            if self.abdock:
+                e += list(first_extra(hs[t - 1])) if t == T0 else [hpr[t], hpp[t]]
+            traj[t] = e if self.abdock else tuple(e)
+        e0 = [tv[0], tp[0], ts[0]]
+        if self.abdock:
+            e0 += [hpr[0], hpp[0]]
+        traj[0] = e0 if self.abdock else tuple(e0)
+        return traj
+
+    @torch.no_grad()
+    def sample(self, v, p, s, res_feat, pair_feat, mask_generate, mask_res, sample_structure=True, sample_sequence=True,
+               pbar=False, noise=None, seed=None, rng_offset=0, **kwargs):
+        """dpm_full.py:236-302.  `noise` (optional) = {'init': {q4,p,s}, t: {axis,bin,ubin,gauss,z,s_next}} replays
+        recorded draws; otherwise a Philox stream seeded from torch's CPU generator is used."""
+        hip.lib()
+        seed = self._new_seed() if seed is None else int(seed)
+        h = self._sched_host()
+        state = hip.sample_init(v.float(), p.float(), s, mask_generate, noise['init'] if noise is not None else None, seed, rng_offset,
+                                h['scale'], h['mean'], sample_structure, sample_sequence)
+        T = self.num_steps
+        out = self._run(state, T, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, True,
+                        noise, seed, rng_offset, pbar)
+        # dpm_full.py:269: the first entry carries zeros_like(s) / ones_like(s) in the two extra slots
+        return self._to_traj(T, *out, first_extra=lambda s_: (torch.zeros_like(s_), torch.ones_like(s_)))
+
+    @torch.no_grad()
+    def optimize(self, v, p, s, opt_step, res_feat, pair_feat, mask_generate, mask_res, sample_structure=True,
+                 sample_sequence=True, pbar=False, noise=None, seed=None, rng_offset=0):
+        """dpm_full.py:304-367: noise the input to step `opt_step`, then denoise."""
+        raise NotImplementedError('FullDPM.optimize: the forward-noising kernels (add_noise) are not built yet')

@@ -1,0 +1,151 @@
+"""encode(): residue and pair embeddings ("next" after the denoising path).
+
+Runs once per sample()/optimize() call and is outside the denoising-steps/sec metric.  In this round it
+is expressed with torch ops on the HIP device (PyTorch-ROCm plumbing); the fused MFMA kernels for the
+L^2 x {225->64, 218->64} GEMMs are the next scope row.  Module / parameter names mirror
+AbDock/src/modules/encoders/residue.py:9-92 and pair.py:10-101 so checkpoints load strictly.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+AA_UNK, ATOM_N, ATOM_CA, ATOM_C = 20, 0, 1, 2
+
+
+class AngularEncoding(nn.Module):
+    def __init__(self, num_funcs=3):
+        super().__init__()
+        self.num_funcs = num_funcs
+        self.register_buffer('freq_bands', torch.FloatTensor([i + 1 for i in range(num_funcs)] + [1. / (i + 1) for i in range(num_funcs)]))
+
+    def get_out_dim(self, in_dim):
+        return in_dim * (1 + 2 * 2 * self.num_funcs)
+
+    def forward(self, x):
+        shape = list(x.shape[:-1]) + [-1]
+        x = x.unsqueeze(-1)
+        return torch.cat([x, torch.sin(x * self.freq_bands), torch.cos(x * self.freq_bands)], dim=-1).reshape(shape)
+
+
+def _unit(v, eps=1e-6):
+    return v / (torch.linalg.norm(v, ord=2, dim=-1, keepdim=True) + eps)
+
+
+def construct_3d_basis(center, p1, p2):
+    e1 = _unit(p1 - center)
+    v2 = p2 - center
+    e2 = _unit(v2 - (e1 * v2).sum(-1, keepdim=True) * e1)
+    return torch.stack([e1, e2, torch.cross(e1, e2, dim=-1)], dim=-1)
+
+
+def _dihedral(p0, p1, p2, p3):
+    v0, v1, v2 = p2 - p1, p0 - p1, p3 - p2
+    u1 = torch.cross(v0, v1, dim=-1)
+    n1 = u1 / torch.linalg.norm(u1, dim=-1, keepdim=True)
+    u2 = torch.cross(v0, v2, dim=-1)
+    n2 = u2 / torch.linalg.norm(u2, dim=-1, keepdim=True)
+    sgn = torch.sign((torch.cross(v1, v2, dim=-1) * v0).sum(-1))
+    return torch.nan_to_num(sgn * torch.acos((n1 * n2).sum(-1).clamp(min=-0.999999, max=0.999999)))
+
+
+def _backbone_dihedrals(pos, chain_nb, res_nb, mask):
+    n, ca, c = pos[:, :, ATOM_N], pos[:, :, ATOM_CA], pos[:, :, ATOM_C]
+    consec = ((res_nb[:, 1:] - res_nb[:, :-1]).abs() == 1) & (chain_nb[:, 1:] == chain_nb[:, :-1]) & mask[:, :-1]
+    nterm, cterm = F.pad(~consec, pad=(1, 0), value=1), F.pad(~consec, pad=(0, 1), value=1)
+    omega = F.pad(_dihedral(ca[:, :-1], c[:, :-1], n[:, 1:], ca[:, 1:]), pad=(1, 0), value=0)
+    phi = F.pad(_dihedral(c[:, :-1], n[:, 1:], ca[:, 1:], c[:, 1:]), pad=(1, 0), value=0)
+    psi = F.pad(_dihedral(n[:, :-1], ca[:, :-1], c[:, :-1], n[:, 1:]), pad=(0, 1), value=0)
+    m = torch.stack([~nterm, ~nterm, ~cterm], dim=-1)
+    return torch.stack([omega, phi, psi], dim=-1) * m, m
+
+
+class ResidueEmbedding(nn.Module):
+
+    def __init__(self, feat_dim, max_num_atoms, max_aa_types=22, hotspot=False):
+        super().__init__()
+        self.max_num_atoms, self.max_aa_types = max_num_atoms, max_aa_types
+        self.aatype_embed = nn.Embedding(max_aa_types, feat_dim)
+        self.dihed_embed = AngularEncoding()
+        self.type_embed = nn.Embedding(10, feat_dim, padding_idx=0)
+        infeat_dim = feat_dim + (max_aa_types * max_num_atoms * 3) + self.dihed_embed.get_out_dim(3) + feat_dim
+        self.hotspot_embed = None
+        if hotspot:      # AbDesign/diffab/modules/encoders/residue.py:19-21
+            infeat_dim += feat_dim
+            self.hotspot_embed = nn.Embedding(10, feat_dim, padding_idx=0)
+        self.mlp = nn.Sequential(nn.Linear(infeat_dim, feat_dim * 2), nn.ReLU(), nn.Linear(feat_dim * 2, feat_dim), nn.ReLU(),
+                                 nn.Linear(feat_dim, feat_dim), nn.ReLU(), nn.Linear(feat_dim, feat_dim))
+
+    def forward(self, aa, res_nb, chain_nb, pos_atoms, mask_atoms, fragment_type, hotspot=None, structure_mask=None, sequence_mask=None):
+        N, L = aa.size()
+        A = self.max_num_atoms
+        mres = mask_atoms[:, :, ATOM_CA]
+        pos, matom = pos_atoms[:, :, :A], mask_atoms[:, :, :A]
+        if sequence_mask is not None:
+            aa = torch.where(sequence_mask, aa, torch.full_like(aa, AA_UNK))
+        f_aa = self.aatype_embed(aa)
+        R = construct_3d_basis(pos[:, :, ATOM_CA], pos[:, :, ATOM_C], pos[:, :, ATOM_N])
+        rel = pos - pos[:, :, ATOM_CA].unsqueeze(2)
+        crd = torch.matmul(R.transpose(-1, -2), rel.transpose(-1, -2)).transpose(-1, -2)       # R^T (x - t)
+        crd = torch.where(matom[:, :, :, None], crd, torch.zeros_like(crd))
+        slot = aa[:, :, None] == torch.arange(self.max_aa_types, device=aa.device)[None, None, :]
+        f_crd = (slot[:, :, :, None, None] * crd[:, :, None]).reshape(N, L, self.max_aa_types * A * 3)
+        if structure_mask is not None:
+            f_crd = f_crd * structure_mask[:, :, None]
+        dih, mdih = _backbone_dihedrals(pos, chain_nb, res_nb, mres)
+        f_dih = (self.dihed_embed(dih[:, :, :, None]) * mdih[:, :, :, None]).reshape(N, L, -1)
+        if structure_mask is not None:
+            dm = structure_mask & torch.roll(structure_mask, 1, 1) & torch.roll(structure_mask, -1, 1)
+            f_dih = f_dih * dm[:, :, None]
+        feats = [f_aa, f_crd, f_dih, self.type_embed(fragment_type)]
+        if self.hotspot_embed is not None:
+            hs = hotspot if hotspot is not None else torch.zeros_like(aa)
+            feats.append(self.hotspot_embed(hs))
+        return self.mlp(torch.cat(feats, dim=-1)) * mres[:, :, None]
+
+
+class PairEmbedding(nn.Module):
+
+    def __init__(self, feat_dim, max_num_atoms, max_aa_types=22, max_relpos=32):
+        super().__init__()
+        self.max_num_atoms, self.max_aa_types, self.max_relpos = max_num_atoms, max_aa_types, max_relpos
+        self.aa_pair_embed = nn.Embedding(max_aa_types * max_aa_types, feat_dim)
+        self.relpos_embed = nn.Embedding(2 * max_relpos + 1, feat_dim)
+        self.aapair_to_distcoef = nn.Embedding(max_aa_types * max_aa_types, max_num_atoms * max_num_atoms)
+        nn.init.zeros_(self.aapair_to_distcoef.weight)
+        self.distance_embed = nn.Sequential(nn.Linear(max_num_atoms * max_num_atoms, feat_dim), nn.ReLU(),
+                                            nn.Linear(feat_dim, feat_dim), nn.ReLU())
+        self.dihedral_embed = AngularEncoding()
+        infeat_dim = feat_dim * 3 + self.dihedral_embed.get_out_dim(2)
+        self.out_mlp = nn.Sequential(nn.Linear(infeat_dim, feat_dim), nn.ReLU(), nn.Linear(feat_dim, feat_dim), nn.ReLU(),
+                                     nn.Linear(feat_dim, feat_dim))
+
+    def forward(self, aa, res_nb, chain_nb, pos_atoms, mask_atoms, structure_mask=None, sequence_mask=None):
+        N, L = aa.size()
+        A = self.max_num_atoms
+        pos, matom = pos_atoms[:, :, :A], mask_atoms[:, :, :A]
+        mres = matom[:, :, ATOM_CA]
+        mpair = mres[:, :, None] * mres[:, None, :]
+        pstruct = structure_mask[:, :, None] * structure_mask[:, None, :] if structure_mask is not None else None
+        if sequence_mask is not None:
+            aa = torch.where(sequence_mask, aa, torch.full_like(aa, AA_UNK))
+        aap = aa[:, :, None] * self.max_aa_types + aa[:, None, :]
+        f_aap = self.aa_pair_embed(aap)
+        same = chain_nb[:, :, None] == chain_nb[:, None, :]
+        rel = torch.clamp(res_nb[:, :, None] - res_nb[:, None, :], min=-self.max_relpos, max=self.max_relpos)
+        f_rel = self.relpos_embed(rel + self.max_relpos) * same[:, :, :, None]
+        d = (torch.linalg.norm(pos[:, :, None, :, None] - pos[:, None, :, None, :], dim=-1, ord=2) / 10).reshape(N, L, L, -1)
+        c = F.softplus(self.aapair_to_distcoef(aap))
+        g = torch.exp(-1 * c * d ** 2)
+        map_ = (matom[:, :, None, :, None] * matom[:, None, :, None, :]).reshape(N, L, L, -1)
+        f_dist = self.distance_embed(g * map_)
+        if pstruct is not None:
+            f_dist = f_dist * pstruct[:, :, :, None]
+        n, ca, cc = pos[:, :, ATOM_N], pos[:, :, ATOM_CA], pos[:, :, ATOM_C]
+        ei = lambda a: a[:, :, None].expand(N, L, L, 3)
+        ej = lambda a: a[:, None, :].expand(N, L, L, 3)
+        dihed = torch.stack([_dihedral(ei(cc), ej(n), ej(ca), ej(cc)), _dihedral(ei(n), ei(ca), ei(cc), ej(n))], dim=-1)
+        f_dih = self.dihedral_embed(dihed)
+        if pstruct is not None:
+            f_dih = f_dih * pstruct[:, :, :, None]
+        out = self.out_mlp(torch.cat([f_aap, f_rel, f_dist, f_dih], dim=-1))
+        return out * mpair[:, :, :, None]

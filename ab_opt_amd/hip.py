@@ -1,0 +1,262 @@
+"""ctypes binding of libabopt_hip.so (the C ABI in include/abopt.h).
+
+PyTorch is used only as the owner of device memory and streams: every call passes
+`tensor.data_ptr()` and `torch.cuda.current_stream().cuda_stream`.  There is no fallback:
+if the library is missing or a tensor is not on a HIP device, these functions raise.
+"""
+import ctypes as C
+import os
+import threading
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
+ABI_VERSION = 1
+
+c_f = C.c_void_p        # device float*
+c_i64 = C.c_void_p      # device int64*
+c_u8 = C.c_void_p       # device uint8*
+
+
+class GaWeights(C.Structure):
+    _fields_ = [(n, c_f) for n in (
+        'w_node', 'w_pair_bias', 'spatial_coef', 'w_out', 'b_out', 'ln1_gamma', 'ln1_beta',
+        'w_mlp0', 'b_mlp0', 'w_mlp1', 'b_mlp1', 'w_mlp2', 'b_mlp2', 'ln2_gamma', 'ln2_beta')]
+
+
+class GaDebug(C.Structure):
+    _fields_ = [('logits', c_f), ('alpha', c_f), ('feat', c_f)]
+
+
+class EpsWeights(C.Structure):
+    _fields_ = ([(n, c_f) for n in ('seq_embed', 'w_mix0', 'b_mix0', 'w_mix1', 'b_mix1')] +
+                [('blocks', C.POINTER(GaWeights)), ('num_layers', C.c_int)] +
+                [(n, c_f) for n in ('w_head1', 'b_head1', 'w_crd2', 'b_crd2', 'w_crd3', 'b_crd3',
+                                    'w_rot2', 'b_rot2', 'w_rot3', 'b_rot3', 'w_seq2', 'b_seq2', 'w_seq3', 'b_seq3',
+                                    'prmsd_ln_gamma', 'prmsd_ln_beta', 'w_prmsd1', 'b_prmsd1', 'w_prmsd2', 'b_prmsd2',
+                                    'w_prmsd3', 'b_prmsd3')] +
+                [('num_bins', C.c_int)])
+
+
+class StepParams(C.Structure):
+    _fields_ = [('t', C.c_int), ('alpha_clamped', C.c_float), ('alpha_bar', C.c_float), ('sigma', C.c_float),
+                ('sqrt_recip_abar', C.c_float), ('sqrt_recipm1_abar', C.c_float), ('igso3_std', C.c_float),
+                ('igso3_gaussian', C.c_int), ('position_scale', C.c_float), ('position_mean', C.c_float * 3),
+                ('pred_x0', C.c_int), ('sample_structure', C.c_int), ('sample_sequence', C.c_int),
+                ('dist_min', C.c_float), ('dist_max', C.c_float), ('ppl_masked', C.c_int)]
+
+
+class StepNoise(C.Structure):
+    _fields_ = [('axis', c_f), ('bin', c_i64), ('ubin', c_f), ('gauss', c_f), ('z', c_f), ('s_next', c_i64)]
+
+
+EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
+           'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
+           'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_denoise_step', 'abopt_sample_init',
+           'abopt_commonness_score']
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load the shared library once; raise (never fall back) if it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                               '(or `make -C ab_opt_amd/csrc`).  ab_opt_amd has no non-HIP execution path.')
+        L = C.CDLL(LIB_PATH)
+        L.abopt_abi_version.restype = C.c_int
+        L.abopt_last_error.restype = C.c_char_p
+        L.abopt_ga_workspace_bytes.restype = C.c_size_t
+        L.abopt_ga_workspace_bytes.argtypes = [C.c_int] * 4
+        L.abopt_eps_workspace_bytes.restype = C.c_size_t
+        L.abopt_eps_workspace_bytes.argtypes = [C.c_int] * 4
+        L.abopt_device_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
+        L.abopt_so3_exp.argtypes = [c_f, c_f, C.c_int64, C.c_void_p]
+        L.abopt_so3_log.argtypes = [c_f, c_f, C.c_int64, C.c_int, C.c_void_p]
+        L.abopt_ga_block_forward.argtypes = [C.POINTER(GaWeights), c_f, c_f, c_f, c_f, c_u8, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(GaDebug), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_ga_encoder_forward.argtypes = [C.POINTER(GaWeights), C.c_int, c_f, c_f, c_f, c_f, c_u8, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_eps_net_forward.argtypes = [C.POINTER(EpsWeights), c_f, c_f, c_i64, c_f, c_f, c_f, c_u8, c_u8,
+                                            c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_denoise_step.argtypes = [C.POINTER(StepParams), C.POINTER(StepNoise), C.c_uint64, C.c_uint64,
+                                         c_f, c_f, c_i64, c_f, c_f, c_f, c_f, c_u8, c_f, c_f, C.c_int, C.c_int,
+                                         c_f, c_f, c_i64, c_f, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
+        L.abopt_sample_init.argtypes = [c_f, c_f, c_i64, c_u8, c_f, c_f, c_i64, C.c_uint64, C.c_uint64,
+                                        C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, c_f, c_f, c_i64, C.c_int, C.c_int, C.c_void_p]
+        L.abopt_commonness_score.argtypes = [c_f, c_f, C.c_int, C.c_int, C.c_void_p]
+        for name in EXPORTS:
+            getattr(L, name)          # AttributeError here = a symbol of include/abopt.h is missing
+        if L.abopt_abi_version() != ABI_VERSION:
+            raise RuntimeError(f'libabopt_hip.so ABI {L.abopt_abi_version()} != expected {ABI_VERSION}; rebuild it')
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f'abopt error {rc}: {lib().abopt_last_error().decode()}')
+
+
+_DT = {torch.float32: 'f32', torch.int64: 'i64', torch.bool: 'u8', torch.uint8: 'u8'}
+
+
+def ptr(t, dtype=None, optional=False):
+    """Device pointer of a contiguous HIP tensor (None -> NULL when optional)."""
+    if t is None:
+        if optional:
+            return None
+        raise ValueError('required tensor is None')
+    if not t.is_cuda:
+        raise RuntimeError('ab_opt_amd kernels run on a HIP device only; got a CPU tensor (there is no CPU path)')
+    if not t.is_contiguous():
+        raise ValueError('tensor must be contiguous')
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f'expected {dtype}, got {t.dtype}')
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Workspace:
+    """Grow-only scratch buffer per (device, stream)."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, nbytes, device):
+        key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            cls._bufs[key] = buf
+        return buf
+
+
+def device_info():
+    cu, lds = C.c_int(), C.c_int()
+    arch = C.create_string_buffer(64)
+    _check(lib().abopt_device_info(C.byref(cu), C.byref(lds), arch, 64))
+    return dict(cu_count=cu.value, lds_bytes_per_cu=lds.value, arch=arch.value.decode())
+
+
+# ------------------------------------------------------------------------------- thin wrappers
+def so3_exp(w):
+    w = w.contiguous()
+    R = torch.empty(w.shape[:-1] + (3, 3), dtype=torch.float32, device=w.device)
+    _check(lib().abopt_so3_exp(ptr(w, torch.float32), ptr(R), w.numel() // 3, stream()))
+    return R
+
+
+def so3_log(R, grad_mode=False):
+    R = R.contiguous()
+    w = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
+    _check(lib().abopt_so3_log(ptr(R, torch.float32), ptr(w), R.numel() // 9, int(grad_mode), stream()))
+    return w
+
+
+def ga_weights_struct(t):
+    """t: dict name -> contiguous device tensor with the field names of GaWeights."""
+    s = GaWeights()
+    for name, _ in GaWeights._fields_:
+        setattr(s, name, ptr(t[name], torch.float32))
+    return s
+
+
+def ga_block_forward(ws, R, t, x, z, mask, debug=False):
+    N, L, F = x.shape
+    Cd = z.shape[-1]
+    out = torch.empty_like(x)
+    dbg, extras = None, {}
+    if debug:
+        extras = dict(logits=torch.empty(N, L, L, 12, device=x.device), alpha=torch.empty(N, L, L, 12, device=x.device),
+                      feat=torch.empty(N, L, 1824, device=x.device))
+        dbg = GaDebug(ptr(extras['logits']), ptr(extras['alpha']), ptr(extras['feat']))
+    nb = lib().abopt_ga_workspace_bytes(N, L, F, Cd)
+    buf = Workspace.get(nb, x.device)
+    _check(lib().abopt_ga_block_forward(C.byref(ws), ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32),
+                                        ptr(x.contiguous(), torch.float32), ptr(z.contiguous(), torch.float32),
+                                        ptr(mask.contiguous(), torch.bool), ptr(out), N, L, F, Cd,
+                                        C.byref(dbg) if dbg is not None else None, ptr(buf), buf.numel(), stream()))
+    return (out, extras) if debug else out
+
+
+def ga_encoder_forward(ws_array, num_layers, R, t, x, z, mask):
+    N, L, F = x.shape
+    Cd = z.shape[-1]
+    out = torch.empty_like(x)
+    nb = lib().abopt_ga_workspace_bytes(N, L, F, Cd)
+    buf = Workspace.get(nb, x.device)
+    _check(lib().abopt_ga_encoder_forward(ws_array, num_layers, ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32),
+                                          ptr(x.contiguous(), torch.float32), ptr(z.contiguous(), torch.float32),
+                                          ptr(mask.contiguous(), torch.bool), ptr(out), N, L, F, Cd, ptr(buf), buf.numel(), stream()))
+    return out
+
+
+def eps_net_forward(ew, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res, has_prmsd, num_bins, grad_mode=False, out=None):
+    N, L = mask_res.shape
+    F, Cd = res_feat.shape[-1], pair_feat.shape[-1]
+    dev = res_feat.device
+    if out is None:
+        out = dict(v_next=torch.empty(N, L, 3, device=dev), R_next=torch.empty(N, L, 3, 3, device=dev),
+                   eps_pos=torch.empty(N, L, 3, device=dev), c=torch.empty(N, L, 20, device=dev),
+                   prmsd_logits=torch.empty(N, num_bins, device=dev) if has_prmsd else None)
+    nb = lib().abopt_eps_workspace_bytes(N, L, F, Cd)
+    buf = Workspace.get(nb, dev)
+    _check(lib().abopt_eps_net_forward(C.byref(ew), ptr(v_t.contiguous(), torch.float32), ptr(p_t.contiguous(), torch.float32),
+                                       ptr(s_t.contiguous(), torch.int64), ptr(res_feat.contiguous(), torch.float32),
+                                       ptr(pair_feat.contiguous(), torch.float32), ptr(beta.contiguous(), torch.float32),
+                                       ptr(mask_generate.contiguous(), torch.bool), ptr(mask_res.contiguous(), torch.bool),
+                                       ptr(out['v_next']), ptr(out['R_next']), ptr(out['eps_pos']), ptr(out['c']),
+                                       ptr(out['prmsd_logits'], optional=True), N, L, F, Cd, int(grad_mode),
+                                       ptr(buf), buf.numel(), stream()))
+    return out
+
+
+def denoise_step(sp, noise, seed, offset, v_t, p_t, s_t, v_net, p_net, c_net, prmsd_logits, mask_generate,
+                 ig_X_row, ig_cdf_row, num_bins, out, want_post=False):
+    N, L = mask_generate.shape
+    nz = None
+    if noise is not None:
+        nz = StepNoise(ptr(noise['axis'], torch.float32), ptr(noise['bin'], torch.int64), ptr(noise['ubin'], torch.float32),
+                       ptr(noise['gauss'], torch.float32), ptr(noise['z'], torch.float32), ptr(noise['s_next'], torch.int64))
+    post = torch.empty(N, L, 20, device=v_t.device) if want_post else None
+    _check(lib().abopt_denoise_step(C.byref(sp), C.byref(nz) if nz is not None else None, seed, offset,
+                                    ptr(v_t, torch.float32), ptr(p_t, torch.float32), ptr(s_t, torch.int64),
+                                    ptr(v_net, torch.float32), ptr(p_net, torch.float32), ptr(c_net, torch.float32),
+                                    ptr(prmsd_logits, optional=True), ptr(mask_generate, torch.bool),
+                                    ptr(ig_X_row, torch.float32), ptr(ig_cdf_row, optional=True), ig_X_row.numel(), num_bins,
+                                    ptr(out['v']), ptr(out['p']), ptr(out['s']), ptr(out.get('prmsd'), optional=True),
+                                    ptr(out.get('ppl'), optional=True), ptr(post, optional=True), N, L, stream()))
+    return post
+
+
+def sample_init(v, p, s, mask_generate, init_noise, seed, offset, scale, mean, sample_structure, sample_sequence):
+    N, L = mask_generate.shape
+    v_i, p_i, s_i = torch.empty_like(v), torch.empty_like(p), torch.empty_like(s)
+    q4 = pn = sr = None
+    if init_noise is not None:
+        q4, pn, sr = init_noise.get('q4'), init_noise.get('p'), init_noise.get('s')
+    mean_arr = (C.c_float * 3)(*[float(m) for m in mean])
+    _check(lib().abopt_sample_init(ptr(v.contiguous(), torch.float32), ptr(p.contiguous(), torch.float32), ptr(s.contiguous(), torch.int64),
+                                   ptr(mask_generate.contiguous(), torch.bool), ptr(q4, optional=True), ptr(pn, optional=True),
+                                   ptr(sr, optional=True), seed, offset, float(scale), mean_arr, int(sample_structure), int(sample_sequence),
+                                   ptr(v_i), ptr(p_i), ptr(s_i), N, L, stream()))
+    return v_i, p_i, s_i
+
+
+def commonness_score(structs):
+    structs = structs.contiguous().float()
+    B, n, _ = structs.shape
+    score = torch.empty(B, device=structs.device)
+    _check(lib().abopt_commonness_score(ptr(structs), ptr(score), B, n, stream()))
+    return score

@@ -1,0 +1,168 @@
+/* abopt.h -- C ABI of libabopt_hip.so: the MI355X (gfx950) denoising hot path of
+ * pengzhangzhi/ab_opt (AbDock / AbDesign).
+ *
+ * The reference is pure Python/PyTorch: it has no FFI of its own, so this is the boundary a
+ * maintainer binds with ctypes under the reference's nn.Module methods (INTEGRATION.md shows the
+ * stub).  Every entry point names the reference function(s) it replaces
+ * (D/ = AbDock/src/, A/ = AbDesign/diffab/ in the reference tree).
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes, no torch types; all floating point is fp32, row-major,
+ *     contiguous; masks are 1 byte per element (torch.bool storage); s_t / aa are int64.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); buffers are owned by
+ *     the caller; `ws` is caller-owned scratch of at least the matching *_workspace_bytes().
+ *   - no global mutable state: re-entrant across streams (one workspace per stream).
+ *   - return 0 on success, else an ABOPT_E* code; abopt_last_error() gives the thread-local text.
+ */
+#ifndef ABOPT_H
+#define ABOPT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABOPT_ABI_VERSION 1
+
+enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
+
+/* Fixed architecture of the IPA block (D/modules/encoders/ga.py:42-43 defaults, used by every shipped config). */
+enum { ABOPT_HEADS = 12, ABOPT_QK_DIM = 32, ABOPT_POINTS = 8, ABOPT_AA = 20,
+       ABOPT_NODE_PROJ = 2016,   /* 3*H*D + 3*H*P*3: query|key|value|query_pt|key_pt|value_pt */
+       ABOPT_IPA_FEAT = 1824 };  /* H*C + H*D + H*P*(3+1+3) at C = 64 */
+
+typedef void* abopt_stream;
+
+int abopt_abi_version(void);
+const char* abopt_last_error(void);
+/* name/CU count/LDS bytes of the current HIP device; arch receives e.g. "gfx950". */
+int abopt_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
+
+/* ---- SO(3) maps: D/modules/common/so3.py:33-57 (so3vec_to_rotation), :10-30,60-63 (rotation_to_so3vec).
+ * w (n,3) <-> R (n,3,3).  grad_mode!=0 selects the reference's autograd-on cosine clamp (-0.999). */
+int abopt_so3_exp(const float* w, float* R, int64_t n, abopt_stream stream);
+int abopt_so3_log(const float* R, float* w, int64_t n, int grad_mode, abopt_stream stream);
+
+/* ---- One GABlock: D/modules/encoders/ga.py:40-178.  Weight layouts are torch's ([out,in]). */
+typedef struct {
+    const float* w_node;        /* [2016, F]  rows: proj_query|proj_key|proj_value|proj_query_point|proj_key_point|proj_value_point (ga.py:54-66) */
+    const float* w_pair_bias;   /* [12, C]    proj_pair_bias.weight (ga.py:59) */
+    const float* spatial_coef;  /* [12]       raw parameter; softplus applied on device (ga.py:62-63,108) */
+    const float* w_out;         /* [F, 1824]  out_transform.weight (ga.py:69-73) */
+    const float* b_out;         /* [F] */
+    const float* ln1_gamma; const float* ln1_beta;   /* layer_norm_1 (D/modules/common/layers.py:109-155) */
+    const float* w_mlp0; const float* b_mlp0;        /* mlp_transition.0/.2/.4, each [F,F] + [F] (ga.py:76-78) */
+    const float* w_mlp1; const float* b_mlp1;
+    const float* w_mlp2; const float* b_mlp2;
+    const float* ln2_gamma; const float* ln2_beta;
+} abopt_ga_weights;
+
+/* Optional intermediates of one block for parity tests (any pointer may be NULL):
+ * logits = (node+pair+spatial)*sqrt(1/3) before masking, alpha after softmax/masking: [N,L,L,12]; feat [N,L,1824]. */
+typedef struct { float* logits; float* alpha; float* feat; } abopt_ga_debug;
+
+size_t abopt_ga_workspace_bytes(int N, int L, int F, int C);
+
+/* GABlock.forward (ga.py:149-178): R [N,L,3,3], t [N,L,3] (normalised coords), x [N,L,F], z [N,L,L,C],
+ * mask [N,L] -> x_out [N,L,F].  F must be 128 and C 64 in this build (the only shipped shapes). */
+int abopt_ga_block_forward(const abopt_ga_weights* w, const float* R, const float* t, const float* x,
+                           const float* z, const uint8_t* mask, float* x_out, int N, int L, int F, int C,
+                           const abopt_ga_debug* dbg, void* ws, size_t ws_bytes, abopt_stream stream);
+
+/* GAEncoder.forward (ga.py:181-193): num_layers blocks over the same R, t, z. */
+int abopt_ga_encoder_forward(const abopt_ga_weights* blocks, int num_layers, const float* R, const float* t,
+                             const float* x, const float* z, const uint8_t* mask, float* x_out,
+                             int N, int L, int F, int C, void* ws, size_t ws_bytes, abopt_stream stream);
+
+/* ---- EpsilonNet: D/modules/diffusion/dpm_full.py:35-112 (A/...:33-102 without the prmsd head).
+ * Head weights are passed packed (see ab_opt_amd/hip.py: pack_eps_weights):
+ *   w_head1 [384,132]: rows eps_crd_net.0 | eps_rot_net.0 | eps_seq_net.0, K padded 131->132 with a zero column
+ *   w_head3_* keep torch shapes.  prmsd_* may be NULL (AbDesign). */
+typedef struct {
+    const float* seq_embed;                 /* [25, F]  current_sequence_embedding.weight */
+    const float* w_mix0; const float* b_mix0;   /* [F, 2F], [F]   res_feat_mixer.0 */
+    const float* w_mix1; const float* b_mix1;   /* [F, F],  [F]   res_feat_mixer.2 */
+    const abopt_ga_weights* blocks; int num_layers;
+    const float* w_head1; const float* b_head1;     /* [3F, F+4], [3F] */
+    const float* w_crd2; const float* b_crd2; const float* w_crd3; const float* b_crd3;   /* [F,F],[F],[3,F],[3] */
+    const float* w_rot2; const float* b_rot2; const float* w_rot3; const float* b_rot3;   /* [F,F],[F],[3,F],[3] */
+    const float* w_seq2; const float* b_seq2; const float* w_seq3; const float* b_seq3;   /* [F,F],[F],[20,F],[20] */
+    const float* prmsd_ln_gamma; const float* prmsd_ln_beta;      /* [F+3] */
+    const float* w_prmsd1; const float* b_prmsd1;                 /* [F, F+4] (K padded), [F] */
+    const float* w_prmsd2; const float* b_prmsd2;                 /* [F, F], [F] */
+    const float* w_prmsd3; const float* b_prmsd3; int num_bins;   /* [num_bins, F], [num_bins] */
+} abopt_eps_weights;
+
+size_t abopt_eps_workspace_bytes(int N, int L, int F, int C);
+
+/* EpsilonNet.forward (dpm_full.py:70-112).  beta [N].  Outputs: v_next [N,L,3], R_next [N,L,3,3],
+ * eps_pos [N,L,3], c_denoised [N,L,20], prmsd_logits [N,num_bins] (NULL when the head is absent). */
+int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_t, const float* p_t, const int64_t* s_t,
+                          const float* res_feat, const float* pair_feat, const float* beta,
+                          const uint8_t* mask_generate, const uint8_t* mask_res,
+                          float* v_next, float* R_next, float* eps_pos, float* c_denoised, float* prmsd_logits,
+                          int N, int L, int F, int C, int grad_mode,
+                          void* ws, size_t ws_bytes, abopt_stream stream);
+
+/* ---- Per-step transitions: D/modules/diffusion/transition.py:42-50,80-101 (position), :146-160
+ * (rotation), :202-245 (amino acid), D/modules/common/so3.py:111-146 (IGSO(3) draw),
+ * dpm_full.py:284-300 (loop body after eps_net), :380-399 (perplexity), prmsd.py:31-47.
+ * Schedule scalars of step t (host reads them from the var_sched buffers): */
+typedef struct {
+    int   t;                 /* current step, T..1 */
+    float alpha_clamped;     /* max(alphas[t], alphas[T-1])          transition.py:84-86 */
+    float alpha_bar;         /* alpha_bars[t] */
+    float sigma;             /* sigmas[t] */
+    float sqrt_recip_abar;   /* sqrt_recip_alphas_cumprod[t]          transition.py:45 */
+    float sqrt_recipm1_abar; /* sqrt_recipm1_alphas_cumprod[t]        transition.py:46 */
+    float igso3_std;         /* angular_distrib_inv.stddevs[t] */
+    int   igso3_gaussian;    /* angular_distrib_inv.approx_flag[t] */
+    float position_scale;    /* FullDPM.position_scale (10.0) */
+    float position_mean[3];
+    int   pred_x0;           /* 1: eps_net output is x0 (AbDock obj=pred_x0), 0: it is the noise */
+    int   sample_structure;  /* dpm_full.py:294-295 */
+    int   sample_sequence;   /* dpm_full.py:296-297 */
+    float dist_min, dist_max;/* prmsd bounds (prmsd.py:41) */
+    int   ppl_masked;        /* 1: perplexity averaged over generated residues (sample, dpm_full.py:293); 0: over all L (optimize, :358) */
+} abopt_step_params;
+
+/* Explicit draws for teacher-forced replay, reference draw order; all NULL => the
+ * device Philox stream (seed, offset) is used instead. */
+typedef struct {
+    const float*   axis;    /* [N,L,3]  randn  -> rotation axis before normalisation  (so3.py:143) */
+    const int64_t* bin;     /* [N,L]    multinomial bin of the IGSO(3) histogram      (so3.py:122) */
+    const float*   ubin;    /* [N,L]    rand   in-bin position                        (so3.py:125) */
+    const float*   gauss;   /* [N,L]    randn  Gaussian branch                        (so3.py:130) */
+    const float*   z;       /* [N,L,3]  randn  position noise                         (transition.py:94-98) */
+    const int64_t* s_next;  /* [N,L]    the multinomial sample itself                 (transition.py:176-177) */
+} abopt_step_noise;
+
+/* One loop iteration after eps_net: state (v_t, p_t in Angstrom, s_t) -> (v_next, p_next in Angstrom, s_next),
+ * plus per-sample prmsd [N] and perplexity [N] (either may be NULL).
+ * igso3_X / igso3_cdf: row t of the inverse-process histogram, [bins] bin starts and [bins-1] normalised CDF
+ * (cdf only used without injected noise). post_out [N,L,20] optional (posterior, for tests). */
+int abopt_denoise_step(const abopt_step_params* sp, const abopt_step_noise* noise,
+                       uint64_t seed, uint64_t offset,
+                       const float* v_t, const float* p_t, const int64_t* s_t,
+                       const float* v_net, const float* p_net, const float* c_net, const float* prmsd_logits,
+                       const uint8_t* mask_generate,
+                       const float* igso3_X, const float* igso3_cdf, int igso3_bins, int num_bins,
+                       float* v_next, float* p_next, int64_t* s_next, float* prmsd, float* perplexity,
+                       float* post_out, int N, int L, abopt_stream stream);
+
+/* Initial state of FullDPM.sample (dpm_full.py:255-269): q4 [N,L,4], pn [N,L,3], sr [N,L] are the
+ * reference's three draws (NULL => Philox).  p in/out in Angstrom.  position_mean is a HOST pointer to 3 floats. */
+int abopt_sample_init(const float* v, const float* p, const int64_t* s, const uint8_t* mask_generate,
+                      const float* q4, const float* pn, const int64_t* sr, uint64_t seed, uint64_t offset,
+                      float position_scale, const float* position_mean, int sample_structure, int sample_sequence,
+                      float* v_init, float* p_init, int64_t* s_init, int N, int L, abopt_stream stream);
+
+/* ---- Batched-sampling reduction: D/tools/runner/design_for_testset.py:556-589 (calc_per_rmsd +
+ * rank_commoness score).  structs [B,n,3] -> score [B] = mean_{b'} RMSD(b,b') * B/(B-1). */
+int abopt_commonness_score(const float* structs, float* score, int B, int n, abopt_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABOPT_H */
