@@ -118,6 +118,7 @@ extern "C" int abopt_ga_block_forward(const abopt_ga_weights* w, const float* R,
     int rc;
     if ((rc = check_dims(N, L, Fd, Cd))) return rc;
     if ((rc = check_ga_weights(w))) return rc;
+    if ((int64_t)N * L == 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(R && t && x && z && mask && x_out && ws, "ga_block_forward: NULL argument");
     Carver cv(ws, ws_bytes);
     GaScratch s = carve_ga(cv, (int64_t)N * L);
@@ -146,6 +147,7 @@ extern "C" int abopt_ga_encoder_forward(const abopt_ga_weights* blocks, int num_
     if ((rc = check_dims(N, L, Fd, Cd))) return rc;
     ABOPT_CHECK_ARG(blocks && num_layers >= 0, "ga_encoder_forward: bad block list");
     for (int i = 0; i < num_layers; ++i) if ((rc = check_ga_weights(&blocks[i]))) return rc;
+    if ((int64_t)N * L == 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(R && t && x && z && mask && x_out && ws, "ga_encoder_forward: NULL argument");
     ABOPT_CHECK_ARG(x != x_out, "ga_encoder_forward: x_out must not alias x");
     Carver cv(ws, ws_bytes);
@@ -197,6 +199,7 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
                     w->w_crd2 && w->b_crd2 && w->w_crd3 && w->b_crd3 && w->w_rot2 && w->b_rot2 && w->w_rot3 && w->b_rot3 &&
                     w->w_seq2 && w->b_seq2 && w->w_seq3 && w->b_seq3, "eps_net_forward: NULL weight pointer");
     for (int i = 0; i < w->num_layers; ++i) if ((rc = check_ga_weights(&w->blocks[i]))) return rc;
+    if ((int64_t)N * L == 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(v_t && p_t && s_t && res_feat && pair_feat && beta && mask_generate && mask_res && v_next && R_next && eps_pos && c_denoised && ws,
                     "eps_net_forward: NULL argument");
     const bool has_prmsd = w->w_prmsd1 != nullptr;

@@ -7,6 +7,8 @@
 // exactly once per (n,i) and everything else stays on chip.
 #include "abopt_common.h"
 #include "kernels.h"
+#include <vector>
+#include <utility>
 
 namespace abopt {
 
@@ -167,6 +169,27 @@ __global__ __launch_bounds__(256) void ipa_core_v0_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------ measurement hook (see abopt_prof_enable)
+namespace prof {
+static bool g_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
+static size_t g_used = 0;
+static void begin(hipStream_t st) {
+    if (!g_on) return;
+    if (g_used == g_pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_on = false; return; }
+        g_pool.emplace_back(a, b);
+    }
+    hipEventRecord(g_pool[g_used].first, st);
+}
+static void end(hipStream_t st) {
+    if (!g_on) return;
+    hipEventRecord(g_pool[g_used].second, st);
+    ++g_used;
+}
+}  // namespace prof
+
 int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
                     const float* w_pair_bias, const float* spatial_coef, float* feat,
                     float* dbg_logits, float* dbg_alpha, int N, int L, hipStream_t st) {
@@ -174,10 +197,32 @@ int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, cons
     const size_t lds = ((size_t)L * (ZLD + H) + 1440) * sizeof(float);
     ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core v0: L=%d needs %zu bytes of LDS (max 163840)", L, lds);
     ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_core_v0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof::begin(st);
     hipLaunchKernelGGL(ipa_core_v0_kernel, dim3(L, N), dim3(256), lds, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,
                        feat, dbg_logits, dbg_alpha, L);
+    prof::end(st);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }
 
 }  // namespace abopt
+
+extern "C" int abopt_prof_enable(int on) {
+    abopt::prof::g_on = on != 0;
+    abopt::prof::g_used = 0;
+    return ABOPT_OK;
+}
+
+extern "C" int abopt_prof_collect(int* launches, double* total_ms) {
+    double tot = 0.0;
+    for (size_t i = 0; i < abopt::prof::g_used; ++i) {
+        float ms = 0.f;
+        ABOPT_HIP(hipEventSynchronize(abopt::prof::g_pool[i].second));
+        ABOPT_HIP(hipEventElapsedTime(&ms, abopt::prof::g_pool[i].first, abopt::prof::g_pool[i].second));
+        tot += ms;
+    }
+    if (launches) *launches = (int)abopt::prof::g_used;
+    if (total_ms) *total_ms = tot;
+    abopt::prof::g_used = 0;
+    return ABOPT_OK;
+}

@@ -83,7 +83,7 @@ class FullDPM(nn.Module):
 
     # ------------------------------------------------------------------ sampling
     def _run(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
-             ppl_masked, noise, seed, rng_offset, pbar, keep_on_device=False):
+             ppl_masked, noise, seed, rng_offset, pbar, stop_after=None):
         """Denoise from step t_start down to 0.  state = (v, p_angstrom, s) on device."""
         dev = res_feat.device
         N, L = mask_res.shape
@@ -112,6 +112,8 @@ class FullDPM(nn.Module):
             from tqdm.auto import tqdm
             it = tqdm(it, total=T0, desc='Sampling')
         for t in it:
+            if stop_after is not None and T0 - t >= stop_after:
+                break
             # dpm_full.py:276: p_t = normalize(traj[t].p)
             torch.div(torch.sub(tp[t], mean), scale, out=p_norm)
             beta = betas[t].expand([N]).contiguous()

@@ -53,7 +53,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_commonness_score']
+           'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect']
 
 _lib = None
 _lock = threading.Lock()
@@ -93,6 +93,8 @@ def lib():
         L.abopt_sample_init.argtypes = [c_f, c_f, c_i64, c_u8, c_f, c_f, c_i64, C.c_uint64, C.c_uint64,
                                         C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, c_f, c_f, c_i64, C.c_int, C.c_int, C.c_void_p]
         L.abopt_commonness_score.argtypes = [c_f, c_f, C.c_int, C.c_int, C.c_void_p]
+        L.abopt_prof_enable.argtypes = [C.c_int]
+        L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
         for name in EXPORTS:
             getattr(L, name)          # AttributeError here = a symbol of include/abopt.h is missing
         if L.abopt_abi_version() != ABI_VERSION:
@@ -260,3 +262,14 @@ def commonness_score(structs):
     score = torch.empty(B, device=structs.device)
     _check(lib().abopt_commonness_score(ptr(structs), ptr(score), B, n, stream()))
     return score
+
+
+def prof_enable(on=True):
+    _check(lib().abopt_prof_enable(int(on)))
+
+
+def prof_collect():
+    """(launches, total_ms) of the IPA-core kernel since prof_enable(True)."""
+    n, ms = C.c_int(), C.c_double()
+    _check(lib().abopt_prof_collect(C.byref(n), C.byref(ms)))
+    return n.value, ms.value

@@ -276,6 +276,15 @@ class ApproxAngularDistribution(nn.Module):
         self._cdf = None
 
     def _histograms(self):
+        # init-time host work; on many-core hosts torch's intra-op pool thrashes on these 8M-element ops
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(min(nthr, 16))
+        try:
+            return self._histograms_impl()
+        finally:
+            torch.set_num_threads(nthr)
+
+    def _histograms_impl(self):
         x = torch.linspace(0, math.pi, self.num_bins)
         l = torch.arange(0, self.num_iters)[None, :]
         X, Y = [], []

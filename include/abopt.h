@@ -162,6 +162,13 @@ int abopt_sample_init(const float* v, const float* p, const int64_t* s, const ui
  * rank_commoness score).  structs [B,n,3] -> score [B] = mean_{b'} RMSD(b,b') * B/(B-1). */
 int abopt_commonness_score(const float* structs, float* score, int B, int n, abopt_stream stream);
 
+/* ---- Measurement hook (bench.py's roofline leg).  When enabled, every launch of the IPA-core kernel is bracketed
+ * by hipEvents on the stream it is launched on; abopt_prof_collect synchronises those events and returns the number
+ * of launches and their summed duration since the last enable.  Process-global, off by default, not for concurrent
+ * use from several host threads (the only global state in the library). */
+int abopt_prof_enable(int on);
+int abopt_prof_collect(int* launches, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,354 @@
+"""Parity of the HIP path (through the C ABI) with the reference goldens and the CPU oracle.  Needs an MI355X.
+
+Tolerances (fp32, stated per SURVEY.md section 8c / BASELINE.md section 4):
+  * per-call outputs (R_next, eps_pos, c, prmsd logits, block outputs)   1e-5 .. 3e-5 abs
+  * positions after a teacher-forced step                                1e-4 Angstrom
+  * orientations are compared as rotation MATRICES; where the reference's own log map is ill-conditioned
+    (theta -> pi, error ~ eps/sin(theta); garbage when cos(theta) clamps at -1) the tolerance
+    scales with 1/sin(theta) and the clamp zone is excluded.
+"""
+import math
+import pytest
+import torch
+
+import cases
+from conftest import load_golden, build_model, max_abs
+from ab_opt_amd.utils import synth
+from test_oracle_golden import standalone_block_sd, standalone_abdesign_dpm, noise_dict
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device('cuda:0')
+
+
+def dev(x):
+    return x.to(DEV) if isinstance(x, torch.Tensor) else x
+
+
+def _log_amplification(R):
+    """(ok, 1/sin(theta)) of the reference log map at rotation matrices R: its error is ~eps/sin(theta), and it
+    returns garbage once cos(theta) clamps at -1 (so3.py:10-22; DESIGN.md "conditioning")."""
+    cos = ((R[..., 0, 0] + R[..., 1, 1] + R[..., 2, 2]) - 1) / 2
+    ok = cos > -1 + 2e-5
+    return ok, 1.0 / torch.sqrt((1 - cos.clamp(-1, 1) ** 2).clamp_min(1e-12))
+
+
+def rot_close(v_got, v_ref, R_pre, base=2e-6, cap=5e-3, R_upstream=None):
+    """exp(v_got) ~ exp(v_ref) with a per-residue tolerance base * amplification, where the amplification is
+    1/sin(theta) of the (well-conditioned) matrix R_pre fed to the log map, times that of an upstream log map
+    (R_upstream) when the compared value went through two of them.  Returns (#checked, worst err/tol)."""
+    from oracle import geometry as G
+    Ra, Rb = G.so3_exp(v_got), G.so3_exp(v_ref)
+    err = (Ra - Rb).abs().amax((-1, -2))
+    ok, amp = _log_amplification(R_pre)
+    if R_upstream is not None:
+        ok2, amp2 = _log_amplification(R_upstream)
+        ok, amp = ok & ok2, amp * amp2
+    tol = (base * amp).clamp(max=cap) + 1e-5
+    ratio = (err / tol)[ok]
+    return int(ok.sum()), (ratio.max().item() if ratio.numel() else 0.0)
+
+
+# ------------------------------------------------------------------------------------------ SO(3)
+def test_so3_maps_vs_reference():
+    from ab_opt_amd import hip
+    g = load_golden('so3')
+    R = hip.so3_exp(dev(cases.SO3_EDGE_W)).cpu()
+    assert max_abs(R, g['exp']) < 1e-6
+    assert max_abs(hip.so3_log(dev(g['exp']), False).cpu(), g['log_nograd']) < 5e-6
+    assert max_abs(hip.so3_log(dev(g['exp']), True).cpu(), g['log_grad']) < 5e-6
+    # round trip on 1e5 random vectors with theta < 3 (well conditioned)
+    w = synth.hash_tensor((100000, 3), 99, scale=3.4)
+    w = w[w.norm(dim=-1) < 3.0]
+    back = hip.so3_log(hip.so3_exp(dev(w)), False).cpu()
+    assert max_abs(back, w) < 5e-4 and (back - w).abs().mean() < 2e-6
+
+
+# ------------------------------------------------------------------------------------------ GABlock
+def _block_on_device(seed=1):
+    from ab_opt_amd.modules import GABlock
+    return synth.fill_module_(GABlock(128, 64), seed=seed).to(DEV).eval()
+
+
+def test_ga_block_parts_vs_reference():
+    g = load_golden('ga_block')
+    blk = _block_on_device()
+    R, t, x, z, mask = cases.ipa_inputs(2, 24, [24, 19])
+    out, parts = blk(dev(R), dev(t), dev(x), dev(z), dev(mask), return_parts=True)
+    ref_logits = (g['l_node'] + g['l_pair'] + g['l_spat']) * math.sqrt(1 / 3)
+    assert max_abs(parts['logits'].cpu(), ref_logits) < 2e-5 * max(1.0, ref_logits.abs().max().item())
+    assert max_abs(parts['alpha'].cpu(), g['alpha']) < 1e-5
+    valid = mask[:, :, None].expand_as(g['feat'])
+    assert max_abs(parts['feat'].cpu()[valid], g['feat'][valid]) < 2e-5
+    assert max_abs(parts['feat'].cpu(), g['feat']) < 2e-5          # masked query rows too (they hold -R^T t, ga.py:136)
+    assert max_abs(out.cpu(), g['out']) < 2e-5                      # all rows incl. padding (SURVEY s9 gotcha 1)
+
+
+def test_ga_block_L128_vs_reference():
+    g = load_golden('ga_block_L128')
+    blk = _block_on_device()
+    R, t, x, z, mask = cases.ipa_inputs(2, 128, [128, 101], salt=150)
+    out = blk(dev(R), dev(t), dev(x), dev(z), dev(mask))
+    assert max_abs(out.cpu(), g['out']) < 3e-5
+
+
+@pytest.mark.parametrize('N,L,lengths', [(1, 1, [1]), (3, 7, [7, 1, 4]), (2, 65, [65, 64]), (1, 200, [200]), (2, 256, [256, 250])])
+def test_ga_block_ragged_vs_oracle(N, L, lengths):
+    from oracle import ipa
+    blk = _block_on_device(seed=5)
+    sd = {k: v.cpu() for k, v in blk.state_dict().items()}
+    R, t, x, z, mask = cases.ipa_inputs(N, L, lengths, salt=400 + L)
+    ref = ipa.ga_block(sd, '', R, t, x, z, mask, mode='mm')
+    out = blk(dev(R), dev(t), dev(x), dev(z), dev(mask))
+    assert max_abs(out.cpu(), ref) < 3e-5
+
+
+def test_ga_block_empty_batch():
+    blk = _block_on_device()
+    out = blk(torch.zeros(0, 8, 3, 3, device=DEV), torch.zeros(0, 8, 3, device=DEV), torch.zeros(0, 8, 128, device=DEV),
+              torch.zeros(0, 8, 8, 64, device=DEV), torch.zeros(0, 8, dtype=torch.bool, device=DEV))
+    assert out.shape == (0, 8, 128)
+
+
+def test_ga_encoder_matches_block_chain():
+    from ab_opt_amd.modules import GAEncoder
+    enc = synth.fill_module_(GAEncoder(128, 64, 3), seed=6).to(DEV).eval()
+    R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(2, 33, [33, 20], salt=500)]
+    y = x
+    for b in enc.blocks:
+        y = b(R, t, y, z, mask)
+    assert torch.equal(enc(R, t, x, z, mask), y)
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_ipa_full_size_invariances():
+    """BASELINE config-2 shape (N=4 of the 32, L=256): SE(3) invariance, batch permutation, padding independence."""
+    from oracle import geometry as G
+    blk = _block_on_device(seed=7)
+    N, L = 4, 256
+    R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(N, L, [256, 256, 231, 256], salt=600)]
+    base = blk(R, t, x, z, mask)
+    # global rigid motion of every frame leaves the invariant features unchanged
+    Q = dev(G.so3_exp(torch.tensor([[0.3, -1.1, 0.7]])))[0]
+    shift = torch.tensor([1.5, -2.0, 0.25], device=DEV)
+    moved = blk(Q @ R, t @ Q.T + shift, x, z, mask)
+    assert max_abs(moved, base) < 2e-4
+    # batch permutation equivariance (bit-exact: every sample is processed independently)
+    perm = torch.tensor([2, 0, 3, 1], device=DEV)
+    assert torch.equal(blk(R[perm], t[perm], x[perm], z[perm], mask[perm]), base[perm])
+    # values in padded key columns / rows of z never reach valid rows
+    z2 = z.clone()
+    z2[2, :, 231:] = 1e3
+    z2[2, 231:, :] = -1e3
+    out2 = blk(R, t, x, z2, mask)
+    assert torch.equal(out2[2, :231], base[2, :231]) and torch.equal(out2[[0, 1, 3]], base[[0, 1, 3]])
+
+
+# ------------------------------------------------------------------------------------------ EpsilonNet
+def _check_eps(out, g, has_prmsd, v_tol_base=2e-6):
+    v_next, R_next, eps_pos, c = [o.cpu() for o in out[:4]]
+    assert max_abs(R_next, g['R_next']) < 2e-5
+    n, worst = rot_close(v_next, g['v_next'], g['R_next'], base=v_tol_base)
+    assert worst < 1.0, worst
+    assert max_abs(eps_pos, g['eps_pos']) < 2e-5
+    assert max_abs(c, g['c']) < 1e-5
+    if has_prmsd:
+        assert max_abs(out[4].cpu(), g['prmsd_logits']) < 2e-5
+
+
+def test_eps_net_abdock_vs_reference():
+    m = build_model(100, 2, device=DEV)
+    for tag, (N, L, lens, gr) in dict(small=(2, 40, [40, 33], [(5, 14), (22, 30)]), L128=(1, 128, [128], [(30, 42)])).items():
+        g = load_golden(f'eps_net_abdock_{tag}')
+        args = [dev(a) for a in cases.eps_inputs(N, L, lens, gr)]
+        _check_eps(m.diffusion.eps_net(*args), g, True)
+
+
+def test_eps_net_abdesign_vs_reference():
+    d = standalone_abdesign_dpm(100, 2).to(DEV)
+    g = load_golden('eps_net_abdesign_small')
+    args = [dev(a) for a in cases.eps_inputs(2, 40, [40, 33], [(5, 14), (22, 30)])]
+    _check_eps(d.eps_net(*args), g, False)
+
+
+def test_eps_net_grad_mode_clamp():
+    """grad_mode selects the -0.999 cosine clamp the reference uses under autograd (so3.py:12-16)."""
+    from oracle import dpm
+    m_cpu = build_model(100, 2)
+    m = build_model(100, 2, device=DEV)
+    args = cases.eps_inputs(2, 40, [40, 33], [(5, 14), (22, 30)])
+    ref = dpm.eps_net(m_cpu.state_dict(), 'diffusion.eps_net.', *args, num_layers=6, prmsd_head=True, grad_mode=True)
+    out = m.diffusion.eps_net(*[dev(a) for a in args], grad_mode=True)
+    n, worst = rot_close(out[0].cpu(), ref[0], ref[1])
+    assert worst < 1.0
+
+
+# ------------------------------------------------------------------------------------------ sampler, teacher-forced
+def _traj_setup(T=10, seed=3):
+    from oracle import embed
+    m_cpu = build_model(T, seed)
+    m = build_model(T, seed, device=DEV)
+    batch = synth.make_batch(2, synth.LAYOUT_128, seed=2022, lengths=[128, 117])
+    return m_cpu, m, batch
+
+
+def test_encode_on_device_vs_reference():
+    g = load_golden('trajectory_abdock_T10')
+    _, m, batch = _traj_setup()
+    with torch.no_grad():
+        rf, pf, R0, p0 = m.encode({k: dev(v) for k, v in batch.items()}, True, True)
+    # encode() is still torch-eager on the device (not a HIP kernel yet); the hash-filled embedding tables
+    # make these features O(1e3) with heavy cancellation, so compare relative to the largest magnitude
+    assert max_abs(rf.cpu(), g['res_feat']) < 2e-4 * g['res_feat'].abs().max().item()
+    assert max_abs(pf.cpu()[:, ::7, ::5], g['pair_feat_sub']) < 2e-4 * g['pair_feat_sub'].abs().max().item()
+    assert max_abs(R0.cpu(), g['R0']) < 2e-6
+
+
+def test_sample_init_vs_reference():
+    from ab_opt_amd import hip
+    g = load_golden('trajectory_abdock_T10')
+    _, m, batch = _traj_setup()
+    v0 = hip.so3_log(dev(g['R0']), False)
+    v_i, p_i, s_i = hip.sample_init(v0, dev(g['p0']), dev(batch['aa']), dev(batch['generate_flag']),
+                                    dict(q4=dev(g['init_q4']), p=dev(g['init_p']), s=dev(g['init_s'])), 0, 0, 10.0, [0.0, 0.0, 0.0], True, True)
+    from oracle import geometry as G
+    assert max_abs(G.so3_exp(v_i.cpu()), G.so3_exp(g['traj10_v'])) < 1e-4
+    assert max_abs(p_i.cpu(), g['traj10_p']) < 1e-5
+    assert torch.equal(s_i.cpu(), g['traj10_s'])
+
+
+def test_denoising_steps_teacher_forced_vs_reference():
+    """Every one of the 10 recorded reference steps (BASELINE config 1), state reset to the reference's each step."""
+    from ab_opt_amd import hip
+    from oracle import dpm, geometry as G
+    g = load_golden('trajectory_abdock_T10')
+    m_cpu, m, batch = _traj_setup()
+    dpm_ = m.diffusion
+    res_feat, gen, mres = dev(g['res_feat']), dev(batch['generate_flag']), dev(batch['mask'])
+    with torch.no_grad():
+        _, pair_feat, _, _ = m.encode({k: dev(v) for k, v in batch.items()}, True, True)
+    nz = noise_dict(g, 10)
+    den = dpm.Denoiser(m_cpu.state_dict(), num_steps=10, variant='abdock', obj='pred_x0', mode='mm',
+                       tables=(None, dict(stddevs=m_cpu.diffusion.trans_rot.angular_distrib_inv.stddevs,
+                                          approx_flag=m_cpu.diffusion.trans_rot.angular_distrib_inv.approx_flag,
+                                          X=m_cpu.diffusion.trans_rot.angular_distrib_inv.X, Y=None)))
+    worst_p = 0.0
+    for t in range(10, 0, -1):
+        state = (dev(g[f'traj{t}_v']), dev(g[f'traj{t}_p']), dev(g[f'traj{t}_s']))
+        noise = {t: {k: dev(v) for k, v in nz[t].items()}}
+        tv, tp, ts, tpr, tpp = _one_step(dpm_, state, t, res_feat, pair_feat, gen, mres, noise[t])
+        # pre-log rotation of the transition, from the oracle on the same inputs (well-conditioned reference for the tolerance)
+        e = dpm.so3_noise(den.tab_inv, torch.full((2, 128), t), nz[t])
+        if t <= 1:
+            e = torch.zeros_like(e)
+        o = den._eps(g[f'traj{t}_v'], den.norm(g[f'traj{t}_p']), g[f'traj{t}_s'], g['res_feat'], pair_feat.cpu(),
+                     den.sch['betas'][t].expand([2]), batch['generate_flag'], batch['mask'], False)
+        R_pre = G.so3_exp(e) @ G.so3_exp(o[0])
+        # the value went through two log maps: the network's (R_next -> v_next) and the transition's (R_pre -> v)
+        n, worst = rot_close(tv.cpu(), g[f'traj{t - 1}_v'], R_pre, base=4e-6, R_upstream=o[1])
+        assert n > 200 and worst < 1.0, (t, n, worst)
+        dp = max_abs(tp.cpu(), g[f'traj{t - 1}_p'])
+        worst_p = max(worst_p, dp)
+        assert dp < 1e-4, (t, dp)
+        assert torch.equal(ts.cpu(), g[f'traj{t - 1}_s'])
+        assert max_abs(tpr.cpu(), g[f'traj{t - 1}_prmsd']) < 1e-4
+        assert max_abs(tpp.cpu(), g[f'traj{t - 1}_ppl']) < 1e-5
+    print('worst per-step position error (Angstrom):', worst_p)
+
+
+def _one_step(dpm_, state, t, res_feat, pair_feat, gen, mres, noise_t):
+    """eps_net + transition for step t from `state` (v, p_angstrom, s); returns the t-1 state and scalars."""
+    tv, tp, ts, tpr, tpp = dpm_._run(tuple(s.clone() for s in state), t, res_feat, pair_feat, gen, mres, True, True, True,
+                                     {t: noise_t}, 0, 0, False, stop_after=1)
+    return tv[t - 1], tp[t - 1], ts[t - 1], tpr[t - 1], tpp[t - 1]
+
+
+def test_model_sample_free_run_with_injected_noise():
+    """model.sample() end-to-end with replayed draws: first steps track the reference; later steps are only required
+    to stay finite and to carry the injected sequence (the dynamics amplify fp32 reordering)."""
+    from oracle import geometry as G
+    g = load_golden('trajectory_abdock_T10')
+    _, m, batch = _traj_setup()
+    nz = noise_dict(g, 10)
+    nzd = {k: {kk: dev(vv) for kk, vv in v.items() if vv is not None} for k, v in nz.items()}
+    traj = m.sample({k: dev(v) for k, v in batch.items()}, sample_opt=dict(sample_structure=True, sample_sequence=True, contig='', noise=nzd))
+    assert sorted(traj) == list(range(11)) and len(traj[10]) == 5 and len(traj[0]) == 5
+    assert traj[0][0].is_cuda and not traj[5][0].is_cuda            # reference layout: t>0 on host, t=0 on device
+    assert max_abs(traj[10][1], g['traj10_p']) < 1e-5
+    assert max_abs(traj[9][1], g['traj9_p']) < 1e-4
+    for t in range(10):
+        assert torch.equal(traj[t][2].cpu(), g[f'traj{t}_s'])
+        assert torch.isfinite(traj[t][1]).all() and torch.isfinite(traj[t][0]).all()
+    ctx = ~batch['generate_flag']
+    assert max_abs(traj[0][1].cpu()[ctx], g['traj0_p'][ctx]) < 1e-4       # context residues never move
+
+
+def test_abdesign_steps_teacher_forced_vs_reference():
+    g = load_golden('trajectory_abdesign_T10')
+    d = standalone_abdesign_dpm(10, 4).to(DEV)
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(2, 40, [40, 33], [(5, 14), (22, 30)], num_steps=10, t=3)
+    nz = noise_dict(g, 10)
+    for t in range(10, 0, -1):
+        state = (dev(g[f'traj{t}_v']), dev(g[f'traj{t}_p']), dev(g[f'traj{t}_s']))
+        tv, tp, ts, tpr, tpp = d._run(state, t, dev(res_feat), dev(pair_feat), dev(gen), dev(mres), True, True, True,
+                                      {t: {k: dev(vv) for k, vv in nz[t].items()}}, 0, 0, False, stop_after=1)
+        assert max_abs(tp[t - 1].cpu(), g[f'traj{t - 1}_p']) < 1e-4, t
+        assert torch.equal(ts[t - 1].cpu(), g[f'traj{t - 1}_s'])
+
+
+# ------------------------------------------------------------------------------------------ device RNG path (statistics)
+def test_device_rng_statistics():
+    """No bitwise parity is possible for RNG; check the draws' distributions."""
+    from ab_opt_amd import hip
+    m = build_model(100, 2, device=DEV)
+    d = m.diffusion
+    N, L = 64, 256
+    t = 60
+    sp = d._step_params(t, True, True, True)
+    inv = d.trans_rot.angular_distrib_inv
+    z3 = torch.zeros(N, L, 3, device=DEV)
+    c_net = torch.softmax(dev(synth.hash_tensor((N, L, 20), 3, scale=4.0)), -1)
+    s_t = torch.randint(0, 20, (N, L), device=DEV)
+    gen = torch.ones(N, L, dtype=torch.bool, device=DEV)
+    out = dict(v=torch.empty(N, L, 3, device=DEV), p=torch.empty(N, L, 3, device=DEV), s=torch.empty(N, L, dtype=torch.int64, device=DEV),
+               prmsd=torch.empty(N, device=DEV), ppl=torch.empty(N, device=DEV))
+    post = hip.denoise_step(sp, None, 1234, 0, z3, z3, s_t, z3, z3, c_net, torch.zeros(N, 40, device=DEV), gen, inv.X[t], inv.cdf()[t], 40, out, want_post=True)
+    # rotation noise: v_next = log(exp(e) exp(0)) = e  => |v| is the IGSO(3) angle
+    theta = out['v'].norm(dim=-1).flatten().cpu().double()
+    Y = inv.Y[t, :-1].cpu().double()
+    X = inv.X[t].cpu().double()
+    edges = X[::256]
+    hist = torch.histc(theta, bins=32, min=0.0, max=float(X[-1]))
+    probs = torch.stack([Y[i * 256:(i + 1) * 256].sum() for i in range(32)])
+    probs = probs / probs.sum()
+    expected = probs * theta.numel()
+    keep = expected > 20
+    chi2 = (((hist - expected) ** 2 / expected)[keep]).sum().item()
+    assert chi2 < 3 * int(keep.sum()), chi2
+    axis = (out['v'] / out['v'].norm(dim=-1, keepdim=True)).reshape(-1, 3).cpu()
+    assert axis.mean(0).abs().max() < 0.02
+    # position noise: p_next = sigma*z*scale with eps = 0 inputs => z moments
+    c0 = 1.0 / math.sqrt(sp.alpha_clamped + 1e-8)
+    zz = (out['p'] / 10.0 / sp.sigma).flatten().cpu()
+    assert abs(zz.mean().item()) < 0.02 and abs(zz.std().item() - 1) < 0.02
+    # categorical: empirical frequencies vs posterior
+    freq = torch.zeros(20)
+    freq.scatter_add_(0, out['s'].flatten().cpu(), torch.ones(N * L))
+    exp_freq = post.reshape(-1, 20).sum(0).cpu()
+    assert ((freq - exp_freq).abs() / exp_freq.clamp_min(50).sqrt()).max() < 5
+    # different offsets decorrelate, same (seed, offset) reproduces
+    out2 = {k: torch.empty_like(v) for k, v in out.items()}
+    hip.denoise_step(sp, None, 1234, 0, z3, z3, s_t, z3, z3, c_net, torch.zeros(N, 40, device=DEV), gen, inv.X[t], inv.cdf()[t], 40, out2)
+    assert torch.equal(out2['v'], out['v']) and torch.equal(out2['s'], out['s'])
+    hip.denoise_step(sp, None, 1234, N * L, z3, z3, s_t, z3, z3, c_net, torch.zeros(N, 40, device=DEV), gen, inv.X[t], inv.cdf()[t], 40, out2)
+    assert not torch.equal(out2['v'], out['v'])
+
+
+def test_commonness_score_vs_reference():
+    from ab_opt_amd import hip
+    g = load_golden('rank_commoness')
+    structs = synth.hash_tensor((16, 36, 3), 55, scale=8.0)
+    structs[3] = structs[5] + 0.01
+    score = hip.commonness_score(dev(structs))
+    assert torch.equal(torch.topk(score, 5, largest=False)[1].cpu(), g['rank'])
+    assert abs(score.sum().item() / 16 - g['avg_rmsd'].item()) < 1e-4
