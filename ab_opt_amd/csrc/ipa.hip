@@ -9,6 +9,7 @@
 #include "kernels.h"
 #include <vector>
 #include <utility>
+#include <cstdlib>
 
 namespace abopt {
 
@@ -169,6 +170,295 @@ __global__ __launch_bounds__(256) void ipa_core_v0_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------ IPA core, version 1 (MFMA, flash-style over j)
+// One 256-thread workgroup = 16 query residues (i-block) of one sample.  Keys are consumed JC=16 at a time with an
+// online softmax, so any L works and z[n,i,:,:] is read from HBM exactly once.  All five contractions run on the fp32
+// matrix cores (v_mfma_f32_16x16x4_f32: an exact fp32 FMA chain, so the 1e-5 parity budget holds):
+//
+//   "i-batched" phases (waves split the 12 heads, M = the 16 query rows):
+//     A: S_node[i,j] = q_i.k_j  (K=32)      + the squared point distances on the VALU            -> LDS  S[i][h][j]
+//     C: fn[i,d] += P[i,j] v[j,d] (K=j), pts[i,e] += P[i,j] vp[j,e]                                <- LDS  P[i][h][j]
+//   "per-i" phase (each wave owns 4 query rows, N = heads):
+//     B: pair bias  lp[j,h] = z[j,:].Wb[h,:] (M=j, K=64);  S = (S_node + lp) sqrt(1/3), mask, running max/sum;
+//        P = exp(S - m);  fp[c,h] += z[j,c] P[j,h] (M=c, K=j).  The softmax statistics live in lanes (h = lane&15), which is
+//        exactly the B-operand layout of the aggregation MFMA and its accumulator column, so P never moves between lanes.
+//   z chunk of a row: one fully coalesced global load (4 rows x 256 B per wave instruction) that is already the A operand
+//   of the aggregation; a wave-private LDS tile transposes it into the A operand of the pair-bias MFMA.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BI = 16;            // query rows per workgroup
+constexpr int JC = 16;            // key rows per chunk
+constexpr int PLD = JC + 4;       // row stride of the S/P tile (floats)
+constexpr int ZSLD = C + 4;       // row stride of the z staging tile (floats)
+constexpr int NPT = H * P * 3;    // 288 point coordinates per residue
+
+struct IpaSmem {
+    float sp[BI][16][PLD];        // S (phase A -> B), then P (phase B -> C); reused for the aggregated points at the end
+    float zst[4][JC][ZSLD];       // per-wave z staging
+    float qg[BI][NPT];            // global-frame query points of the 16 rows
+    float scl[BI][16];            // per-(i,h) rescale factor of the current chunk
+    float lsum[BI][16];           // softmax denominators
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+
+__global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __restrict__ proj, const float* __restrict__ z,
+                                                             const uint8_t* __restrict__ mask, const float* __restrict__ R,
+                                                             const float* __restrict__ t, const float* __restrict__ Wb,
+                                                             const float* __restrict__ spatial_coef, float* __restrict__ feat,
+                                                             float* __restrict__ dbg_logits, int N, int L, int nib, int xcd_remap) {
+    __shared__ __attribute__((aligned(16))) IpaSmem sm;
+    // ---- block -> (sample, i-block).  With N % 8 == 0 all i-blocks of a sample run on one XCD (blocks are dealt
+    // round-robin to the 8 XCDs), so the sample's k/v/point tiles stay in that XCD's L2.  Speed only, never correctness.
+    int n, ib;
+    {
+        const int b = blockIdx.x;
+        if (xcd_remap) { const int xcd = b & 7, k = b >> 3; n = xcd + 8 * (k / nib); ib = k % nib; }
+        else { n = b / nib; ib = b % nib; }
+    }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
+    const int i0 = ib * BI;
+    const int64_t rowbase = (int64_t)n * L;
+    const float* projn = proj + rowbase * NP;
+
+    // ---- prologue
+    for (int e = tid; e < BI * (NPT / 4); e += 256) {          // query points of the block -> LDS
+        const int il = e / (NPT / 4), c4 = e % (NPT / 4);
+        const int i = min(i0 + il, L - 1);
+        reinterpret_cast<float4*>(&sm.qg[il][0])[c4] = reinterpret_cast<const float4*>(projn + (int64_t)i * NP + OFF_QP)[c4];
+    }
+    float coefA[3];
+#pragma unroll
+    for (int hh = 0; hh < 3; ++hh) {
+        const float sc = spatial_coef[wave * 3 + hh];
+        const float gamma = (sc > 20.f) ? sc : log1pf(expf(sc));                       // softplus, ga.py:108
+        coefA[hh] = (-1.f * gamma * 0.16666666666666666f) / 2.f;                        // -gamma sqrt(2/(9*8)) / 2, ga.py:109-110
+    }
+    const float* qrow = projn + (int64_t)min(i0 + fm, L - 1) * NP + OFF_Q + kq * 8;   // q fragments are re-read per chunk (L2 hits)
+    float wb[16];                                                // pair-bias weights (B operand: n = head, step s <-> c = 16 kq + s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fm < H) w4 = reinterpret_cast<const float4*>(Wb + fm * C + kq * 16)[q];
+        wb[q * 4 + 0] = w4.x; wb[q * 4 + 1] = w4.y; wb[q * 4 + 2] = w4.z; wb[q * 4 + 3] = w4.w;
+    }
+    bool mi_b[4];                                                // masks of this wave's 4 query rows (phase B)
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) { const int i = i0 + wave * 4 + ii; mi_b[ii] = (i < L) && mask[rowbase + i] != 0; }
+    bool mi_a[4];                                                // masks of rows 4 kq + r (phases A / C)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int i = i0 + kq * 4 + r; mi_a[r] = (i < L) && mask[rowbase + i] != 0; }
+
+    float m_run[4], l_run[4];
+    f32x4 accP[4][4];                                            // pair aggregation: [row ii][c-tile]
+    f32x4 accV[3][2], accT[3][2];                                // node / point aggregation: [head][n-tile]
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        m_run[ii] = -INFINITY; l_run[ii] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) accP[ii][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int hh = 0; hh < 3; ++hh)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { accV[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; accT[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    __syncthreads();
+
+    const int nchunk = (L + JC - 1) / JC;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int jc0 = ch * JC;
+        // ================================================================= phase A: node + spatial logits -> sp
+        {
+            const int j = min(jc0 + fm, L - 1);
+            const float* pj = projn + (int64_t)j * NP;
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) {
+                const int h = wave * 3 + hh;
+                const float4 k0 = reinterpret_cast<const float4*>(pj + OFF_K + h * D + kq * 8)[0];
+                const float4 k1 = reinterpret_cast<const float4*>(pj + OFF_K + h * D + kq * 8)[1];
+                float4 kg[6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) kg[q] = reinterpret_cast<const float4*>(pj + OFF_KP + h * (P * 3))[q];
+                // A operand: row = query fm, K-permuted: step s <-> channel 8 kq + s (same permutation on the key side)
+                const float4 q0 = reinterpret_cast<const float4*>(qrow + h * D)[0], q1 = reinterpret_cast<const float4*>(qrow + h * D)[1];
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = mfma4(s < 4 ? f4get(q0, s) : f4get(q1, s - 4), s < 4 ? f4get(k0, s) : f4get(k1, s - 4), acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                    // accumulator row = query 4 kq + r, column = key fm
+                    const float4* qgp = reinterpret_cast<const float4*>(&sm.qg[kq * 4 + r][h * (P * 3)]);
+                    float d2 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        const float4 a = qgp[q];
+                        const float dx = a.x - kg[q].x, dy = a.y - kg[q].y, dz = a.z - kg[q].z, dw = a.w - kg[q].w;
+                        d2 = fmaf(dx, dx, d2); d2 = fmaf(dy, dy, d2); d2 = fmaf(dz, dz, d2); d2 = fmaf(dw, dw, d2);
+                    }
+                    sm.sp[kq * 4 + r][h][fm] = acc[r] * 0.17677669529663687f + d2 * coefA[hh];
+                }
+            }
+        }
+        __syncthreads();
+        // ================================================================= phase B: pair bias, softmax, pair aggregation
+        {
+            bool mj[4], jv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int j = jc0 + kq * 4 + r; jv[r] = j < L; mj[r] = jv[r] && mask[rowbase + j] != 0; }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int il = wave * 4 + ii;
+                const int i = min(i0 + il, L - 1);
+                const float* zi = z + ((rowbase + i) * (int64_t)L) * C;
+                float4 zr[4];                                    // aggregation A operand: row jc0 + 4 kq + r, channels 4 fm .. 4 fm + 3
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zr[r] = reinterpret_cast<const float4*>(zi + (int64_t)min(jc0 + kq * 4 + r, L - 1) * C)[fm];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(&sm.zst[wave][kq * 4 + r][fm * 4]) = zr[r];
+                float4 za[4];                                    // pair-bias A operand: row fm, channels 16 kq + 4 q ..
+#pragma unroll
+                for (int q = 0; q < 4; ++q) za[q] = *reinterpret_cast<const float4*>(&sm.zst[wave][fm][kq * 16 + q * 4]);
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc = mfma4(f4get(za[s >> 2], s & 3), wb[s], acc);
+                const float4 tns = *reinterpret_cast<const float4*>(&sm.sp[il][fm][kq * 4]);
+                float sv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                    // accumulator row = key 4 kq + r, column = head fm
+                    float lt = (f4get(tns, r) + acc[r]) * 0.5773502691896258f;
+                    if (dbg_logits && jv[r] && fm < H && (i0 + il) < L) dbg_logits[((rowbase + i) * L + jc0 + kq * 4 + r) * H + fm] = lt;
+                    if (!(mi_b[ii] && mj[r])) lt -= 1e5f;        // ga.py:20-23
+                    sv[r] = jv[r] ? lt : -INFINITY;
+                }
+                if (fm >= H) { sv[0] = jv[0] ? 0.f : -INFINITY; sv[1] = jv[1] ? 0.f : -INFINITY; sv[2] = jv[2] ? 0.f : -INFINITY; sv[3] = jv[3] ? 0.f : -INFINITY; }
+                float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[ii], mx);
+                const float sc = expf(m_run[ii] - m_new);
+                float pv[4], ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pv[r] = expf(sv[r] - m_new); ps += pv[r]; }
+                ps += __shfl_xor(ps, 16, 64);
+                ps += __shfl_xor(ps, 32, 64);
+                l_run[ii] = l_run[ii] * sc + ps;
+                m_run[ii] = m_new;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) accP[ii][mt] *= sc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) accP[ii][mt] = mfma4(f4get(zr[r], mt), pv[r], accP[ii][mt]);
+                *reinterpret_cast<float4*>(&sm.sp[il][fm][kq * 4]) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                if (kq == 0) sm.scl[il][fm] = sc;
+            }
+        }
+        __syncthreads();
+        // ================================================================= phase C: node / point aggregation
+        {
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) {
+                const int h = wave * 3 + hh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sc = sm.scl[kq * 4 + r][h];
+                    accV[hh][0][r] *= sc; accV[hh][1][r] *= sc; accT[hh][0][r] *= sc; accT[hh][1][r] *= sc;
+                }
+                const float4 pa = *reinterpret_cast<const float4*>(&sm.sp[fm][h][kq * 4]);     // A: row = query fm, step s <-> key 4 kq + s
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float* pj = projn + (int64_t)min(jc0 + kq * 4 + s, L - 1) * NP;
+                    const float2 vb = reinterpret_cast<const float2*>(pj + OFF_V + h * D)[fm];    // channels 2 fm (+1): n-tile 0 / 1
+                    float2 tb = make_float2(0.f, 0.f);
+                    if (fm < 12) tb = reinterpret_cast<const float2*>(pj + OFF_VP + h * (P * 3))[fm];
+                    const float a = f4get(pa, s);
+                    accV[hh][0] = mfma4(a, vb.x, accV[hh][0]);
+                    accV[hh][1] = mfma4(a, vb.y, accV[hh][1]);
+                    accT[hh][0] = mfma4(a, tb.x, accT[hh][0]);
+                    accT[hh][1] = mfma4(a, tb.y, accT[hh][1]);
+                }
+            }
+        }
+        // no barrier needed here: phase A of the next chunk writes only this wave's own head slices of sp, which only this
+        // wave read in phase C; phase B of the next chunk starts behind the barrier after phase A.
+    }
+
+    // ---- finalisation: alpha = P / l, zero for masked queries (ga.py:24-25)
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int il = wave * 4 + ii, i = i0 + il;
+        if (kq == 0) sm.lsum[il][fm] = l_run[ii];
+        if (i < L && fm < H) {
+            const float inv = mi_b[ii] ? 1.f / l_run[ii] : 0.f;
+            float* fo = feat + (rowbase + i) * FEAT + fm * C + kq * 16;        // accumulator row c_local = 4 kq + r', tile mt: c = 16 kq + 4 r' + mt
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                reinterpret_cast<float4*>(fo)[r] = make_float4(accP[ii][0][r] * inv, accP[ii][1][r] * inv, accP[ii][2][r] * inv, accP[ii][3][r] * inv);
+        }
+    }
+    __syncthreads();                                             // lsum visible; every wave is done reading sp
+    float* pts = &sm.sp[0][0][0];                                // [BI][H][24] aggregated global-frame points
+#pragma unroll
+    for (int hh = 0; hh < 3; ++hh) {
+        const int h = wave * 3 + hh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int il = kq * 4 + r, i = i0 + il;
+            const float inv = mi_a[r] ? 1.f / sm.lsum[il][h] : 0.f;
+            if (i < L)
+                reinterpret_cast<float2*>(feat + (rowbase + i) * FEAT + H * C + h * D)[fm] = make_float2(accV[hh][0][r] * inv, accV[hh][1][r] * inv);
+            if (fm < 12) *reinterpret_cast<float2*>(&pts[(il * H + h) * (P * 3) + 2 * fm]) = make_float2(accT[hh][0][r] * inv, accT[hh][1][r] * inv);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < BI * H * P; e += 256) {                // local frame, norm, direction (ga.py:136-139)
+        const int il = e / (H * P), hp = e % (H * P), i = i0 + il;
+        if (i >= L) continue;
+        const float* Rr = R + (rowbase + i) * 9;
+        const float* tr = t + (rowbase + i) * 3;
+        const float* a = pts + (il * H * P + hp) * 3;
+        const float dx = a[0] - tr[0], dy = a[1] - tr[1], dz = a[2] - tr[2];
+        const float lx = Rr[0] * dx + Rr[3] * dy + Rr[6] * dz;
+        const float ly = Rr[1] * dx + Rr[4] * dy + Rr[7] * dz;
+        const float lz = Rr[2] * dx + Rr[5] * dy + Rr[8] * dz;
+        const float dist = sqrtf(lx * lx + ly * ly + lz * lz);
+        const float inv = 1.f / (dist + 1e-4f);
+        float* fpnt = feat + (rowbase + i) * FEAT + H * C + H * D;
+        fpnt[hp * 3 + 0] = lx; fpnt[hp * 3 + 1] = ly; fpnt[hp * 3 + 2] = lz;
+        fpnt[H * P * 3 + hp] = dist;
+        float* fdir = fpnt + H * P * 3 + H * P;
+        fdir[hp * 3 + 0] = lx * inv; fdir[hp * 3 + 1] = ly * inv; fdir[hp * 3 + 2] = lz * inv;
+    }
+}
+
+// debug only: alpha from the unmasked logits the fused kernel dumped (ga.py:11-26), one wave per (n, i, h)
+__global__ __launch_bounds__(64) void alpha_from_logits_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ mask,
+                                                               float* __restrict__ alpha, int L) {
+    const int64_t row = blockIdx.x;                              // n * L + i
+    const int h = blockIdx.y, lane = threadIdx.x;
+    const int64_t nbase = (row / L) * L;
+    const bool mi = mask[row] != 0;
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) {
+        float v = logits[(row * L + j) * H + h];
+        if (!(mi && mask[nbase + j] != 0)) v -= 1e5f;
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int j = lane; j < L; j += 64) {
+        float v = logits[(row * L + j) * H + h];
+        if (!(mi && mask[nbase + j] != 0)) v -= 1e5f;
+        sm += expf(v - mx);
+    }
+    sm = wave_sum(sm);
+    for (int j = lane; j < L; j += 64) {
+        float v = logits[(row * L + j) * H + h];
+        if (!(mi && mask[nbase + j] != 0)) v -= 1e5f;
+        alpha[(row * L + j) * H + h] = mi ? expf(v - mx) / sm : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------ measurement hook (see abopt_prof_enable)
 namespace prof {
 static bool g_on = false;
@@ -194,14 +484,30 @@ int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, cons
                     const float* w_pair_bias, const float* spatial_coef, float* feat,
                     float* dbg_logits, float* dbg_alpha, int N, int L, hipStream_t st) {
     if (N == 0 || L == 0) return ABOPT_OK;
-    const size_t lds = ((size_t)L * (ZLD + H) + 1440) * sizeof(float);
-    ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core v0: L=%d needs %zu bytes of LDS (max 163840)", L, lds);
-    ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_core_v0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const int variant = [] { const char* e = getenv("ABOPT_IPA_VARIANT"); return e ? atoi(e) : 1; }();
+    if (variant == 0) {                                          // row-per-workgroup VALU kernel kept for A/B runs (L <= 480)
+        const size_t lds = ((size_t)L * (ZLD + H) + 1440) * sizeof(float);
+        ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core v0: L=%d needs %zu bytes of LDS (max 163840)", L, lds);
+        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_core_v0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        prof::begin(st);
+        hipLaunchKernelGGL(ipa_core_v0_kernel, dim3(L, N), dim3(256), lds, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,
+                           feat, dbg_logits, dbg_alpha, L);
+        prof::end(st);
+        ABOPT_LAUNCH_CHECK();
+        return ABOPT_OK;
+    }
+    const int nib = (L + BI - 1) / BI;
+    ABOPT_CHECK_ARG((int64_t)N * nib < (1ll << 31), "ipa_core: grid too large");
     prof::begin(st);
-    hipLaunchKernelGGL(ipa_core_v0_kernel, dim3(L, N), dim3(256), lds, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,
-                       feat, dbg_logits, dbg_alpha, L);
+    hipLaunchKernelGGL(ipa_core_v1_kernel, dim3((unsigned)(N * nib)), dim3(256), 0, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,
+                       feat, dbg_logits, N, L, nib, (N % 8 == 0) ? 1 : 0);
     prof::end(st);
     ABOPT_LAUNCH_CHECK();
+    if (dbg_alpha) {
+        ABOPT_CHECK_ARG(dbg_logits != nullptr, "ipa_core: alpha dump needs the logits dump");
+        hipLaunchKernelGGL(alpha_from_logits_kernel, dim3((unsigned)(N * L), H), dim3(64), 0, st, dbg_logits, mask, dbg_alpha, L);
+        ABOPT_LAUNCH_CHECK();
+    }
     return ABOPT_OK;
 }
 

@@ -26,25 +26,31 @@ def dev(x):
 
 
 def _log_amplification(R):
-    """(ok, 1/sin(theta)) of the reference log map at rotation matrices R: its error is ~eps/sin(theta), and it
-    returns garbage once cos(theta) clamps at -1 (so3.py:10-22; DESIGN.md "conditioning")."""
+    """(ok, a = 1/sin(theta)) of the reference log map at rotation matrices R (so3.py:10-22).  Its direction error is
+    ~eps*a, but its MAGNITUDE error is ~eps*a^2: sin(theta) in the coefficient comes from sqrt(1 - cos^2) with cos
+    good to one ulp, i.e. a relative error eps/(1+cos) ~ eps*a^2.  Once cos clamps at -1 the output is garbage."""
     cos = ((R[..., 0, 0] + R[..., 1, 1] + R[..., 2, 2]) - 1) / 2
     ok = cos > -1 + 2e-5
     return ok, 1.0 / torch.sqrt((1 - cos.clamp(-1, 1) ** 2).clamp_min(1e-12))
 
 
-def rot_close(v_got, v_ref, R_pre, base=2e-6, cap=5e-3, R_upstream=None):
-    """exp(v_got) ~ exp(v_ref) with a per-residue tolerance base * amplification, where the amplification is
-    1/sin(theta) of the (well-conditioned) matrix R_pre fed to the log map, times that of an upstream log map
-    (R_upstream) when the compared value went through two of them.  Returns (#checked, worst err/tol)."""
+def rot_close(v_got, v_ref, R_pre, base=2e-6, cap=0.05, R_upstream=None):
+    """exp(v_got) ~ exp(v_ref) under the conditioning of the reference's own formulas.  R_pre is the (well-conditioned)
+    matrix that was fed to the log map producing v; R_upstream, if given, the matrix of an earlier log map the value
+    also went through (the network's R_next -> v_next).  Per-residue tolerance base*(a_up^2*a + a^2) + 1e-5; residues
+    whose tolerance exceeds `cap` (the reference's own result is noise there) or that sit in the clamp zone are skipped.
+    Calibration: the CPU oracle with matmul-ordered sums vs the recorded reference reaches 0.6 of this bound at
+    base=1.2e-6 over the 10 recorded steps.  Returns (#checked, worst err/tol)."""
     from oracle import geometry as G
     Ra, Rb = G.so3_exp(v_got), G.so3_exp(v_ref)
     err = (Ra - Rb).abs().amax((-1, -2))
     ok, amp = _log_amplification(R_pre)
+    tol = base * amp ** 2
     if R_upstream is not None:
         ok2, amp2 = _log_amplification(R_upstream)
-        ok, amp = ok & ok2, amp * amp2
-    tol = (base * amp).clamp(max=cap) + 1e-5
+        ok, tol = ok & ok2, base * (amp2 ** 2 * amp + amp ** 2)
+    tol = tol + 1e-5
+    ok = ok & (tol < cap)
     ratio = (err / tol)[ok]
     return int(ok.sum()), (ratio.max().item() if ratio.numel() else 0.0)
 
@@ -145,11 +151,11 @@ def test_ipa_full_size_invariances():
 
 
 # ------------------------------------------------------------------------------------------ EpsilonNet
-def _check_eps(out, g, has_prmsd, v_tol_base=2e-6):
+def _check_eps(out, g, has_prmsd):
     v_next, R_next, eps_pos, c = [o.cpu() for o in out[:4]]
     assert max_abs(R_next, g['R_next']) < 2e-5
-    n, worst = rot_close(v_next, g['v_next'], g['R_next'], base=v_tol_base)
-    assert worst < 1.0, worst
+    n, worst = rot_close(v_next, g['v_next'], g['R_next'])
+    assert n >= 0.9 * v_next[..., 0].numel() and worst < 1.0, (n, worst)
     assert max_abs(eps_pos, g['eps_pos']) < 2e-5
     assert max_abs(c, g['c']) < 1e-5
     if has_prmsd:
@@ -245,8 +251,8 @@ def test_denoising_steps_teacher_forced_vs_reference():
                      den.sch['betas'][t].expand([2]), batch['generate_flag'], batch['mask'], False)
         R_pre = G.so3_exp(e) @ G.so3_exp(o[0])
         # the value went through two log maps: the network's (R_next -> v_next) and the transition's (R_pre -> v)
-        n, worst = rot_close(tv.cpu(), g[f'traj{t - 1}_v'], R_pre, base=4e-6, R_upstream=o[1])
-        assert n > 200 and worst < 1.0, (t, n, worst)
+        n, worst = rot_close(tv.cpu(), g[f'traj{t - 1}_v'], R_pre, R_upstream=o[1])
+        assert n >= 230 and worst < 1.0, (t, n, worst)
         dp = max_abs(tp.cpu(), g[f'traj{t - 1}_p'])
         worst_p = max(worst_p, dp)
         assert dp < 1e-4, (t, dp)
