@@ -193,16 +193,32 @@ constexpr int ZSLD = C + 4;       // row stride of the z staging tile (floats)
 constexpr int NPT = H * P * 3;    // 288 point coordinates per residue
 
 struct IpaSmem {
-    float sp[BI][16][PLD];        // S (phase A -> B), then P (phase B -> C); reused for the aggregated points at the end
+    float sp[BI][16 * PLD + 4];   // S (phase A -> B), then P (phase B -> C), [i][h*PLD + j]; +4: odd slot stride across i; reused for the points at the end
     float zst[4][JC][ZSLD];       // per-wave z staging
-    float qg[BI][NPT];            // global-frame query points of the 16 rows
+    float qg[BI][NPT + 4];        // global-frame query points of the 16 rows (+4: rows 4 kq + r land on distinct banks)
     float scl[BI][16];            // per-(i,h) rescale factor of the current chunk
     float lsum[BI][16];           // softmax denominators
+    float wbs[16][C + 4];         // pair-bias weights, rows 12..15 zero
+    float coef[16];               // -softplus(spatial_coef) sqrt(2/(9 P)) / 2 per head
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// reductions over the four 16-lane rows of a wave (lanes with equal lane & 15) with the gfx950 row-swap instructions
+__device__ __forceinline__ float rows_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 
+template <bool DBG>
 __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __restrict__ proj, const float* __restrict__ z,
                                                              const uint8_t* __restrict__ mask, const float* __restrict__ R,
                                                              const float* __restrict__ t, const float* __restrict__ Wb,
@@ -228,20 +244,17 @@ __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __rest
         const int i = min(i0 + il, L - 1);
         reinterpret_cast<float4*>(&sm.qg[il][0])[c4] = reinterpret_cast<const float4*>(projn + (int64_t)i * NP + OFF_QP)[c4];
     }
-    float coefA[3];
-#pragma unroll
-    for (int hh = 0; hh < 3; ++hh) {
-        const float sc = spatial_coef[wave * 3 + hh];
+    if (tid < H) {
+        const float sc = spatial_coef[tid];
         const float gamma = (sc > 20.f) ? sc : log1pf(expf(sc));                       // softplus, ga.py:108
-        coefA[hh] = (-1.f * gamma * 0.16666666666666666f) / 2.f;                        // -gamma sqrt(2/(9*8)) / 2, ga.py:109-110
+        sm.coef[tid] = (-1.f * gamma * 0.16666666666666666f) / 2.f;                     // -gamma sqrt(2/(9*8)) / 2, ga.py:109-110
     }
     const float* qrow = projn + (int64_t)min(i0 + fm, L - 1) * NP + OFF_Q + kq * 8;   // q fragments are re-read per chunk (L2 hits)
-    float wb[16];                                                // pair-bias weights (B operand: n = head, step s <-> c = 16 kq + s)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int e = tid; e < 16 * (C / 4); e += 256) {             // pair-bias weights -> LDS (B operand: n = head, step s <-> c = 16 kq + s)
+        const int h = e / (C / 4), c4 = e % (C / 4);
         float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fm < H) w4 = reinterpret_cast<const float4*>(Wb + fm * C + kq * 16)[q];
-        wb[q * 4 + 0] = w4.x; wb[q * 4 + 1] = w4.y; wb[q * 4 + 2] = w4.z; wb[q * 4 + 3] = w4.w;
+        if (h < H) w4 = reinterpret_cast<const float4*>(Wb + h * C)[c4];
+        *reinterpret_cast<float4*>(&sm.wbs[h][c4 * 4]) = w4;
     }
     bool mi_b[4];                                                // masks of this wave's 4 query rows (phase B)
 #pragma unroll
@@ -265,6 +278,12 @@ __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __rest
         for (int k = 0; k < 2; ++k) { accV[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; accT[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     __syncthreads();
 
+    f32x4 znext[4];                                             // z prefetch: row (4 wave), chunk 0
+    {
+        const float* zi = z + ((rowbase + min(i0 + wave * 4, L - 1)) * (int64_t)L) * C;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) znext[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zi + (int64_t)min(kq * 4 + r, L - 1) * C) + fm);
+    }
     const int nchunk = (L + JC - 1) / JC;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int jc0 = ch * JC;
@@ -272,9 +291,10 @@ __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __rest
         {
             const int j = min(jc0 + fm, L - 1);
             const float* pj = projn + (int64_t)j * NP;
-#pragma unroll
+#pragma unroll 1
             for (int hh = 0; hh < 3; ++hh) {
                 const int h = wave * 3 + hh;
+                const float coefh = sm.coef[h];
                 const float4 k0 = reinterpret_cast<const float4*>(pj + OFF_K + h * D + kq * 8)[0];
                 const float4 k1 = reinterpret_cast<const float4*>(pj + OFF_K + h * D + kq * 8)[1];
                 float4 kg[6];
@@ -295,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __rest
                         const float dx = a.x - kg[q].x, dy = a.y - kg[q].y, dz = a.z - kg[q].z, dw = a.w - kg[q].w;
                         d2 = fmaf(dx, dx, d2); d2 = fmaf(dy, dy, d2); d2 = fmaf(dz, dz, d2); d2 = fmaf(dw, dw, d2);
                     }
-                    sm.sp[kq * 4 + r][h][fm] = acc[r] * 0.17677669529663687f + d2 * coefA[hh];
+                    sm.sp[kq * 4 + r][h * PLD + fm] = acc[r] * 0.17677669529663687f + d2 * coefh;
                 }
             }
         }
@@ -308,39 +328,47 @@ __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __rest
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const int il = wave * 4 + ii;
-                const int i = min(i0 + il, L - 1);
-                const float* zi = z + ((rowbase + i) * (int64_t)L) * C;
-                float4 zr[4];                                    // aggregation A operand: row jc0 + 4 kq + r, channels 4 fm .. 4 fm + 3
+                f32x4 zr[4];                                     // this row's chunk (prefetched): aggregation A operand
 #pragma unroll
-                for (int r = 0; r < 4; ++r) zr[r] = reinterpret_cast<const float4*>(zi + (int64_t)min(jc0 + kq * 4 + r, L - 1) * C)[fm];
+                for (int r = 0; r < 4; ++r) zr[r] = znext[r];
+                {                                                // prefetch the next row's chunk (next chunk's first row after ii = 3)
+                    const int ni = (ii < 3) ? ii + 1 : 0;
+                    const int njc0 = (ii < 3) ? jc0 : jc0 + JC;
+                    const int i = min(i0 + wave * 4 + ni, L - 1);
+                    const float* zi = z + ((rowbase + i) * (int64_t)L) * C;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(&sm.zst[wave][kq * 4 + r][fm * 4]) = zr[r];
-                float4 za[4];                                    // pair-bias A operand: row fm, channels 16 kq + 4 q ..
+                    for (int r = 0; r < 4; ++r)
+                        znext[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zi + (int64_t)min(njc0 + kq * 4 + r, L - 1) * C) + fm);
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) za[q] = *reinterpret_cast<const float4*>(&sm.zst[wave][fm][kq * 16 + q * 4]);
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&sm.zst[wave][kq * 4 + r][fm * 4]) = zr[r];
+                f32x4 acc4[4];                                   // four independent chains (the 16x16x4 MFMA has a 40-cycle dependent latency)
 #pragma unroll
-                for (int s = 0; s < 16; ++s) acc = mfma4(f4get(za[s >> 2], s & 3), wb[s], acc);
-                const float4 tns = *reinterpret_cast<const float4*>(&sm.sp[il][fm][kq * 4]);
+                for (int q = 0; q < 4; ++q) {                    // pair-bias: A row fm, channels 16 kq + 4 q ..; B = Wb rows (heads)
+                    const float4 za = *reinterpret_cast<const float4*>(&sm.zst[wave][fm][kq * 16 + q * 4]);
+                    const float4 wv = *reinterpret_cast<const float4*>(&sm.wbs[fm][kq * 16 + q * 4]);
+                    acc4[q] = mfma4(za.x, wv.x, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    acc4[q] = mfma4(za.y, wv.y, acc4[q]); acc4[q] = mfma4(za.z, wv.z, acc4[q]); acc4[q] = mfma4(za.w, wv.w, acc4[q]);
+                }
+                const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+                const float4 tns = *reinterpret_cast<const float4*>(&sm.sp[il][fm * PLD + kq * 4]);
                 float sv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {                    // accumulator row = key 4 kq + r, column = head fm
                     float lt = (f4get(tns, r) + acc[r]) * 0.5773502691896258f;
-                    if (dbg_logits && jv[r] && fm < H && (i0 + il) < L) dbg_logits[((rowbase + i) * L + jc0 + kq * 4 + r) * H + fm] = lt;
+                    if (DBG && jv[r] && fm < H && (i0 + il) < L) dbg_logits[((rowbase + i0 + il) * L + jc0 + kq * 4 + r) * H + fm] = lt;
                     if (!(mi_b[ii] && mj[r])) lt -= 1e5f;        // ga.py:20-23
-                    sv[r] = jv[r] ? lt : -INFINITY;
+                    sv[r] = (fm < H) ? lt : 0.f;
+                    sv[r] = jv[r] ? sv[r] : -INFINITY;
                 }
-                if (fm >= H) { sv[0] = jv[0] ? 0.f : -INFINITY; sv[1] = jv[1] ? 0.f : -INFINITY; sv[2] = jv[2] ? 0.f : -INFINITY; sv[3] = jv[3] ? 0.f : -INFINITY; }
                 float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = rows_max(mx);
                 const float m_new = fmaxf(m_run[ii], mx);
-                const float sc = expf(m_run[ii] - m_new);
+                const float sc = __expf(m_run[ii] - m_new);
                 float pv[4], ps = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { pv[r] = expf(sv[r] - m_new); ps += pv[r]; }
-                ps += __shfl_xor(ps, 16, 64);
-                ps += __shfl_xor(ps, 32, 64);
+                for (int r = 0; r < 4; ++r) { pv[r] = __expf(sv[r] - m_new); ps += pv[r]; }
+                ps = rows_sum(ps);
                 l_run[ii] = l_run[ii] * sc + ps;
                 m_run[ii] = m_new;
 #pragma unroll
@@ -348,9 +376,10 @@ __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __rest
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) accP[ii][mt] = mfma4(f4get(zr[r], mt), pv[r], accP[ii][mt]);
-                *reinterpret_cast<float4*>(&sm.sp[il][fm][kq * 4]) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                    for (int mt = 0; mt < 4; ++mt) accP[ii][mt] = mfma4(zr[r][mt], pv[r], accP[ii][mt]);
+                *reinterpret_cast<float4*>(&sm.sp[il][fm * PLD + kq * 4]) = make_float4(pv[0], pv[1], pv[2], pv[3]);
                 if (kq == 0) sm.scl[il][fm] = sc;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
@@ -364,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __rest
                     const float sc = sm.scl[kq * 4 + r][h];
                     accV[hh][0][r] *= sc; accV[hh][1][r] *= sc; accT[hh][0][r] *= sc; accT[hh][1][r] *= sc;
                 }
-                const float4 pa = *reinterpret_cast<const float4*>(&sm.sp[fm][h][kq * 4]);     // A: row = query fm, step s <-> key 4 kq + s
+                const float4 pa = *reinterpret_cast<const float4*>(&sm.sp[fm][h * PLD + kq * 4]);     // A: row = query fm, step s <-> key 4 kq + s
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const float* pj = projn + (int64_t)min(jc0 + kq * 4 + s, L - 1) * NP;
@@ -377,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __rest
                     accT[hh][0] = mfma4(a, tb.x, accT[hh][0]);
                     accT[hh][1] = mfma4(a, tb.y, accT[hh][1]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // no barrier needed here: phase A of the next chunk writes only this wave's own head slices of sp, which only this
@@ -397,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __rest
         }
     }
     __syncthreads();                                             // lsum visible; every wave is done reading sp
-    float* pts = &sm.sp[0][0][0];                                // [BI][H][24] aggregated global-frame points
+    float* pts = &sm.sp[0][0];                                // [BI][H][24] aggregated global-frame points
 #pragma unroll
     for (int hh = 0; hh < 3; ++hh) {
         const int h = wave * 3 + hh;
@@ -499,8 +529,12 @@ int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, cons
     const int nib = (L + BI - 1) / BI;
     ABOPT_CHECK_ARG((int64_t)N * nib < (1ll << 31), "ipa_core: grid too large");
     prof::begin(st);
-    hipLaunchKernelGGL(ipa_core_v1_kernel, dim3((unsigned)(N * nib)), dim3(256), 0, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,
-                       feat, dbg_logits, N, L, nib, (N % 8 == 0) ? 1 : 0);
+    if (dbg_logits)
+        hipLaunchKernelGGL(ipa_core_v1_kernel<true>, dim3((unsigned)(N * nib)), dim3(256), 0, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,
+                           feat, dbg_logits, N, L, nib, (N % 8 == 0) ? 1 : 0);
+    else
+        hipLaunchKernelGGL(ipa_core_v1_kernel<false>, dim3((unsigned)(N * nib)), dim3(256), 0, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,
+                           feat, dbg_logits, N, L, nib, (N % 8 == 0) ? 1 : 0);
     prof::end(st);
     ABOPT_LAUNCH_CHECK();
     if (dbg_alpha) {
