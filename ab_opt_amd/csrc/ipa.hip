@@ -5,18 +5,13 @@
 //   _pair_aggregation :114-118, _node_aggregation :120-125, _spatial_aggregation :127-147.
 // The reference materialises (N,L,L,12,{24,32,64}) temporaries; here z[n,i,:,:] is read from HBM
 // exactly once per (n,i) and everything else stays on chip.
-#include "abopt_common.h"
+#include "ipa_common.h"
 #include "kernels.h"
 #include <vector>
 #include <utility>
 #include <cstdlib>
 
 namespace abopt {
-
-constexpr int H = ABOPT_HEADS, D = ABOPT_QK_DIM, P = ABOPT_POINTS, C = 64;
-constexpr int NP = ABOPT_NODE_PROJ;          // 2016 floats per residue
-constexpr int OFF_Q = 0, OFF_K = H * D, OFF_V = 2 * H * D, OFF_QP = 3 * H * D, OFF_KP = OFF_QP + H * P * 3, OFF_VP = OFF_KP + H * P * 3;
-constexpr int FEAT = ABOPT_IPA_FEAT;         // 1824
 
 // ------------------------------------------------------------------ local -> global of the point sets
 // geometry.py:72-91 applied to proj_{query,key,value}_point outputs (ga.py:96-105,129-132): p <- R p + t, in place.
@@ -184,14 +179,6 @@ __global__ __launch_bounds__(256) void ipa_core_v0_kernel(const float* __restric
 //        exactly the B-operand layout of the aggregation MFMA and its accumulator column, so P never moves between lanes.
 //   z chunk of a row: one fully coalesced global load (4 rows x 256 B per wave instruction) that is already the A operand
 //   of the aggregation; a wave-private LDS tile transposes it into the A operand of the pair-bias MFMA.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BI = 16;            // query rows per workgroup
-constexpr int JC = 16;            // key rows per chunk
-constexpr int PLD = JC + 4;       // row stride of the S/P tile (floats)
-constexpr int ZSLD = C + 4;       // row stride of the z staging tile (floats)
-constexpr int NPT = H * P * 3;    // 288 point coordinates per residue
-
 struct IpaSmem {
     float sp[BI][16 * PLD + 4];   // S (phase A -> B), then P (phase B -> C), [i][h*PLD + j]; +4: odd slot stride across i; reused for the points at the end
     float zst[4][JC][ZSLD];       // per-wave z staging
@@ -201,22 +188,6 @@ struct IpaSmem {
     float wbs[16][C + 4];         // pair-bias weights, rows 12..15 zero
     float coef[16];               // -softplus(spatial_coef) sqrt(2/(9 P)) / 2 per head
 };
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-// reductions over the four 16-lane rows of a wave (lanes with equal lane & 15) with the gfx950 row-swap instructions
-__device__ __forceinline__ float rows_max(float v) {
-    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-__device__ __forceinline__ float rows_sum(float v) {
-    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-__device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 
 template <bool DBG>
 __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __restrict__ proj, const float* __restrict__ z,
@@ -494,7 +465,7 @@ namespace prof {
 static bool g_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
 static size_t g_used = 0;
-static void begin(hipStream_t st) {
+void begin(hipStream_t st) {
     if (!g_on) return;
     if (g_used == g_pool.size()) {
         hipEvent_t a, b;
@@ -503,7 +474,7 @@ static void begin(hipStream_t st) {
     }
     hipEventRecord(g_pool[g_used].first, st);
 }
-static void end(hipStream_t st) {
+void end(hipStream_t st) {
     if (!g_on) return;
     hipEventRecord(g_pool[g_used].second, st);
     ++g_used;
@@ -528,6 +499,16 @@ int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, cons
     }
     const int nib = (L + BI - 1) / BI;
     ABOPT_CHECK_ARG((int64_t)N * nib < (1ll << 31), "ipa_core: grid too large");
+    if (variant == 2) {
+        int rc = launch_ipa_core_ws(proj, z, mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, N, L, st);
+        if (rc) return rc;
+        if (dbg_alpha) {
+            ABOPT_CHECK_ARG(dbg_logits != nullptr, "ipa_core: alpha dump needs the logits dump");
+            hipLaunchKernelGGL(alpha_from_logits_kernel, dim3((unsigned)(N * L), H), dim3(64), 0, st, dbg_logits, mask, dbg_alpha, L);
+            ABOPT_LAUNCH_CHECK();
+        }
+        return ABOPT_OK;
+    }
     prof::begin(st);
     if (dbg_logits)
         hipLaunchKernelGGL(ipa_core_v1_kernel<true>, dim3((unsigned)(N * nib)), dim3(256), 0, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,

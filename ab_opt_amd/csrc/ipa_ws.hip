@@ -1,0 +1,343 @@
+// IPA core, wave-specialised version ("ws") for CDNA4: same maths and tiling as ipa_core_v1 (ipa.hip: 16 query rows
+// per workgroup, keys in chunks of 16, online softmax, fp32 MFMA everywhere), but the two kinds of work run in
+// DIFFERENT waves of a 512-thread workgroup, pipelined one chunk apart:
+//
+//   waves 0-3  "pair waves":  phase B(t)  -- stream z, pair-bias MFMA, softmax, pair aggregation        (4 query rows each)
+//   waves 4-7  "node waves":  phase C(t-1) then phase A(t+1) -- node/point aggregation, q.k and point distances (3 heads each)
+//
+// Each SIMD hosts one pair wave and one node wave, so the matrix pipe always has two independent instruction streams
+// with complementary mixes (HBM streaming + MFMA vs L2 gathers + VALU + MFMA), one barrier per chunk instead of two, and
+// every global operand is fetched a whole pipeline stage before it is used (node waves hold the k/kg and v/vp fragments
+// of the next stage in registers; pair waves prefetch the next z row).  The S/P tile and the rescale factors are
+// double-buffered in LDS so the stages never touch the same buffer between two barriers.
+//
+// Reference semantics: AbDock/src/modules/encoders/ga.py:11-26,81-147 (see ipa.hip for the line-by-line mapping).
+#include "ipa_common.h"
+#include "kernels.h"
+#include <cstdlib>
+
+namespace abopt {
+
+struct WsSmem {
+    float sp[2][BI][16 * PLD + 4];   // S then P per chunk parity, [i][h*PLD + j]
+    float zst[4][JC][ZSLD];          // per-pair-wave z staging (transposes the chunk for the pair-bias MFMA)
+    float qg[BI][NPT + 4];           // global-frame query points of the block
+    float scl[2][BI][16];            // rescale factor of chunk parity
+    float lsum[BI][16];              // softmax denominators
+    float wbs[16][C + 4];            // pair-bias weights, rows 12..15 zero
+    float coef[16];                  // -softplus(spatial_coef) sqrt(2/(9 P)) / 2
+    float q[BI][H * D + 4];          // queries of the block (phase A operand A)
+};
+
+struct KFrag { float4 k0, k1, g[6]; };                 // phase A operands of one head: 8 key channels + 24 key-point coords
+struct VFrag { float2 v[4], p[4]; };                   // phase C operands of one head: 4 keys x (2 value channels, 2 point coords)
+
+__device__ __forceinline__ void load_kfrag(KFrag& f, const float* pj, int h, int kq) {
+    const float4* kp = reinterpret_cast<const float4*>(pj + OFF_K + h * D + kq * 8);
+    f.k0 = kp[0]; f.k1 = kp[1];
+    const float4* gp = reinterpret_cast<const float4*>(pj + OFF_KP + h * (P * 3));
+#pragma unroll
+    for (int q = 0; q < 6; ++q) f.g[q] = gp[q];
+}
+
+__device__ __forceinline__ void load_vfrag(VFrag& f, const float* projn, int jc0, int L, int h, int fm, int kq) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float* pj = projn + (int64_t)min(jc0 + kq * 4 + s, L - 1) * NP;
+        f.v[s] = reinterpret_cast<const float2*>(pj + OFF_V + h * D)[fm];
+        f.p[s] = (fm < 12) ? reinterpret_cast<const float2*>(pj + OFF_VP + h * (P * 3))[fm] : make_float2(0.f, 0.f);
+    }
+}
+
+template <bool DBG>
+__global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __restrict__ proj, const float* __restrict__ z,
+                                                             const uint8_t* __restrict__ mask, const float* __restrict__ R,
+                                                             const float* __restrict__ t, const float* __restrict__ Wb,
+                                                             const float* __restrict__ spatial_coef, float* __restrict__ feat,
+                                                             float* __restrict__ dbg_logits, int N, int L, int nib, int xcd_remap, int abl) {
+    __shared__ __attribute__((aligned(16))) WsSmem sm;
+    int n, ib;
+    {   // all i-blocks of a sample on one XCD when N % 8 == 0 (L2 locality of its k/v tiles; speed only)
+        const int b = blockIdx.x;
+        if (xcd_remap) { const int xcd = b & 7, k = b >> 3; n = xcd + 8 * (k / nib); ib = k % nib; }
+        else { n = b / nib; ib = b % nib; }
+    }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
+    const bool pair_wave = wave < 4;
+    const int w4 = wave & 3;
+    const int i0 = ib * BI;
+    const int64_t rowbase = (int64_t)n * L;
+    const float* projn = proj + rowbase * NP;
+    const int nchunk = (L + JC - 1) / JC;
+
+    // ---- prologue (all 8 waves)
+    for (int e = tid; e < BI * (NPT / 4); e += 512) {
+        const int il = e / (NPT / 4), c4 = e % (NPT / 4);
+        const int i = min(i0 + il, L - 1);
+        *reinterpret_cast<float4*>(&sm.qg[il][c4 * 4]) = reinterpret_cast<const float4*>(projn + (int64_t)i * NP + OFF_QP)[c4];
+    }
+    for (int e = tid; e < BI * (H * D / 4); e += 512) {
+        const int il = e / (H * D / 4), c4 = e % (H * D / 4);
+        *reinterpret_cast<float4*>(&sm.q[il][c4 * 4]) = reinterpret_cast<const float4*>(projn + (int64_t)min(i0 + il, L - 1) * NP + OFF_Q)[c4];
+    }
+    for (int e = tid; e < 16 * (C / 4); e += 512) {
+        const int h = e / (C / 4), c4 = e % (C / 4);
+        float4 w4v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h < H) w4v = reinterpret_cast<const float4*>(Wb + h * C)[c4];
+        *reinterpret_cast<float4*>(&sm.wbs[h][c4 * 4]) = w4v;
+    }
+    if (tid < H) {
+        const float sc = spatial_coef[tid];
+        const float gamma = (sc > 20.f) ? sc : log1pf(expf(sc));                       // softplus, ga.py:108
+        sm.coef[tid] = (-1.f * gamma * 0.16666666666666666f) / 2.f;                     // ga.py:109-110 with sqrt(2/(9*8)) = 1/6
+    }
+    __syncthreads();
+
+    if (pair_wave) {
+        // =========================================================================== pair waves: phase B
+        bool mi_b[4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) { const int i = i0 + w4 * 4 + ii; mi_b[ii] = (i < L) && mask[rowbase + i] != 0; }
+        float m_run[4], l_run[4];
+        f32x4 accP[4][4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            m_run[ii] = -INFINITY; l_run[ii] = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) accP[ii][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // z ring: 4 register slots of one row chunk each (4 x 16 B per lane); rows are requested 3 ahead of their use so
+        // that ~12 KB per pair wave (48 KB per CU) is always in flight: HBM latency under load is ~2 us.
+        f32x4 ring[4][4];
+#define WS_ISSUE_Z(SLOT, ROW, CH)                                                                                        \
+    {                                                                                                                    \
+        const float* zi_ = z + ((rowbase + ((abl & 16) ? 0 : min(i0 + w4 * 4 + (ROW), L - 1))) * (int64_t)L) * C;        \
+        if (!(abl & 512)) _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                              \
+            ring[SLOT][r_] = *(reinterpret_cast<const f32x4*>(zi_ + (int64_t)min((CH) * JC + kq * 4 + r_, L - 1) * C) + fm); \
+    }
+        WS_ISSUE_Z(0, 0, 0) WS_ISSUE_Z(1, 1, 0) WS_ISSUE_Z(2, 2, 0)
+        __syncthreads();                                                    // barrier #0: S(0) ready
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int jc0 = ch * JC, buf = ch & 1;
+            bool mj[4], jv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int j = jc0 + kq * 4 + r; jv[r] = j < L; mj[r] = jv[r] && mask[rowbase + j] != 0; }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int il = w4 * 4 + ii;
+                WS_ISSUE_Z((ii + 3) & 3, (ii + 3) & 3, ch + ((ii + 3) >> 2))            // 3 rows ahead (clamped past the end: harmless re-read)
+                f32x4 zr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zr[r] = ring[ii][r];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&sm.zst[w4][kq * 4 + r][fm * 4]) = zr[r];
+                f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                if (!(abl & 2))
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 za = *reinterpret_cast<const float4*>(&sm.zst[w4][fm][kq * 16 + q * 4]);
+                    const float4 wv = *reinterpret_cast<const float4*>(&sm.wbs[fm][kq * 16 + q * 4]);
+                    acc4[q] = mfma4(za.x, wv.x, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    acc4[q] = mfma4(za.y, wv.y, acc4[q]); acc4[q] = mfma4(za.z, wv.z, acc4[q]); acc4[q] = mfma4(za.w, wv.w, acc4[q]);
+                }
+                const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+                const float4 tns = *reinterpret_cast<const float4*>(&sm.sp[buf][il][fm * PLD + kq * 4]);
+                float sv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float lt = (f4get(tns, r) + acc[r]) * 0.5773502691896258f;
+                    if (DBG && jv[r] && fm < H && (i0 + il) < L) dbg_logits[((rowbase + i0 + il) * L + jc0 + kq * 4 + r) * H + fm] = lt;
+                    if (!(mi_b[ii] && mj[r])) lt -= 1e5f;                   // ga.py:20-23
+                    sv[r] = (fm < H) ? lt : 0.f;
+                    sv[r] = jv[r] ? sv[r] : -INFINITY;
+                }
+                const float mx = rows_max(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+                const float m_new = fmaxf(m_run[ii], mx);
+                const float sc = __expf(m_run[ii] - m_new);
+                float pv[4], ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pv[r] = (abl & 4) ? sv[r] * 1e-3f : __expf(sv[r] - m_new); ps += pv[r]; }
+                ps = rows_sum(ps);
+                l_run[ii] = l_run[ii] * sc + ps;
+                m_run[ii] = m_new;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) accP[ii][mt] *= sc;
+                if (!(abl & 1))
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) accP[ii][mt] = mfma4(zr[r][mt], pv[r], accP[ii][mt]);
+                *reinterpret_cast<float4*>(&sm.sp[buf][il][fm * PLD + kq * 4]) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                if (kq == 0) sm.scl[buf][il][fm] = sc;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!(abl & 8)) __syncthreads();                                // barrier #(ch+1)
+        }
+        // alpha = P / l, zero for masked queries (ga.py:24-25); pair features out
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int il = w4 * 4 + ii, i = i0 + il;
+            if (kq == 0) sm.lsum[il][fm] = l_run[ii];
+            if (i < L && fm < H) {
+                const float inv = mi_b[ii] ? 1.f / l_run[ii] : 0.f;
+                float* fo = feat + (rowbase + i) * FEAT + fm * C + kq * 16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    reinterpret_cast<float4*>(fo)[r] = make_float4(accP[ii][0][r] * inv, accP[ii][1][r] * inv, accP[ii][2][r] * inv, accP[ii][3][r] * inv);
+            }
+        }
+        __syncthreads();                                                    // F1: lsum visible, node waves done with C(last)
+        __syncthreads();                                                    // F2: aggregated points in LDS
+    } else {
+        // =========================================================================== node waves: phases A and C
+        bool mi_a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int i = i0 + kq * 4 + r; mi_a[r] = (i < L) && mask[rowbase + i] != 0; }
+        f32x4 accV[3][2], accT[3][2];
+#pragma unroll
+        for (int hh = 0; hh < 3; ++hh)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { accV[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; accT[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        KFrag kf[3];
+        VFrag vf[3];
+
+        auto phase_a = [&](int ch) {                                        // S(ch) -> sp[ch & 1], consuming kf
+            const int buf = ch & 1;
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) {
+                const int h = w4 * 3 + hh;
+                const float coefh = sm.coef[h];
+                // A operand: row = query fm, K-permuted: step s <-> channel 8 kq + s (same permutation on the key side)
+#ifndef WS_Q_GLOBAL
+                const float4 q0 = *reinterpret_cast<const float4*>(&sm.q[fm][h * D + kq * 8]);
+                const float4 q1 = *reinterpret_cast<const float4*>(&sm.q[fm][h * D + kq * 8 + 4]);
+#else
+                const float* qrow = projn + (int64_t)min(i0 + fm, L - 1) * NP + OFF_Q + kq * 8;
+                const float4 q0 = reinterpret_cast<const float4*>(qrow + h * D)[0], q1 = reinterpret_cast<const float4*>(qrow + h * D)[1];
+#endif
+                f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;                 // two chains (dependent-MFMA latency)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { acc0 = mfma4(f4get(q0, s), f4get(kf[hh].k0, s), acc0); acc1 = mfma4(f4get(q1, s), f4get(kf[hh].k1, s), acc1); }
+                const f32x4 acc = acc0 + acc1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                               // accumulator row = query 4 kq + r, column = key fm
+                    const float4* qgp = reinterpret_cast<const float4*>(&sm.qg[kq * 4 + r][h * (P * 3)]);
+                    float d2 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        const float4 a = qgp[q];
+                        const float dx = a.x - kf[hh].g[q].x, dy = a.y - kf[hh].g[q].y, dz = a.z - kf[hh].g[q].z, dw = a.w - kf[hh].g[q].w;
+                        d2 = fmaf(dx, dx, d2); d2 = fmaf(dy, dy, d2); d2 = fmaf(dz, dz, d2); d2 = fmaf(dw, dw, d2);
+                    }
+                    sm.sp[buf][kq * 4 + r][h * PLD + fm] = acc[r] * 0.17677669529663687f + d2 * coefh;
+                }
+            }
+        };
+        auto issue_k = [&](int ch) {                                        // fetch phase-A operands of chunk ch
+            if (abl & 128) return;
+            const float* pj = projn + (int64_t)min(ch * JC + fm, L - 1) * NP;
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) load_kfrag(kf[hh], pj, w4 * 3 + hh, kq);
+        };
+        auto issue_v = [&](int ch) {                                        // fetch phase-C operands of chunk ch
+            if (abl & 256) return;
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) load_vfrag(vf[hh], projn, ch * JC, L, w4 * 3 + hh, fm, kq);
+        };
+        auto phase_c = [&](int ch) {                                        // consume P(ch) from sp[ch & 1] and vf
+            const int buf = ch & 1;
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) {
+                const int h = w4 * 3 + hh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sc = sm.scl[buf][kq * 4 + r][h];
+                    accV[hh][0][r] *= sc; accV[hh][1][r] *= sc; accT[hh][0][r] *= sc; accT[hh][1][r] *= sc;
+                }
+                const float4 pa = *reinterpret_cast<const float4*>(&sm.sp[buf][fm][h * PLD + kq * 4]);   // A: row = query fm, step s <-> key 4 kq + s
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float a = f4get(pa, s);
+                    accV[hh][0] = mfma4(a, vf[hh].v[s].x, accV[hh][0]);
+                    accV[hh][1] = mfma4(a, vf[hh].v[s].y, accV[hh][1]);
+                    accT[hh][0] = mfma4(a, vf[hh].p[s].x, accT[hh][0]);
+                    accT[hh][1] = mfma4(a, vf[hh].p[s].y, accT[hh][1]);
+                }
+            }
+        };
+
+        issue_k(0);
+        phase_a(0);
+        if (nchunk > 1) issue_k(1);
+        issue_v(0);
+        __syncthreads();                                                    // barrier #0
+        for (int ch = 0; ch < nchunk; ++ch) {
+            if (ch >= 1) {
+                if (!(abl & 64)) phase_c(ch - 1);
+                issue_v(ch);
+            }
+            if (ch + 1 < nchunk) {
+                if (!(abl & 32)) phase_a(ch + 1);
+                if (ch + 2 < nchunk) issue_k(ch + 2);
+            }
+            if (!(abl & 8)) __syncthreads();                                // barrier #(ch+1)
+        }
+        phase_c(nchunk - 1);
+        __syncthreads();                                                    // F1
+        float* pts = &sm.sp[0][0][0];                                       // [BI][H][24]; both sp buffers are free now
+#pragma unroll
+        for (int hh = 0; hh < 3; ++hh) {
+            const int h = w4 * 3 + hh;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int il = kq * 4 + r, i = i0 + il;
+                const float inv = mi_a[r] ? 1.f / sm.lsum[il][h] : 0.f;
+                if (i < L)
+                    reinterpret_cast<float2*>(feat + (rowbase + i) * FEAT + H * C + h * D)[fm] = make_float2(accV[hh][0][r] * inv, accV[hh][1][r] * inv);
+                if (fm < 12) *reinterpret_cast<float2*>(&pts[(il * H + h) * (P * 3) + 2 * fm]) = make_float2(accT[hh][0][r] * inv, accT[hh][1][r] * inv);
+            }
+        }
+        __syncthreads();                                                    // F2
+    }
+
+    // ---- all waves: local frame, norm, direction of the aggregated points (ga.py:136-139)
+    const float* pts = &sm.sp[0][0][0];
+    for (int e = tid; e < BI * H * P; e += 512) {
+        const int il = e / (H * P), hp = e % (H * P), i = i0 + il;
+        if (i >= L) continue;
+        const float* Rr = R + (rowbase + i) * 9;
+        const float* tr = t + (rowbase + i) * 3;
+        const float* a = pts + (il * H * P + hp) * 3;
+        const float dx = a[0] - tr[0], dy = a[1] - tr[1], dz = a[2] - tr[2];
+        const float lx = Rr[0] * dx + Rr[3] * dy + Rr[6] * dz;
+        const float ly = Rr[1] * dx + Rr[4] * dy + Rr[7] * dz;
+        const float lz = Rr[2] * dx + Rr[5] * dy + Rr[8] * dz;
+        const float dist = sqrtf(lx * lx + ly * ly + lz * lz);
+        const float inv = 1.f / (dist + 1e-4f);
+        float* fpnt = feat + (rowbase + i) * FEAT + H * C + H * D;
+        fpnt[hp * 3 + 0] = lx; fpnt[hp * 3 + 1] = ly; fpnt[hp * 3 + 2] = lz;
+        fpnt[H * P * 3 + hp] = dist;
+        float* fdir = fpnt + H * P * 3 + H * P;
+        fdir[hp * 3 + 0] = lx * inv; fdir[hp * 3 + 1] = ly * inv; fdir[hp * 3 + 2] = lz * inv;
+    }
+}
+
+int launch_ipa_core_ws(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
+                       const float* w_pair_bias, const float* spatial_coef, float* feat, float* dbg_logits,
+                       int N, int L, hipStream_t st) {
+    const int nib = (L + BI - 1) / BI;
+    const int remap = (N % 8 == 0) ? 1 : 0;
+    static const int abl = [] { const char* e = getenv("ABOPT_IPA_ABLATE"); return e ? atoi(e) : 0; }();   // timing experiments only (wrong results)
+    prof::begin(st);
+    if (dbg_logits)
+        hipLaunchKernelGGL(ipa_core_ws_kernel<true>, dim3((unsigned)(N * nib)), dim3(512), 0, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,
+                           feat, dbg_logits, N, L, nib, remap, abl);
+    else
+        hipLaunchKernelGGL(ipa_core_ws_kernel<false>, dim3((unsigned)(N * nib)), dim3(512), 0, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,
+                           feat, dbg_logits, N, L, nib, remap, abl);
+    prof::end(st);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+}  // namespace abopt
