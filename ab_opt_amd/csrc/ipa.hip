@@ -485,7 +485,7 @@ int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, cons
                     const float* w_pair_bias, const float* spatial_coef, float* feat,
                     float* dbg_logits, float* dbg_alpha, int N, int L, hipStream_t st) {
     if (N == 0 || L == 0) return ABOPT_OK;
-    static const int variant = [] { const char* e = getenv("ABOPT_IPA_VARIANT"); return e ? atoi(e) : 1; }();
+    static const int variant = [] { const char* e = getenv("ABOPT_IPA_VARIANT"); return e ? atoi(e) : 2; }();   // 2 = wave-specialised (default), 1 = single-role MFMA kernel, 0 = VALU kernel; 0/1 are kept for A/B timing
     if (variant == 0) {                                          // row-per-workgroup VALU kernel kept for A/B runs (L <= 480)
         const size_t lds = ((size_t)L * (ZLD + H) + 1440) * sizeof(float);
         ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core v0: L=%d needs %zu bytes of LDS (max 163840)", L, lds);
