@@ -203,6 +203,93 @@ __global__ __launch_bounds__(256) void sample_init_kernel(const float* __restric
     s_init[i] = (gen && sample_sequence) ? srand_ : s[i];
 }
 
+// Forward noising of all three modalities (transition.py:62-78,120-144,179-200); one thread per residue.
+__global__ __launch_bounds__(256) void add_noise_kernel(const int64_t* __restrict__ t, const float* __restrict__ alpha_bars,
+                                                        const float* __restrict__ fstd, const uint8_t* __restrict__ fapprox,
+                                                        const float* __restrict__ fX, const float* __restrict__ fcdf, int bins,
+                                                        abopt_addnoise_noise nz, uint64_t seed, uint64_t offset,
+                                                        const float* __restrict__ v_0, const float* __restrict__ p_0, const int64_t* __restrict__ s_0,
+                                                        const uint8_t* __restrict__ mask_generate, float scale, float m0, float m1, float m2,
+                                                        int noise_structure, int noise_sequence, int grad_mode,
+                                                        float* __restrict__ v_noisy, float* __restrict__ p_noisy, int64_t* __restrict__ s_noisy,
+                                                        float* __restrict__ eps_p, int L, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const int64_t tt = t[i / L];
+    const bool gen = mask_generate[i] != 0;
+    const float abar = alpha_bars[tt];
+    const float c0 = sqrtf(abar), c1 = sqrtf(1.f - abar);
+    const float mean[3] = {m0, m1, m2};
+    float ax, ay, az, ubin, gss, ex, ey, ez, useq;
+    int64_t bin;
+    if (nz.axis) {
+        ax = nz.axis[i * 3]; ay = nz.axis[i * 3 + 1]; az = nz.axis[i * 3 + 2];
+        bin = nz.bin[i]; ubin = nz.ubin[i]; gss = nz.gauss[i];
+        ex = nz.pos[i * 3]; ey = nz.pos[i * 3 + 1]; ez = nz.pos[i * 3 + 2];
+        useq = 0.f;
+    } else {
+        const Philox rng(seed);
+        const uint4 r0 = rng(offset + (uint64_t)i, 0xA00000ull), r1 = rng(offset + (uint64_t)i, 0xA00001ull), r2 = rng(offset + (uint64_t)i, 0xA00002ull);
+        float d0;
+        box_muller(r0.x, r0.y, ax, ay);
+        box_muller(r0.z, r0.w, az, gss);
+        box_muller(r1.x, r1.y, ex, ey);
+        box_muller(r1.z, r1.w, ez, d0);
+        ubin = u01(r2.x); useq = u01(r2.y);
+        const float ub = u01(r2.z);
+        const float* cdf = fcdf + tt * (int64_t)(bins - 1);
+        int lo = 0, hi = bins - 2;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] > ub) hi = mid; else lo = mid + 1; }
+        bin = lo;
+    }
+    // rotation
+    const float vx = v_0[i * 3], vy = v_0[i * 3 + 1], vz = v_0[i * 3 + 2];
+    float nvx = vx, nvy = vy, nvz = vz;
+    if (noise_structure) {
+        const float* X = fX + tt * (int64_t)bins;
+        const float sd = fstd[tt];
+        const float nrm = fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-12f);
+        const float hist = X[bin] + ubin * (X[bin + 1] - X[bin]);
+        const float gau = fmodf(fabsf(sd * 2.f + gss * sd), PI_F);
+        const float th = fapprox[tt] ? gau : hist;
+        const Mat3 E = so3_exp(ax / nrm * th, ay / nrm * th, az / nrm * th);
+        const Mat3 Rn = matmul3(E, so3_exp(c0 * vx, c0 * vy, c0 * vz));
+        const Vec3 w = so3_log(Rn, grad_mode != 0);
+        if (gen) { nvx = w.x; nvy = w.y; nvz = w.z; }
+    }
+    v_noisy[i * 3] = nvx; v_noisy[i * 3 + 1] = nvy; v_noisy[i * 3 + 2] = nvz;
+    // position
+    const float en[3] = {ex, ey, ez};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float p0n = (p_0[i * 3 + k] - mean[k]) / scale;
+        const float pn = (gen && noise_structure) ? c0 * p0n + c1 * en[k] : p0n;
+        p_noisy[i * 3 + k] = pn * scale + mean[k];
+        if (eps_p) eps_p[i * 3 + k] = noise_structure ? en[k] : 0.f;
+    }
+    // sequence
+    const int64_t s0 = s_0[i];
+    int64_t sn = s0;
+    if (noise_sequence) {
+        if (nz.axis) sn = nz.s_noisy[i];
+        else {
+            const bool ok = s0 >= 0 && s0 < KAA;
+            float tot = 0.f, c[KAA];
+#pragma unroll
+            for (int k = 0; k < KAA; ++k) {
+                const float oh = (ok && s0 == k) ? 1.f : 0.f;
+                c[k] = (gen ? (abar * oh) + ((1.f - abar) / (float)KAA) : oh) + 1e-8f;
+                tot += c[k];
+            }
+            const float target = useq * tot;
+            float cum = 0.f;
+            sn = KAA - 1;
+            for (int k = 0; k < KAA; ++k) { cum += c[k]; if (cum > target) { sn = k; break; } }
+        }
+    }
+    s_noisy[i] = sn;
+}
+
 // score[b] = sum_b' sqrt(mean_n |x_b - x_b'|^2) / (B - 1)   (design_for_testset.py:556-563,586-588)
 __global__ __launch_bounds__(256) void commonness_kernel(const float* __restrict__ x, float* __restrict__ score, int B, int n) {
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -257,6 +344,30 @@ extern "C" int abopt_sample_init(const float* v, const float* p, const int64_t* 
     hipLaunchKernelGGL(sample_init_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, p, s, mask_generate, q4, pn, sr,
                        seed, offset, position_scale, position_mean[0], position_mean[1], position_mean[2], sample_structure, sample_sequence,
                        v_init, p_init, s_init, rows);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+extern "C" int abopt_add_noise(const int64_t* t, const float* alpha_bars, const float* fwd_stddevs, const uint8_t* fwd_approx,
+                               const float* fwd_X, const float* fwd_cdf, int bins, int num_sched,
+                               const abopt_addnoise_noise* noise, uint64_t seed, uint64_t offset,
+                               const float* v_0, const float* p_0, const int64_t* s_0, const uint8_t* mask_generate,
+                               float position_scale, const float* position_mean, int noise_structure, int noise_sequence, int grad_mode,
+                               float* v_noisy, float* p_noisy, int64_t* s_noisy, float* eps_p, int N, int L, abopt_stream stream) {
+    ABOPT_CHECK_ARG(t && alpha_bars && fwd_stddevs && fwd_approx && fwd_X && v_0 && p_0 && s_0 && mask_generate && position_mean &&
+                    v_noisy && p_noisy && s_noisy && bins >= 2 && num_sched >= 1, "add_noise: bad arguments");
+    abopt_addnoise_noise nz = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (noise && noise->axis) {
+        ABOPT_CHECK_ARG(noise->bin && noise->ubin && noise->gauss && noise->pos && (noise->s_noisy || !noise_sequence), "add_noise: injected noise must provide every draw");
+        nz = *noise;
+    } else {
+        ABOPT_CHECK_ARG(fwd_cdf, "add_noise: device RNG path needs the CDF table");
+    }
+    const int64_t rows = (int64_t)N * L;
+    if (rows == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, alpha_bars, fwd_stddevs, fwd_approx,
+                       fwd_X, fwd_cdf, bins, nz, seed, offset, v_0, p_0, s_0, mask_generate, position_scale, position_mean[0], position_mean[1],
+                       position_mean[2], noise_structure, noise_sequence, grad_mode, v_noisy, p_noisy, s_noisy, eps_p, L, rows);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

@@ -60,7 +60,7 @@ class FullDPM(nn.Module):
                 mean=g(self.position_mean.flatten())))
         return self._host_sched[1]
 
-    def _step_params(self, t, sample_structure, sample_sequence, ppl_masked):
+    def _step_params(self, t, sample_structure, sample_sequence, ppl_masked, optimize_mode=False):
         h = self._sched_host()
         sp = hip.StepParams()
         sp.t = t
@@ -71,7 +71,7 @@ class FullDPM(nn.Module):
         sp.position_scale = h['scale']
         for k in range(3):
             sp.position_mean[k] = h['mean'][k]
-        sp.pred_x0 = int(self.abdock and self.obj == 'pred_x0')
+        sp.pred_x0 = int(self.abdock and self.obj == 'pred_x0' and not optimize_mode)
         sp.sample_structure, sp.sample_sequence = int(sample_structure), int(sample_sequence)
         sp.dist_min, sp.dist_max = float(self.dist_min), float(self.dist_max)
         sp.ppl_masked = int(ppl_masked)
@@ -83,7 +83,7 @@ class FullDPM(nn.Module):
 
     # ------------------------------------------------------------------ sampling
     def _run(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
-             ppl_masked, noise, seed, rng_offset, pbar, stop_after=None):
+             ppl_masked, noise, seed, rng_offset, pbar, stop_after=None, optimize_mode=False):
         """Denoise from step t_start down to 0.  state = (v, p_angstrom, s) on device."""
         dev = res_feat.device
         N, L = mask_res.shape
@@ -119,7 +119,7 @@ class FullDPM(nn.Module):
             beta = betas[t].expand([N]).contiguous()
             hip.eps_net_forward(ew, tv[t], p_norm, ts[t], res_feat, pair_feat, beta, mask_generate, mask_res,
                                 self.abdock, self.num_bins, False, out=net)
-            sp = self._step_params(t, sample_structure, sample_sequence, ppl_masked)
+            sp = self._step_params(t, sample_structure, sample_sequence, ppl_masked, optimize_mode)
             out = dict(v=tv[t - 1], p=tp[t - 1], s=ts[t - 1])
             if self.abdock:
                 out.update(prmsd=tpr[t - 1], ppl=tpp[t - 1])
@@ -165,4 +165,20 @@ class FullDPM(nn.Module):
     def optimize(self, v, p, s, opt_step, res_feat, pair_feat, mask_generate, mask_res, sample_structure=True,
                  sample_sequence=True, pbar=False, noise=None, seed=None, rng_offset=0):
         """dpm_full.py:304-367: noise the input to step `opt_step`, then denoise."""
-        raise NotImplementedError('FullDPM.optimize: the forward-noising kernels (add_noise) are not built yet')
+        hip.lib()
+        seed = self._new_seed() if seed is None else int(seed)
+        h = self._sched_host()
+        N = v.shape[0]
+        t = torch.full([N], opt_step, dtype=torch.long, device=res_feat.device)
+        init_noise = noise.get('init') if noise is not None else None
+        # dpm_full.py:320-339: noise structure and/or sequence to step opt_step (position in Angstrom in and out)
+        state = hip.add_noise(t, self.trans_pos.var_sched.alpha_bars, self.trans_rot.angular_distrib_fwd, init_noise, seed, rng_offset,
+                              v.float(), p.float(), s, mask_generate, h['scale'], h['mean'],
+                              noise_structure=sample_structure, noise_sequence=sample_sequence, grad_mode=False)
+        state = (state[0], state[1], torch.where(mask_generate, state[2], s))       # dpm_full.py:335
+        # dpm_full.py:351-358: the loop feeds the net's third output to the position update as noise whatever `obj` is,
+        # and averages the perplexity over all residues (calc_perplexity(logits) without a mask)
+        out = self._run(state, opt_step, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, False,
+                        noise, seed, rng_offset + N * v.shape[1], pbar, optimize_mode=True)
+        traj = self._to_traj(opt_step, *out, first_extra=lambda s_: (torch.zeros_like(s_), torch.ones_like(s_)))
+        return {k: tuple(e) for k, e in traj.items()}

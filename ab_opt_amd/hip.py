@@ -46,6 +46,10 @@ class StepParams(C.Structure):
                 ('dist_min', C.c_float), ('dist_max', C.c_float), ('ppl_masked', C.c_int)]
 
 
+class AddNoiseNoise(C.Structure):
+    _fields_ = [('axis', c_f), ('bin', c_i64), ('ubin', c_f), ('gauss', c_f), ('pos', c_f), ('s_noisy', c_i64)]
+
+
 class StepNoise(C.Structure):
     _fields_ = [('axis', c_f), ('bin', c_i64), ('ubin', c_f), ('gauss', c_f), ('z', c_f), ('s_next', c_i64)]
 
@@ -53,7 +57,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect']
+           'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect']
 
 _lib = None
 _lock = threading.Lock()
@@ -93,6 +97,9 @@ def lib():
         L.abopt_sample_init.argtypes = [c_f, c_f, c_i64, c_u8, c_f, c_f, c_i64, C.c_uint64, C.c_uint64,
                                         C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, c_f, c_f, c_i64, C.c_int, C.c_int, C.c_void_p]
         L.abopt_commonness_score.argtypes = [c_f, c_f, C.c_int, C.c_int, C.c_void_p]
+        L.abopt_add_noise.argtypes = [c_i64, c_f, c_f, c_u8, c_f, c_f, C.c_int, C.c_int, C.POINTER(AddNoiseNoise), C.c_uint64, C.c_uint64,
+                                      c_f, c_f, c_i64, c_u8, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,
+                                      c_f, c_f, c_i64, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_prof_enable.argtypes = [C.c_int]
         L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
         for name in EXPORTS:
@@ -254,6 +261,27 @@ def sample_init(v, p, s, mask_generate, init_noise, seed, offset, scale, mean, s
                                    ptr(sr, optional=True), seed, offset, float(scale), mean_arr, int(sample_structure), int(sample_sequence),
                                    ptr(v_i), ptr(p_i), ptr(s_i), N, L, stream()))
     return v_i, p_i, s_i
+
+
+def add_noise(t, alpha_bars, fwd, noise, seed, offset, v_0, p_0, s_0, mask_generate, scale, mean,
+              noise_structure=True, noise_sequence=True, grad_mode=False, want_eps=False):
+    """fwd: ApproxAngularDistribution of the forward process (buffers stddevs, approx_flag, X + cdf())."""
+    N, L = mask_generate.shape
+    v_n, p_n, s_n = torch.empty_like(v_0), torch.empty_like(p_0), torch.empty_like(s_0)
+    eps = torch.empty_like(p_0) if want_eps else None
+    nz = None
+    if noise is not None:
+        nz = AddNoiseNoise(ptr(noise['axis'], torch.float32), ptr(noise['bin'], torch.int64), ptr(noise['ubin'], torch.float32),
+                           ptr(noise['gauss'], torch.float32), ptr(noise['pos'], torch.float32), ptr(noise.get('s_noisy'), torch.int64, optional=True))
+    mean_arr = (C.c_float * 3)(*[float(m) for m in mean])
+    cdf = fwd.cdf() if noise is None else None
+    _check(lib().abopt_add_noise(ptr(t.contiguous(), torch.int64), ptr(alpha_bars, torch.float32), ptr(fwd.stddevs, torch.float32),
+                                 ptr(fwd.approx_flag, torch.bool), ptr(fwd.X, torch.float32), ptr(cdf, optional=True), fwd.X.shape[1], fwd.X.shape[0],
+                                 C.byref(nz) if nz is not None else None, seed, offset,
+                                 ptr(v_0.contiguous(), torch.float32), ptr(p_0.contiguous(), torch.float32), ptr(s_0.contiguous(), torch.int64),
+                                 ptr(mask_generate.contiguous(), torch.bool), float(scale), mean_arr, int(noise_structure), int(noise_sequence),
+                                 int(grad_mode), ptr(v_n), ptr(p_n), ptr(s_n), ptr(eps, optional=True), N, L, stream()))
+    return (v_n, p_n, s_n, eps) if want_eps else (v_n, p_n, s_n)
 
 
 def commonness_score(structs):

@@ -289,6 +289,46 @@ def test_model_sample_free_run_with_injected_noise():
     assert max_abs(traj[0][1].cpu()[ctx], g['traj0_p'][ctx]) < 1e-4       # context residues never move
 
 
+def test_optimize_vs_reference():
+    """FullDPM.optimize: forward noising to step 4 with the reference's recorded draws, then 4 teacher-forced steps."""
+    from oracle import geometry as G
+    g = load_golden('optimize_abdock_T10_k4')
+    gt = load_golden('trajectory_abdock_T10')
+    _, m, batch = _traj_setup()
+    d = m.diffusion
+    b = {k: dev(v) for k, v in batch.items()}
+    with torch.no_grad():
+        rf, pf, R0, p0 = m.encode(b, True, True)
+    from ab_opt_amd import hip
+    v0 = hip.so3_log(dev(gt['R0']), False)
+    init = dict(axis=dev(g['rot_axis']), bin=dev(g['rot_bin']), ubin=dev(g['rot_ubin']), gauss=dev(g['rot_gauss']), pos=dev(g['pos']), s_noisy=dev(g['s_noisy']))
+    nz = {t: {k: dev(g[f't{t}_{k}']) for k in ('axis', 'bin', 'ubin', 'gauss', 'z', 's_next')} for t in range(4, 0, -1)}
+    nz['init'] = init
+    traj = d.optimize(v0, dev(gt['p0']), b['aa'], 4, dev(gt['res_feat']), pf, b['generate_flag'], b['mask'], noise=nz)
+    assert sorted(traj) == [0, 1, 2, 3, 4] and len(traj[4]) == 5 and isinstance(traj[2], tuple)
+    # noised start state
+    assert max_abs(traj[4][1].cpu(), g['traj4_p']) < 1e-4 and torch.equal(traj[4][2].cpu(), g['traj4_s'])
+    assert max_abs(G.so3_exp(traj[4][0].cpu()), G.so3_exp(g['traj4_v'])) < 5e-4
+    # each step from the reference's state (teacher-forced); optimize feeds the net output as noise and uses unmasked perplexity
+    for t in range(4, 0, -1):
+        state = (dev(g[f'traj{t}_v']), dev(g[f'traj{t}_p']), dev(g[f'traj{t}_s']))
+        tv, tp, ts, tpr, tpp = d._run(state, t, dev(gt['res_feat']), pf, b['generate_flag'], b['mask'], True, True, False,
+                                      {t: nz[t]}, 0, 0, False, stop_after=1, optimize_mode=True)
+        assert max_abs(tp[t - 1].cpu(), g[f'traj{t - 1}_p']) < 1e-4, t
+        assert torch.equal(ts[t - 1].cpu(), g[f'traj{t - 1}_s'])
+
+
+def test_sample_sharded_single_rank_and_rng_reproducibility():
+    from ab_opt_amd import sampler
+    _, m, batch = _traj_setup()
+    b = {k: dev(v) for k, v in synth.make_batch(4, synth.LAYOUT_128, seed=11, replicate=True).items()}
+    traj, (a, e), top, cand = sampler.sample_sharded(m, b, dict(sample_structure=True, sample_sequence=True, contig=''), k=2, seed=42)
+    assert (a, e) == (0, 4) and cand.shape == (4, 12, 3) and top.shape == (2,)
+    traj2, _, top2, cand2 = sampler.sample_sharded(m, {k: v.clone() for k, v in b.items()}, dict(sample_structure=True, sample_sequence=True, contig=''), k=2, seed=42)
+    assert torch.equal(cand, cand2) and torch.equal(top, top2)          # same Philox seed => identical samples
+    assert not torch.equal(cand[0], cand[1])                             # replicated inputs still give distinct samples
+
+
 def test_abdesign_steps_teacher_forced_vs_reference():
     g = load_golden('trajectory_abdesign_T10')
     d = standalone_abdesign_dpm(10, 4).to(DEV)
