@@ -2,7 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include "abopt_common.h"
+#include "ipa_common.h"
 #include "kernels.h"
 
 namespace abopt {
@@ -28,12 +28,12 @@ struct Carver {
     }
 };
 
-constexpr int F = 128, C = 64, FI = F + 4;
+constexpr int F = 128, FI = F + 4;
 
 struct GaScratch { float *proj, *feat, *u, *y, *h1, *h2; };
 static GaScratch carve_ga(Carver& cv, int64_t M) {
     GaScratch s;
-    s.proj = cv.f((size_t)M * ABOPT_NODE_PROJ);
+    s.proj = cv.f((size_t)M * NP);
     s.feat = cv.f((size_t)M * ABOPT_IPA_FEAT);
     s.u = cv.f((size_t)M * F);
     s.y = cv.f((size_t)M * F);
@@ -47,7 +47,7 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     const int64_t M = (int64_t)N * L;
     int rc;
     // node projections: q|k|v|qp|kp|vp in one GEMM, then points to the global frame
-    if ((rc = launch_linear(x, F, w->w_node, F, nullptr, s.proj, ABOPT_NODE_PROJ, (int)M, ABOPT_NODE_PROJ, F, false, st))) return rc;
+    if ((rc = launch_linear(x, F, w->w_node, F, nullptr, s.proj, NP, (int)M, ABOPT_NODE_PROJ, F, false, st))) return rc;
     if ((rc = launch_points_to_global(s.proj, R, t, M, st))) return rc;
     float* feat = (dbg && dbg->feat) ? dbg->feat : s.feat;
     if ((rc = launch_ipa_core(s.proj, z, mask, R, t, w->w_pair_bias, w->spatial_coef, feat,

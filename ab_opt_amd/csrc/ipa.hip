@@ -14,25 +14,40 @@
 namespace abopt {
 
 // ------------------------------------------------------------------ local -> global of the point sets
-// geometry.py:72-91 applied to proj_{query,key,value}_point outputs (ga.py:96-105,129-132): p <- R p + t, in place.
+// geometry.py:72-91 applied to proj_{query,key,value}_point outputs (ga.py:96-105,129-132): p <- R p + t, in place, one
+// thread per (residue, point set, head).  Also emits |p|^2 summed over the head's 8 points for the query and key sets:
+// the wave-specialised IPA kernel evaluates the squared point distances as |q|^2 + |k|^2 - 2 q.k on the matrix cores.
 __global__ __launch_bounds__(256) void points_to_global_kernel(float* __restrict__ proj, const float* __restrict__ R,
                                                                const float* __restrict__ t, int64_t rows) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (row, point)
-    const int npts = 3 * H * P;                                              // 288 points per residue
-    if (idx >= rows * npts) return;
-    const int64_t row = idx / npts;
-    const int pt = (int)(idx % npts);
-    float* p = proj + row * NP + OFF_QP + pt * 3;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * 3 * H) return;
+    const int64_t row = idx / (3 * H);
+    const int sh = (int)(idx % (3 * H)), set = sh / H, h = sh % H;
+    float* p = proj + row * NP + OFF_QP + set * (H * P * 3) + h * (P * 3);
     const float* Rr = R + row * 9;
     const float* tr = t + row * 3;
-    const float x = p[0], y = p[1], z = p[2];
-    p[0] = Rr[0] * x + Rr[1] * y + Rr[2] * z + tr[0];
-    p[1] = Rr[3] * x + Rr[4] * y + Rr[5] * z + tr[1];
-    p[2] = Rr[6] * x + Rr[7] * y + Rr[8] * z + tr[2];
+    const float r0 = Rr[0], r1 = Rr[1], r2 = Rr[2], r3 = Rr[3], r4 = Rr[4], r5 = Rr[5], r6 = Rr[6], r7 = Rr[7], r8 = Rr[8];
+    const float t0 = tr[0], t1 = tr[1], t2 = tr[2];
+    float4 v[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v[q] = reinterpret_cast<const float4*>(p)[q];
+    float* f = reinterpret_cast<float*>(v);
+    float nrm = 0.f;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const float x = f[k * 3], y = f[k * 3 + 1], z = f[k * 3 + 2];
+        const float gx = r0 * x + r1 * y + r2 * z + t0, gy = r3 * x + r4 * y + r5 * z + t1, gz = r6 * x + r7 * y + r8 * z + t2;
+        f[k * 3] = gx; f[k * 3 + 1] = gy; f[k * 3 + 2] = gz;
+        nrm = fmaf(gx, gx, nrm); nrm = fmaf(gy, gy, nrm); nrm = fmaf(gz, gz, nrm);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) reinterpret_cast<float4*>(p)[q] = v[q];
+    if (set == 0) proj[row * NP + OFF_NQ + h] = nrm;
+    if (set == 1) proj[row * NP + OFF_NK + h] = nrm;
 }
 
 int launch_points_to_global(float* proj, const float* R, const float* t, int64_t rows, hipStream_t st) {
-    const int64_t total = rows * 3 * H * P;
+    const int64_t total = rows * 3 * H;
     if (total == 0) return ABOPT_OK;
     hipLaunchKernelGGL(points_to_global_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, proj, R, t, rows);
     ABOPT_LAUNCH_CHECK();

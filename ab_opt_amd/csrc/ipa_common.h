@@ -5,8 +5,12 @@
 namespace abopt {
 
 constexpr int H = ABOPT_HEADS, D = ABOPT_QK_DIM, P = ABOPT_POINTS, C = 64;
-constexpr int NP = ABOPT_NODE_PROJ;          // 2016 floats per residue
+// Row layout of the per-residue projection buffer: the 2016 outputs of the fused node projection GEMM
+// (q|k|v|q_pts|k_pts|v_pts) followed by the squared norms of the 8 global-frame query / key points of every head
+// (written by points_to_global), padded to 2048 floats = one 8 KB row.
+constexpr int NP = 2048;
 constexpr int OFF_Q = 0, OFF_K = H * D, OFF_V = 2 * H * D, OFF_QP = 3 * H * D, OFF_KP = OFF_QP + H * P * 3, OFF_VP = OFF_KP + H * P * 3;
+constexpr int OFF_NQ = ABOPT_NODE_PROJ, OFF_NK = OFF_NQ + H;
 constexpr int FEAT = ABOPT_IPA_FEAT;         // 1824
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -21,7 +21,7 @@ namespace abopt {
 struct WsSmem {
     float sp[2][BI][16 * PLD + 4];   // S then P per chunk parity, [i][h*PLD + j]
     float zst[4][JC][ZSLD];          // per-pair-wave z staging (transposes the chunk for the pair-bias MFMA)
-    float qg[BI][NPT + 4];           // global-frame query points of the block
+    float nq[BI][16];                // |q_pts|^2 per (query row, head)
     float scl[2][BI][16];            // rescale factor of chunk parity
     float lsum[BI][16];              // softmax denominators
     float wbs[16][C + 4];            // pair-bias weights, rows 12..15 zero
@@ -29,15 +29,16 @@ struct WsSmem {
     float q[BI][H * D + 4];          // queries of the block (phase A operand A)
 };
 
-struct KFrag { float4 k0, k1, g[6]; };                 // phase A operands of one head: 8 key channels + 24 key-point coords
+struct KFrag { float4 k0, k1; float2 g[3]; float nk; }; // phase A operands of one head: 8 key channels, 6 key-point coords, |k_pts|^2
 struct VFrag { float2 v[4], p[4]; };                   // phase C operands of one head: 4 keys x (2 value channels, 2 point coords)
 
 __device__ __forceinline__ void load_kfrag(KFrag& f, const float* pj, int h, int kq) {
     const float4* kp = reinterpret_cast<const float4*>(pj + OFF_K + h * D + kq * 8);
     f.k0 = kp[0]; f.k1 = kp[1];
-    const float4* gp = reinterpret_cast<const float4*>(pj + OFF_KP + h * (P * 3));
+    // point coordinates are the K dimension of the q_pts.k_pts MFMA: step s <-> coordinate 8 (s >> 1) + 2 kq + (s & 1)
 #pragma unroll
-    for (int q = 0; q < 6; ++q) f.g[q] = gp[q];
+    for (int u = 0; u < 3; ++u) f.g[u] = *reinterpret_cast<const float2*>(pj + OFF_KP + h * (P * 3) + 8 * u + 2 * kq);
+    f.nk = pj[OFF_NK + h];
 }
 
 __device__ __forceinline__ void load_vfrag(VFrag& f, const float* projn, int jc0, int L, int h, int fm, int kq) {
@@ -71,10 +72,9 @@ __global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __rest
     const int nchunk = (L + JC - 1) / JC;
 
     // ---- prologue (all 8 waves)
-    for (int e = tid; e < BI * (NPT / 4); e += 512) {
-        const int il = e / (NPT / 4), c4 = e % (NPT / 4);
-        const int i = min(i0 + il, L - 1);
-        *reinterpret_cast<float4*>(&sm.qg[il][c4 * 4]) = reinterpret_cast<const float4*>(projn + (int64_t)i * NP + OFF_QP)[c4];
+    if (tid < BI * 16) {
+        const int il = tid >> 4, h = tid & 15;
+        sm.nq[il][h] = (h < H) ? projn[(int64_t)min(i0 + il, L - 1) * NP + OFF_NQ + h] : 0.f;
     }
     for (int e = tid; e < BI * (H * D / 4); e += 512) {
         const int il = e / (H * D / 4), c4 = e % (H * D / 4);
@@ -200,6 +200,14 @@ __global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __rest
             for (int k = 0; k < 2; ++k) { accV[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; accT[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         KFrag kf[3];
         VFrag vf[3];
+        float2 qgf[3][3];                                                   // query-point fragments (A operand: row = query fm, same K permutation as KFrag::g)
+        {
+            const float* qprow = projn + (int64_t)min(i0 + fm, L - 1) * NP + OFF_QP + 2 * kq;
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh)
+#pragma unroll
+                for (int u = 0; u < 3; ++u) qgf[hh][u] = *reinterpret_cast<const float2*>(qprow + (w4 * 3 + hh) * (P * 3) + 8 * u);
+        }
 
         auto phase_a = [&](int ch) {                                        // S(ch) -> sp[ch & 1], consuming kf
             const int buf = ch & 1;
@@ -219,16 +227,13 @@ __global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __rest
 #pragma unroll
                 for (int s = 0; s < 4; ++s) { acc0 = mfma4(f4get(q0, s), f4get(kf[hh].k0, s), acc0); acc1 = mfma4(f4get(q1, s), f4get(kf[hh].k1, s), acc1); }
                 const f32x4 acc = acc0 + acc1;
+                // squared point distances: |q|^2 + |k|^2 - 2 q.k, the cross term on the matrix cores (K = 24 coordinates)
+                f32x4 accp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 3; ++u) { accp = mfma4(qgf[hh][u].x, kf[hh].g[u].x, accp); accp = mfma4(qgf[hh][u].y, kf[hh].g[u].y, accp); }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {                               // accumulator row = query 4 kq + r, column = key fm
-                    const float4* qgp = reinterpret_cast<const float4*>(&sm.qg[kq * 4 + r][h * (P * 3)]);
-                    float d2 = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) {
-                        const float4 a = qgp[q];
-                        const float dx = a.x - kf[hh].g[q].x, dy = a.y - kf[hh].g[q].y, dz = a.z - kf[hh].g[q].z, dw = a.w - kf[hh].g[q].w;
-                        d2 = fmaf(dx, dx, d2); d2 = fmaf(dy, dy, d2); d2 = fmaf(dz, dz, d2); d2 = fmaf(dw, dw, d2);
-                    }
+                    const float d2 = (sm.nq[kq * 4 + r][h] + kf[hh].nk) - 2.f * accp[r];
                     sm.sp[buf][kq * 4 + r][h * PLD + fm] = acc[r] * 0.17677669529663687f + d2 * coefh;
                 }
             }
