@@ -29,13 +29,14 @@ struct Carver {
 };
 
 constexpr int F = 128, FI = F + 4;
+constexpr int OUT_KSPLIT = 4;     // out_transform (K = 1824, N = 128) has only M/64 * 2 tiles: split K so it fills the chip
 
 struct GaScratch { float *proj, *feat, *u, *y, *h1, *h2; };
 static GaScratch carve_ga(Carver& cv, int64_t M) {
     GaScratch s;
     s.proj = cv.f((size_t)M * NP);
     s.feat = cv.f((size_t)M * ABOPT_IPA_FEAT);
-    s.u = cv.f((size_t)M * F);
+    s.u = cv.f((size_t)M * F * OUT_KSPLIT);
     s.y = cv.f((size_t)M * F);
     s.h1 = cv.f((size_t)M * F);
     s.h2 = cv.f((size_t)M * F);
@@ -53,8 +54,9 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     if ((rc = launch_ipa_core(s.proj, z, mask, R, t, w->w_pair_bias, w->spatial_coef, feat,
                               dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, N, L, st))) return rc;
     // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
-    if ((rc = launch_linear(feat, ABOPT_IPA_FEAT, w->w_out, ABOPT_IPA_FEAT, w->b_out, s.u, F, (int)M, F, ABOPT_IPA_FEAT, false, st))) return rc;
-    if ((rc = launch_residual_layernorm(x, s.u, mask, w->ln1_gamma, w->ln1_beta, s.y, M, st))) return rc;
+    if ((rc = launch_linear(feat, ABOPT_IPA_FEAT, w->w_out, ABOPT_IPA_FEAT, nullptr, s.u, F, (int)M, F, ABOPT_IPA_FEAT, false, st,
+                            OUT_KSPLIT, M * F))) return rc;
+    if ((rc = launch_residual_layernorm(x, s.u, mask, w->ln1_gamma, w->ln1_beta, s.y, M, st, OUT_KSPLIT, M * F, w->b_out))) return rc;
     if ((rc = launch_linear(s.y, F, w->w_mlp0, F, w->b_mlp0, s.h1, F, (int)M, F, F, true, st))) return rc;
     if ((rc = launch_linear(s.h1, F, w->w_mlp1, F, w->b_mlp1, s.h2, F, (int)M, F, F, true, st))) return rc;
     if ((rc = launch_linear(s.h2, F, w->w_mlp2, F, w->b_mlp2, s.h1, F, (int)M, F, F, false, st))) return rc;

@@ -21,7 +21,8 @@ template <bool RELU>
 __global__ __launch_bounds__(256) void gemm_xwT_kernel(const float* __restrict__ X, int ldx,
                                                        const float* __restrict__ W, int ldw,
                                                        const float* __restrict__ bias,
-                                                       float* __restrict__ Y, int ldy, int M, int N, int K) {
+                                                       float* __restrict__ Y, int ldy, int M, int N, int K,
+                                                       int kchunk, int64_t slab_stride) {
     __shared__ __attribute__((aligned(16))) float Xs[GBM * GLD];
     __shared__ __attribute__((aligned(16))) float Ws[GBN * GLD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -40,9 +41,13 @@ __global__ __launch_bounds__(256) void gemm_xwT_kernel(const float* __restrict__
     const float* xp = X + (size_t)(m0 + lr) * ldx + lc;
     const float* wp = W + (size_t)(n0 + lr) * ldw + lc;
 
-    for (int k0 = 0; k0 < K; k0 += GBK) {
+    // split-K: blockIdx.z owns K range [z*kchunk, (z+1)*kchunk) and writes its partial product to slab z (the consumer sums
+    // the slabs in a fixed order, so results stay deterministic -- no atomics)
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    Y += (int64_t)blockIdx.z * slab_stride;
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), wv = xv;
-        const bool kok = (k0 + lc) < K;
+        const bool kok = (k0 + lc) < kend;
         if (xrow_ok && kok) xv = *reinterpret_cast<const float4*>(xp + k0);
         if (wrow_ok && kok) wv = *reinterpret_cast<const float4*>(wp + k0);
         __syncthreads();
@@ -87,13 +92,15 @@ __global__ __launch_bounds__(256) void gemm_xwT_kernel(const float* __restrict__
 }
 
 int launch_linear(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
-                  int M, int N, int K, bool relu, hipStream_t st) {
+                  int M, int N, int K, bool relu, hipStream_t st, int ksplit, int64_t slab_stride) {
     if (M <= 0 || N <= 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || (!relu && !bias)), "linear: split-K partials carry neither bias nor activation");
+    const int kchunk = ksplit == 1 ? K : ((K + ksplit * GBK - 1) / (ksplit * GBK)) * GBK;
     ABOPT_CHECK_ARG((K % 4) == 0 && (ldx % 4) == 0 && (ldw % 4) == 0, "linear: K/ldx/ldw must be multiples of 4 (K=%d ldx=%d ldw=%d)", K, ldx, ldw);
     ABOPT_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0, "linear: X/W must be 16-byte aligned");
-    dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM);
-    if (relu) hipLaunchKernelGGL(gemm_xwT_kernel<true>, grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, M, N, K);
-    else      hipLaunchKernelGGL(gemm_xwT_kernel<false>, grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, M, N, K);
+    dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM, ksplit);
+    if (relu) hipLaunchKernelGGL(gemm_xwT_kernel<true>, grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, M, N, K, kchunk, slab_stride);
+    else      hipLaunchKernelGGL(gemm_xwT_kernel<false>, grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, M, N, K, kchunk, slab_stride);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

@@ -6,8 +6,9 @@
 namespace abopt {
 
 // gemm.hip ------------------------------------------------------------------------------------
+// ksplit > 1: split-K, slab z of the partial products at Y + z*slab_stride (no bias / activation; the consumer reduces).
 int launch_linear(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
-                  int M, int N, int K, bool relu, hipStream_t st);
+                  int M, int N, int K, bool relu, hipStream_t st, int ksplit = 1, int64_t slab_stride = 0);
 
 // ipa.hip -------------------------------------------------------------------------------------
 // proj [N*L, 2016] holds q|k|v|qp|kp|vp with the three point sets already in the global frame.
@@ -19,9 +20,9 @@ int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, cons
 // rows.hip ------------------------------------------------------------------------------------
 int launch_so3_exp(const float* w, float* R, int64_t n, hipStream_t st);
 int launch_so3_log(const float* R, float* w, int64_t n, int grad_mode, hipStream_t st);
-// y = LN(x + (mask ? u : 0)); mask may be NULL (no masking). F == 128.
+// y = LN(x + (mask ? u : 0)), u = sum of `nslab` slabs (stride slab_stride floats) + ubias (may be NULL); mask may be NULL. F == 128.
 int launch_residual_layernorm(const float* x, const float* u, const uint8_t* mask, const float* gamma, const float* beta,
-                              float* y, int64_t rows, hipStream_t st);
+                              float* y, int64_t rows, hipStream_t st, int nslab = 1, int64_t slab_stride = 0, const float* ubias = nullptr);
 // cat[row] = [res_feat[row] | embed[s_t[row]]], F == 128
 int launch_embed_concat(const float* res_feat, const int64_t* s_t, const float* embed, float* cat, int64_t rows, hipStream_t st);
 // infeat[row, 0:128] = x, [128:131] = beta, sin beta, cos beta, [131] = 0 ; optional LN'd copy for the prmsd head

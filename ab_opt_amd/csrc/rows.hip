@@ -43,13 +43,19 @@ int launch_so3_log(const float* R, float* w, int64_t n, int grad_mode, hipStream
 // row, two features per lane (F = 128).  ga.py:175-177.
 __global__ __launch_bounds__(256) void residual_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                                  const uint8_t* __restrict__ mask, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, float* __restrict__ y, int64_t rows) {
+                                                                 const float* __restrict__ beta, float* __restrict__ y, int64_t rows,
+                                                                 int nslab, int64_t slab_stride, const float* __restrict__ ubias) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const bool keep = mask ? (mask[row] != 0) : true;
     const float2 xv = reinterpret_cast<const float2*>(x + row * F)[lane];
     float2 uv = reinterpret_cast<const float2*>(u + row * F)[lane];
+    for (int sl = 1; sl < nslab; ++sl) {                      // split-K partial slabs, summed in slab order
+        const float2 w = reinterpret_cast<const float2*>(u + sl * slab_stride + row * F)[lane];
+        uv.x += w.x; uv.y += w.y;
+    }
+    if (ubias) { const float2 bb = reinterpret_cast<const float2*>(ubias)[lane]; uv.x += bb.x; uv.y += bb.y; }
     if (!keep) uv = make_float2(0.f, 0.f);
     const float a = xv.x + uv.x, b = xv.y + uv.y;
     const float mean = wave_sum(a + b) * (1.f / F);
@@ -61,9 +67,10 @@ __global__ __launch_bounds__(256) void residual_layernorm_kernel(const float* __
 }
 
 int launch_residual_layernorm(const float* x, const float* u, const uint8_t* mask, const float* gamma, const float* beta,
-                              float* y, int64_t rows, hipStream_t st) {
+                              float* y, int64_t rows, hipStream_t st, int nslab, int64_t slab_stride, const float* ubias) {
     if (rows == 0) return ABOPT_OK;
-    hipLaunchKernelGGL(residual_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, u, mask, gamma, beta, y, rows);
+    hipLaunchKernelGGL(residual_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, u, mask, gamma, beta, y, rows,
+                       nslab, slab_stride, ubias);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }
