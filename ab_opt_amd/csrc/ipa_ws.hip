@@ -20,7 +20,7 @@ namespace abopt {
 
 struct WsSmem {
     float sp[2][BI][16 * PLD + 4];   // S then P per chunk parity, [i][h*PLD + j]
-    float zst[4][JC][ZSLD];          // per-pair-wave z staging (transposes the chunk for the pair-bias MFMA)
+    float zst[8][JC][ZSLD];          // per-pair-wave z staging (transposes the chunk for the pair-bias MFMA)
     float nq[BI][16];                // |q_pts|^2 per (query row, head)
     float scl[2][BI][16];            // rescale factor of chunk parity
     float lsum[BI][16];              // softmax denominators
@@ -50,8 +50,10 @@ __device__ __forceinline__ void load_vfrag(VFrag& f, const float* projn, int jc0
     }
 }
 
-template <bool DBG>
-__global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __restrict__ proj, const float* __restrict__ z,
+// NPW = number of pair waves (4 or 8); each owns RPW = 16 / NPW query rows.  NPW = 8 gives 12 waves = 3 per SIMD (two pair
+// waves + one node wave): three independent instruction streams per matrix pipe at <= 168 VGPRs each.
+template <bool DBG, int NPW>
+__global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_kernel(const float* __restrict__ proj, const float* __restrict__ z,
                                                              const uint8_t* __restrict__ mask, const float* __restrict__ R,
                                                              const float* __restrict__ t, const float* __restrict__ Wb,
                                                              const float* __restrict__ spatial_coef, float* __restrict__ feat,
@@ -64,23 +66,25 @@ __global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __rest
         else { n = b / nib; ib = b % nib; }
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
-    const bool pair_wave = wave < 4;
-    const int w4 = wave & 3;
+    const int nchunk = (L + JC - 1) / JC;
+    constexpr int RPW = BI / NPW, UC = 4 / RPW, NT = (NPW + 4) * 64;      // rows per pair wave, chunks per ring revolution, threads
+    const bool pair_wave = wave < NPW;
+    const int w4 = pair_wave ? wave : wave - NPW;                           // index within the role
+    const int nchunk2 = ((nchunk + UC - 1) / UC) * UC;                     // both roles run the same (possibly padded) number of chunks
     const int i0 = ib * BI;
     const int64_t rowbase = (int64_t)n * L;
     const float* projn = proj + rowbase * NP;
-    const int nchunk = (L + JC - 1) / JC;
 
     // ---- prologue (all 8 waves)
     if (tid < BI * 16) {
         const int il = tid >> 4, h = tid & 15;
         sm.nq[il][h] = (h < H) ? projn[(int64_t)min(i0 + il, L - 1) * NP + OFF_NQ + h] : 0.f;
     }
-    for (int e = tid; e < BI * (H * D / 4); e += 512) {
+    for (int e = tid; e < BI * (H * D / 4); e += NT) {
         const int il = e / (H * D / 4), c4 = e % (H * D / 4);
         *reinterpret_cast<float4*>(&sm.q[il][c4 * 4]) = reinterpret_cast<const float4*>(projn + (int64_t)min(i0 + il, L - 1) * NP + OFF_Q)[c4];
     }
-    for (int e = tid; e < 16 * (C / 4); e += 512) {
+    for (int e = tid; e < 16 * (C / 4); e += NT) {
         const int h = e / (C / 4), c4 = e % (C / 4);
         float4 w4v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (h < H) w4v = reinterpret_cast<const float4*>(Wb + h * C)[c4];
@@ -95,13 +99,13 @@ __global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __rest
 
     if (pair_wave) {
         // =========================================================================== pair waves: phase B
-        bool mi_b[4];
+        bool mi_b[RPW];
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) { const int i = i0 + w4 * 4 + ii; mi_b[ii] = (i < L) && mask[rowbase + i] != 0; }
-        float m_run[4], l_run[4];
-        f32x4 accP[4][4];
+        for (int ii = 0; ii < RPW; ++ii) { const int i = i0 + w4 * RPW + ii; mi_b[ii] = (i < L) && mask[rowbase + i] != 0; }
+        float m_run[RPW], l_run[RPW];
+        f32x4 accP[RPW][4];
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
+        for (int ii = 0; ii < RPW; ++ii) {
             m_run[ii] = -INFINITY; l_run[ii] = 0.f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) accP[ii][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -111,24 +115,30 @@ __global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __rest
         f32x4 ring[4][4];
 #define WS_ISSUE_Z(SLOT, ROW, CH)                                                                                        \
     {                                                                                                                    \
-        const float* zi_ = z + ((rowbase + ((abl & 16) ? 0 : min(i0 + w4 * 4 + (ROW), L - 1))) * (int64_t)L) * C;        \
+        const float* zi_ = z + ((rowbase + ((abl & 16) ? 0 : min(i0 + w4 * RPW + (ROW), L - 1))) * (int64_t)L) * C;        \
         if (!(abl & 512)) _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                              \
             ring[SLOT][r_] = *(reinterpret_cast<const f32x4*>(zi_ + (int64_t)min((CH) * JC + kq * 4 + r_, L - 1) * C) + fm); \
     }
-        WS_ISSUE_Z(0, 0, 0) WS_ISSUE_Z(1, 1, 0) WS_ISSUE_Z(2, 2, 0)
+        // ring position p = c * RPW + ii (c = chunk within the revolution) is also the slot; requests run 3 positions ahead
+        WS_ISSUE_Z(0, 0 % RPW, 0 / RPW) WS_ISSUE_Z(1, 1 % RPW, 1 / RPW) WS_ISSUE_Z(2, 2 % RPW, 2 / RPW)
         __syncthreads();                                                    // barrier #0: S(0) ready
-        for (int ch = 0; ch < nchunk; ++ch) {
+        for (int ch0 = 0; ch0 < nchunk2; ch0 += UC) {
+#pragma unroll
+          for (int c = 0; c < UC; ++c) {
+            const int ch = ch0 + c;
             const int jc0 = ch * JC, buf = ch & 1;
             bool mj[4], jv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const int j = jc0 + kq * 4 + r; jv[r] = j < L; mj[r] = jv[r] && mask[rowbase + j] != 0; }
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int il = w4 * 4 + ii;
-                WS_ISSUE_Z((ii + 3) & 3, (ii + 3) & 3, ch + ((ii + 3) >> 2))            // 3 rows ahead (clamped past the end: harmless re-read)
+            for (int ii = 0; ii < RPW; ++ii) {
+                const int il = w4 * RPW + ii;
+                constexpr int dummy_ = 0; (void)dummy_;
+                const int pos = c * RPW + ii;                               // compile-time after unrolling
+                WS_ISSUE_Z((pos + 3) & 3, (pos + 3) % RPW, ch0 + (pos + 3) / RPW)       // 3 positions ahead (clamped past the end: harmless re-read)
                 f32x4 zr[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) zr[r] = ring[ii][r];
+                for (int r = 0; r < 4; ++r) zr[r] = ring[pos][r];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&sm.zst[w4][kq * 4 + r][fm * 4]) = zr[r];
                 f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -172,11 +182,12 @@ __global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __rest
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!(abl & 8)) __syncthreads();                                // barrier #(ch+1)
+          }
         }
         // alpha = P / l, zero for masked queries (ga.py:24-25); pair features out
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int il = w4 * 4 + ii, i = i0 + il;
+        for (int ii = 0; ii < RPW; ++ii) {
+            const int il = w4 * RPW + ii, i = i0 + il;
             if (kq == 0) sm.lsum[il][fm] = l_run[ii];
             if (i < L && fm < H) {
                 const float inv = mi_b[ii] ? 1.f / l_run[ii] : 0.f;
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __rest
         };
         auto issue_v = [&](int ch) {                                        // fetch phase-C operands of chunk ch
             if (abl & 256) return;
+            if (NPW == 8) return;                                           // 3 waves/SIMD: no registers to park them; phase C loads just in time
 #pragma unroll
             for (int hh = 0; hh < 3; ++hh) load_vfrag(vf[hh], projn, ch * JC, L, w4 * 3 + hh, fm, kq);
         };
@@ -259,35 +271,37 @@ __global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __rest
                     const float sc = sm.scl[buf][kq * 4 + r][h];
                     accV[hh][0][r] *= sc; accV[hh][1][r] *= sc; accT[hh][0][r] *= sc; accT[hh][1][r] *= sc;
                 }
+                if (NPW == 8) load_vfrag(vf[0], projn, ch * JC, L, h, fm, kq);
+                const VFrag& vfh = vf[NPW == 8 ? 0 : hh];
                 const float4 pa = *reinterpret_cast<const float4*>(&sm.sp[buf][fm][h * PLD + kq * 4]);   // A: row = query fm, step s <-> key 4 kq + s
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const float a = f4get(pa, s);
-                    accV[hh][0] = mfma4(a, vf[hh].v[s].x, accV[hh][0]);
-                    accV[hh][1] = mfma4(a, vf[hh].v[s].y, accV[hh][1]);
-                    accT[hh][0] = mfma4(a, vf[hh].p[s].x, accT[hh][0]);
-                    accT[hh][1] = mfma4(a, vf[hh].p[s].y, accT[hh][1]);
+                    accV[hh][0] = mfma4(a, vfh.v[s].x, accV[hh][0]);
+                    accV[hh][1] = mfma4(a, vfh.v[s].y, accV[hh][1]);
+                    accT[hh][0] = mfma4(a, vfh.p[s].x, accT[hh][0]);
+                    accT[hh][1] = mfma4(a, vfh.p[s].y, accT[hh][1]);
                 }
             }
         };
 
         issue_k(0);
         phase_a(0);
-        if (nchunk > 1) issue_k(1);
+        if (nchunk2 > 1) issue_k(1);
         issue_v(0);
         __syncthreads();                                                    // barrier #0
-        for (int ch = 0; ch < nchunk; ++ch) {
+        for (int ch = 0; ch < nchunk2; ++ch) {
             if (ch >= 1) {
                 if (!(abl & 64)) phase_c(ch - 1);
                 issue_v(ch);
             }
-            if (ch + 1 < nchunk) {
+            if (ch + 1 < nchunk2) {
                 if (!(abl & 32)) phase_a(ch + 1);
-                if (ch + 2 < nchunk) issue_k(ch + 2);
+                if (ch + 2 < nchunk2) issue_k(ch + 2);
             }
             if (!(abl & 8)) __syncthreads();                                // barrier #(ch+1)
         }
-        phase_c(nchunk - 1);
+        phase_c(nchunk2 - 1);
         __syncthreads();                                                    // F1
         float* pts = &sm.sp[0][0][0];                                       // [BI][H][24]; both sp buffers are free now
 #pragma unroll
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void ipa_core_ws_kernel(const float* __rest
 
     // ---- all waves: local frame, norm, direction of the aggregated points (ga.py:136-139)
     const float* pts = &sm.sp[0][0][0];
-    for (int e = tid; e < BI * H * P; e += 512) {
+    for (int e = tid; e < BI * H * P; e += NT) {
         const int il = e / (H * P), hp = e % (H * P), i = i0 + il;
         if (i >= L) continue;
         const float* Rr = R + (rowbase + i) * 9;
@@ -334,12 +348,11 @@ int launch_ipa_core_ws(const float* proj, const float* z, const uint8_t* mask, c
     const int remap = (N % 8 == 0) ? 1 : 0;
     static const int abl = [] { const char* e = getenv("ABOPT_IPA_ABLATE"); return e ? atoi(e) : 0; }();   // timing experiments only (wrong results)
     prof::begin(st);
-    if (dbg_logits)
-        hipLaunchKernelGGL(ipa_core_ws_kernel<true>, dim3((unsigned)(N * nib)), dim3(512), 0, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,
-                           feat, dbg_logits, N, L, nib, remap, abl);
-    else
-        hipLaunchKernelGGL(ipa_core_ws_kernel<false>, dim3((unsigned)(N * nib)), dim3(512), 0, st, proj, z, mask, R, t, w_pair_bias, spatial_coef,
-                           feat, dbg_logits, N, L, nib, remap, abl);
+    static const int npw = [] { const char* e = getenv("ABOPT_IPA_PAIR_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();   // 8 pair waves (3 waves/SIMD) measured slower (311 vs 270 us): kept for A/B
+#define WS_LAUNCH(DBGV, NPWV) hipLaunchKernelGGL((ipa_core_ws_kernel<DBGV, NPWV>), dim3((unsigned)(N * nib)), dim3((NPWV + 4) * 64), 0, st, proj, z, \
+                                                 mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, N, L, nib, remap, abl)
+    if (dbg_logits) { if (npw == 8) WS_LAUNCH(true, 8); else WS_LAUNCH(true, 4); }
+    else            { if (npw == 8) WS_LAUNCH(false, 8); else WS_LAUNCH(false, 4); }
     prof::end(st);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
