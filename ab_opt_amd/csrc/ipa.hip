@@ -498,7 +498,7 @@ void end(hipStream_t st) {
 
 int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
                     const float* w_pair_bias, const float* spatial_coef, float* feat,
-                    float* dbg_logits, float* dbg_alpha, int N, int L, hipStream_t st) {
+                    float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache, int N, int L, hipStream_t st) {
     if (N == 0 || L == 0) return ABOPT_OK;
     static const int variant = [] { const char* e = getenv("ABOPT_IPA_VARIANT"); return e ? atoi(e) : 2; }();   // 2 = wave-specialised (default), 1 = single-role MFMA kernel, 0 = VALU kernel; 0/1 are kept for A/B timing
     if (variant == 0) {                                          // row-per-workgroup VALU kernel kept for A/B runs (L <= 480)
@@ -515,7 +515,7 @@ int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, cons
     const int nib = (L + BI - 1) / BI;
     ABOPT_CHECK_ARG((int64_t)N * nib < (1ll << 31), "ipa_core: grid too large");
     if (variant == 2) {
-        int rc = launch_ipa_core_ws(proj, z, mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, N, L, st);
+        int rc = launch_ipa_core_ws(proj, z, mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, N, L, st);
         if (rc) return rc;
         if (dbg_alpha) {
             ABOPT_CHECK_ARG(dbg_logits != nullptr, "ipa_core: alpha dump needs the logits dump");

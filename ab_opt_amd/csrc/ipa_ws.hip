@@ -52,12 +52,12 @@ __device__ __forceinline__ void load_vfrag(VFrag& f, const float* projn, int jc0
 
 // NPW = number of pair waves (4 or 8); each owns RPW = 16 / NPW query rows.  NPW = 8 gives 12 waves = 3 per SIMD (two pair
 // waves + one node wave): three independent instruction streams per matrix pipe at <= 168 VGPRs each.
-template <bool DBG, int NPW>
+template <bool DBG, int NPW, bool CACHED>
 __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_kernel(const float* __restrict__ proj, const float* __restrict__ z,
                                                              const uint8_t* __restrict__ mask, const float* __restrict__ R,
                                                              const float* __restrict__ t, const float* __restrict__ Wb,
                                                              const float* __restrict__ spatial_coef, float* __restrict__ feat,
-                                                             float* __restrict__ dbg_logits, int N, int L, int nib, int xcd_remap, int abl) {
+                                                             float* __restrict__ dbg_logits, const float* __restrict__ pbc, int N, int L, int nib, int xcd_remap, int abl) {
     __shared__ __attribute__((aligned(16))) WsSmem sm;
     int n, ib;
     {   // all i-blocks of a sample on one XCD when N % 8 == 0 (L2 locality of its k/v tiles; speed only)
@@ -113,11 +113,14 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
         // z ring: 4 register slots of one row chunk each (4 x 16 B per lane); rows are requested 3 ahead of their use so
         // that ~12 KB per pair wave (48 KB per CU) is always in flight: HBM latency under load is ~2 us.
         f32x4 ring[4][4];
+        f32x4 ringb[4];                                                     // CACHED: the row chunk's precomputed pair bias, lane (head fm, keys 4 kq ..)
 #define WS_ISSUE_Z(SLOT, ROW, CH)                                                                                        \
     {                                                                                                                    \
-        const float* zi_ = z + ((rowbase + ((abl & 16) ? 0 : min(i0 + w4 * RPW + (ROW), L - 1))) * (int64_t)L) * C;        \
+        const int64_t zrow_ = rowbase + ((abl & 16) ? 0 : min(i0 + w4 * RPW + (ROW), L - 1));                            \
+        const float* zi_ = z + (zrow_ * (int64_t)L) * C;                                                                 \
         if (!(abl & 512)) _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                              \
             ring[SLOT][r_] = *(reinterpret_cast<const f32x4*>(zi_ + (int64_t)min((CH) * JC + kq * 4 + r_, L - 1) * C) + fm); \
+        if (CACHED) ringb[SLOT] = *(reinterpret_cast<const f32x4*>(pbc + (zrow_ * nchunk + min((CH), nchunk - 1)) * 256) + lane);  \
     }
         // ring position p = c * RPW + ii (c = chunk within the revolution) is also the slot; requests run 3 positions ahead
         WS_ISSUE_Z(0, 0 % RPW, 0 / RPW) WS_ISSUE_Z(1, 1 % RPW, 1 / RPW) WS_ISSUE_Z(2, 2 % RPW, 2 / RPW)
@@ -139,18 +142,23 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                 f32x4 zr[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) zr[r] = ring[pos][r];
+                f32x4 acc;
+                if (CACHED) {
+                    acc = ringb[pos];                                       // pair bias of this (row, chunk) from the per-call cache
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&sm.zst[w4][kq * 4 + r][fm * 4]) = zr[r];
-                f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                if (!(abl & 2))
+                    for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&sm.zst[w4][kq * 4 + r][fm * 4]) = zr[r];
+                    f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                    if (!(abl & 2))
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 za = *reinterpret_cast<const float4*>(&sm.zst[w4][fm][kq * 16 + q * 4]);
-                    const float4 wv = *reinterpret_cast<const float4*>(&sm.wbs[fm][kq * 16 + q * 4]);
-                    acc4[q] = mfma4(za.x, wv.x, (f32x4){0.f, 0.f, 0.f, 0.f});
-                    acc4[q] = mfma4(za.y, wv.y, acc4[q]); acc4[q] = mfma4(za.z, wv.z, acc4[q]); acc4[q] = mfma4(za.w, wv.w, acc4[q]);
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 za = *reinterpret_cast<const float4*>(&sm.zst[w4][fm][kq * 16 + q * 4]);
+                        const float4 wv = *reinterpret_cast<const float4*>(&sm.wbs[fm][kq * 16 + q * 4]);
+                        acc4[q] = mfma4(za.x, wv.x, (f32x4){0.f, 0.f, 0.f, 0.f});
+                        acc4[q] = mfma4(za.y, wv.y, acc4[q]); acc4[q] = mfma4(za.z, wv.z, acc4[q]); acc4[q] = mfma4(za.w, wv.w, acc4[q]);
+                    }
+                    acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
                 }
-                const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
                 const float4 tns = *reinterpret_cast<const float4*>(&sm.sp[buf][il][fm * PLD + kq * 4]);
                 float sv[4];
 #pragma unroll
@@ -341,18 +349,67 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
     }
 }
 
+// Pair-bias cache: lp[l][n,i,j,h] = z[n,i,j,:] . Wb_l[h,:] for every layer l in ONE pass over z (ga.py:88-90).  z and the
+// weights do not change during the 100 steps of FullDPM.sample, so the sampler builds this once per call and the per-step
+// kernel reads 48 useful bytes per (i,j) instead of spending 64 of its 218 MFMAs per chunk (and an LDS transpose) on it.
+// Layout per layer: [N*L (query row)][nchunk][16 (head, 12 used)][16 (key in chunk)] -- exactly the per-lane float4 the pair
+// waves consume, 1 KB contiguous per (row, chunk).  Same MFMA chain order as the fused path => bit-identical logits.
+struct WbList { const float* w[8]; };
+
+__global__ __launch_bounds__(256) void pair_bias_cache_kernel(const float* __restrict__ z, WbList wl, int num_layers, float* __restrict__ cache,
+                                                              int64_t rows, int L, int nchunk) {
+    __shared__ __attribute__((aligned(16))) float zst[4][JC][ZSLD];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fm = lane & 15, kq = lane >> 4;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + wave;                  // (query row, chunk)
+    if (unit >= rows * nchunk) return;
+    const int64_t row = unit / nchunk;
+    const int ch = (int)(unit % nchunk);
+    const float* zi = z + (row * (int64_t)L) * C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x4*>(&zst[wave][kq * 4 + r][fm * 4]) = *(reinterpret_cast<const f32x4*>(zi + (int64_t)min(ch * JC + kq * 4 + r, L - 1) * C) + fm);
+    float4 za[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) za[q] = *reinterpret_cast<const float4*>(&zst[wave][fm][kq * 16 + q * 4]);
+    for (int l = 0; l < num_layers; ++l) {
+        f32x4 acc4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fm < H) wv = reinterpret_cast<const float4*>(wl.w[l] + fm * C + kq * 16)[q];
+            acc4[q] = mfma4(za[q].x, wv.x, (f32x4){0.f, 0.f, 0.f, 0.f});
+            acc4[q] = mfma4(za[q].y, wv.y, acc4[q]); acc4[q] = mfma4(za[q].z, wv.z, acc4[q]); acc4[q] = mfma4(za[q].w, wv.w, acc4[q]);
+        }
+        const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+        *(reinterpret_cast<f32x4*>(cache + ((int64_t)l * rows * nchunk + unit) * 256) + lane) = acc;
+    }
+}
+
+int launch_pair_bias_cache(const float* z, const float* const* wb, int num_layers, float* cache, int N, int L, hipStream_t st) {
+    ABOPT_CHECK_ARG(num_layers >= 1 && num_layers <= 8, "pair_bias_cache: 1..8 layers supported (got %d)", num_layers);
+    WbList wl;
+    for (int l = 0; l < 8; ++l) wl.w[l] = l < num_layers ? wb[l] : nullptr;
+    const int nchunk = (L + JC - 1) / JC;
+    const int64_t units = (int64_t)N * L * nchunk;
+    if (units == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(pair_bias_cache_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, z, wl, num_layers, cache, (int64_t)N * L, L, nchunk);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
 int launch_ipa_core_ws(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
                        const float* w_pair_bias, const float* spatial_coef, float* feat, float* dbg_logits,
-                       int N, int L, hipStream_t st) {
+                       const float* pair_bias_cache, int N, int L, hipStream_t st) {
     const int nib = (L + BI - 1) / BI;
     const int remap = (N % 8 == 0) ? 1 : 0;
     static const int abl = [] { const char* e = getenv("ABOPT_IPA_ABLATE"); return e ? atoi(e) : 0; }();   // timing experiments only (wrong results)
     prof::begin(st);
     static const int npw = [] { const char* e = getenv("ABOPT_IPA_PAIR_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();   // 8 pair waves (3 waves/SIMD) measured slower (311 vs 270 us): kept for A/B
-#define WS_LAUNCH(DBGV, NPWV) hipLaunchKernelGGL((ipa_core_ws_kernel<DBGV, NPWV>), dim3((unsigned)(N * nib)), dim3((NPWV + 4) * 64), 0, st, proj, z, \
-                                                 mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, N, L, nib, remap, abl)
-    if (dbg_logits) { if (npw == 8) WS_LAUNCH(true, 8); else WS_LAUNCH(true, 4); }
-    else            { if (npw == 8) WS_LAUNCH(false, 8); else WS_LAUNCH(false, 4); }
+#define WS_LAUNCH(DBGV, NPWV, CV) hipLaunchKernelGGL((ipa_core_ws_kernel<DBGV, NPWV, CV>), dim3((unsigned)(N * nib)), dim3((NPWV + 4) * 64), 0, st, proj, z, \
+                                                     mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, N, L, nib, remap, abl)
+    if (pair_bias_cache) { if (dbg_logits) WS_LAUNCH(true, 4, true); else WS_LAUNCH(false, 4, true); }
+    else if (dbg_logits) { if (npw == 8) WS_LAUNCH(true, 8, false); else WS_LAUNCH(true, 4, false); }
+    else                 { if (npw == 8) WS_LAUNCH(false, 8, false); else WS_LAUNCH(false, 4, false); }
     prof::end(st);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;

@@ -15,7 +15,7 @@ int launch_linear(const float* X, int ldx, const float* W, int ldw, const float*
 int launch_points_to_global(float* proj, const float* R, const float* t, int64_t rows, hipStream_t st);
 int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
                     const float* w_pair_bias, const float* spatial_coef, float* feat,
-                    float* dbg_logits, float* dbg_alpha, int N, int L, hipStream_t st);
+                    float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache, int N, int L, hipStream_t st);
 
 // rows.hip ------------------------------------------------------------------------------------
 int launch_so3_exp(const float* w, float* R, int64_t n, hipStream_t st);

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -56,7 +56,7 @@ class StepNoise(C.Structure):
 
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
-           'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_denoise_step', 'abopt_sample_init',
+           'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
            'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect']
 
 _lib = None
@@ -89,8 +89,11 @@ def lib():
         L.abopt_ga_encoder_forward.argtypes = [C.POINTER(GaWeights), C.c_int, c_f, c_f, c_f, c_f, c_u8, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_eps_net_forward.argtypes = [C.POINTER(EpsWeights), c_f, c_f, c_i64, c_f, c_f, c_f, c_u8, c_u8,
-                                            c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f,
                                             C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_pair_bias_cache_bytes.restype = C.c_size_t
+        L.abopt_pair_bias_cache_bytes.argtypes = [C.c_int] * 3
+        L.abopt_pair_bias_cache.argtypes = [C.POINTER(GaWeights), C.c_int, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.abopt_denoise_step.argtypes = [C.POINTER(StepParams), C.POINTER(StepNoise), C.c_uint64, C.c_uint64,
                                          c_f, c_f, c_i64, c_f, c_f, c_f, c_f, c_u8, c_f, c_f, C.c_int, C.c_int,
                                          c_f, c_f, c_i64, c_f, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
@@ -211,7 +214,8 @@ def ga_encoder_forward(ws_array, num_layers, R, t, x, z, mask):
     return out
 
 
-def eps_net_forward(ew, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res, has_prmsd, num_bins, grad_mode=False, out=None):
+def eps_net_forward(ew, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res, has_prmsd, num_bins, grad_mode=False, out=None,
+                    pair_bias_cache=None):
     N, L = mask_res.shape
     F, Cd = res_feat.shape[-1], pair_feat.shape[-1]
     dev = res_feat.device
@@ -227,8 +231,18 @@ def eps_net_forward(ew, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate,
                                        ptr(mask_generate.contiguous(), torch.bool), ptr(mask_res.contiguous(), torch.bool),
                                        ptr(out['v_next']), ptr(out['R_next']), ptr(out['eps_pos']), ptr(out['c']),
                                        ptr(out['prmsd_logits'], optional=True), N, L, F, Cd, int(grad_mode),
-                                       ptr(buf), buf.numel(), stream()))
+                                       ptr(pair_bias_cache, torch.float32, optional=True), ptr(buf), buf.numel(), stream()))
     return out
+
+
+def pair_bias_cache(blocks_array, num_layers, pair_feat):
+    """proj_pair_bias(pair_feat) of every block, once per sampling call (include/abopt.h: abopt_pair_bias_cache)."""
+    N, L = pair_feat.shape[:2]
+    nb = lib().abopt_pair_bias_cache_bytes(N, L, num_layers)
+    cache = torch.empty(nb // 4, dtype=torch.float32, device=pair_feat.device)
+    _check(lib().abopt_pair_bias_cache(blocks_array, num_layers, ptr(pair_feat.contiguous(), torch.float32), ptr(cache), N, L,
+                                       pair_feat.shape[-1], stream()))
+    return cache
 
 
 def denoise_step(sp, noise, seed, offset, v_t, p_t, s_t, v_net, p_net, c_net, prmsd_logits, mask_generate,

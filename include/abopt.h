@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 1
+#define ABOPT_ABI_VERSION 2
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -96,6 +96,14 @@ typedef struct {
 
 size_t abopt_eps_workspace_bytes(int N, int L, int F, int C);
 
+/* Per-call pair-bias cache: proj_pair_bias(z) of EVERY block (ga.py:88-90) in one pass over pair_feat.  pair_feat and
+ * the weights are constant over the steps of FullDPM.sample / optimize (dpm_full.py:274-283), so the sampler builds the
+ * cache once per call and passes it to every abopt_eps_net_forward; the per-step kernel then skips that contraction
+ * (bit-identical results).  cache: abopt_pair_bias_cache_bytes(N, L, num_layers) bytes, caller-owned. */
+size_t abopt_pair_bias_cache_bytes(int N, int L, int num_layers);
+int abopt_pair_bias_cache(const abopt_ga_weights* blocks, int num_layers, const float* pair_feat, float* cache,
+                          int N, int L, int C, abopt_stream stream);
+
 /* EpsilonNet.forward (dpm_full.py:70-112).  beta [N].  Outputs: v_next [N,L,3], R_next [N,L,3,3],
  * eps_pos [N,L,3], c_denoised [N,L,20], prmsd_logits [N,num_bins] (NULL when the head is absent). */
 int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_t, const float* p_t, const int64_t* s_t,
@@ -103,6 +111,7 @@ int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_t, const fl
                           const uint8_t* mask_generate, const uint8_t* mask_res,
                           float* v_next, float* R_next, float* eps_pos, float* c_denoised, float* prmsd_logits,
                           int N, int L, int F, int C, int grad_mode,
+                          const float* pair_bias_cache /* NULL: compute the pair bias inside the step */,
                           void* ws, size_t ws_bytes, abopt_stream stream);
 
 /* ---- Per-step transitions: D/modules/diffusion/transition.py:42-50,80-101 (position), :146-160

@@ -269,6 +269,26 @@ def _one_step(dpm_, state, t, res_feat, pair_feat, gen, mres, noise_t):
     return tv[t - 1], tp[t - 1], ts[t - 1], tpr[t - 1], tpp[t - 1]
 
 
+def test_pair_bias_cache_is_bit_identical():
+    """The per-call pair-bias cache (abopt_pair_bias_cache) must not change a single bit of a denoising step."""
+    g = load_golden('trajectory_abdock_T10')
+    _, m, batch = _traj_setup()
+    d = m.diffusion
+    b = {k: dev(v) for k, v in batch.items()}
+    with torch.no_grad():
+        _, pf, _, _ = m.encode(b, True, True)
+    nz = noise_dict(g, 10)
+    t = 6
+    state = (dev(g[f'traj{t}_v']), dev(g[f'traj{t}_p']), dev(g[f'traj{t}_s']))
+    noise = {t: {k: dev(v) for k, v in nz[t].items()}}
+    outs = []
+    for use in (True, False):
+        tv, tp, ts, tpr, tpp = d._run(tuple(s.clone() for s in state), t, dev(g['res_feat']), pf, b['generate_flag'], b['mask'], True, True, True,
+                                      noise, 0, 0, False, stop_after=1, use_bias_cache=use)
+        outs.append((tv[t - 1].clone(), tp[t - 1].clone(), tpr[t - 1].clone()))
+    assert all(torch.equal(a, c) for a, c in zip(*outs))
+
+
 def test_model_sample_free_run_with_injected_noise():
     """model.sample() end-to-end with replayed draws: first steps track the reference; later steps are only required
     to stay finite and to carry the injected sequence (the dynamics amplify fp32 reordering)."""
