@@ -15,6 +15,7 @@
 #include "ipa_common.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <cstdio>
 
 namespace abopt {
 
@@ -50,6 +51,13 @@ __device__ __forceinline__ void load_vfrag(VFrag& f, const float* projn, int jc0
     }
 }
 
+#ifdef WS_TIMING   // developer build (-DWS_TIMING): s_memtime section timers of one workgroup
+#define TSTAMP(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
+__device__ long long g_ws_timing[2][8];
+#else
+#define TSTAMP(k)
+#endif
+
 // NPW = number of pair waves (4 or 8); each owns RPW = 16 / NPW query rows.  NPW = 8 gives 12 waves = 3 per SIMD (two pair
 // waves + one node wave): three independent instruction streams per matrix pipe at <= 168 VGPRs each.
 template <bool DBG, int NPW, bool CACHED>
@@ -67,6 +75,9 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
     const int nchunk = (L + JC - 1) / JC;
+#ifdef WS_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
     constexpr int RPW = BI / NPW, UC = 4 / RPW, NT = (NPW + 4) * 64;      // rows per pair wave, chunks per ring revolution, threads
     const bool pair_wave = wave < NPW;
     const int w4 = pair_wave ? wave : wave - NPW;                           // index within the role
@@ -118,6 +129,10 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
     {                                                                                                                    \
         const int64_t zrow_ = rowbase + ((abl & 16) ? 0 : min(i0 + w4 * RPW + (ROW), L - 1));                            \
         const float* zi_ = z + (zrow_ * (int64_t)L) * C;                                                                 \
+        if (abl & 1024) {   /* timing experiment: same bytes, but the workgroup's 16 row-chunks of a step are contiguous (tiled layout) */ \
+            const float* zt_ = z + ((rowbase + i0) * (int64_t)L + ((int64_t)min((CH), nchunk - 1) * BI + w4 * RPW + (ROW)) * JC) * C;        \
+            _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) ring[SLOT][r_] = *(reinterpret_cast<const f32x4*>(zt_ + (kq * 4 + r_) * C) + fm);  \
+        } else                                                                                                           \
         if (!(abl & 512)) _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                              \
             ring[SLOT][r_] = *(reinterpret_cast<const f32x4*>(zi_ + (int64_t)min((CH) * JC + kq * 4 + r_, L - 1) * C) + fm); \
         if (CACHED) ringb[SLOT] = *(reinterpret_cast<const f32x4*>(pbc + (zrow_ * nchunk + min((CH), nchunk - 1)) * 256) + lane);  \
@@ -125,6 +140,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
         // ring position p = c * RPW + ii (c = chunk within the revolution) is also the slot; requests run 3 positions ahead
         WS_ISSUE_Z(0, 0 % RPW, 0 / RPW) WS_ISSUE_Z(1, 1 % RPW, 1 / RPW) WS_ISSUE_Z(2, 2 % RPW, 2 / RPW)
         __syncthreads();                                                    // barrier #0: S(0) ready
+        TSTAMP(0)
         for (int ch0 = 0; ch0 < nchunk2; ch0 += UC) {
 #pragma unroll
           for (int c = 0; c < UC; ++c) {
@@ -142,6 +158,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                 f32x4 zr[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) zr[r] = ring[pos][r];
+                TSTAMP(1)
                 f32x4 acc;
                 if (CACHED) {
                     acc = ringb[pos];                                       // pair bias of this (row, chunk) from the per-call cache
@@ -159,6 +176,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                     }
                     acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
                 }
+                TSTAMP(2)
                 const float4 tns = *reinterpret_cast<const float4*>(&sm.sp[buf][il][fm * PLD + kq * 4]);
                 float sv[4];
 #pragma unroll
@@ -180,6 +198,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                 m_run[ii] = m_new;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) accP[ii][mt] *= sc;
+                TSTAMP(3)
                 if (!(abl & 1))
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -187,9 +206,11 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                     for (int mt = 0; mt < 4; ++mt) accP[ii][mt] = mfma4(zr[r][mt], pv[r], accP[ii][mt]);
                 *reinterpret_cast<float4*>(&sm.sp[buf][il][fm * PLD + kq * 4]) = make_float4(pv[0], pv[1], pv[2], pv[3]);
                 if (kq == 0) sm.scl[buf][il][fm] = sc;
+                TSTAMP(4)
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!(abl & 8)) __syncthreads();                                // barrier #(ch+1)
+            TSTAMP(5)
           }
         }
         // alpha = P / l, zero for masked queries (ga.py:24-25); pair features out
@@ -205,6 +226,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                     reinterpret_cast<float4*>(fo)[r] = make_float4(accP[ii][0][r] * inv, accP[ii][1][r] * inv, accP[ii][2][r] * inv, accP[ii][3][r] * inv);
             }
         }
+        TSTAMP(6)
         __syncthreads();                                                    // F1: lsum visible, node waves done with C(last)
         __syncthreads();                                                    // F2: aggregated points in LDS
     } else {
@@ -298,18 +320,25 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
         if (nchunk2 > 1) issue_k(1);
         issue_v(0);
         __syncthreads();                                                    // barrier #0
+        TSTAMP(0)
         for (int ch = 0; ch < nchunk2; ++ch) {
             if (ch >= 1) {
                 if (!(abl & 64)) phase_c(ch - 1);
+                TSTAMP(1)
                 issue_v(ch);
+                TSTAMP(2)
             }
             if (ch + 1 < nchunk2) {
                 if (!(abl & 32)) phase_a(ch + 1);
+                TSTAMP(3)
                 if (ch + 2 < nchunk2) issue_k(ch + 2);
+                TSTAMP(4)
             }
             if (!(abl & 8)) __syncthreads();                                // barrier #(ch+1)
+            TSTAMP(5)
         }
         phase_c(nchunk2 - 1);
+        TSTAMP(6)
         __syncthreads();                                                    // F1
         float* pts = &sm.sp[0][0][0];                                       // [BI][H][24]; both sp buffers are free now
 #pragma unroll
@@ -347,6 +376,11 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
         float* fdir = fpnt + H * P * 3 + H * P;
         fdir[hp * 3 + 0] = lx * inv; fdir[hp * 3 + 1] = ly * inv; fdir[hp * 3 + 2] = lz * inv;
     }
+#ifdef WS_TIMING
+    TSTAMP(7)
+    if (blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == NPW))
+        for (int k = 0; k < 8; ++k) g_ws_timing[wave == 0 ? 0 : 1][k] = tacc[k];
+#endif
 }
 
 // Pair-bias cache: lp[l][n,i,j,h] = z[n,i,j,:] . Wb_l[h,:] for every layer l in ONE pass over z (ga.py:88-90).  z and the
@@ -412,6 +446,20 @@ int launch_ipa_core_ws(const float* proj, const float* z, const uint8_t* mask, c
     else                 { if (npw == 8) WS_LAUNCH(false, 8, false); else WS_LAUNCH(false, 4, false); }
     prof::end(st);
     ABOPT_LAUNCH_CHECK();
+#ifdef WS_TIMING
+    {
+        long long h[2][8];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ws_timing), sizeof(h));
+        static int calls = 0;
+        if (++calls == 8) {
+            fprintf(stderr, "[ws timing, cycles of WG 17] pair: pre %lld | wait-z(+stage) %lld | pairbias %lld | softmax %lld | agg+Pwrite %lld | barrier %lld | final %lld | epilogue %lld\n",
+                    h[0][0], h[0][1], h[0][2], h[0][3], h[0][4], h[0][5], h[0][6], h[0][7]);
+            fprintf(stderr, "[ws timing, cycles of WG 17] node: pre %lld | phase_c %lld | issue_v %lld | phase_a %lld | issue_k %lld | barrier %lld | last_c %lld | epilogue %lld\n",
+                    h[1][0], h[1][1], h[1][2], h[1][3], h[1][4], h[1][5], h[1][6], h[1][7]);
+        }
+    }
+#endif
     return ABOPT_OK;
 }
 
