@@ -27,6 +27,10 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy ceiling)
+# HBM bytes per ipa_core launch from the PMC counters (separate rocprofv3 --pmc passes on this command, FETCH_SIZE doubled per
+# the gfx950 correction): profiles/r01_f_pmc_ipa_core_cached.txt.  740 MB read + 60 MB written; 137 MB above the algorithmic
+# bytes = the per-call pair-bias cache stream that replaces the in-kernel pair-bias contraction.
+MEASURED_TRAFFIC = {(32, 256): 361290.7 * 1024 * 2 + 58368.6 * 1024}
 
 
 def ipa_core_bytes(N, L, C=64):
@@ -176,7 +180,7 @@ def main():
                                    f'batch {N} per GPU, distinct pair features per sample, device Philox RNG',
                        'samples_per_gpu': N, 'residues': L, 'sampler_steps': T, 'parallelism': f'independent samples x{world}'},
             'roofline': {'bound': 'hbm', 'kernel': 'ipa_core', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None, 'launches': launches,
+                         'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': MEASURED_TRAFFIC.get((N, L)), 'launches': launches,
                          'avg_launch_ms': round(per_launch_ms, 4), 'algorithmic_bytes_per_launch': ipa_core_bytes(N, L)},
         }
         if world == 1 and not args.no_cpu_baseline:
