@@ -81,6 +81,13 @@ class FullDPM(nn.Module):
     def _new_seed():
         return int(torch.randint(0, 2 ** 62, (1,)).item())
 
+    # ------------------------------------------------------------------ training loss
+    def forward(self, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_res, denoise_structure, denoise_sequence, t=None, noise=None):
+        """dpm_full.py:156-234.  Noising runs in the HIP kernel; the differentiable denoiser + losses currently run as torch
+        ops on the device so autograd supplies the backward (ab_opt_amd/training.py; interim until the IPA backward kernel)."""
+        from .training import fulldpm_loss
+        return fulldpm_loss(self, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_res, denoise_structure, denoise_sequence, t=t, noise=noise)
+
     # ------------------------------------------------------------------ sampling
     def _run(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
              ppl_masked, noise, seed, rng_offset, pbar, stop_after=None, optimize_mode=False, use_bias_cache=True):

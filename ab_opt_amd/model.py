@@ -86,7 +86,17 @@ class _DiffabBase(nn.Module):
         return res_feat, pair_feat, R, pos[:, :, ATOM_CA]
 
     def forward(self, batch):
-        raise NotImplementedError('training loss (FullDPM.forward) needs the IPA backward kernels, which are not built yet')
+        """diffab.py:85-112 -> loss dict (AbDock: prmsd, dist, rot, pos, seq; AbDesign: rot, pos, seq)."""
+        g = lambda k, d=None: _cfg_get(self.cfg, k, d)
+        mask_generate = batch['generate_flag']
+        if self.ABDOCK and g('mask_ratio_min', False):
+            mask_generate = torch.logical_and(mask_generate, generate_random_mask_from(mask_generate, g('mask_ratio_min'), g('mask_ratio_max')))
+            batch['generate_flag'] = mask_generate
+        mask_res = batch['mask']
+        res_feat, pair_feat, R_0, p_0 = self.encode(batch, remove_structure=g('train_structure', True), remove_sequence=g('train_sequence', True))
+        v_0 = hip.so3_log(R_0.detach(), grad_mode=True)          # frames come from input coordinates: no gradient flows here
+        return self.diffusion(v_0, p_0, batch['aa'], res_feat, pair_feat, mask_generate, mask_res,
+                              denoise_structure=g('train_structure', True), denoise_sequence=g('train_sequence', True))
 
     @torch.no_grad()
     def sample(self, batch, sample_opt={'sample_structure': True, 'sample_sequence': True, 'contig': ''}):

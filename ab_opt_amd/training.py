@@ -1,0 +1,198 @@
+"""Training loss of the denoiser (FullDPM.forward) with gradients.
+
+Status: the forward noising runs in the HIP kernel `abopt_add_noise`; the differentiable part
+(EpsilonNet + losses) is expressed here with torch ops on the HIP device so that autograd provides the backward pass.
+This is the INTERIM training path: the hand-written IPA backward kernel is the next scope row, and this
+module is what it will be verified against.  It is never used by sample()/optimize(), and it is not a CPU fallback: the
+noising step requires the HIP library and device tensors.
+
+Maths follows the reference line by line (D/ = AbDock/src/):
+  GABlock.forward               D/modules/encoders/ga.py:149-178   (contractions as einsum instead of 5-D broadcast products)
+  EpsilonNet.forward            D/modules/diffusion/dpm_full.py:70-112
+  FullDPM.forward               D/modules/diffusion/dpm_full.py:156-234 (AbDesign: A/modules/diffusion/dpm_full.py:138-191)
+  rotation_matrix_cosine_loss   dpm_full.py:15-32;  calc_dist_loss :369-378;  pRMSDCa loss  D/modules/common/prmsd.py:49-70
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+H, D, P, K_AA = 12, 32, 8, 20
+
+
+# ------------------------------------------------------------------ differentiable geometry (so3.py, geometry.py)
+def _hat(w):
+    x, y, z = w.unbind(-1)
+    o = torch.zeros_like(x)
+    return torch.stack([o, z, -y, -z, o, x, y, -x, o], dim=-1).reshape(w.shape[:-1] + (3, 3))
+
+
+def so3_exp(w):
+    S = _hat(w)
+    th = torch.linalg.norm(w, dim=-1)
+    b = (torch.sin(th) + 1e-8) / (th + 1e-8)
+    c = (1 - torch.cos(th) + 1e-8) / (th ** 2 + 2e-8)
+    eye = torch.eye(3, dtype=w.dtype, device=w.device).expand(S.shape)
+    return eye + b[..., None, None] * S + c[..., None, None] * (S @ S)
+
+
+def so3_log(R, min_cos=-0.999):
+    """rotation_to_so3vec under autograd: the reference clamps the cosine at -0.999 when grad is enabled (so3.py:12-16)."""
+    tr = R[..., 0, 0] + R[..., 1, 1] + R[..., 2, 2]
+    ct = ((tr - 1) / 2).clamp_min(min_cos)
+    st = torch.sqrt(1 - ct ** 2)
+    th = torch.acos(ct)
+    A = ((th + 1e-8) / (2 * st + 2e-8))[..., None, None] * (R - R.transpose(-1, -2))
+    return torch.stack([A[..., 1, 2], A[..., 2, 0], A[..., 0, 1]], dim=-1)
+
+
+def quat1ijk_to_rot(e):
+    b, c, d = e.unbind(-1)
+    s = torch.sqrt(1 + b ** 2 + c ** 2 + d ** 2)
+    a, b, c, d = 1 / s, b / s, c / s, d / s
+    m = [a ** 2 + b ** 2 - c ** 2 - d ** 2, 2 * b * c - 2 * a * d, 2 * b * d + 2 * a * c,
+         2 * b * c + 2 * a * d, a ** 2 - b ** 2 + c ** 2 - d ** 2, 2 * c * d - 2 * a * b,
+         2 * b * d - 2 * a * c, 2 * c * d + 2 * a * b, a ** 2 - b ** 2 - c ** 2 + d ** 2]
+    return torch.stack(m, -1).reshape(e.shape[:-1] + (3, 3))
+
+
+def _to_global(R, t, p):        # p: (N, L, K, 3)
+    return torch.einsum('nlab,nlkb->nlka', R, p) + t.unsqueeze(2)
+
+
+def _to_local(R, t, q):
+    return torch.einsum('nlba,nlkb->nlka', R, q - t.unsqueeze(2))
+
+
+def _ln(x, mod):
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / (var + mod.epsilon).sqrt() * mod.gamma + mod.beta
+
+
+# ------------------------------------------------------------------ network
+def ga_block(blk, R, t, x, z, mask):
+    N, L, _ = x.shape
+    q = blk.proj_query(x).view(N, L, H, D)
+    k = blk.proj_key(x).view(N, L, H, D)
+    v = blk.proj_value(x).view(N, L, H, D)
+    qp = _to_global(R, t, blk.proj_query_point(x).view(N, L, H * P, 3)).reshape(N, L, H, P * 3)
+    kp = _to_global(R, t, blk.proj_key_point(x).view(N, L, H * P, 3)).reshape(N, L, H, P * 3)
+    vp = _to_global(R, t, blk.proj_value_point(x).view(N, L, H * P, 3)).reshape(N, L, H, P, 3)
+    l_node = torch.einsum('nihd,njhd->nijh', q, k) * (1 / math.sqrt(D))
+    l_pair = blk.proj_pair_bias(z)
+    d2 = (qp ** 2).sum(-1).unsqueeze(2) + (kp ** 2).sum(-1).unsqueeze(1) - 2 * torch.einsum('nihe,njhe->nijh', qp, kp)
+    gamma = F.softplus(blk.spatial_coef)
+    l_spat = d2 * ((-1 * gamma * math.sqrt(2 / (9 * P))) / 2)
+    logits = (l_node + l_pair + l_spat) * math.sqrt(1 / 3)
+    mrow = mask.view(N, L, 1, 1)
+    mpair = mrow & mask.view(N, 1, L, 1)
+    alpha = torch.softmax(torch.where(mpair, logits, logits - 1e5), dim=2)
+    alpha = torch.where(mrow, alpha, torch.zeros_like(alpha))
+    f_pair = torch.einsum('nijh,nijc->nihc', alpha, z).reshape(N, L, -1)
+    f_node = torch.einsum('nijh,njhd->nihd', alpha, v).reshape(N, L, -1)
+    agg = torch.einsum('nijh,njhpa->nihpa', alpha, vp).reshape(N, L, H * P, 3)
+    loc = _to_local(R, t, agg)
+    dist = loc.norm(dim=-1)
+    direc = loc / (dist.unsqueeze(-1) + 1e-4)
+    feat = torch.cat([f_pair, f_node, loc.reshape(N, L, -1), dist, direc.reshape(N, L, -1)], dim=-1)
+    u = blk.out_transform(feat)
+    u = torch.where(mask.unsqueeze(-1), u, torch.zeros_like(u))
+    y = _ln(x + u, blk.layer_norm_1)
+    return _ln(y + blk.mlp_transition(y), blk.layer_norm_2)
+
+
+def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res):
+    N, L = mask_res.shape
+    R = so3_exp(v_t)
+    x = net.res_feat_mixer(torch.cat([res_feat, net.current_sequence_embedding(s_t)], dim=-1))
+    for blk in net.encoder.blocks:
+        x = ga_block(blk, R, p_t, x, pair_feat, mask_res)
+    temb = torch.stack([beta, torch.sin(beta), torch.cos(beta)], dim=-1)[:, None, :].expand(N, L, 3)
+    feat = torch.cat([x, temb], dim=-1)
+    gen3 = mask_generate[:, :, None].expand(N, L, 3)
+    eps_crd = net.eps_crd_net(feat)
+    eps_pos = torch.where(gen3, torch.einsum('nlab,nlb->nla', R, eps_crd), torch.zeros_like(eps_crd))
+    R_next = R @ quat1ijk_to_rot(net.eps_rot_net(feat))
+    v_next = torch.where(gen3, so3_log(R_next), v_t)
+    c = net.eps_seq_net(feat)
+    if net.no_bins is None:
+        return v_next, R_next, eps_pos, c
+    pp = net.prmsd_predictor
+    h = pp.linear_3(pp.linear_2(pp.linear_1(_ln(feat, pp.layer_norm)).relu()).relu())
+    return v_next, R_next, eps_pos, c, h.mean(dim=1)
+
+
+# ------------------------------------------------------------------ losses
+def _one_hot20(x):
+    ok = (x >= 0) & (x < K_AA)
+    return (F.one_hot(x.clamp(0, K_AA - 1), K_AA) * ok[..., None]).float()
+
+
+def _posterior(alpha_bars, x_t, x_0, t):
+    c_t = x_t if x_t.dim() == 3 else _one_hot20(x_t)
+    c_0 = x_0 if x_0.dim() == 3 else _one_hot20(x_0)
+    a = alpha_bars[t][:, None, None]
+    th = ((a * c_t) + (1 - a) / K_AA) * ((a * c_0) + (1 - a) / K_AA)       # transition.py:223-224: alpha_bar_t in both factors
+    return th / (th.sum(dim=-1, keepdim=True) + 1e-8)
+
+
+def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_res, denoise_structure, denoise_sequence,
+                 t=None, noise=None, seed=None):
+    """FullDPM.forward -> dict of scalar losses (AbDock: prmsd, dist (pred_x0), rot, pos, seq; AbDesign: rot, pos, seq)."""
+    from . import hip
+    hip.lib()
+    N, L = res_feat.shape[:2]
+    dev = res_feat.device
+    vs = dpm.trans_pos.var_sched
+    if t is None:
+        t = torch.randint(0, dpm.num_steps, (N,), dtype=torch.long, device=dev)
+    h = dpm._sched_host()
+    seed = dpm._new_seed() if seed is None else int(seed)
+    with torch.no_grad():                       # noising has no learnable parameters; native kernel (transition.py:62-78,120-144,179-200)
+        v_n, p_n_ang, s_n, eps_p = hip.add_noise(t, vs.alpha_bars, dpm.trans_rot.angular_distrib_fwd, noise, seed, 0,
+                                                 v_0.detach().float(), p_0.detach().float(), s_0, mask_generate, h['scale'], h['mean'],
+                                                 noise_structure=denoise_structure, noise_sequence=denoise_sequence, grad_mode=True, want_eps=True)
+    p0n = dpm._normalize_position(p_0)
+    p_n = dpm._normalize_position(p_n_ang)
+    R_0 = so3_exp(v_0)
+    beta = vs.betas[t]
+    out = eps_net(dpm.eps_net, v_n, p_n, s_n, res_feat, pair_feat, beta, mask_generate, mask_res)
+    v_pred, R_pred, p_pred, c_den = out[:4]
+    genf = mask_generate.float()
+    denom = genf.sum() + 1e-8
+    loss = {}
+    if dpm.abdock:
+        if dpm.obj == 'pred_x0':
+            p_true, pred_p0 = p0n, p_pred
+        else:
+            p_true = p_n
+            a = vs.sqrt_recip_alphas_cumprod[t].view(-1, 1, 1)
+            b = vs.sqrt_recipm1_alphas_cumprod[t].view(-1, 1, 1)
+            pred_p0 = torch.where(mask_generate[..., None].expand_as(p0n), a * p0n - b * p_pred, p0n)
+        pa = dpm._unnormalize_position(pred_p0) * mask_generate.unsqueeze(-1)
+        pb = dpm._unnormalize_position(p0n) * mask_generate.unsqueeze(-1)
+        rmsd = torch.sqrt(((pa - pb) ** 2).sum(-1).sum(-1) / mask_generate.sum(-1)).detach()
+        off = dpm.prmsd.tobin.offset
+        diff = torch.abs(rmsd.unsqueeze(-1) - off)
+        onehot = torch.zeros_like(diff).scatter_(-1, torch.argmin(diff, -1, keepdim=True), 1.0)
+        err = -(onehot * F.log_softmax(out[4], dim=-1)).sum(-1)
+        m0 = mask_generate[:, 0]
+        loss['prmsd'] = (err * m0).sum() / (m0.sum() + 1e-10)
+        if dpm.obj == 'pred_x0':
+            dp, dt = torch.cdist(p_pred, p_pred), torch.cdist(p_true, p_true)
+            sel = mask_generate[:, :, None].expand_as(dp) & (mask_res[:, :, None] & mask_res[:, None, :])
+            loss['dist'] = F.smooth_l1_loss(torch.masked_select(dp, sel), torch.masked_select(dt, sel), reduction='none').mean()
+        pos_target = p_true
+    else:
+        pos_target = eps_p
+    cp = R_pred.transpose(-2, -1).reshape(-1, 3)
+    ct = R_0.transpose(-2, -1).reshape(-1, 3)
+    lr = F.cosine_embedding_loss(cp, ct, torch.ones(cp.shape[0], dtype=torch.long, device=dev), reduction='none')
+    lr = lr.reshape(list(R_pred.shape[:-2]) + [3]).sum(-1)
+    loss['rot'] = (lr * genf).sum() / denom
+    loss['pos'] = (F.mse_loss(p_pred, pos_target, reduction='none').sum(-1) * genf).sum() / denom
+    post_true = _posterior(vs.alpha_bars, s_n, s_0, t)
+    log_pred = torch.log(_posterior(vs.alpha_bars, s_n, c_den, t) + 1e-8)
+    kl = F.kl_div(input=log_pred, target=post_true, reduction='none', log_target=False).sum(-1)
+    loss['seq'] = (kl * genf).sum() / denom
+    return loss
