@@ -29,7 +29,7 @@ struct Carver {
 };
 
 constexpr int F = 128, FI = F + 4;
-constexpr int OUT_KSPLIT = 4;     // out_transform (K = 1824, N = 128) has only M/64 * 2 tiles: split K so it fills the chip
+constexpr int OUT_KSPLIT = 8;     // out_transform (K = 1824, N = 128) has only M/64 * 2 tiles: split K so it fills the chip
 
 struct GaScratch { float *proj, *feat, *u, *y, *h1, *h2; };
 static GaScratch carve_ga(Carver& cv, int64_t M) {
@@ -56,11 +56,8 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
     if ((rc = launch_linear(feat, ABOPT_IPA_FEAT, w->w_out, ABOPT_IPA_FEAT, nullptr, s.u, F, (int)M, F, ABOPT_IPA_FEAT, false, st,
                             OUT_KSPLIT, M * F))) return rc;
-    if ((rc = launch_residual_layernorm(x, s.u, mask, w->ln1_gamma, w->ln1_beta, s.y, M, st, OUT_KSPLIT, M * F, w->b_out))) return rc;
-    if ((rc = launch_linear(s.y, F, w->w_mlp0, F, w->b_mlp0, s.h1, F, (int)M, F, F, true, st))) return rc;
-    if ((rc = launch_linear(s.h1, F, w->w_mlp1, F, w->b_mlp1, s.h2, F, (int)M, F, F, true, st))) return rc;
-    if ((rc = launch_linear(s.h2, F, w->w_mlp2, F, w->b_mlp2, s.h1, F, (int)M, F, F, false, st))) return rc;
-    if ((rc = launch_residual_layernorm(s.y, s.h1, nullptr, w->ln2_gamma, w->ln2_beta, x_out, M, st))) return rc;
+    if ((rc = launch_fused_ln_mlp(x, s.u, OUT_KSPLIT, M * F, w->b_out, mask, w->ln1_gamma, w->ln1_beta, w->w_mlp0, w->b_mlp0, w->w_mlp1, w->b_mlp1,
+                                  w->w_mlp2, w->b_mlp2, w->ln2_gamma, w->ln2_beta, x_out, M, st))) return rc;
     return ABOPT_OK;
 }
 

@@ -129,10 +129,6 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
     {                                                                                                                    \
         const int64_t zrow_ = rowbase + ((abl & 16) ? 0 : min(i0 + w4 * RPW + (ROW), L - 1));                            \
         const float* zi_ = z + (zrow_ * (int64_t)L) * C;                                                                 \
-        if (abl & 1024) {   /* timing experiment: same bytes, but the workgroup's 16 row-chunks of a step are contiguous (tiled layout) */ \
-            const float* zt_ = z + ((rowbase + i0) * (int64_t)L + ((int64_t)min((CH), nchunk - 1) * BI + w4 * RPW + (ROW)) * JC) * C;        \
-            _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) ring[SLOT][r_] = *(reinterpret_cast<const f32x4*>(zt_ + (kq * 4 + r_) * C) + fm);  \
-        } else                                                                                                           \
         if (!(abl & 512)) _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                              \
             ring[SLOT][r_] = *(reinterpret_cast<const f32x4*>(zi_ + (int64_t)min((CH) * JC + kq * 4 + r_, L - 1) * C) + fm); \
         if (CACHED) ringb[SLOT] = *(reinterpret_cast<const f32x4*>(pbc + (zrow_ * nchunk + min((CH), nchunk - 1)) * 256) + lane);  \
