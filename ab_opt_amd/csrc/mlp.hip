@@ -4,7 +4,8 @@
 // (reference AbDock/src/modules/encoders/ga.py:174-177, LayerNorm: AbDock/src/modules/common/layers.py:146-155).
 // Replaces two LayerNorm launches and three 128x128 GEMM launches whose operands (8192 x 128 activations) are tiny: the
 // work per row block is latency/launch bound, so a 256-thread workgroup keeps its 32 rows on chip (LDS) through all three
-// layers and streams the three 64 KB weight matrices from L2.  fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32.
+// layers and stages each 64 KB weight matrix into LDS once (register-prefetched behind the previous phase).
+// fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32.
 #include "abopt_common.h"
 #include "kernels.h"
 
@@ -15,31 +16,51 @@ constexpr int F = 128, XLD = F + 4;
 
 __device__ __forceinline__ f32x4 mfma4m(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// one dense layer, one wave: 16 rows x 64 output columns (n-tiles 4*half .. 4*half+3) = X[16, 128] . W[64 rows of it, 128]^T.
-// All weight fragments of the layer are requested up front (they come from L2; 32 independent loads in flight).
-__device__ __forceinline__ void wave_linear(const float (*xs)[XLD], const float* __restrict__ W, int half, int fm, int kq, f32x4 (&acc)[4]) {
+constexpr int MR = 32;                     // rows per workgroup
+constexpr int WPT = F * F / 4 / 256;       // float4 weight loads per thread per layer (16)
+
+// the 64 KB weight matrix of one layer travels global -> registers (issued early, hidden behind the previous phase) -> LDS
+struct WRegs { f32x4 v[WPT]; };
+__device__ __forceinline__ WRegs mlp_load_w(const float* __restrict__ W) {
+    WRegs r;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* wrow = W + (size_t)(half * 64 + fm) * F + kq * 4;      // lane group kq supplies k = 16 kb + 4 kq + s
-    float4 b[F / 16][4];                                                // the wave's whole 64 x 128 weight slice: 32 loads in flight at once
+    for (int i = 0; i < WPT; ++i) r.v[i] = reinterpret_cast<const f32x4*>(W)[i * 256 + threadIdx.x];
+    return r;
+}
+__device__ __forceinline__ void mlp_store_w(float (*wl)[XLD], const WRegs& r) {
 #pragma unroll
-    for (int kb = 0; kb < F / 16; ++kb)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) b[kb][nt] = *reinterpret_cast<const float4*>(wrow + (size_t)nt * 16 * F + kb * 16);
-#pragma unroll
-    for (int kb = 0; kb < F / 16; ++kb) {
-        const float4 a = *reinterpret_cast<const float4*>(&xs[fm][kb * 16 + kq * 4]);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            acc[nt] = mfma4m(a.x, b[kb][nt].x, acc[nt]); acc[nt] = mfma4m(a.y, b[kb][nt].y, acc[nt]);
-            acc[nt] = mfma4m(a.z, b[kb][nt].z, acc[nt]); acc[nt] = mfma4m(a.w, b[kb][nt].w, acc[nt]);
-        }
+    for (int i = 0; i < WPT; ++i) {
+        const int e = (i * 256 + threadIdx.x) * 4;
+        *reinterpret_cast<f32x4*>(&wl[e >> 7][e & 127]) = r.v[i];
     }
 }
 
-// 128 threads = 2 waves = the two column halves (64 output columns each) of one 16-row group.  Small workgroups on purpose:
-// the phases are latency chains (L2 weight loads, LayerNorm reductions), several co-resident workgroups per CU overlap them.
-__global__ __launch_bounds__(128) void fused_ln_mlp_kernel(const float* __restrict__ x, const float* __restrict__ u, int nslab, int64_t slab_stride,
+// one dense layer, one wave: 16 rows x 64 output columns = X[16, 128] . W[64 rows of it, 128]^T, both operands from LDS.
+// W is the MFMA A operand, so the accumulator is the transposed tile: a lane holds 4 consecutive output columns of row fm.
+__device__ __forceinline__ void wave_linear(const float (*xs)[XLD], const float (*wl)[XLD], int half, int fm, int kq, f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < F / 16; ++kb) {
+        const float4 a = *reinterpret_cast<const float4*>(&xs[fm][kb * 16 + kq * 4]);
+        float4 b[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) b[nt] = *reinterpret_cast<const float4*>(&wl[half * 64 + nt * 16 + fm][kb * 16 + kq * 4]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma4m(b[nt].x, a.x, acc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma4m(b[nt].y, a.y, acc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma4m(b[nt].z, a.z, acc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma4m(b[nt].w, a.w, acc[nt]);
+    }
+}
+
+// 256 threads = 4 waves = (2 groups of 16 rows) x (2 column halves).  One workgroup per CU (118 KB of LDS): 32 rows stay on
+// chip through LayerNorm1, the three layers and LayerNorm2; each layer's weights are staged once per workgroup.
+template <int NSLAB>
+__global__ __launch_bounds__(256) void fused_ln_mlp_kernel(const float* __restrict__ x, const float* __restrict__ u, int64_t slab_stride,
                                                            const float* __restrict__ ubias, const uint8_t* __restrict__ mask,
                                                            const float* __restrict__ g1, const float* __restrict__ be1,
                                                            const float* __restrict__ W0, const float* __restrict__ b0,
@@ -47,22 +68,25 @@ __global__ __launch_bounds__(128) void fused_ln_mlp_kernel(const float* __restri
                                                            const float* __restrict__ W2, const float* __restrict__ b2,
                                                            const float* __restrict__ g2, const float* __restrict__ be2,
                                                            float* __restrict__ out, int64_t rows) {
-    __shared__ __attribute__((aligned(16))) float ys[1][16][XLD];     // LayerNorm1 output (residual of the MLP)
-    __shared__ __attribute__((aligned(16))) float ha[1][16][XLD];     // activations, ping
-    __shared__ __attribute__((aligned(16))) float hb[1][16][XLD];     // activations, pong
+    __shared__ __attribute__((aligned(16))) float ys[MR][XLD];     // LayerNorm1 output (residual of the MLP)
+    __shared__ __attribute__((aligned(16))) float ha[MR][XLD];     // activations, ping
+    __shared__ __attribute__((aligned(16))) float hb[MR][XLD];     // activations, pong
+    __shared__ __attribute__((aligned(16))) float wl[F][XLD];      // current layer's weights
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fm = lane & 15, kq = lane >> 4;
-    const int rg = 0, half = wave & 1;
-    const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int rg = wave >> 1, half = wave & 1;
+    const int64_t row0 = (int64_t)blockIdx.x * MR;
+    WRegs wreg = mlp_load_w(W0);
 
-    // ---- LayerNorm1: the two waves of a row group take 8 rows each, one row at a time across the wave
+    // ---- LayerNorm1: each wave takes 8 rows, one row at a time across the wave
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int r = half * 8 + rr;
+    for (int rr = 0; rr < MR / 4; ++rr) {
+        const int r = wave * (MR / 4) + rr;
         const int64_t row = min(row0 + r, rows - 1);
         const bool keep = mask ? (mask[row] != 0) : true;
         const float2 xv = reinterpret_cast<const float2*>(x + row * F)[lane];
         float2 uv = reinterpret_cast<const float2*>(u + row * F)[lane];
-        for (int sl = 1; sl < nslab; ++sl) { const float2 w = reinterpret_cast<const float2*>(u + sl * slab_stride + row * F)[lane]; uv.x += w.x; uv.y += w.y; }
+#pragma unroll
+        for (int sl = 1; sl < NSLAB; ++sl) { const float2 w = reinterpret_cast<const float2*>(u + sl * slab_stride + row * F)[lane]; uv.x += w.x; uv.y += w.y; }
         if (ubias) { const float2 bb = reinterpret_cast<const float2*>(ubias)[lane]; uv.x += bb.x; uv.y += bb.y; }
         if (!keep) uv = make_float2(0.f, 0.f);
         const float a = xv.x + uv.x, b = xv.y + uv.y;
@@ -71,43 +95,51 @@ __global__ __launch_bounds__(128) void fused_ln_mlp_kernel(const float* __restri
         const float var = wave_sum(da * da + db * db) * (1.f / F);
         const float sd = sqrtf(var + 1e-10f);
         const float2 g = reinterpret_cast<const float2*>(g1)[lane], bt = reinterpret_cast<const float2*>(be1)[lane];
-        *reinterpret_cast<float2*>(&ys[rg][r][2 * lane]) = make_float2(da / sd * g.x + bt.x, db / sd * g.y + bt.y);
+        *reinterpret_cast<float2*>(&ys[r][2 * lane]) = make_float2(da / sd * g.x + bt.x, db / sd * g.y + bt.y);
     }
+    mlp_store_w(wl, wreg);
+    wreg = mlp_load_w(W1);
     __syncthreads();
     f32x4 acc[4];
     // ---- layer 0: relu(W0 y + b0) -> ha
-    wave_linear(ys[rg], W0, half, fm, kq, acc);
+    wave_linear(ys + rg * 16, wl, half, fm, kq, acc);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int col = half * 64 + nt * 16 + fm;
-        const float bv = b0[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ha[rg][kq * 4 + r][col] = fmaxf(acc[nt][r] + bv, 0.f);
+        const int col = half * 64 + nt * 16 + kq * 4;
+        const float4 bv = *reinterpret_cast<const float4*>(b0 + col);
+        *reinterpret_cast<float4*>(&ha[rg * 16 + fm][col]) = make_float4(fmaxf(acc[nt][0] + bv.x, 0.f), fmaxf(acc[nt][1] + bv.y, 0.f),
+                                                                          fmaxf(acc[nt][2] + bv.z, 0.f), fmaxf(acc[nt][3] + bv.w, 0.f));
     }
+    __syncthreads();
+    mlp_store_w(wl, wreg);
+    wreg = mlp_load_w(W2);
     __syncthreads();
     // ---- layer 1: relu(W1 h + b1) -> hb
-    wave_linear(ha[rg], W1, half, fm, kq, acc);
+    wave_linear(ha + rg * 16, wl, half, fm, kq, acc);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int col = half * 64 + nt * 16 + fm;
-        const float bv = b1[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hb[rg][kq * 4 + r][col] = fmaxf(acc[nt][r] + bv, 0.f);
+        const int col = half * 64 + nt * 16 + kq * 4;
+        const float4 bv = *reinterpret_cast<const float4*>(b1 + col);
+        *reinterpret_cast<float4*>(&hb[rg * 16 + fm][col]) = make_float4(fmaxf(acc[nt][0] + bv.x, 0.f), fmaxf(acc[nt][1] + bv.y, 0.f),
+                                                                          fmaxf(acc[nt][2] + bv.z, 0.f), fmaxf(acc[nt][3] + bv.w, 0.f));
     }
+    __syncthreads();
+    mlp_store_w(wl, wreg);
     __syncthreads();
     // ---- layer 2 + residual -> ha, then LayerNorm2
-    wave_linear(hb[rg], W2, half, fm, kq, acc);
+    wave_linear(hb + rg * 16, wl, half, fm, kq, acc);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int col = half * 64 + nt * 16 + fm;
-        const float bv = b2[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ha[rg][kq * 4 + r][col] = ys[rg][kq * 4 + r][col] + (acc[nt][r] + bv);
+        const int col = half * 64 + nt * 16 + kq * 4;
+        const float4 bv = *reinterpret_cast<const float4*>(b2 + col);
+        const float4 yv = *reinterpret_cast<const float4*>(&ys[rg * 16 + fm][col]);
+        *reinterpret_cast<float4*>(&ha[rg * 16 + fm][col]) = make_float4(yv.x + (acc[nt][0] + bv.x), yv.y + (acc[nt][1] + bv.y),
+                                                                          yv.z + (acc[nt][2] + bv.z), yv.w + (acc[nt][3] + bv.w));
     }
     __syncthreads();
-    for (int r = half * 8; r < half * 8 + 8; ++r) {
+    for (int r = wave * (MR / 4); r < (wave + 1) * (MR / 4); ++r) {
         const int64_t row = row0 + r;
-        const float2 v = *reinterpret_cast<const float2*>(&ha[rg][r][2 * lane]);
+        const float2 v = *reinterpret_cast<const float2*>(&ha[r][2 * lane]);
         const float mean = wave_sum(v.x + v.y) * (1.f / F);
         const float da = v.x - mean, db = v.y - mean;
         const float var = wave_sum(da * da + db * db) * (1.f / F);
@@ -121,8 +153,17 @@ int launch_fused_ln_mlp(const float* x, const float* u, int nslab, int64_t slab_
                         const float* g1, const float* be1, const float* W0, const float* b0, const float* W1, const float* b1,
                         const float* W2, const float* b2, const float* g2, const float* be2, float* out, int64_t rows, hipStream_t st) {
     if (rows == 0) return ABOPT_OK;
-    hipLaunchKernelGGL(fused_ln_mlp_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(128), 0, st, x, u, nslab, slab_stride, ubias, mask,
-                       g1, be1, W0, b0, W1, b1, W2, b2, g2, be2, out, rows);
+#define ABOPT_MLP_LAUNCH(NS)                                                                                                  \
+    hipLaunchKernelGGL(fused_ln_mlp_kernel<NS>, dim3((unsigned)((rows + MR - 1) / MR)), dim3(256), 0, st, x, u, slab_stride, ubias, mask, \
+                       g1, be1, W0, b0, W1, b1, W2, b2, g2, be2, out, rows)
+    switch (nslab) {
+        case 1: ABOPT_MLP_LAUNCH(1); break;
+        case 2: ABOPT_MLP_LAUNCH(2); break;
+        case 4: ABOPT_MLP_LAUNCH(4); break;
+        case 8: ABOPT_MLP_LAUNCH(8); break;
+        default: ABOPT_CHECK_ARG(false, "fused_ln_mlp: unsupported slab count %d", nslab);
+    }
+#undef ABOPT_MLP_LAUNCH
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }
