@@ -86,6 +86,37 @@ extern "C" int abopt_device_info(int* cu_count, int* lds_bytes_per_cu, char* arc
     return ABOPT_OK;
 }
 
+static int check_encode_inputs(const abopt_encode_inputs* in, const char* who) {
+    ABOPT_CHECK_ARG(in, "%s: NULL inputs", who);
+    ABOPT_CHECK_ARG(in->N >= 0 && in->L >= 0 && (int64_t)in->N * in->L < (1ll << 31) / 64, "%s: bad batch dims N=%d L=%d", who, in->N, in->L);
+    if ((int64_t)in->N * in->L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(in->aa && in->res_nb && in->chain_nb && in->pos_atoms && in->mask_atoms, "%s: NULL input tensor", who);
+    return ABOPT_OK;
+}
+
+extern "C" size_t abopt_residue_embed_workspace_bytes(int N, int L, int atoms, int hotspot) { return residue_embed_ws_bytes(N, L, atoms, hotspot); }
+extern "C" size_t abopt_pair_embed_workspace_bytes(int N, int L, int atoms) { return pair_embed_ws_bytes(N, L, atoms); }
+
+extern "C" int abopt_residue_embed_forward(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* res_feat, float* R, float* p,
+                                           void* ws, size_t ws_bytes, abopt_stream stream) {
+    int rc;
+    if ((rc = check_encode_inputs(in, "residue_embed_forward"))) return rc;
+    if ((int64_t)in->N * in->L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(in->fragment_type && w && w->aatype_embed && w->type_embed && w->freq_bands && w->w0 && w->b0 && w->w1 && w->b1 && w->w2 && w->b2 && w->w3 && w->b3 && ws,
+                    "residue_embed_forward: NULL argument");
+    return launch_residue_embed(in, w, res_feat, R, p, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat,
+                                        void* ws, size_t ws_bytes, abopt_stream stream) {
+    int rc;
+    if ((rc = check_encode_inputs(in, "pair_embed_forward"))) return rc;
+    if ((int64_t)in->N * in->L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(w && w->aa_pair_embed && w->relpos_embed && w->aapair_to_distcoef && w->freq_bands && w->wd0 && w->bd0 && w->wd1 && w->bd1 &&
+                    w->wo0 && w->bo0 && w->wo1 && w->bo1 && w->wo2 && w->bo2 && pair_feat && ws, "pair_embed_forward: NULL argument");
+    return launch_pair_embed(in, w, pair_feat, ws, ws_bytes, (hipStream_t)stream);
+}
+
 extern "C" int abopt_so3_exp(const float* w, float* R, int64_t n, abopt_stream stream) {
     ABOPT_CHECK_ARG(w && R && n >= 0, "so3_exp: bad arguments");
     return launch_so3_exp(w, R, n, (hipStream_t)stream);

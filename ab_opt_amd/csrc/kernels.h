@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/abopt.h"
 
 namespace abopt {
 
@@ -38,5 +39,12 @@ int launch_heads_epilogue(const float* R, const float* v_t, const float* eps_crd
                           int64_t rows, int grad_mode, hipStream_t st);
 // out[n, b] = mean_l in[n, l, b]
 int launch_mean_over_L(const float* in, float* out, int N, int L, int B, hipStream_t st);
+
+// embed.hip: encode() ----------------------------------------------------------------------------
+size_t residue_embed_ws_bytes(int N, int L, int A, int hotspot);
+int launch_residue_embed(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* res_feat, float* R, float* p,
+                         void* ws, size_t ws_bytes, hipStream_t st);
+size_t pair_embed_ws_bytes(int N, int L, int A);
+int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace abopt

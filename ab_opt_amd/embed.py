@@ -1,13 +1,17 @@
-"""encode(): residue and pair embeddings ("next" after the denoising path).
+"""encode(): residue and pair embeddings.
 
-Runs once per sample()/optimize() call and is outside the denoising-steps/sec metric.  In this round it
-is expressed with torch ops on the HIP device (PyTorch-ROCm plumbing); the fused MFMA kernels for the
-L^2 x {225->64, 218->64} GEMMs are the next scope row.  Module / parameter names mirror
+Runs once per sample()/optimize() call (outside the denoising-steps/sec metric) and every iteration in
+training.  Inference (`torch.no_grad()`) executes in libabopt_hip.so (`forward_hip`, csrc/embed.hip: one
+register-resident MFMA kernel for the pair embedding, a feature kernel + MFMA GEMMs for the residue
+embedding).  The `forward` methods below are the differentiable statement of the same maths used on the
+training path (torch autograd on the HIP device).  Module / parameter names mirror
 AbDock/src/modules/encoders/residue.py:9-92 and pair.py:10-101 so checkpoints load strictly.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import hip
 
 AA_UNK, ATOM_N, ATOM_CA, ATOM_C = 20, 0, 1, 2
 
@@ -75,6 +79,24 @@ class ResidueEmbedding(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(infeat_dim, feat_dim * 2), nn.ReLU(), nn.Linear(feat_dim * 2, feat_dim), nn.ReLU(),
                                  nn.Linear(feat_dim, feat_dim), nn.ReLU(), nn.Linear(feat_dim, feat_dim))
 
+    def _hip_weights(self):
+        ps = [self.aatype_embed.weight, self.type_embed.weight, self.dihed_embed.freq_bands] + [m.weight for m in self.mlp if isinstance(m, nn.Linear)] + \
+             [m.bias for m in self.mlp if isinstance(m, nn.Linear)] + ([self.hotspot_embed.weight] if self.hotspot_embed is not None else [])
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, '_hip_key', None) != key:
+            lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
+            t = [p.detach().contiguous() for p in (self.aatype_embed.weight, self.type_embed.weight, self.dihed_embed.freq_bands,
+                                                   lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias, lin[3].weight, lin[3].bias)]
+            hs = self.hotspot_embed.weight.detach().contiguous() if self.hotspot_embed is not None else None
+            w = hip.ResidueEmbedWeights(hip.ptr(t[0], torch.float32), hip.ptr(t[1], torch.float32), hip.ptr(hs, torch.float32, optional=True),
+                                        *[hip.ptr(x, torch.float32) for x in t[2:]])
+            self._hip_key, self._hip_w, self._hip_keep = key, w, t + [hs]
+        return self._hip_w
+
+    def forward_hip(self, inp):
+        """Inference path: abopt_residue_embed_forward -> res_feat (N,L,128), R (N,L,3,3), p = CA (N,L,3)."""
+        return hip.residue_embed_forward(inp, self._hip_weights(), self.hotspot_embed is not None)
+
     def forward(self, aa, res_nb, chain_nb, pos_atoms, mask_atoms, fragment_type, hotspot=None, structure_mask=None, sequence_mask=None):
         N, L = aa.size()
         A = self.max_num_atoms
@@ -118,6 +140,21 @@ class PairEmbedding(nn.Module):
         infeat_dim = feat_dim * 3 + self.dihedral_embed.get_out_dim(2)
         self.out_mlp = nn.Sequential(nn.Linear(infeat_dim, feat_dim), nn.ReLU(), nn.Linear(feat_dim, feat_dim), nn.ReLU(),
                                      nn.Linear(feat_dim, feat_dim))
+
+    def _hip_weights(self):
+        lin = [m for m in list(self.distance_embed) + list(self.out_mlp) if isinstance(m, nn.Linear)]
+        ps = [self.aa_pair_embed.weight, self.relpos_embed.weight, self.aapair_to_distcoef.weight, self.dihedral_embed.freq_bands]
+        for m in lin:
+            ps += [m.weight, m.bias]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, '_hip_key', None) != key:
+            t = [p.detach().contiguous() for p in ps]
+            self._hip_key, self._hip_w, self._hip_keep = key, hip.PairEmbedWeights(*[hip.ptr(x, torch.float32) for x in t]), t
+        return self._hip_w
+
+    def forward_hip(self, inp):
+        """Inference path: abopt_pair_embed_forward -> pair_feat (N,L,L,64)."""
+        return hip.pair_embed_forward(inp, self._hip_weights())
 
     def forward(self, aa, res_nb, chain_nb, pos_atoms, mask_atoms, structure_mask=None, sequence_mask=None):
         N, L = aa.size()

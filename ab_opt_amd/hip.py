@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -38,6 +38,21 @@ class EpsWeights(C.Structure):
                 [('num_bins', C.c_int)])
 
 
+class EncodeInputs(C.Structure):
+    _fields_ = ([('N', C.c_int), ('L', C.c_int), ('atoms_in', C.c_int), ('atoms', C.c_int)] +
+                [(n, C.c_void_p) for n in ('aa', 'res_nb', 'chain_nb', 'fragment_type', 'hotspot', 'pos_atoms', 'mask_atoms',
+                                           'structure_mask', 'sequence_mask')])
+
+
+class ResidueEmbedWeights(C.Structure):
+    _fields_ = [(n, c_f) for n in ('aatype_embed', 'type_embed', 'hotspot_embed', 'freq_bands', 'w0', 'b0', 'w1', 'b1', 'w2', 'b2', 'w3', 'b3')]
+
+
+class PairEmbedWeights(C.Structure):
+    _fields_ = [(n, c_f) for n in ('aa_pair_embed', 'relpos_embed', 'aapair_to_distcoef', 'freq_bands', 'wd0', 'bd0', 'wd1', 'bd1',
+                                   'wo0', 'bo0', 'wo1', 'bo1', 'wo2', 'bo2')]
+
+
 class StepParams(C.Structure):
     _fields_ = [('t', C.c_int), ('alpha_clamped', C.c_float), ('alpha_bar', C.c_float), ('sigma', C.c_float),
                 ('sqrt_recip_abar', C.c_float), ('sqrt_recipm1_abar', C.c_float), ('igso3_std', C.c_float),
@@ -57,7 +72,8 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect']
+           'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect',
+           'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward']
 
 _lib = None
 _lock = threading.Lock()
@@ -105,6 +121,12 @@ def lib():
                                       c_f, c_f, c_i64, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_prof_enable.argtypes = [C.c_int]
         L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.abopt_residue_embed_workspace_bytes.restype = C.c_size_t
+        L.abopt_residue_embed_workspace_bytes.argtypes = [C.c_int] * 4
+        L.abopt_pair_embed_workspace_bytes.restype = C.c_size_t
+        L.abopt_pair_embed_workspace_bytes.argtypes = [C.c_int] * 3
+        L.abopt_residue_embed_forward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(ResidueEmbedWeights), c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_pair_embed_forward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         for name in EXPORTS:
             getattr(L, name)          # AttributeError here = a symbol of include/abopt.h is missing
         if L.abopt_abi_version() != ABI_VERSION:
@@ -304,6 +326,39 @@ def commonness_score(structs):
     score = torch.empty(B, device=structs.device)
     _check(lib().abopt_commonness_score(ptr(structs), ptr(score), B, n, stream()))
     return score
+
+
+def encode_inputs(aa, res_nb, chain_nb, pos_atoms, mask_atoms, atoms, fragment_type=None, hotspot=None, structure_mask=None, sequence_mask=None):
+    """-> (EncodeInputs, keepalive list).  Tensors are made contiguous; the struct only borrows their pointers."""
+    N, L = aa.shape
+    keep = [aa.contiguous(), res_nb.contiguous(), chain_nb.contiguous(), pos_atoms.contiguous(), mask_atoms.contiguous()]
+    opt = [None if t is None else t.contiguous() for t in (fragment_type, hotspot, structure_mask, sequence_mask)]
+    s = EncodeInputs(N, L, pos_atoms.shape[2], atoms, ptr(keep[0], torch.int64), ptr(keep[1], torch.int64), ptr(keep[2], torch.int64),
+                     ptr(opt[0], torch.int64, optional=True), ptr(opt[1], torch.int64, optional=True), ptr(keep[3], torch.float32),
+                     ptr(keep[4], torch.bool), ptr(opt[2], torch.bool, optional=True), ptr(opt[3], torch.bool, optional=True))
+    return s, keep + opt
+
+
+def residue_embed_forward(inp, weights, has_hotspot):
+    N, L = inp.N, inp.L
+    dev = torch.device('cuda', torch.cuda.current_device())
+    res_feat = torch.empty(N, L, 128, device=dev)
+    R = torch.empty(N, L, 3, 3, device=dev)
+    p = torch.empty(N, L, 3, device=dev)
+    nb = lib().abopt_residue_embed_workspace_bytes(N, L, inp.atoms, int(has_hotspot))
+    buf = Workspace.get(nb, dev)
+    _check(lib().abopt_residue_embed_forward(C.byref(inp), C.byref(weights), ptr(res_feat), ptr(R), ptr(p), ptr(buf), buf.numel(), stream()))
+    return res_feat, R, p
+
+
+def pair_embed_forward(inp, weights):
+    N, L = inp.N, inp.L
+    dev = torch.device('cuda', torch.cuda.current_device())
+    pair_feat = torch.empty(N, L, L, 64, device=dev)
+    nb = lib().abopt_pair_embed_workspace_bytes(N, L, inp.atoms)
+    buf = Workspace.get(nb, dev)
+    _check(lib().abopt_pair_embed_forward(C.byref(inp), C.byref(weights), ptr(pair_feat), ptr(buf), buf.numel(), stream()))
+    return pair_feat
 
 
 def prof_enable(on=True):

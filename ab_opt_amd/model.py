@@ -75,6 +75,12 @@ class _DiffabBase(nn.Module):
         sm = ctx if remove_structure else None
         qm = ctx if remove_sequence else None
         extra = {} if self.ABDOCK else dict(hotspot=batch.get('hotspot'))
+        if not torch.is_grad_enabled():          # sample / optimize: HIP kernels (csrc/embed.hip); training keeps the autograd statement
+            inp, keep = hip.encode_inputs(batch['aa'], batch['res_nb'], batch['chain_nb'], batch['pos_heavyatom'], batch['mask_heavyatom'],
+                                          self.residue_embed.max_num_atoms, fragment_type=batch['fragment_type'], hotspot=extra.get('hotspot'),
+                                          structure_mask=sm, sequence_mask=qm)
+            res_feat, R, p = self.residue_embed.forward_hip(inp)
+            return res_feat, self.pair_embed.forward_hip(inp), R, p
         res_feat = self.residue_embed(aa=batch['aa'], res_nb=batch['res_nb'], chain_nb=batch['chain_nb'],
                                       pos_atoms=batch['pos_heavyatom'], mask_atoms=batch['mask_heavyatom'],
                                       fragment_type=batch['fragment_type'], structure_mask=sm, sequence_mask=qm, **extra)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 2
+#define ABOPT_ABI_VERSION 3
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -187,6 +187,57 @@ int abopt_add_noise(const int64_t* t, const float* alpha_bars, const float* fwd_
 
 /* ---- Batched-sampling reduction: D/tools/runner/design_for_testset.py:556-589 (calc_per_rmsd +
  * rank_commoness score).  structs [B,n,3] -> score [B] = mean_{b'} RMSD(b,b') * B/(B-1). */
+/* ---- encode(): D/models/diffab.py:39-83.  ResidueEmbedding.forward (D/modules/encoders/residue.py:26-92; the AbDesign
+ * variant adds hotspot_embed, A/modules/encoders/residue.py:19-21), PairEmbedding.forward (D/modules/encoders/pair.py:37-101),
+ * construct_3d_basis (D/modules/common/geometry.py:47-69).  Feature widths are fixed: res_feat_dim 128, pair_feat_dim 64,
+ * max_aa_types 22, max_relpos 32. */
+typedef struct {
+    int N, L;
+    int atoms_in;                    /* atoms per residue in pos_atoms / mask_atoms (15) */
+    int atoms;                       /* atoms the embeddings use: 15 ('full') or 5 ('backbone+CB'), D/models/diffab.py:13-16 */
+    const int64_t* aa;               /* [N,L] */
+    const int64_t* res_nb;           /* [N,L] */
+    const int64_t* chain_nb;         /* [N,L] */
+    const int64_t* fragment_type;    /* [N,L]  (residue embedding only) */
+    const int64_t* hotspot;          /* [N,L] or NULL -> zeros (AbDesign residue embedding only) */
+    const float*   pos_atoms;        /* [N,L,atoms_in,3] Angstrom */
+    const uint8_t* mask_atoms;       /* [N,L,atoms_in] */
+    const uint8_t* structure_mask;   /* [N,L] or NULL (diffab.py:47-55) */
+    const uint8_t* sequence_mask;    /* [N,L] or NULL */
+} abopt_encode_inputs;
+
+typedef struct {
+    const float* aatype_embed;       /* [22, 128] */
+    const float* type_embed;         /* [10, 128] */
+    const float* hotspot_embed;      /* [10, 128] or NULL (AbDock) */
+    const float* freq_bands;         /* [6] dihed_embed.freq_bands */
+    const float* w0; const float* b0;/* mlp.0 [256, in], in = 128 + 22*atoms*3 + 39 + 128 (+128 with hotspot) */
+    const float* w1; const float* b1;/* mlp.2 [128, 256] */
+    const float* w2; const float* b2;/* mlp.4 [128, 128] */
+    const float* w3; const float* b3;/* mlp.6 [128, 128] */
+} abopt_residue_embed_weights;
+
+typedef struct {
+    const float* aa_pair_embed;      /* [484, 64] */
+    const float* relpos_embed;       /* [65, 64] */
+    const float* aapair_to_distcoef; /* [484, atoms*atoms] */
+    const float* freq_bands;         /* [6] dihedral_embed.freq_bands */
+    const float* wd0; const float* bd0;   /* distance_embed.0 [64, atoms*atoms] */
+    const float* wd1; const float* bd1;   /* distance_embed.2 [64, 64] */
+    const float* wo0; const float* bo0;   /* out_mlp.0 [64, 218] */
+    const float* wo1; const float* bo1;   /* out_mlp.2 [64, 64] */
+    const float* wo2; const float* bo2;   /* out_mlp.4 [64, 64] */
+} abopt_pair_embed_weights;
+
+size_t abopt_residue_embed_workspace_bytes(int N, int L, int atoms, int hotspot);
+/* -> res_feat [N,L,128]; R [N,L,3,3] = construct_3d_basis(CA, C, N); p [N,L,3] = CA (diffab.py:76-83) */
+int abopt_residue_embed_forward(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* res_feat, float* R, float* p,
+                                void* ws, size_t ws_bytes, abopt_stream stream);
+size_t abopt_pair_embed_workspace_bytes(int N, int L, int atoms);
+/* -> pair_feat [N,L,L,64] */
+int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat,
+                             void* ws, size_t ws_bytes, abopt_stream stream);
+
 int abopt_commonness_score(const float* structs, float* score, int B, int n, abopt_stream stream);
 
 /* ---- Measurement hook (bench.py's roofline leg).  When enabled, every launch of the IPA-core kernel is bracketed

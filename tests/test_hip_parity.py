@@ -203,11 +203,94 @@ def test_encode_on_device_vs_reference():
     _, m, batch = _traj_setup()
     with torch.no_grad():
         rf, pf, R0, p0 = m.encode({k: dev(v) for k, v in batch.items()}, True, True)
-    # encode() is still torch-eager on the device (not a HIP kernel yet); the hash-filled embedding tables
-    # make these features O(1e3) with heavy cancellation, so compare relative to the largest magnitude
+    # HIP encode (csrc/embed.hip).  The hash-filled embedding tables make these features O(1e3) with heavy cancellation,
+    # so compare relative to the largest magnitude
     assert max_abs(rf.cpu(), g['res_feat']) < 2e-4 * g['res_feat'].abs().max().item()
     assert max_abs(pf.cpu()[:, ::7, ::5], g['pair_feat_sub']) < 2e-4 * g['pair_feat_sub'].abs().max().item()
     assert max_abs(R0.cpu(), g['R0']) < 2e-6
+
+
+def test_encode_small_fixture_ragged_masks():
+    """The reference's encode() on ragged lengths (24 / 19 of 128), two chains, both mask modes (golden encode_small)."""
+    g = load_golden('encode_small')
+    m = build_model(10, 3, device=DEV)
+    batch = synth.make_batch(2, synth.LAYOUT_128, seed=99, lengths=[24, 19])
+    batch['generate_flag'][:, 8:13] = True
+    batch['fragment_type'][:, :12] = 1
+    batch['fragment_type'][:, 12:] = 3
+    batch['fragment_type'] = batch['fragment_type'] * batch['mask']
+    batch['chain_nb'][:, 12:] = 1
+    b = {k: dev(v) for k, v in batch.items()}
+    with torch.no_grad():
+        rf, pf, R0, p0 = m.encode(dict(b), True, True)
+        rf2, pf2, _, _ = m.encode(dict(b), True, False)
+    sr, sp = g['res_feat'].abs().max().item(), g['pair_feat'].abs().max().item()
+    eye = torch.eye(pf.shape[1], dtype=torch.bool)[None, :, :, None]           # diagonal: sign of a zero triple product, see below
+    dpf = (pf.cpu() - g['pair_feat']).abs()
+    assert max_abs(rf.cpu(), g['res_feat']) < 2e-4 * sr and (dpf * ~eye).max().item() < 2e-4 * sp and (dpf * eye).max().item() < 2e-3 * sp
+    assert max_abs(R0.cpu(), g['R0']) < 2e-6 and max_abs(p0.cpu(), g['p0']) == 0
+    assert max_abs(rf2.cpu(), g['res_feat_seqkept']) < 2e-4 * sr
+    assert max_abs(pf2.cpu().double().sum((1, 2)), g['pair_feat_seqkept_sum']) < 2e-4 * g['pair_feat_seqkept_sum'].abs().max().item()
+
+
+@pytest.mark.parametrize('flavour,resolution,L,flags', [
+    ('abdock', 'full', 128, (True, True)), ('abdock', 'full', 128, (False, True)), ('abdock', 'full', 128, (False, False)),
+    ('abdock', 'backbone+CB', 128, (True, True)), ('abdesign', 'full', 128, (True, False)), ('abdesign', 'full', 256, (True, True))])
+def test_encode_hip_vs_autograd_statement(flavour, resolution, L, flags):
+    """HIP inference encode against the differentiable torch statement of the same module on the device (which is pinned to
+    the reference by the golden fixtures): both resolutions, hotspot embedding, every mask mode, ragged and full lengths."""
+    from ab_opt_amd import get_model
+    cfg = cases.cfg_abdock(10)
+    cfg['resolution'] = resolution
+    if flavour == 'abdesign':
+        for k in ('num_bins', 'dist_min', 'dist_max'):
+            cfg.pop(k)
+        cfg['diffusion'].pop('obj')
+    from conftest import AttrDict
+    m = synth.fill_module_(get_model(AttrDict(cfg)).eval(), seed=17).to(DEV)
+    # non-trivial distance coefficients (the reference initialises them to zero; trained values are not)
+    with torch.no_grad():
+        m.pair_embed.aapair_to_distcoef.weight.copy_(dev(synth.hash_tensor(tuple(m.pair_embed.aapair_to_distcoef.weight.shape), 23, scale=2.0)))
+    layout = synth.LAYOUT_256 if L == 256 else synth.LAYOUT_128
+    lengths = [L, L - 11, L // 2 + 3]
+    batch = {k: dev(v) for k, v in synth.make_batch(3, layout, seed=5, lengths=lengths).items()}
+    # side chains on every other residue (the synthetic complexes carry backbone + CB only), some atoms missing
+    batch['pos_heavyatom'][:, :, 5:] = batch['pos_heavyatom'][:, :, 1:2] + dev(synth.hash_tensor((3, L, 10, 3), 41, scale=3.0))
+    batch['mask_heavyatom'][:, ::2, 5:12] = True
+    batch['mask_heavyatom'][:, ::6, 3] = False
+    batch['mask_heavyatom'] &= batch['mask'][:, :, None]
+    if flavour == 'abdesign':
+        batch['hotspot'] = (dev(synth.hash_tensor((3, L), 31, scale=1.0)) > 0.7).long() * batch['mask'].long()
+    with torch.enable_grad():
+        ref = [t.detach() for t in m.encode(dict(batch), *flags)]
+    # the same statement in float64: the yardstick.  The hash-filled tables give O(1e3) features with heavy cancellation
+    # (and acos near its clamp on the i == j diagonal), so fp32 results differ from the exact value by ~1e-4 relative
+    # whatever the summation order; the HIP path must be as close to the fp64 value as the fp32 torch statement is.
+    m64 = get_model(AttrDict(cfg)).eval()
+    m64.load_state_dict(m.state_dict())
+    m64 = m64.to(DEV).double()
+    b64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+    with torch.enable_grad():
+        ref64 = [t.detach() for t in m64.encode(dict(b64), *flags)]
+    with torch.no_grad():
+        out = m.encode(dict(batch), *flags)
+    for name, a, b, c in zip(('res_feat', 'pair_feat', 'R', 'p'), out, ref, ref64):
+        assert a.shape == b.shape, name
+        e_hip, e_t32 = (a.double() - c).abs(), (b.double() - c).abs()
+        assert e_hip.max().item() <= 1.5 * e_t32.max().item() + 1e-6, name
+        assert e_hip.mean().item() <= 1.5 * e_t32.mean().item() + 1e-7, name
+        if name == 'pair_feat':
+            # i == j: the psi-like dihedral (N_i, CA_i, C_i, N_i) is +-acos(0.999999) with the SIGN of an exactly-zero triple
+            # product (pair.py:86-88 / geometry.py:336-362), i.e. of rounding noise -- implementation-defined in the reference
+            # itself, so the diagonal is held to a looser bound
+            eye = torch.eye(L, dtype=torch.bool, device=DEV)[None, :, :, None]
+            scale = max(1.0, c.abs().max().item())
+            assert ((a - b).abs() * ~eye).max().item() <= 2e-4 * scale, name
+            assert ((a - b).abs() * eye).max().item() <= 2e-3 * scale, name
+        else:
+            assert max_abs(a, b) <= 2e-4 * max(1.0, c.abs().max().item()), name
+    # masked pairs / residues are exactly zero
+    assert out[1][~(batch['mask'][:, :, None] & batch['mask'][:, None, :])].abs().max().item() == 0
 
 
 def test_sample_init_vs_reference():

@@ -247,9 +247,12 @@ def test_encode_small():
     rf2, pf2, _, _ = embed.encode(sd, batch, True, False)
     assert max_abs(rf2, g['res_feat_seqkept']) < 2e-5
     assert max_abs(pf2.double().sum((1, 2)), g['pair_feat_seqkept_sum']) < 1e-3
-    # the product's own encode (torch ops, device-agnostic plumbing) against the same fixture
-    with torch.no_grad():
-        prf, ppf, pR, pp = m.encode({k: v.clone() for k, v in batch.items()}, True, True)
+    # the product's differentiable encode (training path, torch autograd) against the same fixture; the inference path is
+    # HIP-only and is checked in test_hip_parity.py
+    with torch.enable_grad():
+        prf, ppf, pR, pp = [t.detach() for t in m.encode({k: v.clone() for k, v in batch.items()}, True, True)]
+    with torch.no_grad(), pytest.raises(RuntimeError, match='no CPU path'):
+        m.encode({k: v.clone() for k, v in batch.items()}, True, True)
     assert max_abs(prf, g['res_feat']) < 2e-5 and max_abs(ppf, g['pair_feat']) < 2e-5 and max_abs(pR, g['R0']) < 1e-6
 
 
