@@ -16,6 +16,15 @@ void set_error(const char* fmt, ...);
     ::abopt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return ABOPT_EHIP; } } while (0)
 #define ABOPT_LAUNCH_CHECK() ABOPT_HIP(hipGetLastError())
 
+// Lanes of ONE wave exchanging data through LDS (write, then read what other lanes wrote): the hardware executes a wave's
+// LDS instructions in order, but the compiler may reorder a ds_read above a ds_write it cannot prove aliased.  This pins the
+// order at wavefront scope (no s_barrier; at most an s_waitcnt).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -326,8 +326,10 @@ __global__ __launch_bounds__(256, 2) void ipa_core_v1_kernel(const float* __rest
                     for (int r = 0; r < 4; ++r)
                         znext[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zi + (int64_t)min(njc0 + kq * 4 + r, L - 1) * C) + fm);
                 }
+                wave_lds_sync();                                            // previous row's transposed reads are done
 #pragma unroll
                 for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&sm.zst[wave][kq * 4 + r][fm * 4]) = zr[r];
+                wave_lds_sync();                                            // cross-lane transpose through LDS
                 f32x4 acc4[4];                                   // four independent chains (the 16x16x4 MFMA has a 40-cycle dependent latency)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                    // pair-bias: A row fm, channels 16 kq + 4 q ..; B = Wb rows (heads)
@@ -514,7 +516,7 @@ int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, cons
     }
     const int nib = (L + BI - 1) / BI;
     ABOPT_CHECK_ARG((int64_t)N * nib < (1ll << 31), "ipa_core: grid too large");
-    if (variant == 2) {
+    if (variant == 2 && L <= 2048) {                             // the wave-specialised kernel stages the key mask in LDS (WS_MAX_L); longer complexes take v1
         int rc = launch_ipa_core_ws(proj, z, mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, N, L, st);
         if (rc) return rc;
         if (dbg_alpha) {

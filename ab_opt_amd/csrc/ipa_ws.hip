@@ -19,6 +19,8 @@
 
 namespace abopt {
 
+constexpr int WS_MAX_L = 2048;       // longest complex this kernel takes (key mask staged in LDS); longer ones use ipa_core_v1
+
 struct WsSmem {
     float sp[2][BI][16 * PLD + 4];   // S then P per chunk parity, [i][h*PLD + j]
     float zst[8][JC][ZSLD];          // per-pair-wave z staging (transposes the chunk for the pair-bias MFMA)
@@ -28,6 +30,7 @@ struct WsSmem {
     float wbs[16][C + 4];            // pair-bias weights, rows 12..15 zero
     float coef[16];                  // -softplus(spatial_coef) sqrt(2/(9 P)) / 2
     float q[BI][H * D + 4];          // queries of the block (phase A operand A)
+    uint8_t mk[WS_MAX_L + 64];           // key mask of the sample (no global loads besides the z ring inside the pair-wave loop)
 };
 
 struct KFrag { float4 k0, k1; float2 g[3]; float nk; }; // phase A operands of one head: 8 key channels, 6 key-point coords, |k_pts|^2
@@ -65,7 +68,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                                                              const uint8_t* __restrict__ mask, const float* __restrict__ R,
                                                              const float* __restrict__ t, const float* __restrict__ Wb,
                                                              const float* __restrict__ spatial_coef, float* __restrict__ feat,
-                                                             float* __restrict__ dbg_logits, const float* __restrict__ pbc, int N, int L, int nib, int xcd_remap, int abl) {
+                                                             float* __restrict__ dbg_logits, const float* __restrict__ pbc, int N, int L, int nib, int xcd_remap) {
     __shared__ __attribute__((aligned(16))) WsSmem sm;
     int n, ib;
     {   // all i-blocks of a sample on one XCD when N % 8 == 0 (L2 locality of its k/v tiles; speed only)
@@ -101,6 +104,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
         if (h < H) w4v = reinterpret_cast<const float4*>(Wb + h * C)[c4];
         *reinterpret_cast<float4*>(&sm.wbs[h][c4 * 4]) = w4v;
     }
+    for (int e = tid; e < nchunk2 * JC; e += NT) sm.mk[e] = (e < L) ? mask[rowbase + e] : 0;
     if (tid < H) {
         const float sc = spatial_coef[tid];
         const float gamma = (sc > 20.f) ? sc : log1pf(expf(sc));                       // softplus, ga.py:108
@@ -127,9 +131,9 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
         f32x4 ringb[4];                                                     // CACHED: the row chunk's precomputed pair bias, lane (head fm, keys 4 kq ..)
 #define WS_ISSUE_Z(SLOT, ROW, CH)                                                                                        \
     {                                                                                                                    \
-        const int64_t zrow_ = rowbase + ((abl & 16) ? 0 : min(i0 + w4 * RPW + (ROW), L - 1));                            \
+        const int64_t zrow_ = rowbase + min(i0 + w4 * RPW + (ROW), L - 1);                            \
         const float* zi_ = z + (zrow_ * (int64_t)L) * C;                                                                 \
-        if (!(abl & 512)) _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                              \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                              \
             ring[SLOT][r_] = *(reinterpret_cast<const f32x4*>(zi_ + (int64_t)min((CH) * JC + kq * 4 + r_, L - 1) * C) + fm); \
         if (CACHED) ringb[SLOT] = *(reinterpret_cast<const f32x4*>(pbc + (zrow_ * nchunk + min((CH), nchunk - 1)) * 256) + lane);  \
     }
@@ -143,8 +147,9 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
             const int ch = ch0 + c;
             const int jc0 = ch * JC, buf = ch & 1;
             bool mj[4], jv[4];
+            const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(&sm.mk[jc0 + kq * 4]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const int j = jc0 + kq * 4 + r; jv[r] = j < L; mj[r] = jv[r] && mask[rowbase + j] != 0; }
+            for (int r = 0; r < 4; ++r) { const int j = jc0 + kq * 4 + r; jv[r] = j < L; mj[r] = ((mk4 >> (8 * r)) & 0xffu) != 0; }
 #pragma unroll
             for (int ii = 0; ii < RPW; ++ii) {
                 const int il = w4 * RPW + ii;
@@ -159,10 +164,11 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                 if (CACHED) {
                     acc = ringb[pos];                                       // pair bias of this (row, chunk) from the per-call cache
                 } else {
+                    wave_lds_sync();                                        // previous row's transposed reads are done
 #pragma unroll
                     for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&sm.zst[w4][kq * 4 + r][fm * 4]) = zr[r];
+                    wave_lds_sync();                                        // cross-lane transpose through LDS
                     f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                    if (!(abl & 2))
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float4 za = *reinterpret_cast<const float4*>(&sm.zst[w4][fm][kq * 16 + q * 4]);
@@ -188,14 +194,13 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                 const float sc = __expf(m_run[ii] - m_new);
                 float pv[4], ps = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { pv[r] = (abl & 4) ? sv[r] * 1e-3f : __expf(sv[r] - m_new); ps += pv[r]; }
+                for (int r = 0; r < 4; ++r) { pv[r] = __expf(sv[r] - m_new); ps += pv[r]; }
                 ps = rows_sum(ps);
                 l_run[ii] = l_run[ii] * sc + ps;
                 m_run[ii] = m_new;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) accP[ii][mt] *= sc;
                 TSTAMP(3)
-                if (!(abl & 1))
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -205,7 +210,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                 TSTAMP(4)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!(abl & 8)) __syncthreads();                                // barrier #(ch+1)
+            __syncthreads();                                                // barrier #(ch+1)
             TSTAMP(5)
           }
         }
@@ -276,13 +281,11 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
             }
         };
         auto issue_k = [&](int ch) {                                        // fetch phase-A operands of chunk ch
-            if (abl & 128) return;
             const float* pj = projn + (int64_t)min(ch * JC + fm, L - 1) * NP;
 #pragma unroll
             for (int hh = 0; hh < 3; ++hh) load_kfrag(kf[hh], pj, w4 * 3 + hh, kq);
         };
         auto issue_v = [&](int ch) {                                        // fetch phase-C operands of chunk ch
-            if (abl & 256) return;
             if (NPW == 8) return;                                           // 3 waves/SIMD: no registers to park them; phase C loads just in time
 #pragma unroll
             for (int hh = 0; hh < 3; ++hh) load_vfrag(vf[hh], projn, ch * JC, L, w4 * 3 + hh, fm, kq);
@@ -319,18 +322,18 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
         TSTAMP(0)
         for (int ch = 0; ch < nchunk2; ++ch) {
             if (ch >= 1) {
-                if (!(abl & 64)) phase_c(ch - 1);
+                phase_c(ch - 1);
                 TSTAMP(1)
                 issue_v(ch);
                 TSTAMP(2)
             }
             if (ch + 1 < nchunk2) {
-                if (!(abl & 32)) phase_a(ch + 1);
+                phase_a(ch + 1);
                 TSTAMP(3)
                 if (ch + 2 < nchunk2) issue_k(ch + 2);
                 TSTAMP(4)
             }
-            if (!(abl & 8)) __syncthreads();                                // barrier #(ch+1)
+            __syncthreads();                                                // barrier #(ch+1)
             TSTAMP(5)
         }
         phase_c(nchunk2 - 1);
@@ -398,6 +401,7 @@ __global__ __launch_bounds__(256) void pair_bias_cache_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         *reinterpret_cast<f32x4*>(&zst[wave][kq * 4 + r][fm * 4]) = *(reinterpret_cast<const f32x4*>(zi + (int64_t)min(ch * JC + kq * 4 + r, L - 1) * C) + fm);
+    wave_lds_sync();                                                      // cross-lane transpose through LDS
     float4 za[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) za[q] = *reinterpret_cast<const float4*>(&zst[wave][fm][kq * 16 + q * 4]);
@@ -432,11 +436,10 @@ int launch_ipa_core_ws(const float* proj, const float* z, const uint8_t* mask, c
                        const float* pair_bias_cache, int N, int L, hipStream_t st) {
     const int nib = (L + BI - 1) / BI;
     const int remap = (N % 8 == 0) ? 1 : 0;
-    static const int abl = [] { const char* e = getenv("ABOPT_IPA_ABLATE"); return e ? atoi(e) : 0; }();   // timing experiments only (wrong results)
     prof::begin(st);
     static const int npw = [] { const char* e = getenv("ABOPT_IPA_PAIR_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();   // 8 pair waves (3 waves/SIMD) measured slower (311 vs 270 us): kept for A/B
 #define WS_LAUNCH(DBGV, NPWV, CV) hipLaunchKernelGGL((ipa_core_ws_kernel<DBGV, NPWV, CV>), dim3((unsigned)(N * nib)), dim3((NPWV + 4) * 64), 0, st, proj, z, \
-                                                     mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, N, L, nib, remap, abl)
+                                                     mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, N, L, nib, remap)
     if (pair_bias_cache) { if (dbg_logits) WS_LAUNCH(true, 4, true); else WS_LAUNCH(false, 4, true); }
     else if (dbg_logits) { if (npw == 8) WS_LAUNCH(true, 8, false); else WS_LAUNCH(true, 4, false); }
     else                 { if (npw == 8) WS_LAUNCH(false, 8, false); else WS_LAUNCH(false, 4, false); }
