@@ -31,8 +31,8 @@ struct Carver {
 constexpr int F = 128, FI = F + 4;
 constexpr int OUT_KSPLIT = 4;     // out_transform (K = 1824, N = 128) has only M/64 * 2 tiles: split K so it fills the chip
 
-struct GaScratch { float *proj, *feat, *u, *y, *h1, *h2; };
-static GaScratch carve_ga(Carver& cv, int64_t M) {
+struct GaScratch { float *proj, *feat, *u, *y, *h1, *h2, *kvf; };
+static GaScratch carve_ga(Carver& cv, int64_t M, int N, int L) {
     GaScratch s;
     s.proj = cv.f((size_t)M * NP);
     s.feat = cv.f((size_t)M * ABOPT_IPA_FEAT);
@@ -40,6 +40,7 @@ static GaScratch carve_ga(Carver& cv, int64_t M) {
     s.y = cv.f((size_t)M * F);
     s.h1 = cv.f((size_t)M * F);
     s.h2 = cv.f((size_t)M * F);
+    s.kvf = cv.f(ipa_kvfrag_floats(N, L));
     return s;
 }
 
@@ -49,10 +50,10 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     int rc;
     // node projections: q|k|v|qp|kp|vp in one GEMM, then points to the global frame
     if ((rc = launch_linear(x, F, w->w_node, F, nullptr, s.proj, NP, (int)M, ABOPT_NODE_PROJ, F, false, st))) return rc;
-    if ((rc = launch_points_to_global(s.proj, R, t, M, st))) return rc;
+    if ((rc = launch_points_to_global(s.proj, R, t, M, st, s.kvf, N, L))) return rc;
     float* feat = (dbg && dbg->feat) ? dbg->feat : s.feat;
     if ((rc = launch_ipa_core(s.proj, z, mask, R, t, w->w_pair_bias, w->spatial_coef, feat,
-                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, N, L, st))) return rc;
+                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, s.kvf, N, L, st))) return rc;
     // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
     if ((rc = launch_linear(feat, ABOPT_IPA_FEAT, w->w_out, ABOPT_IPA_FEAT, nullptr, s.u, F, (int)M, F, ABOPT_IPA_FEAT, false, st,
                             OUT_KSPLIT, M * F))) return rc;
@@ -130,7 +131,7 @@ extern "C" size_t abopt_ga_workspace_bytes(int N, int L, int Fd, int Cd) {
     (void)Fd; (void)Cd;
     Carver cv(nullptr, 0);
     const int64_t M = (int64_t)N * L;
-    carve_ga(cv, M);
+    carve_ga(cv, M, N, L);
     cv.f((size_t)M * F);   // ping-pong buffer for the encoder
     return cv.off;
 }
@@ -151,7 +152,7 @@ extern "C" int abopt_ga_block_forward(const abopt_ga_weights* w, const float* R,
     if ((int64_t)N * L == 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(R && t && x && z && mask && x_out && ws, "ga_block_forward: NULL argument");
     Carver cv(ws, ws_bytes);
-    GaScratch s = carve_ga(cv, (int64_t)N * L);
+    GaScratch s = carve_ga(cv, (int64_t)N * L, N, L);
     if (!cv.ok) { set_error("ga_block_forward: workspace too small (%zu bytes given)", ws_bytes); return ABOPT_EWORKSPACE; }
     return ga_block(w, R, t, x, z, mask, x_out, N, L, dbg, s, (hipStream_t)stream);
 }
@@ -186,7 +187,7 @@ extern "C" int abopt_ga_encoder_forward(const abopt_ga_weights* blocks, int num_
     ABOPT_CHECK_ARG(x != x_out, "ga_encoder_forward: x_out must not alias x");
     Carver cv(ws, ws_bytes);
     const int64_t M = (int64_t)N * L;
-    GaScratch s = carve_ga(cv, M);
+    GaScratch s = carve_ga(cv, M, N, L);
     float* pong = cv.f((size_t)M * F);
     if (!cv.ok) { set_error("ga_encoder_forward: workspace too small (%zu bytes given)", ws_bytes); return ABOPT_EWORKSPACE; }
     return ga_encoder(blocks, num_layers, R, t, x, z, mask, x_out, N, L, s, pong, (hipStream_t)stream);
@@ -209,9 +210,9 @@ extern "C" int abopt_pair_bias_cache(const abopt_ga_weights* blocks, int num_lay
 // ---------------------------------------------------------------------------------- EpsilonNet
 namespace {
 struct EpsScratch { GaScratch ga; float *pong, *R, *cat, *x0, *xe, *infeat, *infeat_ln, *hh1, *hh2, *out3, *pr1, *pr2, *pr3; };
-EpsScratch carve_eps(Carver& cv, int64_t M, int num_bins) {
+EpsScratch carve_eps(Carver& cv, int64_t M, int N, int L, int num_bins) {
     EpsScratch e;
-    e.ga = carve_ga(cv, M);
+    e.ga = carve_ga(cv, M, N, L);
     e.pong = cv.f((size_t)M * F);
     e.R = cv.f((size_t)M * 9);
     e.cat = cv.f((size_t)M * 2 * F);
@@ -232,7 +233,7 @@ EpsScratch carve_eps(Carver& cv, int64_t M, int num_bins) {
 extern "C" size_t abopt_eps_workspace_bytes(int N, int L, int Fd, int Cd) {
     (void)Fd; (void)Cd;
     Carver cv(nullptr, 0);
-    carve_eps(cv, (int64_t)N * L, 64);
+    carve_eps(cv, (int64_t)N * L, N, L, 64);
     return cv.off;
 }
 
@@ -258,7 +259,7 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
     const int64_t M = (int64_t)N * L;
     if (M == 0) return ABOPT_OK;
     Carver cv(ws, ws_bytes);
-    EpsScratch e = carve_eps(cv, M, 64);
+    EpsScratch e = carve_eps(cv, M, N, L, 64);
     if (!cv.ok) { set_error("eps_net_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, abopt_eps_workspace_bytes(N, L, Fd, Cd)); return ABOPT_EWORKSPACE; }
 
     // dpm_full.py:86  R = exp(v_t)

@@ -14,6 +14,13 @@
 namespace abopt {
 
 // ------------------------------------------------------------------ local -> global of the point sets
+static int ipa_variant() {
+    static const int variant = [] { const char* e = getenv("ABOPT_IPA_VARIANT"); return e ? atoi(e) : 2; }();   // 2 = wave-specialised (default), 1 = single-role MFMA kernel, 0 = VALU kernel; 0/1 are kept for A/B timing
+    return variant;
+}
+// the wave-specialised kernel stages the key mask in LDS (WS_MAX_L = 2048 keys); longer complexes take v1
+bool ipa_uses_kvfrag(int L) { return ipa_variant() == 2 && L <= 2048; }
+
 // geometry.py:72-91 applied to proj_{query,key,value}_point outputs (ga.py:96-105,129-132): p <- R p + t, in place, one
 // thread per (residue, point set, head).  Also emits |p|^2 summed over the head's 8 points for the query and key sets:
 // the wave-specialised IPA kernel evaluates the squared point distances as |q|^2 + |k|^2 - 2 q.k on the matrix cores.
@@ -46,10 +53,87 @@ __global__ __launch_bounds__(256) void points_to_global_kernel(float* __restrict
     if (set == 1) proj[row * NP + OFF_NK + h] = nrm;
 }
 
-int launch_points_to_global(float* proj, const float* R, const float* t, int64_t rows, hipStream_t st) {
+// Same transform, plus the key / value operands of the wave-specialised IPA kernel re-laid out in MFMA fragment order
+// ("kvfrag"): one workgroup per (sample, 16-key chunk).  Every i-block of a sample consumes the same 16 x (k | k_pts | v |
+// v_pts) tile per chunk; gathering it row by row from proj costs the node waves ~40 poorly coalesced loads per chunk, the
+// fragment copy turns that into 24 fully coalesced 1 KB loads.  Layout, float4 units:
+//   kvfrag[((n * nchunk + ch) * H + h) * 8 + slot][lane],  lane = (fm = lane & 15, kq = lane >> 4)
+//   slot 0,1: k[j = 16 ch + fm][h][8 kq + 0..3], [.. + 4..7]          slot 2: k_pts coords (2 kq + {0,1}, 8 + 2 kq + {0,1}) of head h
+//   slot 3:   k_pts coords 16 + 2 kq + {0,1}, |k_pts|^2, 0             slot 4 + s: (v[j = 16 ch + 4 kq + s][h][2 fm + {0,1}], v_pts coords 2 fm + {0,1} or 0 for fm >= 12)
+__global__ __launch_bounds__(256) void points_to_global_frags_kernel(float* __restrict__ proj, const float* __restrict__ R,
+                                                                     const float* __restrict__ t, float* __restrict__ kvfrag, int L, int nchunk) {
+    __shared__ float pts[JC][2 * NPT + H + 4];                   // k_pts | v_pts (global frame) | |k_pts|^2 of the chunk's 16 rows
+    const int n = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, tid = threadIdx.x;
+    const int64_t rowbase = (int64_t)n * L;
+    for (int item = tid; item < JC * 3 * H; item += 256) {
+        const int r = item / (3 * H), sh = item % (3 * H), set = sh / H, h = sh % H;
+        const int j = ch * JC + r;
+        const int64_t row = rowbase + min(j, L - 1);
+        float* p = proj + row * NP + OFF_QP + set * NPT + h * (P * 3);
+        const float* Rr = R + row * 9;
+        const float* tr = t + row * 3;
+        const float r0 = Rr[0], r1 = Rr[1], r2 = Rr[2], r3 = Rr[3], r4 = Rr[4], r5 = Rr[5], r6 = Rr[6], r7 = Rr[7], r8 = Rr[8];
+        const float t0 = tr[0], t1 = tr[1], t2 = tr[2];
+        float4 v[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] = reinterpret_cast<const float4*>(p)[q];
+        float* f = reinterpret_cast<float*>(v);
+        float nrm = 0.f;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const float x = f[k * 3], y = f[k * 3 + 1], z = f[k * 3 + 2];
+            const float gx = r0 * x + r1 * y + r2 * z + t0, gy = r3 * x + r4 * y + r5 * z + t1, gz = r6 * x + r7 * y + r8 * z + t2;
+            f[k * 3] = gx; f[k * 3 + 1] = gy; f[k * 3 + 2] = gz;
+            nrm = fmaf(gx, gx, nrm); nrm = fmaf(gy, gy, nrm); nrm = fmaf(gz, gz, nrm);
+        }
+        if (set >= 1) {
+#pragma unroll
+            for (int k = 0; k < P * 3; ++k) pts[r][(set - 1) * NPT + h * (P * 3) + k] = f[k];
+            if (set == 1) pts[r][2 * NPT + h] = nrm;
+        }
+        if (j < L) {                                               // rows past the end are clamped copies: transform them in LDS only
+#pragma unroll
+            for (int q = 0; q < 6; ++q) reinterpret_cast<float4*>(p)[q] = v[q];
+            if (set == 0) proj[row * NP + OFF_NQ + h] = nrm;
+            if (set == 1) proj[row * NP + OFF_NK + h] = nrm;
+        }
+    }
+    __syncthreads();
+    float4* out = reinterpret_cast<float4*>(kvfrag) + (int64_t)blockIdx.x * H * 8 * 64;
+    for (int e = tid; e < H * 8 * 64; e += 256) {
+        const int lane = e & 63, slot = (e >> 6) & 7, h = e >> 9, fm = lane & 15, kq = lane >> 4;
+        float4 o;
+        if (slot < 2) {
+            const int64_t row = rowbase + min(ch * JC + fm, L - 1);
+            o = *reinterpret_cast<const float4*>(proj + row * NP + OFF_K + h * D + kq * 8 + slot * 4);
+        } else if (slot == 2) {
+            const float* kp = &pts[fm][h * (P * 3)];
+            o = make_float4(kp[2 * kq], kp[2 * kq + 1], kp[8 + 2 * kq], kp[8 + 2 * kq + 1]);
+        } else if (slot == 3) {
+            const float* kp = &pts[fm][h * (P * 3)];
+            o = make_float4(kp[16 + 2 * kq], kp[16 + 2 * kq + 1], pts[fm][2 * NPT + h], 0.f);
+        } else {
+            const int r = kq * 4 + (slot - 4);
+            const int64_t row = rowbase + min(ch * JC + r, L - 1);
+            const float2 vv = *reinterpret_cast<const float2*>(proj + row * NP + OFF_V + h * D + 2 * fm);
+            const float* vp = &pts[r][NPT + h * (P * 3)];
+            o = make_float4(vv.x, vv.y, fm < 12 ? vp[2 * fm] : 0.f, fm < 12 ? vp[2 * fm + 1] : 0.f);
+        }
+        out[e] = o;
+    }
+}
+
+size_t ipa_kvfrag_floats(int N, int L) { return (size_t)N * ((L + JC - 1) / JC) * H * 8 * 64 * 4; }
+
+int launch_points_to_global(float* proj, const float* R, const float* t, int64_t rows, hipStream_t st, float* kvfrag, int N, int L) {
     const int64_t total = rows * 3 * H;
     if (total == 0) return ABOPT_OK;
-    hipLaunchKernelGGL(points_to_global_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, proj, R, t, rows);
+    if (kvfrag && ipa_uses_kvfrag(L)) {
+        const int nchunk = (L + JC - 1) / JC;
+        hipLaunchKernelGGL(points_to_global_frags_kernel, dim3((unsigned)(N * nchunk)), dim3(256), 0, st, proj, R, t, kvfrag, L, nchunk);
+    } else {
+        hipLaunchKernelGGL(points_to_global_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, proj, R, t, rows);
+    }
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }
@@ -500,9 +584,9 @@ void end(hipStream_t st) {
 
 int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
                     const float* w_pair_bias, const float* spatial_coef, float* feat,
-                    float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache, int N, int L, hipStream_t st) {
+                    float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache, const float* kvfrag, int N, int L, hipStream_t st) {
     if (N == 0 || L == 0) return ABOPT_OK;
-    static const int variant = [] { const char* e = getenv("ABOPT_IPA_VARIANT"); return e ? atoi(e) : 2; }();   // 2 = wave-specialised (default), 1 = single-role MFMA kernel, 0 = VALU kernel; 0/1 are kept for A/B timing
+    const int variant = ipa_variant();
     if (variant == 0) {                                          // row-per-workgroup VALU kernel kept for A/B runs (L <= 480)
         const size_t lds = ((size_t)L * (ZLD + H) + 1440) * sizeof(float);
         ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core v0: L=%d needs %zu bytes of LDS (max 163840)", L, lds);
@@ -516,8 +600,9 @@ int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, cons
     }
     const int nib = (L + BI - 1) / BI;
     ABOPT_CHECK_ARG((int64_t)N * nib < (1ll << 31), "ipa_core: grid too large");
-    if (variant == 2 && L <= 2048) {                             // the wave-specialised kernel stages the key mask in LDS (WS_MAX_L); longer complexes take v1
-        int rc = launch_ipa_core_ws(proj, z, mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, N, L, st);
+    if (ipa_uses_kvfrag(L)) {
+        ABOPT_CHECK_ARG(kvfrag != nullptr, "ipa_core: the wave-specialised kernel needs the key/value fragment buffer");
+        int rc = launch_ipa_core_ws(proj, z, mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, kvfrag, N, L, st);
         if (rc) return rc;
         if (dbg_alpha) {
             ABOPT_CHECK_ARG(dbg_logits != nullptr, "ipa_core: alpha dump needs the logits dump");

@@ -36,21 +36,20 @@ struct WsSmem {
 struct KFrag { float4 k0, k1; float2 g[3]; float nk; }; // phase A operands of one head: 8 key channels, 6 key-point coords, |k_pts|^2
 struct VFrag { float2 v[4], p[4]; };                   // phase C operands of one head: 4 keys x (2 value channels, 2 point coords)
 
-__device__ __forceinline__ void load_kfrag(KFrag& f, const float* pj, int h, int kq) {
-    const float4* kp = reinterpret_cast<const float4*>(pj + OFF_K + h * D + kq * 8);
-    f.k0 = kp[0]; f.k1 = kp[1];
-    // point coordinates are the K dimension of the q_pts.k_pts MFMA: step s <-> coordinate 8 (s >> 1) + 2 kq + (s & 1)
-#pragma unroll
-    for (int u = 0; u < 3; ++u) f.g[u] = *reinterpret_cast<const float2*>(pj + OFF_KP + h * (P * 3) + 8 * u + 2 * kq);
-    f.nk = pj[OFF_NK + h];
+// operands of (chunk, head) from the fragment-order copy written by points_to_global_frags_kernel (ipa.hip): 4 + 4 fully
+// coalesced 1 KB loads instead of 14 row gathers
+__device__ __forceinline__ void load_kfrag(KFrag& f, const f32x4* __restrict__ fr, int lane) {
+    const f32x4 a = fr[lane], b = fr[64 + lane], c = fr[128 + lane], d = fr[192 + lane];
+    f.k0 = make_float4(a[0], a[1], a[2], a[3]); f.k1 = make_float4(b[0], b[1], b[2], b[3]);
+    f.g[0] = make_float2(c[0], c[1]); f.g[1] = make_float2(c[2], c[3]); f.g[2] = make_float2(d[0], d[1]);
+    f.nk = d[2];
 }
 
-__device__ __forceinline__ void load_vfrag(VFrag& f, const float* projn, int jc0, int L, int h, int fm, int kq) {
+__device__ __forceinline__ void load_vfrag(VFrag& f, const f32x4* __restrict__ fr, int lane) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const float* pj = projn + (int64_t)min(jc0 + kq * 4 + s, L - 1) * NP;
-        f.v[s] = reinterpret_cast<const float2*>(pj + OFF_V + h * D)[fm];
-        f.p[s] = (fm < 12) ? reinterpret_cast<const float2*>(pj + OFF_VP + h * (P * 3))[fm] : make_float2(0.f, 0.f);
+        const f32x4 a = fr[(4 + s) * 64 + lane];
+        f.v[s] = make_float2(a[0], a[1]); f.p[s] = make_float2(a[2], a[3]);
     }
 }
 
@@ -68,7 +67,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                                                              const uint8_t* __restrict__ mask, const float* __restrict__ R,
                                                              const float* __restrict__ t, const float* __restrict__ Wb,
                                                              const float* __restrict__ spatial_coef, float* __restrict__ feat,
-                                                             float* __restrict__ dbg_logits, const float* __restrict__ pbc, int N, int L, int nib, int xcd_remap) {
+                                                             float* __restrict__ dbg_logits, const float* __restrict__ pbc, const float* __restrict__ kvfrag, int N, int L, int nib, int xcd_remap) {
     __shared__ __attribute__((aligned(16))) WsSmem sm;
     int n, ib;
     {   // all i-blocks of a sample on one XCD when N % 8 == 0 (L2 locality of its k/v tiles; speed only)
@@ -242,6 +241,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
             for (int k = 0; k < 2; ++k) { accV[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; accT[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         KFrag kf[3];
         VFrag vf[3];
+        const f32x4* kvn = reinterpret_cast<const f32x4*>(kvfrag) + (int64_t)n * nchunk * H * 512;   // this sample's fragments
         float2 qgf[3][3];                                                   // query-point fragments (A operand: row = query fm, same K permutation as KFrag::g)
         {
             const float* qprow = projn + (int64_t)min(i0 + fm, L - 1) * NP + OFF_QP + 2 * kq;
@@ -281,14 +281,13 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
             }
         };
         auto issue_k = [&](int ch) {                                        // fetch phase-A operands of chunk ch
-            const float* pj = projn + (int64_t)min(ch * JC + fm, L - 1) * NP;
 #pragma unroll
-            for (int hh = 0; hh < 3; ++hh) load_kfrag(kf[hh], pj, w4 * 3 + hh, kq);
+            for (int hh = 0; hh < 3; ++hh) load_kfrag(kf[hh], kvn + ((int64_t)min(ch, nchunk - 1) * H + w4 * 3 + hh) * 512, lane);
         };
         auto issue_v = [&](int ch) {                                        // fetch phase-C operands of chunk ch
             if (NPW == 8) return;                                           // 3 waves/SIMD: no registers to park them; phase C loads just in time
 #pragma unroll
-            for (int hh = 0; hh < 3; ++hh) load_vfrag(vf[hh], projn, ch * JC, L, w4 * 3 + hh, fm, kq);
+            for (int hh = 0; hh < 3; ++hh) load_vfrag(vf[hh], kvn + ((int64_t)min(ch, nchunk - 1) * H + w4 * 3 + hh) * 512, lane);
         };
         auto phase_c = [&](int ch) {                                        // consume P(ch) from sp[ch & 1] and vf
             const int buf = ch & 1;
@@ -300,7 +299,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                     const float sc = sm.scl[buf][kq * 4 + r][h];
                     accV[hh][0][r] *= sc; accV[hh][1][r] *= sc; accT[hh][0][r] *= sc; accT[hh][1][r] *= sc;
                 }
-                if (NPW == 8) load_vfrag(vf[0], projn, ch * JC, L, h, fm, kq);
+                if (NPW == 8) load_vfrag(vf[0], kvn + ((int64_t)min(ch, nchunk - 1) * H + h) * 512, lane);
                 const VFrag& vfh = vf[NPW == 8 ? 0 : hh];
                 const float4 pa = *reinterpret_cast<const float4*>(&sm.sp[buf][fm][h * PLD + kq * 4]);   // A: row = query fm, step s <-> key 4 kq + s
 #pragma unroll
@@ -433,13 +432,13 @@ int launch_pair_bias_cache(const float* z, const float* const* wb, int num_layer
 
 int launch_ipa_core_ws(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
                        const float* w_pair_bias, const float* spatial_coef, float* feat, float* dbg_logits,
-                       const float* pair_bias_cache, int N, int L, hipStream_t st) {
+                       const float* pair_bias_cache, const float* kvfrag, int N, int L, hipStream_t st) {
     const int nib = (L + BI - 1) / BI;
     const int remap = (N % 8 == 0) ? 1 : 0;
     prof::begin(st);
     static const int npw = [] { const char* e = getenv("ABOPT_IPA_PAIR_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();   // 8 pair waves (3 waves/SIMD) measured slower (311 vs 270 us): kept for A/B
 #define WS_LAUNCH(DBGV, NPWV, CV) hipLaunchKernelGGL((ipa_core_ws_kernel<DBGV, NPWV, CV>), dim3((unsigned)(N * nib)), dim3((NPWV + 4) * 64), 0, st, proj, z, \
-                                                     mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, N, L, nib, remap)
+                                                     mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, kvfrag, N, L, nib, remap)
     if (pair_bias_cache) { if (dbg_logits) WS_LAUNCH(true, 4, true); else WS_LAUNCH(false, 4, true); }
     else if (dbg_logits) { if (npw == 8) WS_LAUNCH(true, 8, false); else WS_LAUNCH(true, 4, false); }
     else                 { if (npw == 8) WS_LAUNCH(false, 8, false); else WS_LAUNCH(false, 4, false); }

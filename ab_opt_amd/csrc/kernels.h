@@ -13,10 +13,13 @@ int launch_linear(const float* X, int ldx, const float* W, int ldw, const float*
 
 // ipa.hip -------------------------------------------------------------------------------------
 // proj [N*L, 2016] holds q|k|v|qp|kp|vp with the three point sets already in the global frame.
-int launch_points_to_global(float* proj, const float* R, const float* t, int64_t rows, hipStream_t st);
+// kvfrag != NULL (and the wave-specialised kernel in use): also emits its key/value operands in MFMA fragment order
+bool ipa_uses_kvfrag(int L);
+size_t ipa_kvfrag_floats(int N, int L);
+int launch_points_to_global(float* proj, const float* R, const float* t, int64_t rows, hipStream_t st, float* kvfrag, int N, int L);
 int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
                     const float* w_pair_bias, const float* spatial_coef, float* feat,
-                    float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache, int N, int L, hipStream_t st);
+                    float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache, const float* kvfrag, int N, int L, hipStream_t st);
 
 // rows.hip ------------------------------------------------------------------------------------
 int launch_so3_exp(const float* w, float* R, int64_t n, hipStream_t st);
