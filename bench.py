@@ -28,9 +28,9 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy ceiling)
 # HBM bytes per ipa_core launch from the PMC counters (separate rocprofv3 --pmc passes on this command, FETCH_SIZE doubled per
-# the gfx950 correction): profiles/r01_f_pmc_ipa_core_cached.txt.  740 MB read + 60 MB written; 137 MB above the algorithmic
+# the gfx950 correction): profiles/r01_g_pmc_ipa_core.txt.  745 MB read + 60 MB written; 142 MB above the algorithmic
 # bytes = the per-call pair-bias cache stream that replaces the in-kernel pair-bias contraction.
-MEASURED_TRAFFIC = {(32, 256): 361290.7 * 1024 * 2 + 58368.6 * 1024}
+MEASURED_TRAFFIC = {(32, 256): 363911.5 * 1024 * 2 + 58368.1 * 1024}
 
 
 def ipa_core_bytes(N, L, C=64):
