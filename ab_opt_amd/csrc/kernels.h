@@ -12,7 +12,7 @@ int launch_linear(const float* X, int ldx, const float* W, int ldw, const float*
                   int M, int N, int K, bool relu, hipStream_t st, int ksplit = 1, int64_t slab_stride = 0);
 
 // ipa.hip -------------------------------------------------------------------------------------
-// proj [N*L, 2016] holds q|k|v|qp|kp|vp with the three point sets already in the global frame.
+// proj [N*L, NP = 2048]: q|k|v|qp|kp|vp (2016) with the three point sets in the global frame, then |q_pts|^2, |k_pts|^2 per head.
 // kvfrag != NULL (and the wave-specialised kernel in use): also emits its key/value operands in MFMA fragment order
 bool ipa_uses_kvfrag(int L);
 size_t ipa_kvfrag_floats(int N, int L);
