@@ -143,6 +143,30 @@ static int check_dims(int N, int L, int Fd, int Cd) {
     return ABOPT_OK;
 }
 
+extern "C" size_t abopt_ipa_train_workspace_bytes(int N, int L) { return ipa_train_ws_floats(N, L) * sizeof(float); }
+
+extern "C" int abopt_ipa_core_train_forward(const float* proj_local, const float* R, const float* t, const float* pair_feat, const uint8_t* mask,
+                                            const float* w_pair_bias, const float* spatial_coef, float* feat, float* alpha,
+                                            int N, int L, int Cd, void* ws, size_t ws_bytes, abopt_stream stream) {
+    int rc;
+    if ((rc = check_dims(N, L, F, Cd))) return rc;
+    if ((int64_t)N * L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(proj_local && R && t && pair_feat && mask && w_pair_bias && spatial_coef && feat && alpha && ws, "ipa_core_train_forward: NULL argument");
+    if (ws_bytes < ipa_train_ws_floats(N, L) * sizeof(float)) { set_error("ipa_core_train_forward: workspace too small (%zu bytes given)", ws_bytes); return ABOPT_EWORKSPACE; }
+    return launch_ipa_train_forward(proj_local, R, t, pair_feat, mask, w_pair_bias, spatial_coef, feat, alpha, N, L, (float*)ws, (hipStream_t)stream);
+}
+
+extern "C" int abopt_ipa_pair_backward(const float* pair_feat, const float* alpha, const float* dalpha_node, const float* delta,
+                                       const float* dfeat, int ld_dfeat, const float* w_pair_bias, float* g, float* dpair_feat,
+                                       int N, int L, int Cd, abopt_stream stream) {
+    int rc;
+    if ((rc = check_dims(N, L, F, Cd))) return rc;
+    if ((int64_t)N * L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(pair_feat && alpha && dalpha_node && delta && dfeat && w_pair_bias && g && dpair_feat && ld_dfeat >= ABOPT_HEADS * 64 && (ld_dfeat % 4) == 0,
+                    "ipa_pair_backward: bad argument");
+    return launch_ipa_pair_backward(pair_feat, alpha, dalpha_node, delta, dfeat, ld_dfeat, w_pair_bias, g, dpair_feat, N, L, (hipStream_t)stream);
+}
+
 extern "C" int abopt_ga_block_forward(const abopt_ga_weights* w, const float* R, const float* t, const float* x, const float* z,
                                       const uint8_t* mask, float* x_out, int N, int L, int Fd, int Cd, const abopt_ga_debug* dbg,
                                       void* ws, size_t ws_bytes, abopt_stream stream) {

@@ -43,6 +43,13 @@ int launch_heads_epilogue(const float* R, const float* v_t, const float* eps_crd
 // out[n, b] = mean_l in[n, l, b]
 int launch_mean_over_L(const float* in, float* out, int N, int L, int B, hipStream_t st);
 
+// ipa_train.hip: training side of the IPA core -----------------------------------------------------
+size_t ipa_train_ws_floats(int N, int L);
+int launch_ipa_train_forward(const float* proj_local, const float* R, const float* t, const float* z, const uint8_t* mask,
+                             const float* Wb, const float* spatial_coef, float* feat, float* alpha, int N, int L, float* ws, hipStream_t st);
+int launch_ipa_pair_backward(const float* z, const float* alpha, const float* dalpha_node, const float* delta, const float* dfeat, int ld_dfeat,
+                             const float* Wb, float* g_out, float* dz, int N, int L, hipStream_t st);
+
 // embed.hip: encode() ----------------------------------------------------------------------------
 size_t residue_embed_ws_bytes(int N, int L, int A, int hotspot);
 int launch_residue_embed(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* res_feat, float* R, float* p,

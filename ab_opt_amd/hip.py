@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,6 +73,7 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
            'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect',
+           'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward']
 
 _lib = None
@@ -121,6 +122,10 @@ def lib():
                                       c_f, c_f, c_i64, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_prof_enable.argtypes = [C.c_int]
         L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.abopt_ipa_train_workspace_bytes.restype = C.c_size_t
+        L.abopt_ipa_train_workspace_bytes.argtypes = [C.c_int] * 2
+        L.abopt_ipa_core_train_forward.argtypes = [c_f, c_f, c_f, c_f, c_u8, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_ipa_pair_backward.argtypes = [c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.abopt_residue_embed_workspace_bytes.restype = C.c_size_t
         L.abopt_residue_embed_workspace_bytes.argtypes = [C.c_int] * 4
         L.abopt_pair_embed_workspace_bytes.restype = C.c_size_t
@@ -326,6 +331,33 @@ def commonness_score(structs):
     score = torch.empty(B, device=structs.device)
     _check(lib().abopt_commonness_score(ptr(structs), ptr(score), B, n, stream()))
     return score
+
+
+def ipa_core_train_forward(proj_local, R, t, z, mask, w_pair_bias, spatial_coef):
+    """Training-mode IPA core: -> feat (N,L,1824), alpha (N,L,L,12)  (include/abopt.h: abopt_ipa_core_train_forward)."""
+    N, L = mask.shape
+    dev = z.device
+    feat = torch.empty(N, L, 1824, device=dev)
+    alpha = torch.empty(N, L, L, 12, device=dev)
+    nb = lib().abopt_ipa_train_workspace_bytes(N, L)
+    buf = Workspace.get(nb, dev)
+    _check(lib().abopt_ipa_core_train_forward(ptr(proj_local.contiguous(), torch.float32), ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32),
+                                              ptr(z.contiguous(), torch.float32), ptr(mask.contiguous(), torch.bool),
+                                              ptr(w_pair_bias.contiguous(), torch.float32), ptr(spatial_coef.contiguous(), torch.float32),
+                                              ptr(feat), ptr(alpha), N, L, z.shape[-1], ptr(buf), buf.numel(), stream()))
+    return feat, alpha
+
+
+def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias):
+    """-> g (N,L,L,12), dz (N,L,L,C)  (include/abopt.h: abopt_ipa_pair_backward)."""
+    N, L = z.shape[:2]
+    g = torch.empty_like(alpha)
+    dz = torch.empty_like(z)
+    dfeat = dfeat.contiguous()
+    _check(lib().abopt_ipa_pair_backward(ptr(z.contiguous(), torch.float32), ptr(alpha.contiguous(), torch.float32), ptr(dalpha_node.contiguous(), torch.float32),
+                                         ptr(delta.contiguous(), torch.float32), ptr(dfeat, torch.float32), dfeat.shape[-1],
+                                         ptr(w_pair_bias.contiguous(), torch.float32), ptr(g), ptr(dz), N, L, z.shape[-1], stream()))
+    return g, dz
 
 
 def encode_inputs(aa, res_nb, chain_nb, pos_atoms, mask_atoms, atoms, fragment_type=None, hotspot=None, structure_mask=None, sequence_mask=None):

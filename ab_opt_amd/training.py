@@ -1,10 +1,13 @@
 """Training loss of the denoiser (FullDPM.forward) with gradients.
 
-Status: the forward noising runs in the HIP kernel `abopt_add_noise`; the differentiable part
-(EpsilonNet + losses) is expressed here with torch ops on the HIP device so that autograd provides the backward pass.
-This is the INTERIM training path: the hand-written IPA backward kernel is the next scope row, and this
-module is what it will be verified against.  It is never used by sample()/optimize(), and it is not a CPU fallback: the
-noising step requires the HIP library and device tensors.
+Status: the forward noising runs in the HIP kernel `abopt_add_noise`; inside every GABlock the
+IPA core -- the part that streams pair_feat -- is a custom autograd function on two HIP entry points
+(`abopt_ipa_core_train_forward`, `abopt_ipa_pair_backward`, csrc/ipa_train.hip): forward keeps alpha (N,L,L,12) instead of
+the reference's (N,L,L,12,64) broadcast products, backward reads z once and writes dz once; the remaining (N,L,L,12)-sized
+gradient contractions, the dense projections, LayerNorm/MLP, heads and losses are torch ops (library GEMMs) in the
+autograd graph.  `ga_block(..., native=False)` is the plain torch statement of the same block: it is what the native path is
+verified against (and what the reference's recorded gradients pin).  Nothing here is used by sample()/optimize(), and it
+is not a CPU fallback: noising and the IPA core require the HIP library and device tensors.
 
 Maths follows the reference line by line (D/ = AbDock/src/):
   GABlock.forward               D/modules/encoders/ga.py:149-178   (contractions as einsum instead of 5-D broadcast products)
@@ -69,9 +72,84 @@ def _ln(x, mod):
     return (x - mu) / (var + mod.epsilon).sqrt() * mod.gamma + mod.beta
 
 
+# ------------------------------------------------------------------ IPA core as an autograd function on the HIP kernels
+class IpaCore(torch.autograd.Function):
+    """feat = IPA(proj, z): ga.py:81-147 between the six projections and out_transform.
+
+    proj (N,L,2016) = [q|k|v|q_pts|k_pts|v_pts] with the points still in the residue frames; R, t, mask carry no gradient
+    (they come from the noised state)."""
+
+    @staticmethod
+    def forward(ctx, proj, z, R, t, mask, w_pair_bias, spatial_coef):
+        from . import hip
+        feat, alpha = hip.ipa_core_train_forward(proj, R, t, z, mask, w_pair_bias, spatial_coef.reshape(-1))
+        ctx.save_for_backward(proj, z, R, t, w_pair_bias, spatial_coef, feat, alpha)
+        return feat
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, dfeat):
+        from . import hip
+        proj, z, R, t, Wb, gamma_raw, feat, alpha = ctx.saved_tensors
+        N, L = proj.shape[:2]
+        HD, HP = H * D, H * P
+        q, k, v = (proj[..., i * HD:(i + 1) * HD].reshape(N, L, H, D) for i in range(3))
+        pts = [proj[..., 3 * HD + i * HP * 3: 3 * HD + (i + 1) * HP * 3].reshape(N, L, HP, 3) for i in range(3)]
+        qg, kg, vg = (_to_global(R, t, p).reshape(N, L, H, P * 3) for p in pts)
+        dfeat = dfeat.contiguous()
+        dfn = dfeat[..., H * 64: H * 64 + HD].reshape(N, L, H, D)
+        o = H * 64 + HD
+        dloc, ddist, ddir = dfeat[..., o:o + HP * 3].reshape(N, L, HP, 3), dfeat[..., o + HP * 3:o + HP * 4], dfeat[..., o + HP * 4:].reshape(N, L, HP, 3)
+        loc = feat[..., o:o + HP * 3].reshape(N, L, HP, 3)
+        # points epilogue (ga.py:136-139): loc = R^T (agg - t), dist = |loc|, dir = loc / (dist + 1e-4)
+        n = loc.norm(dim=-1, keepdim=True)
+        unit = torch.where(n > 0, loc / n.clamp_min(1e-30), torch.zeros_like(loc))
+        inv = 1.0 / (n + 1e-4)
+        dl = dloc + ddir * inv + (ddist.unsqueeze(-1) - (ddir * loc).sum(-1, keepdim=True) * inv * inv) * unit
+        dag = torch.einsum('nlab,nlkb->nlka', R, dl).reshape(N, L, H, P * 3)
+        ag = _to_global(R, t, loc).reshape(N, L, H, P * 3)
+        # delta_ih = sum_j alpha dalpha = <dfeat, feat> over the three aggregated outputs
+        delta = (dfeat[..., :H * 64] * feat[..., :H * 64]).reshape(N, L, H, 64).sum(-1) \
+            + (dfn * feat[..., H * 64:o].reshape(N, L, H, D)).sum(-1) + (dag * ag).sum(-1)
+        da_node = torch.einsum('nihd,njhd->nijh', dfn, v) + torch.einsum('nihx,njhx->nijh', dag, vg)
+        g, dz = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb)          # the z-streaming part
+        del da_node
+        dv = torch.einsum('nijh,nihd->njhd', alpha, dfn)
+        dvg = torch.einsum('nijh,nihx->njhx', alpha, dag)
+        sc = 1.0 / math.sqrt(D)
+        dq = torch.einsum('nijh,njhd->nihd', g, k) * sc
+        dk = torch.einsum('nijh,nihd->njhd', g, q) * sc
+        gam = gamma_raw.reshape(-1)
+        cfac = math.sqrt(2 / (9 * P)) / 2
+        coef = (-F.softplus(gam) * cfac)[:, None]                                   # (H, 1)
+        dqg = 2 * coef * (qg * g.sum(2).unsqueeze(-1) - torch.einsum('nijh,njhx->nihx', g, kg))
+        dkg = 2 * coef * (kg * g.sum(1).unsqueeze(-1) - torch.einsum('nijh,nihx->njhx', g, qg))
+        d2 = (qg ** 2).sum(-1).unsqueeze(2) + (kg ** 2).sum(-1).unsqueeze(1) - 2 * torch.einsum('nihx,njhx->nijh', qg, kg)
+        dgamma = ((g * d2).sum((0, 1, 2)) * (-torch.sigmoid(gam) * cfac)).reshape(gamma_raw.shape)
+        dWb = torch.einsum('nijh,nijc->hc', g, z)
+        loc_grad = lambda d: torch.einsum('nlba,nlkb->nlka', R, d.reshape(N, L, HP, 3)).reshape(N, L, HP * 3)     # R^T d
+        dproj = torch.cat([dq.reshape(N, L, HD), dk.reshape(N, L, HD), dv.reshape(N, L, HD), loc_grad(dqg), loc_grad(dkg), loc_grad(dvg)], dim=-1)
+        return dproj, dz, None, None, None, dWb, dgamma
+
+
+NATIVE_IPA = True      # tests flip this to compare the native path with the plain torch statement
+
+
+def _block_tail(blk, x, feat, mask):
+    u = blk.out_transform(feat)
+    u = torch.where(mask.unsqueeze(-1), u, torch.zeros_like(u))
+    y = _ln(x + u, blk.layer_norm_1)
+    return _ln(y + blk.mlp_transition(y), blk.layer_norm_2)
+
+
 # ------------------------------------------------------------------ network
-def ga_block(blk, R, t, x, z, mask):
+def ga_block(blk, R, t, x, z, mask, native=None):
     N, L, _ = x.shape
+    if NATIVE_IPA if native is None else native:
+        w_node = torch.cat([blk.proj_query.weight, blk.proj_key.weight, blk.proj_value.weight,
+                            blk.proj_query_point.weight, blk.proj_key_point.weight, blk.proj_value_point.weight], dim=0)
+        feat = IpaCore.apply(x @ w_node.t(), z, R.detach(), t.detach(), mask, blk.proj_pair_bias.weight, blk.spatial_coef)
+        return _block_tail(blk, x, feat, mask)
     q = blk.proj_query(x).view(N, L, H, D)
     k = blk.proj_key(x).view(N, L, H, D)
     v = blk.proj_value(x).view(N, L, H, D)
@@ -95,10 +173,7 @@ def ga_block(blk, R, t, x, z, mask):
     dist = loc.norm(dim=-1)
     direc = loc / (dist.unsqueeze(-1) + 1e-4)
     feat = torch.cat([f_pair, f_node, loc.reshape(N, L, -1), dist, direc.reshape(N, L, -1)], dim=-1)
-    u = blk.out_transform(feat)
-    u = torch.where(mask.unsqueeze(-1), u, torch.zeros_like(u))
-    y = _ln(x + u, blk.layer_norm_1)
-    return _ln(y + blk.mlp_transition(y), blk.layer_norm_2)
+    return _block_tail(blk, x, feat, mask)
 
 
 def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 3
+#define ABOPT_ABI_VERSION 4
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -187,6 +187,22 @@ int abopt_add_noise(const int64_t* t, const float* alpha_bars, const float* fwd_
 
 /* ---- Batched-sampling reduction: D/tools/runner/design_for_testset.py:556-589 (calc_per_rmsd +
  * rank_commoness score).  structs [B,n,3] -> score [B] = mean_{b'} RMSD(b,b') * B/(B-1). */
+/* ---- Training side of the IPA core (FullDPM.forward, D/modules/diffusion/dpm_full.py:156-234; the autograd of
+ * GABlock.forward, ga.py:81-147).  The host keeps the dense projections, LayerNorm/MLP and losses in its autograd graph
+ * (library GEMMs) and calls these two for the part that streams pair_feat:
+ *   forward : proj_local [N,L,2016] = x . [Wq|Wk|Wv|Wqp|Wkp|Wvp]^T (points still in the residue frames)
+ *             -> feat [N,L,1824] (the input of out_transform, ga.py:174) and alpha [N,L,L,12] (ga.py:166)
+ *   backward: g [N,L,L,12] = d loss / d logits (after the sqrt(1/3) scale) and dpair_feat [N,L,L,C] of this block, from
+ *             alpha, dalpha_node[n,i,j,h] = <dfeat_node_ih, v_jh> + <dagg_pts_ih, v_pts_jh>, delta[n,i,h] = sum_j alpha dalpha,
+ *             dfeat (its first 12*C columns are d feat_p2n, row stride ld_dfeat) and proj_pair_bias.weight. */
+size_t abopt_ipa_train_workspace_bytes(int N, int L);
+int abopt_ipa_core_train_forward(const float* proj_local, const float* R, const float* t, const float* pair_feat, const uint8_t* mask,
+                                 const float* w_pair_bias, const float* spatial_coef, float* feat, float* alpha,
+                                 int N, int L, int C, void* ws, size_t ws_bytes, abopt_stream stream);
+int abopt_ipa_pair_backward(const float* pair_feat, const float* alpha, const float* dalpha_node, const float* delta,
+                            const float* dfeat, int ld_dfeat, const float* w_pair_bias, float* g, float* dpair_feat,
+                            int N, int L, int C, abopt_stream stream);
+
 /* ---- encode(): D/models/diffab.py:39-83.  ResidueEmbedding.forward (D/modules/encoders/residue.py:26-92; the AbDesign
  * variant adds hotspot_embed, A/modules/encoders/residue.py:19-21), PairEmbedding.forward (D/modules/encoders/pair.py:37-101),
  * construct_3d_basis (D/modules/common/geometry.py:47-69).  Feature widths are fixed: res_feat_dim 128, pair_feat_dim 64,

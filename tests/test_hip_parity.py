@@ -460,6 +460,29 @@ def test_training_loss_and_grads_vs_reference():
     d.zero_grad()
 
 
+@pytest.mark.parametrize('N,L,lengths', [(2, 24, [24, 19]), (3, 70, [70, 33, 1]), (2, 256, [256, 250])])
+def test_ipa_core_autograd_function_vs_torch_statement(N, L, lengths):
+    """Native training block (HIP forward with alpha kept, HIP z-streaming backward + (N,L,L,12) GEMMs) against the plain
+    torch statement of the same GABlock (which the reference's recorded gradients pin): output and every gradient."""
+    from ab_opt_amd import training
+    blk = _block_on_device(seed=9)
+    with torch.no_grad():
+        blk.spatial_coef.copy_(dev(synth.hash_tensor((1, 1, 1, 12), 77, scale=1.0)))
+    R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(N, L, lengths, salt=700 + L)]
+    wout = dev(synth.hash_tensor((N, L, 128), 78, scale=1.0))
+    res = {}
+    for native in (False, True):
+        blk.zero_grad()
+        xx, zz = x.clone().requires_grad_(True), z.clone().requires_grad_(True)
+        out = training.ga_block(blk, R, t, xx, zz, mask, native=native)
+        (out * wout).sum().backward()
+        res[native] = dict(out=out.detach(), dx=xx.grad, dz=zz.grad, **{'d_' + n: p.grad.clone() for n, p in blk.named_parameters()})
+    for k, ref in res[False].items():
+        tol = 2e-5 if k == 'out' else 2e-4
+        assert max_abs(res[True][k], ref) <= tol * max(1.0, ref.abs().max().item()), k
+    blk.zero_grad()
+
+
 def test_model_forward_trains_end_to_end():
     """model(batch) -> loss dict -> backward -> finite gradients on every trainable tensor that the loss touches."""
     m = build_model(10, 3, device=DEV).train()
