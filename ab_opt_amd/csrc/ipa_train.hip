@@ -9,11 +9,15 @@
 //     g_ijh      = alpha_ijh (dalpha_ijh - delta_ih) / sqrt(3)                 (softmax backward of ga.py:11-26 and the logit scale, ga.py:165)
 //     dz_ijc     = sum_h alpha_ijh dfp_ihc + g_ijh Wb_hc                       (pair aggregation + proj_pair_bias, ga.py:88-90)
 // delta_ih = sum_j alpha_ijh dalpha_ijh is supplied by the host as <d feat, feat> of the aggregated outputs (the
-// flash-attention identity).  g is written for the (N,L,L,12)-sized q/k/point/Wb gradient GEMMs.
+// flash-attention identity).  g is written for the q/k/point/Wb gradient GEMMs, which are plain batched L x L products.
 #include "ipa_common.h"
 #include "kernels.h"
 
 namespace abopt {
+
+// alpha, dalpha_node and g use the head-major layout (N, 12, L, L): every (n, h) slice is then a plain row-major L x L
+// matrix for the batched library GEMMs the host runs on them.
+constexpr int TJ = 256;                                                    // keys per LDS tile
 
 // One workgroup per query row (n, i): 4 waves, each handles 4 keys per iteration (lane = (jl, x)): x = head in phase 1
 // (dalpha, g), x = group of 4 channels in phase 2 (dz).  The two phases exchange (alpha, g) through a wave-private LDS tile.
@@ -23,8 +27,11 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
                                                                 float* __restrict__ g_out, float* __restrict__ dz, int L) {
     __shared__ __attribute__((aligned(16))) float zs[4][4][C + 4];       // per wave: 4 key rows of z
     __shared__ __attribute__((aligned(16))) float ag[4][4][2][16];        // per wave: alpha, g of 4 keys x 12 heads
+    __shared__ float as[H][TJ + 4], ns[H][TJ + 4], gs[H][TJ + 4];         // row i of alpha / dalpha_node / g for one key tile, all heads
     const int64_t row = blockIdx.x;                                        // n * L + i
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jl = lane >> 4, x = lane & 15;
+    const int64_t n = row / L;
+    const int i = (int)(row % L);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, jl = lane >> 4, x = lane & 15;
     const float* dfp = dfeat + row * ld_dfeat;                             // [12][64]
     // phase-1 operand: dfp[h = x][0:64];  phase-2 operands: dfp[0:12][4x .. 4x+3], Wb[0:12][4x .. 4x+3]
     float4 d1[16];
@@ -35,41 +42,84 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
     for (int h = 0; h < H; ++h) { d2[h] = reinterpret_cast<const float4*>(dfp + h * C)[x]; w2[h] = reinterpret_cast<const float4*>(Wb + h * C)[x]; }
     const float del = (x < H) ? delta[row * H + x] : 0.f;
     const float* zrow = z + row * (int64_t)L * C;
-    const float* arow = alpha + row * (int64_t)L * H;
-    const float* nrow = dalpha_node + row * (int64_t)L * H;
-    float* grow = g_out + row * (int64_t)L * H;
     float* dzrow = dz + row * (int64_t)L * C;
-    for (int j0 = wave * 4; j0 < L; j0 += 16) {
-        const int j = j0 + jl;
-        const bool ok = j < L;
-        const int jc = ok ? j : L - 1;
-        // stage the wave's 4 z rows: lane (jl, x) loads channels 4x..4x+3 of key j (1 KB per wave, coalesced)
-        const float4 zv = reinterpret_cast<const float4*>(zrow + (int64_t)jc * C)[x];
-        wave_lds_sync();
-        *reinterpret_cast<float4*>(&zs[wave][jl][x * 4]) = zv;
-        float a = 0.f, dn = 0.f;
-        if (x < H) { a = arow[(int64_t)jc * H + x]; dn = nrow[(int64_t)jc * H + x]; }
-        wave_lds_sync();
-        // phase 1: dalpha for (key jl, head x)
-        float acc = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float4 zz = *reinterpret_cast<const float4*>(&zs[wave][jl][q * 4]);
-            acc = fmaf(d1[q].x, zz.x, acc); acc = fmaf(d1[q].y, zz.y, acc); acc = fmaf(d1[q].z, zz.z, acc); acc = fmaf(d1[q].w, zz.w, acc);
-        }
-        const float gv = a * ((dn + acc) - del) * 0.5773502691896258f;
-        if (x < H && ok) grow[(int64_t)j * H + x] = gv;
-        ag[wave][jl][0][x] = a; ag[wave][jl][1][x] = gv;
-        wave_lds_sync();
-        // phase 2: dz for (key jl, channels 4x..4x+3)
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t hm = ((n * H) * (int64_t)L + i) * L;                     // (n, h = 0, i, j = 0); heads are L*L apart
+    const int64_t hstride = (int64_t)L * L;
+    for (int jt = 0; jt < L; jt += TJ) {
+        __syncthreads();                                                   // previous tile's g has been written out
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            const float ah = ag[wave][jl][0][h], gh = ag[wave][jl][1][h];
-            o.x = fmaf(ah, d2[h].x, o.x); o.y = fmaf(ah, d2[h].y, o.y); o.z = fmaf(ah, d2[h].z, o.z); o.w = fmaf(ah, d2[h].w, o.w);
-            o.x = fmaf(gh, w2[h].x, o.x); o.y = fmaf(gh, w2[h].y, o.y); o.z = fmaf(gh, w2[h].z, o.z); o.w = fmaf(gh, w2[h].w, o.w);
+            const int j = jt + tid;
+            as[h][tid] = (j < L) ? alpha[hm + h * hstride + j] : 0.f;
+            ns[h][tid] = (j < L) ? dalpha_node[hm + h * hstride + j] : 0.f;
         }
-        if (ok) reinterpret_cast<float4*>(dzrow + (int64_t)j * C)[x] = o;
+        __syncthreads();
+        // the wave's 4 z rows per iteration: lane (jl, x) loads channels 4x..4x+3 of key j (1 KB per wave, coalesced), one iteration ahead
+        float4 znext = reinterpret_cast<const float4*>(zrow + (int64_t)min(jt + wave * 4 + jl, L - 1) * C)[x];
+        for (int jj = wave * 4; jj < TJ && jt + jj < L; jj += 16) {
+            const int j = jt + jj + jl;
+            const bool ok = j < L;
+            const float4 zv = znext;
+            znext = reinterpret_cast<const float4*>(zrow + (int64_t)min(j + 16, L - 1) * C)[x];
+            wave_lds_sync();
+            *reinterpret_cast<float4*>(&zs[wave][jl][x * 4]) = zv;
+            const float a = (x < H) ? as[x][jj + jl] : 0.f, dn = (x < H) ? ns[x][jj + jl] : 0.f;
+            wave_lds_sync();
+            // phase 1: dalpha for (key jl, head x)
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float4 zz = *reinterpret_cast<const float4*>(&zs[wave][jl][q * 4]);
+                acc = fmaf(d1[q].x, zz.x, acc); acc = fmaf(d1[q].y, zz.y, acc); acc = fmaf(d1[q].z, zz.z, acc); acc = fmaf(d1[q].w, zz.w, acc);
+            }
+            const float gv = a * ((dn + acc) - del) * 0.5773502691896258f;
+            if (x < H) gs[x][jj + jl] = gv;
+            ag[wave][jl][0][x] = a; ag[wave][jl][1][x] = gv;
+            wave_lds_sync();
+            // phase 2: dz for (key jl, channels 4x..4x+3)
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float ah = ag[wave][jl][0][h], gh = ag[wave][jl][1][h];
+                o.x = fmaf(ah, d2[h].x, o.x); o.y = fmaf(ah, d2[h].y, o.y); o.z = fmaf(ah, d2[h].z, o.z); o.w = fmaf(ah, d2[h].w, o.w);
+                o.x = fmaf(gh, w2[h].x, o.x); o.y = fmaf(gh, w2[h].y, o.y); o.z = fmaf(gh, w2[h].z, o.z); o.w = fmaf(gh, w2[h].w, o.w);
+            }
+            if (ok) reinterpret_cast<float4*>(dzrow + (int64_t)j * C)[x] = o;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const int j = jt + tid;
+            if (j < L) g_out[hm + h * hstride + j] = gs[h][tid];
+        }
+    }
+}
+
+// masked softmax of the logits dump, written head-major (ga.py:11-26): one workgroup per (n, i); the row's L x 12 logits are
+// staged in LDS with coalesced loads, wave w reduces heads 3w..3w+2, rows of alpha[n, h, i, :] are written coalesced
+__global__ __launch_bounds__(256) void alpha_head_major_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ mask,
+                                                               float* __restrict__ alpha, int L) {
+    extern __shared__ float lg[];                                // [L][12] then overwritten with the probabilities
+    const int64_t row = blockIdx.x;                              // n * L + i
+    const int64_t n = row / L, nbase = n * L;
+    const int i = (int)(row % L), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool mi = mask[row] != 0;
+    const float* src = logits + row * (int64_t)L * H;
+    for (int e = tid; e < L * H; e += 256) {
+        float v = src[e];
+        if (!(mi && mask[nbase + e / H] != 0)) v -= 1e5f;
+        lg[e] = v;
+    }
+    __syncthreads();
+    for (int h = wave * 3; h < wave * 3 + 3; ++h) {
+        float mx = -INFINITY;
+        for (int j = lane; j < L; j += 64) mx = fmaxf(mx, lg[j * H + h]);
+        mx = wave_max(mx);
+        float sm = 0.f;
+        for (int j = lane; j < L; j += 64) sm += expf(lg[j * H + h] - mx);
+        sm = wave_sum(sm);
+        float* out = alpha + ((n * H + h) * (int64_t)L + i) * L;
+        for (int j = lane; j < L; j += 64) out[j] = mi ? expf(lg[j * H + h] - mx) / sm : 0.f;
     }
 }
 
@@ -81,9 +131,9 @@ int launch_ipa_pair_backward(const float* z, const float* alpha, const float* da
     return ABOPT_OK;
 }
 
-size_t ipa_train_ws_floats(int N, int L) { return (size_t)N * L * NP + ipa_kvfrag_floats(N, L) + 64; }
+size_t ipa_train_ws_floats(int N, int L) { return (size_t)N * L * NP + ipa_kvfrag_floats(N, L) + (size_t)N * L * L * H + 64; }
 
-// proj_local [N*L, 2016] (points in the residue frames, as the six projections produce them) -> feat [N*L, 1824], alpha [N, L, L, 12]
+// proj_local [N*L, 2016] (points in the residue frames, as the six projections produce them) -> feat [N*L, 1824], alpha [N, 12, L, L]
 int launch_ipa_train_forward(const float* proj_local, const float* R, const float* t, const float* z, const uint8_t* mask,
                              const float* Wb, const float* spatial_coef, float* feat, float* alpha, int N, int L, float* ws, hipStream_t st) {
     const int64_t M = (int64_t)N * L;
@@ -94,8 +144,14 @@ int launch_ipa_train_forward(const float* proj_local, const float* R, const floa
                                (size_t)ABOPT_NODE_PROJ * sizeof(float), (size_t)M, hipMemcpyDeviceToDevice, st));
     int rc;
     if ((rc = launch_points_to_global(proj, R, t, M, st, kvf, N, L))) return rc;
-    // alpha doubles as the logits dump: alpha_from_logits rewrites it in place
-    return launch_ipa_core(proj, z, mask, R, t, Wb, spatial_coef, feat, alpha, alpha, nullptr, kvf, N, L, st);
+    float* logits = kvf + ipa_kvfrag_floats(N, L);
+    if ((rc = launch_ipa_core(proj, z, mask, R, t, Wb, spatial_coef, feat, logits, nullptr, nullptr, kvf, N, L, st))) return rc;
+    const size_t lds = (size_t)L * H * sizeof(float);
+    ABOPT_CHECK_ARG(lds <= 96 * 1024, "ipa_core_train_forward: L=%d too long (max 2048)", L);
+    ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha_head_major_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(alpha_head_major_kernel, dim3((unsigned)M), dim3(256), lds, st, logits, mask, alpha, L);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
 }
 
 }  // namespace abopt

@@ -334,11 +334,11 @@ def commonness_score(structs):
 
 
 def ipa_core_train_forward(proj_local, R, t, z, mask, w_pair_bias, spatial_coef):
-    """Training-mode IPA core: -> feat (N,L,1824), alpha (N,L,L,12)  (include/abopt.h: abopt_ipa_core_train_forward)."""
+    """Training-mode IPA core: -> feat (N,L,1824), alpha head-major (N,12,L,L)  (include/abopt.h: abopt_ipa_core_train_forward)."""
     N, L = mask.shape
     dev = z.device
     feat = torch.empty(N, L, 1824, device=dev)
-    alpha = torch.empty(N, L, L, 12, device=dev)
+    alpha = torch.empty(N, 12, L, L, device=dev)
     nb = lib().abopt_ipa_train_workspace_bytes(N, L)
     buf = Workspace.get(nb, dev)
     _check(lib().abopt_ipa_core_train_forward(ptr(proj_local.contiguous(), torch.float32), ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32),
@@ -349,7 +349,7 @@ def ipa_core_train_forward(proj_local, R, t, z, mask, w_pair_bias, spatial_coef)
 
 
 def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias):
-    """-> g (N,L,L,12), dz (N,L,L,C)  (include/abopt.h: abopt_ipa_pair_backward)."""
+    """alpha, dalpha_node head-major (N,12,L,L) -> g (N,12,L,L), dz (N,L,L,C)  (include/abopt.h: abopt_ipa_pair_backward)."""
     N, L = z.shape[:2]
     g = torch.empty_like(alpha)
     dz = torch.empty_like(z)

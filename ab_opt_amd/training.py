@@ -93,11 +93,12 @@ class IpaCore(torch.autograd.Function):
         proj, z, R, t, Wb, gamma_raw, feat, alpha = ctx.saved_tensors
         N, L = proj.shape[:2]
         HD, HP = H * D, H * P
-        q, k, v = (proj[..., i * HD:(i + 1) * HD].reshape(N, L, H, D) for i in range(3))
+        hm = lambda a: a.permute(0, 2, 1, 3)                                        # (N,L,H,*) <-> (N,H,L,*): head-major views for batched GEMMs
+        q, k, v = (hm(proj[..., i * HD:(i + 1) * HD].reshape(N, L, H, D)) for i in range(3))
         pts = [proj[..., 3 * HD + i * HP * 3: 3 * HD + (i + 1) * HP * 3].reshape(N, L, HP, 3) for i in range(3)]
-        qg, kg, vg = (_to_global(R, t, p).reshape(N, L, H, P * 3) for p in pts)
+        qg, kg, vg = (hm(_to_global(R, t, p).reshape(N, L, H, P * 3)) for p in pts)
         dfeat = dfeat.contiguous()
-        dfn = dfeat[..., H * 64: H * 64 + HD].reshape(N, L, H, D)
+        dfn = hm(dfeat[..., H * 64: H * 64 + HD].reshape(N, L, H, D))
         o = H * 64 + HD
         dloc, ddist, ddir = dfeat[..., o:o + HP * 3].reshape(N, L, HP, 3), dfeat[..., o + HP * 3:o + HP * 4], dfeat[..., o + HP * 4:].reshape(N, L, HP, 3)
         loc = feat[..., o:o + HP * 3].reshape(N, L, HP, 3)
@@ -106,29 +107,29 @@ class IpaCore(torch.autograd.Function):
         unit = torch.where(n > 0, loc / n.clamp_min(1e-30), torch.zeros_like(loc))
         inv = 1.0 / (n + 1e-4)
         dl = dloc + ddir * inv + (ddist.unsqueeze(-1) - (ddir * loc).sum(-1, keepdim=True) * inv * inv) * unit
-        dag = torch.einsum('nlab,nlkb->nlka', R, dl).reshape(N, L, H, P * 3)
+        dag_l = torch.einsum('nlab,nlkb->nlka', R, dl).reshape(N, L, H, P * 3)
         ag = _to_global(R, t, loc).reshape(N, L, H, P * 3)
         # delta_ih = sum_j alpha dalpha = <dfeat, feat> over the three aggregated outputs
         delta = (dfeat[..., :H * 64] * feat[..., :H * 64]).reshape(N, L, H, 64).sum(-1) \
-            + (dfn * feat[..., H * 64:o].reshape(N, L, H, D)).sum(-1) + (dag * ag).sum(-1)
-        da_node = torch.einsum('nihd,njhd->nijh', dfn, v) + torch.einsum('nihx,njhx->nijh', dag, vg)
+            + (hm(dfn) * feat[..., H * 64:o].reshape(N, L, H, D)).sum(-1) + (dag_l * ag).sum(-1)
+        dag = hm(dag_l)
+        T = lambda a: a.transpose(-1, -2)
+        da_node = dfn @ T(v) + dag @ T(vg)                                          # (N,H,L,L)
         g, dz = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb)          # the z-streaming part
         del da_node
-        dv = torch.einsum('nijh,nihd->njhd', alpha, dfn)
-        dvg = torch.einsum('nijh,nihx->njhx', alpha, dag)
+        dv, dvg = T(alpha) @ dfn, T(alpha) @ dag
         sc = 1.0 / math.sqrt(D)
-        dq = torch.einsum('nijh,njhd->nihd', g, k) * sc
-        dk = torch.einsum('nijh,nihd->njhd', g, q) * sc
+        dq, dk = (g @ k) * sc, (T(g) @ q) * sc
         gam = gamma_raw.reshape(-1)
         cfac = math.sqrt(2 / (9 * P)) / 2
-        coef = (-F.softplus(gam) * cfac)[:, None]                                   # (H, 1)
-        dqg = 2 * coef * (qg * g.sum(2).unsqueeze(-1) - torch.einsum('nijh,njhx->nihx', g, kg))
-        dkg = 2 * coef * (kg * g.sum(1).unsqueeze(-1) - torch.einsum('nijh,nihx->njhx', g, qg))
-        d2 = (qg ** 2).sum(-1).unsqueeze(2) + (kg ** 2).sum(-1).unsqueeze(1) - 2 * torch.einsum('nihx,njhx->nijh', qg, kg)
-        dgamma = ((g * d2).sum((0, 1, 2)) * (-torch.sigmoid(gam) * cfac)).reshape(gamma_raw.shape)
-        dWb = torch.einsum('nijh,nijc->hc', g, z)
-        loc_grad = lambda d: torch.einsum('nlba,nlkb->nlka', R, d.reshape(N, L, HP, 3)).reshape(N, L, HP * 3)     # R^T d
-        dproj = torch.cat([dq.reshape(N, L, HD), dk.reshape(N, L, HD), dv.reshape(N, L, HD), loc_grad(dqg), loc_grad(dkg), loc_grad(dvg)], dim=-1)
+        coef = (-F.softplus(gam) * cfac).view(1, H, 1, 1)
+        dqg = 2 * coef * (qg * g.sum(-1, keepdim=True) - g @ kg)
+        dkg = 2 * coef * (kg * g.sum(-2).unsqueeze(-1) - T(g) @ qg)
+        d2 = (qg ** 2).sum(-1, keepdim=True) + (kg ** 2).sum(-1).unsqueeze(-2) - 2 * (qg @ T(kg))
+        dgamma = ((g * d2).sum((0, 2, 3)) * (-torch.sigmoid(gam) * cfac)).reshape(gamma_raw.shape)
+        dWb = (g.reshape(N, H, L * L) @ z.reshape(N, L * L, -1)).sum(0)
+        loc_grad = lambda d: torch.einsum('nlba,nlkb->nlka', R, hm(d).reshape(N, L, HP, 3)).reshape(N, L, HP * 3)     # R^T d
+        dproj = torch.cat([hm(dq).reshape(N, L, HD), hm(dk).reshape(N, L, HD), hm(dv).reshape(N, L, HD), loc_grad(dqg), loc_grad(dkg), loc_grad(dvg)], dim=-1)
         return dproj, dz, None, None, None, dWb, dgamma
 
 

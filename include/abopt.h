@@ -191,9 +191,9 @@ int abopt_add_noise(const int64_t* t, const float* alpha_bars, const float* fwd_
  * GABlock.forward, ga.py:81-147).  The host keeps the dense projections, LayerNorm/MLP and losses in its autograd graph
  * (library GEMMs) and calls these two for the part that streams pair_feat:
  *   forward : proj_local [N,L,2016] = x . [Wq|Wk|Wv|Wqp|Wkp|Wvp]^T (points still in the residue frames)
- *             -> feat [N,L,1824] (the input of out_transform, ga.py:174) and alpha [N,L,L,12] (ga.py:166)
- *   backward: g [N,L,L,12] = d loss / d logits (after the sqrt(1/3) scale) and dpair_feat [N,L,L,C] of this block, from
- *             alpha, dalpha_node[n,i,j,h] = <dfeat_node_ih, v_jh> + <dagg_pts_ih, v_pts_jh>, delta[n,i,h] = sum_j alpha dalpha,
+ *             -> feat [N,L,1824] (the input of out_transform, ga.py:174) and alpha (ga.py:166) HEAD-MAJOR [N,12,L,L]
+ *   backward: g [N,12,L,L] = d loss / d logits (after the sqrt(1/3) scale) and dpair_feat [N,L,L,C] of this block, from
+ *             alpha, dalpha_node[n,h,i,j] = <dfeat_node_ih, v_jh> + <dagg_pts_ih, v_pts_jh>, delta[n,i,h] = sum_j alpha dalpha,
  *             dfeat (its first 12*C columns are d feat_p2n, row stride ld_dfeat) and proj_pair_bias.weight. */
 size_t abopt_ipa_train_workspace_bytes(int N, int L);
 int abopt_ipa_core_train_forward(const float* proj_local, const float* R, const float* t, const float* pair_feat, const uint8_t* mask,

@@ -1,8 +1,9 @@
 """Time model.encode() (residue + pair embedding) on the GPU: python tools/bench_encode.py [N] [L] [iters]."""
 import sys, time
 import torch
-sys.path.insert(0, '.')
-sys.path.insert(0, 'tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from conftest import build_model
 from ab_opt_amd.utils.synth import make_batch, LAYOUT_256, LAYOUT_128
 

@@ -1,7 +1,9 @@
 """Developer check: HIP encode vs the torch statement in fp32 and fp64 on the device."""
 import sys, copy
 import torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import cases
 from conftest import AttrDict
 from ab_opt_amd import get_model

@@ -1,6 +1,8 @@
 """Developer check: where do the IPA-core outputs differ from the golden ga_block fixture?"""
 import sys, math
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 import cases
 from conftest import load_golden
