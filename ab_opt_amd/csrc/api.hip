@@ -118,6 +118,18 @@ extern "C" int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abo
     return launch_pair_embed(in, w, pair_feat, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" int abopt_reconstruct_backbone_partially(const float* pos_ctx, const float* R_new, const float* t_new, const int64_t* aa,
+                                                    const int64_t* chain_nb, const int64_t* res_nb, const uint8_t* mask_atoms,
+                                                    const uint8_t* mask_recons, const float* bb_table, const float* o_table,
+                                                    float* pos_new, uint8_t* mask_new, int N, int L, int A, abopt_stream stream) {
+    ABOPT_CHECK_ARG(N >= 0 && L >= 0 && A >= 4, "reconstruct_backbone_partially: bad dims N=%d L=%d A=%d (A >= 4)", N, L, A);
+    if ((int64_t)N * L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(pos_ctx && R_new && t_new && aa && chain_nb && res_nb && mask_atoms && mask_recons && bb_table && o_table && pos_new && mask_new,
+                    "reconstruct_backbone_partially: NULL argument");
+    return launch_reconstruct_backbone(pos_ctx, R_new, t_new, aa, chain_nb, res_nb, mask_atoms, mask_recons, bb_table, o_table, pos_new, mask_new,
+                                       N, L, A, (hipStream_t)stream);
+}
+
 extern "C" int abopt_so3_exp(const float* w, float* R, int64_t n, abopt_stream stream) {
     ABOPT_CHECK_ARG(w && R && n >= 0, "so3_exp: bad arguments");
     return launch_so3_exp(w, R, n, (hipStream_t)stream);

@@ -410,6 +410,64 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backbone reconstruction
+// reconstruct_backbone_partially (AbDock/src/modules/common/geometry.py:404-480): the step right after the sampler
+// (design_for_pdb.py:166-223).  One thread per residue: N, CA, C = R l + t with l the ideal local coordinates of the residue
+// type; O through the psi frame (psi of the RECONSTRUCTED backbone and the next residue's N, zero at chain ends / breaks);
+// merged into the context atoms where mask_recons.
+__global__ void reconstruct_backbone_kernel(const float* __restrict__ pos_ctx, const float* __restrict__ Rn, const float* __restrict__ tn,
+                                            const int64_t* __restrict__ aa, const int64_t* __restrict__ chain_nb, const int64_t* __restrict__ res_nb,
+                                            const uint8_t* __restrict__ mask_atoms, const uint8_t* __restrict__ mask_recons,
+                                            const float* __restrict__ bb_table, const float* __restrict__ o_table,
+                                            float* __restrict__ pos_new, uint8_t* __restrict__ mask_new, int64_t rows, int L, int A) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int l = (int)(row % L);
+    const bool rec = mask_recons[row] != 0;
+    float* po = pos_new + row * A * 3;
+    uint8_t* mo = mask_new + row * A;
+    if (!rec) {
+        for (int k = 0; k < A * 3; ++k) po[k] = pos_ctx[row * A * 3 + k];
+        for (int a = 0; a < A; ++a) mo[a] = mask_atoms[row * A + a];
+        return;
+    }
+    auto to_global = [&](int64_t r, const float* loc) {
+        const float* R = Rn + r * 9;
+        const float* t = tn + r * 3;
+        return v3(R[0] * loc[0] + R[1] * loc[1] + R[2] * loc[2] + t[0], R[3] * loc[0] + R[4] * loc[1] + R[5] * loc[2] + t[1],
+                  R[6] * loc[0] + R[7] * loc[1] + R[8] * loc[2] + t[2]);
+    };
+    const int a0 = (int)min(max(aa[row], (int64_t)0), (int64_t)20);
+    const float* bb = bb_table + a0 * 9;
+    const V3 n = to_global(row, bb), ca = to_global(row, bb + 3), c = to_global(row, bb + 6);
+    float psi = 0.f;
+    if (l < L - 1 && llabs((long long)(res_nb[row + 1] - res_nb[row])) == 1 && chain_nb[row + 1] == chain_nb[row] && mask_atoms[row * A + 1]) {
+        const int a1 = (int)min(max(aa[row + 1], (int64_t)0), (int64_t)20);
+        psi = dihedral_from_four_points(n, ca, c, to_global(row + 1, bb_table + a1 * 9));
+    }
+    const float sp = sinf(psi), cp = cosf(psi);
+    // O = R R_psi o + t, R_psi = rot_x(psi)
+    const float* o = o_table + a0 * 3;
+    const float lo[3] = {o[0], cp * o[1] - sp * o[2], sp * o[1] + cp * o[2]};
+    const V3 ox = to_global(row, lo);
+    const V3 at[4] = {n, ca, c, ox};
+    for (int a = 0; a < A; ++a) {
+        po[a * 3 + 0] = a < 4 ? at[a].x : 0.f; po[a * 3 + 1] = a < 4 ? at[a].y : 0.f; po[a * 3 + 2] = a < 4 ? at[a].z : 0.f;
+        mo[a] = a < 4 ? 1 : 0;
+    }
+}
+
+int launch_reconstruct_backbone(const float* pos_ctx, const float* R_new, const float* t_new, const int64_t* aa, const int64_t* chain_nb,
+                                const int64_t* res_nb, const uint8_t* mask_atoms, const uint8_t* mask_recons, const float* bb_table,
+                                const float* o_table, float* pos_new, uint8_t* mask_new, int N, int L, int A, hipStream_t st) {
+    const int64_t rows = (int64_t)N * L;
+    if (rows == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(reconstruct_backbone_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, st, pos_ctx, R_new, t_new, aa, chain_nb, res_nb,
+                       mask_atoms, mask_recons, bb_table, o_table, pos_new, mask_new, rows, L, A);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,7 +73,7 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
            'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect',
-           'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_pair_backward',
+           'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward']
 
 _lib = None
@@ -122,6 +122,7 @@ def lib():
                                       c_f, c_f, c_i64, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_prof_enable.argtypes = [C.c_int]
         L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.abopt_reconstruct_backbone_partially.argtypes = [c_f, c_f, c_f, c_i64, c_i64, c_i64, c_u8, c_u8, c_f, c_f, c_f, c_u8] + [C.c_int] * 3 + [C.c_void_p]
         L.abopt_ipa_train_workspace_bytes.restype = C.c_size_t
         L.abopt_ipa_train_workspace_bytes.argtypes = [C.c_int] * 2
         L.abopt_ipa_core_train_forward.argtypes = [c_f, c_f, c_f, c_f, c_u8, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -391,6 +392,28 @@ def pair_embed_forward(inp, weights):
     buf = Workspace.get(nb, dev)
     _check(lib().abopt_pair_embed_forward(C.byref(inp), C.byref(weights), ptr(pair_feat), ptr(buf), buf.numel(), stream()))
     return pair_feat
+
+
+_BB_TABLES = {}
+
+
+def reconstruct_backbone_partially(pos_ctx, R_new, t_new, aa, chain_nb, res_nb, mask_atoms, mask_recons):
+    """geometry.py:404-480 on the device -> (pos_new (N,L,A,3), mask_new (N,L,A) bool)."""
+    dev = pos_ctx.device
+    if dev not in _BB_TABLES:
+        import numpy as np
+        d = np.load(os.path.join(_HERE, 'data', 'backbone_ideal.npz'))
+        _BB_TABLES[dev] = (torch.from_numpy(d['bb_table']).to(dev).contiguous(), torch.from_numpy(d['o_table']).to(dev).contiguous())
+    bb, ot = _BB_TABLES[dev]
+    N, L, A = mask_atoms.shape
+    pos_new = torch.empty(N, L, A, 3, device=dev)
+    mask_new = torch.empty(N, L, A, dtype=torch.bool, device=dev)
+    _check(lib().abopt_reconstruct_backbone_partially(ptr(pos_ctx.contiguous(), torch.float32), ptr(R_new.contiguous(), torch.float32),
+                                                      ptr(t_new.contiguous(), torch.float32), ptr(aa.contiguous(), torch.int64),
+                                                      ptr(chain_nb.contiguous(), torch.int64), ptr(res_nb.contiguous(), torch.int64),
+                                                      ptr(mask_atoms.contiguous(), torch.bool), ptr(mask_recons.contiguous(), torch.bool),
+                                                      ptr(bb), ptr(ot), ptr(pos_new), ptr(mask_new), N, L, A, stream()))
+    return pos_new, mask_new
 
 
 def prof_enable(on=True):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 4
+#define ABOPT_ABI_VERSION 5
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -253,6 +253,15 @@ size_t abopt_pair_embed_workspace_bytes(int N, int L, int atoms);
 /* -> pair_feat [N,L,L,64] */
 int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat,
                              void* ws, size_t ws_bytes, abopt_stream stream);
+
+/* ---- reconstruct_backbone_partially: D/modules/common/geometry.py:404-480 (called on every saved frame right after the
+ * sampler, D/tools/runner/design_for_pdb.py:166-223).  pos_ctx/pos_new [N,L,A,3], mask_atoms/mask_new [N,L,A], R_new [N,L,3,3],
+ * t_new [N,L,3] in Angstrom, mask_recons [N,L]; bb_table [21,3,3] / o_table [21,3] are the ideal local backbone coordinates
+ * per residue type (D/utils/protein/constants.py:310-320; shipped as ab_opt_amd/data/backbone_ideal.npz). */
+int abopt_reconstruct_backbone_partially(const float* pos_ctx, const float* R_new, const float* t_new, const int64_t* aa,
+                                         const int64_t* chain_nb, const int64_t* res_nb, const uint8_t* mask_atoms,
+                                         const uint8_t* mask_recons, const float* bb_table, const float* o_table,
+                                         float* pos_new, uint8_t* mask_new, int N, int L, int A, abopt_stream stream);
 
 int abopt_commonness_score(const float* structs, float* score, int B, int n, abopt_stream stream);
 

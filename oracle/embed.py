@@ -110,3 +110,22 @@ def encode(sd, batch, remove_structure, remove_sequence, A=15):
     pair = pair_embedding(sd, 'pair_embed.', A, batch['aa'], batch['res_nb'], batch['chain_nb'], pos, matom, sm, qm)
     R = G.frames_from_backbone(pos[:, :, ATOM_CA], pos[:, :, ATOM_C], pos[:, :, ATOM_N])
     return res, pair, R, pos[:, :, ATOM_CA]
+
+
+def reconstruct_backbone_partially(pos_ctx, R_new, t_new, aa, chain_nb, res_nb, mask_atoms, mask_recons, bb_table, o_table):
+    """D/modules/common/geometry.py:404-480: N, CA, C from the ideal local coordinates of the residue type, O through the psi
+    frame (psi from the reconstructed backbone and the next residue's N), merged into the context where mask_recons."""
+    N, L, A = mask_atoms.shape
+    aa = aa.clamp(0, 20)
+    bb = G.to_global(R_new, t_new, bb_table[aa])                                  # (N,L,3,3)
+    dih, _ = backbone_dihedrals(bb, chain_nb, res_nb, mask_atoms[:, :, ATOM_CA])
+    psi = dih[..., 2]
+    s, c = torch.sin(psi), torch.cos(psi)
+    o, z = torch.ones_like(s), torch.zeros_like(s)
+    R_psi = torch.stack([o, z, z, z, c, -s, z, s, c], dim=-1).reshape(N, L, 3, 3)
+    O = G.to_global(R_new @ R_psi, t_new, o_table[aa].unsqueeze(2))               # compose_chain([(R,t),(R_psi,0)])
+    rec = F.pad(torch.cat([bb, O], dim=2), pad=(0, 0, 0, A - 4), value=0)
+    pos_new = torch.where(mask_recons[:, :, None, None].expand_as(pos_ctx), rec, pos_ctx)
+    mbb = torch.zeros_like(mask_atoms)
+    mbb[:, :, :4] = True
+    return pos_new, torch.where(mask_recons[:, :, None].expand_as(mask_atoms), mbb, mask_atoms)

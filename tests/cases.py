@@ -57,3 +57,17 @@ SO3_EDGE_W = torch.tensor([
     [0.0, 0.0, 0.0], [1e-6, 0.0, 0.0], [1e-3, -2e-3, 5e-4], [0.3, -0.2, 0.1], [1.0, 2.0, -0.5],
     [3.1, 0.0, 0.0], [0.0, 3.14159, 0.0], [2.2, 2.2, 0.1], [-1.7, 0.4, 2.5], [0.05, 0.05, 0.05],
 ], dtype=torch.float32)
+
+
+def reconstruct_batch():
+    """Inputs of the reconstruct_small fixture (tests/golden/make_golden.py::case_reconstruct): ragged, two chains, a
+    generated stretch across the chain break."""
+    from ab_opt_amd.utils import synth
+    batch = synth.make_batch(2, synth.LAYOUT_128, seed=41, lengths=[40, 33])
+    batch['chain_nb'][:, 22:] = 1
+    batch['res_nb'][:, 22:] = batch['res_nb'][:, 22:] - 21
+    batch['generate_flag'][:] = False
+    batch['generate_flag'][:, 5:12] = True
+    batch['generate_flag'][:, 20:25] = True
+    batch['generate_flag'] &= batch['mask']
+    return batch

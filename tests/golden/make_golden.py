@@ -337,6 +337,31 @@ def case_encode():
     save('encode_small', res_feat=rf, pair_feat=pf, R0=R0, p0=p0, res_feat_seqkept=rf2, pair_feat_seqkept_sum=pf2.double().sum((1, 2)))
 
 
+def case_reconstruct():
+    """reconstruct_backbone_partially (geometry.py:404-480) on a ragged two-chain batch; also dumps the ideal backbone
+    tables (constants.py:310-320: data, 21 residue types) the function reads."""
+    from src.modules.common import geometry as G
+    from src.utils.protein import constants as K
+    batch = synth.make_batch(2, synth.LAYOUT_128, seed=41, lengths=[40, 33])
+    batch['chain_nb'][:, 22:] = 1
+    batch['res_nb'][:, 22:] = batch['res_nb'][:, 22:] - 21
+    batch['generate_flag'][:] = False
+    batch['generate_flag'][:, 5:12] = True
+    batch['generate_flag'][:, 20:25] = True                         # spans the chain break
+    batch['generate_flag'] &= batch['mask']
+    N, L = batch['aa'].shape
+    v_new = synth.hash_tensor((N, L, 3), 61, scale=2.0)
+    t_new = batch['pos_heavyatom'][:, :, 1] + synth.hash_tensor((N, L, 3), 62, scale=1.5)
+    aa_new = (synth.hash_tensor((N, L), 63, scale=10.0).abs() * 2).long().clamp(max=19)
+    from src.modules.common.so3 import so3vec_to_rotation
+    R_new = so3vec_to_rotation(v_new)
+    pos_new, mask_new = G.reconstruct_backbone_partially(pos_ctx=batch['pos_heavyatom'], R_new=R_new, t_new=t_new, aa=aa_new,
+                                                         chain_nb=batch['chain_nb'], res_nb=batch['res_nb'],
+                                                         mask_atoms=batch['mask_heavyatom'], mask_recons=batch['generate_flag'])
+    save('reconstruct_small', R_new=R_new, t_new=t_new, aa_new=aa_new, pos_new=pos_new, mask_new=mask_new,
+         bb_table=K.backbone_atom_coordinates_tensor, o_table=K.bb_oxygen_coordinate_tensor)
+
+
 def case_rank():
     sys.path.insert(0, os.path.join(REF, 'AbDock'))
     # design_for_testset imports heavy deps at module import; restate-free: load the three pure functions by exec of
@@ -357,7 +382,7 @@ if __name__ == '__main__':
     sys.path.insert(0, os.path.join(REF, 'AbDock'))
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['so3', 'ga_block', 'eps_net', 'schedule_tables', 'trajectory', 'abdesign_sample',
-                             'training', 'encode', 'rank']
+                             'training', 'encode', 'rank', 'reconstruct']
     for w in which:
         print('==', w)
         globals()['case_' + w]()

@@ -293,6 +293,30 @@ def test_encode_hip_vs_autograd_statement(flavour, resolution, L, flags):
     assert out[1][~(batch['mask'][:, :, None] & batch['mask'][:, None, :])].abs().max().item() == 0
 
 
+def test_reconstruct_backbone_partially_vs_reference():
+    from ab_opt_amd import geometry
+    g = load_golden('reconstruct_small')
+    b = {k: dev(v) for k, v in cases.reconstruct_batch().items()}
+    pos, m = geometry.reconstruct_backbone_partially(pos_ctx=b['pos_heavyatom'], R_new=dev(g['R_new']), t_new=dev(g['t_new']), aa=dev(g['aa_new']),
+                                                     chain_nb=b['chain_nb'], res_nb=b['res_nb'], mask_atoms=b['mask_heavyatom'],
+                                                     mask_recons=b['generate_flag'])
+    assert max_abs(pos.cpu(), g['pos_new']) < 2e-5                      # Angstrom
+    assert torch.equal(m.cpu(), g['mask_new'].bool())
+    # rigid-motion equivariance at full size: moving every frame moves the rebuilt atoms with it
+    from oracle import geometry as G
+    N, L = 4, 256
+    bb = {k: dev(v) for k, v in synth.make_batch(N, synth.LAYOUT_256, seed=8).items()}
+    v = dev(synth.hash_tensor((N, L, 3), 5, scale=2.0))
+    t = bb['pos_heavyatom'][:, :, 1].contiguous()
+    Q = dev(G.so3_exp(torch.tensor([[0.4, 0.2, -0.9]])))[0]
+    R = geometry.so3vec_to_rotation(v)
+    p0, _ = geometry.reconstruct_backbone_partially(bb['pos_heavyatom'], R, t, bb['aa'], bb['chain_nb'], bb['res_nb'], bb['mask_heavyatom'], bb['generate_flag'])
+    p1, _ = geometry.reconstruct_backbone_partially(bb['pos_heavyatom'], Q @ R, t @ Q.T, bb['aa'], bb['chain_nb'], bb['res_nb'], bb['mask_heavyatom'], bb['generate_flag'])
+    gen = bb['generate_flag']
+    assert max_abs(p1[gen][:, :4], p0[gen][:, :4] @ Q.T) < 2e-4
+    assert torch.equal(p0[~gen], bb['pos_heavyatom'][~gen])
+
+
 def test_sample_init_vs_reference():
     from ab_opt_amd import hip
     g = load_golden('trajectory_abdock_T10')

@@ -256,6 +256,18 @@ def test_encode_small():
     assert max_abs(prf, g['res_feat']) < 2e-5 and max_abs(ppf, g['pair_feat']) < 2e-5 and max_abs(pR, g['R0']) < 1e-6
 
 
+def test_reconstruct_backbone_partially():
+    g = load_golden('reconstruct_small')
+    b = cases.reconstruct_batch()
+    pos, m = embed.reconstruct_backbone_partially(b['pos_heavyatom'], g['R_new'], g['t_new'], g['aa_new'], b['chain_nb'], b['res_nb'],
+                                                  b['mask_heavyatom'], b['generate_flag'], g['bb_table'], g['o_table'])
+    assert max_abs(pos, g['pos_new']) < 1e-6 and torch.equal(m, g['mask_new'].bool())
+    # the tables the product ships are the reference's
+    import numpy as np, os
+    d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ab_opt_amd', 'data', 'backbone_ideal.npz'))
+    assert np.array_equal(d['bb_table'], g['bb_table'].numpy()) and np.array_equal(d['o_table'], g['o_table'].numpy())
+
+
 def test_rank_commoness():
     g = load_golden('rank_commoness')
     structs = synth.hash_tensor((16, 36, 3), 55, scale=8.0)
