@@ -60,8 +60,8 @@ __device__ long long g_ws_timing[2][8];
 #define TSTAMP(k)
 #endif
 
-// NPW = number of pair waves (4 or 8); each owns RPW = 16 / NPW query rows.  NPW = 8 gives 12 waves = 3 per SIMD (two pair
-// waves + one node wave): three independent instruction streams per matrix pipe at <= 168 VGPRs each.
+// NPW = number of pair waves; each owns RPW = 16 / NPW query rows.  Only NPW = 4 is instantiated: 8 pair waves (3 waves per SIMD,
+// <= 168 VGPRs) spilled and measured 349 us against 239 us.
 template <bool DBG, int NPW, bool CACHED>
 __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_kernel(const float* __restrict__ proj, const float* __restrict__ z,
                                                              const uint8_t* __restrict__ mask, const float* __restrict__ R,
@@ -88,28 +88,29 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
     const int64_t rowbase = (int64_t)n * L;
     const float* projn = proj + rowbase * NP;
 
-    // ---- prologue (all 8 waves)
-    if (tid < BI * 16) {
-        const int il = tid >> 4, h = tid & 15;
-        sm.nq[il][h] = (h < H) ? projn[(int64_t)min(i0 + il, L - 1) * NP + OFF_NQ + h] : 0.f;
+    // ---- prologue (all 8 waves), run by each role AFTER it has put its first global loads in flight
+#define WS_PROLOGUE_FILL() {                                                                                            \
+    if (tid < BI * 16) {                                                                                               \
+        const int il = tid >> 4, h = tid & 15;                                                                         \
+        sm.nq[il][h] = (h < H) ? projn[(int64_t)min(i0 + il, L - 1) * NP + OFF_NQ + h] : 0.f;                          \
+    }                                                                                                                  \
+    for (int e = tid; e < BI * (H * D / 4); e += NT) {                                                                 \
+        const int il = e / (H * D / 4), c4 = e % (H * D / 4);                                                          \
+        *reinterpret_cast<float4*>(&sm.q[il][c4 * 4]) = reinterpret_cast<const float4*>(projn + (int64_t)min(i0 + il, L - 1) * NP + OFF_Q)[c4]; \
+    }                                                                                                                  \
+    for (int e = tid; e < 16 * (C / 4); e += NT) {                                                                     \
+        const int h = e / (C / 4), c4 = e % (C / 4);                                                                   \
+        float4 w4v = make_float4(0.f, 0.f, 0.f, 0.f);                                                                  \
+        if (h < H) w4v = reinterpret_cast<const float4*>(Wb + h * C)[c4];                                              \
+        *reinterpret_cast<float4*>(&sm.wbs[h][c4 * 4]) = w4v;                                                          \
+    }                                                                                                                  \
+    for (int e = tid; e < nchunk2 * JC; e += NT) sm.mk[e] = (e < L) ? mask[rowbase + e] : 0;                           \
+    if (tid < H) {                                                                                                     \
+        const float sc = spatial_coef[tid];                                                                            \
+        const float gamma = (sc > 20.f) ? sc : log1pf(expf(sc));                                                       \
+        sm.coef[tid] = (-1.f * gamma * 0.16666666666666666f) / 2.f;                                                    \
+    }                                                                                                                  \
     }
-    for (int e = tid; e < BI * (H * D / 4); e += NT) {
-        const int il = e / (H * D / 4), c4 = e % (H * D / 4);
-        *reinterpret_cast<float4*>(&sm.q[il][c4 * 4]) = reinterpret_cast<const float4*>(projn + (int64_t)min(i0 + il, L - 1) * NP + OFF_Q)[c4];
-    }
-    for (int e = tid; e < 16 * (C / 4); e += NT) {
-        const int h = e / (C / 4), c4 = e % (C / 4);
-        float4 w4v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h < H) w4v = reinterpret_cast<const float4*>(Wb + h * C)[c4];
-        *reinterpret_cast<float4*>(&sm.wbs[h][c4 * 4]) = w4v;
-    }
-    for (int e = tid; e < nchunk2 * JC; e += NT) sm.mk[e] = (e < L) ? mask[rowbase + e] : 0;
-    if (tid < H) {
-        const float sc = spatial_coef[tid];
-        const float gamma = (sc > 20.f) ? sc : log1pf(expf(sc));                       // softplus, ga.py:108
-        sm.coef[tid] = (-1.f * gamma * 0.16666666666666666f) / 2.f;                     // ga.py:109-110 with sqrt(2/(9*8)) = 1/6
-    }
-    __syncthreads();
 
     if (pair_wave) {
         // =========================================================================== pair waves: phase B
@@ -138,6 +139,8 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
     }
         // ring position p = c * RPW + ii (c = chunk within the revolution) is also the slot; requests run 3 positions ahead
         WS_ISSUE_Z(0, 0 % RPW, 0 / RPW) WS_ISSUE_Z(1, 1 % RPW, 1 / RPW) WS_ISSUE_Z(2, 2 % RPW, 2 / RPW)
+        WS_PROLOGUE_FILL()
+        __syncthreads();                                                    // prologue tile visible
         __syncthreads();                                                    // barrier #0: S(0) ready
         TSTAMP(0)
         for (int ch0 = 0; ch0 < nchunk2; ch0 += UC) {
@@ -285,7 +288,6 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
             for (int hh = 0; hh < 3; ++hh) load_kfrag(kf[hh], kvn + ((int64_t)min(ch, nchunk - 1) * H + w4 * 3 + hh) * 512, lane);
         };
         auto issue_v = [&](int ch) {                                        // fetch phase-C operands of chunk ch
-            if (NPW == 8) return;                                           // 3 waves/SIMD: no registers to park them; phase C loads just in time
 #pragma unroll
             for (int hh = 0; hh < 3; ++hh) load_vfrag(vf[hh], kvn + ((int64_t)min(ch, nchunk - 1) * H + w4 * 3 + hh) * 512, lane);
         };
@@ -299,8 +301,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                     const float sc = sm.scl[buf][kq * 4 + r][h];
                     accV[hh][0][r] *= sc; accV[hh][1][r] *= sc; accT[hh][0][r] *= sc; accT[hh][1][r] *= sc;
                 }
-                if (NPW == 8) load_vfrag(vf[0], kvn + ((int64_t)min(ch, nchunk - 1) * H + h) * 512, lane);
-                const VFrag& vfh = vf[NPW == 8 ? 0 : hh];
+                const VFrag& vfh = vf[hh];
                 const float4 pa = *reinterpret_cast<const float4*>(&sm.sp[buf][fm][h * PLD + kq * 4]);   // A: row = query fm, step s <-> key 4 kq + s
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -314,6 +315,8 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
         };
 
         issue_k(0);
+        WS_PROLOGUE_FILL()
+        __syncthreads();                                                    // prologue tile visible
         phase_a(0);
         if (nchunk2 > 1) issue_k(1);
         issue_v(0);
@@ -436,12 +439,11 @@ int launch_ipa_core_ws(const float* proj, const float* z, const uint8_t* mask, c
     const int nib = (L + BI - 1) / BI;
     const int remap = (N % 8 == 0) ? 1 : 0;
     prof::begin(st);
-    static const int npw = [] { const char* e = getenv("ABOPT_IPA_PAIR_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();   // 8 pair waves (3 waves/SIMD) measured slower (311 vs 270 us): kept for A/B
 #define WS_LAUNCH(DBGV, NPWV, CV) hipLaunchKernelGGL((ipa_core_ws_kernel<DBGV, NPWV, CV>), dim3((unsigned)(N * nib)), dim3((NPWV + 4) * 64), 0, st, proj, z, \
                                                      mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, kvfrag, N, L, nib, remap)
     if (pair_bias_cache) { if (dbg_logits) WS_LAUNCH(true, 4, true); else WS_LAUNCH(false, 4, true); }
-    else if (dbg_logits) { if (npw == 8) WS_LAUNCH(true, 8, false); else WS_LAUNCH(true, 4, false); }
-    else                 { if (npw == 8) WS_LAUNCH(false, 8, false); else WS_LAUNCH(false, 4, false); }
+    else if (dbg_logits) WS_LAUNCH(true, 4, false);
+    else                 WS_LAUNCH(false, 4, false);
     prof::end(st);
     ABOPT_LAUNCH_CHECK();
 #ifdef WS_TIMING
