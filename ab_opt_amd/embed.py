@@ -16,6 +16,80 @@ from . import hip
 AA_UNK, ATOM_N, ATOM_CA, ATOM_C = 20, 0, 1, 2
 
 
+# ------------------------------------------------------------------ autograd helpers for the L^2-sized training statement
+# torch's generic backward for an embedding looked up at N*L*L indices (sort + segmented scatter) and for a Linear applied to
+# N*L*L rows (one skinny GEMM with K = N*L*L) are the two slowest pieces of encode()'s backward; both have structure.
+def _splitk_tn(a, b, chunk=4096):
+    """a^T @ b for tall a (M, I), b (M, J): batched over row chunks so the library runs many K=chunk GEMMs instead of one skinny
+    K=M GEMM, then a short sum."""
+    M = a.shape[0]
+    S = M // chunk
+    out = None
+    if S >= 2:
+        out = torch.bmm(a[:S * chunk].view(S, chunk, -1).transpose(1, 2), b[:S * chunk].view(S, chunk, -1)).sum(0)
+    rest = a[S * chunk if S >= 2 else 0:]
+    if rest.shape[0]:
+        tail = rest.t() @ b[S * chunk if S >= 2 else 0:]
+        out = tail if out is None else out + tail
+    return out
+
+
+class _TallLinear(torch.autograd.Function):
+    """F.linear for x with millions of rows; weight gradient through _splitk_tn."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = (dy2 @ weight).view_as(x) if ctx.needs_input_grad[0] else None
+        return dx, _splitk_tn(dy2, x2), dy2.sum(0)
+
+
+def _tall_mlp(seq, x):
+    for m in seq:
+        x = _TallLinear.apply(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+    return x
+
+
+class _AAPairLookup(torch.autograd.Function):
+    """table[aa_i * T + aa_j] for all (i, j): the gradient of a (T*T, C) table is two small one-hot contractions
+    (over j, then over i) instead of a scatter of N*L*L rows."""
+
+    @staticmethod
+    def forward(ctx, table, aa, T):
+        ctx.save_for_backward(aa)
+        ctx.T = T
+        return table[aa[:, :, None] * T + aa[:, None, :]]
+
+    @staticmethod
+    def backward(ctx, dout):
+        aa, = ctx.saved_tensors
+        oh = F.one_hot(aa, ctx.T).to(dout.dtype)                                   # (N, L, T)
+        tmp = torch.einsum('njb,nijc->nibc', oh, dout)
+        return torch.einsum('nia,nibc->abc', oh, tmp).reshape(ctx.T * ctx.T, -1), None, None
+
+
+class _SmallTableLookup(torch.autograd.Function):
+    """table[idx] for a small table and millions of indices: gradient = one_hot(idx)^T @ dout."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx)
+        ctx.rows = table.shape[0]
+        return table[idx]
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, = ctx.saved_tensors
+        oh = F.one_hot(idx.reshape(-1), ctx.rows).to(dout.dtype)
+        return _splitk_tn(oh, dout.reshape(-1, dout.shape[-1])), None
+
+
 class AngularEncoding(nn.Module):
     def __init__(self, num_funcs=3):
         super().__init__()
@@ -165,16 +239,15 @@ class PairEmbedding(nn.Module):
         pstruct = structure_mask[:, :, None] * structure_mask[:, None, :] if structure_mask is not None else None
         if sequence_mask is not None:
             aa = torch.where(sequence_mask, aa, torch.full_like(aa, AA_UNK))
-        aap = aa[:, :, None] * self.max_aa_types + aa[:, None, :]
-        f_aap = self.aa_pair_embed(aap)
+        f_aap = _AAPairLookup.apply(self.aa_pair_embed.weight, aa, self.max_aa_types)
         same = chain_nb[:, :, None] == chain_nb[:, None, :]
         rel = torch.clamp(res_nb[:, :, None] - res_nb[:, None, :], min=-self.max_relpos, max=self.max_relpos)
-        f_rel = self.relpos_embed(rel + self.max_relpos) * same[:, :, :, None]
+        f_rel = _SmallTableLookup.apply(self.relpos_embed.weight, rel + self.max_relpos) * same[:, :, :, None]
         d = (torch.linalg.norm(pos[:, :, None, :, None] - pos[:, None, :, None, :], dim=-1, ord=2) / 10).reshape(N, L, L, -1)
-        c = F.softplus(self.aapair_to_distcoef(aap))
+        c = F.softplus(_AAPairLookup.apply(self.aapair_to_distcoef.weight, aa, self.max_aa_types))
         g = torch.exp(-1 * c * d ** 2)
         map_ = (matom[:, :, None, :, None] * matom[:, None, :, None, :]).reshape(N, L, L, -1)
-        f_dist = self.distance_embed(g * map_)
+        f_dist = _tall_mlp(self.distance_embed, g * map_)
         if pstruct is not None:
             f_dist = f_dist * pstruct[:, :, :, None]
         n, ca, cc = pos[:, :, ATOM_N], pos[:, :, ATOM_CA], pos[:, :, ATOM_C]
@@ -184,5 +257,5 @@ class PairEmbedding(nn.Module):
         f_dih = self.dihedral_embed(dihed)
         if pstruct is not None:
             f_dih = f_dih * pstruct[:, :, :, None]
-        out = self.out_mlp(torch.cat([f_aap, f_rel, f_dist, f_dih], dim=-1))
+        out = _tall_mlp(self.out_mlp, torch.cat([f_aap, f_rel, f_dist, f_dih], dim=-1))
         return out * mpair[:, :, :, None]

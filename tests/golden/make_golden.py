@@ -334,7 +334,18 @@ def case_encode():
     with torch.no_grad():
         rf, pf, R0, p0 = m.encode({k: v.clone() for k, v in batch.items()}, True, True)
         rf2, pf2, _, _ = m.encode({k: v.clone() for k, v in batch.items()}, True, False)
-    save('encode_small', res_feat=rf, pair_feat=pf, R0=R0, p0=p0, res_feat_seqkept=rf2, pair_feat_seqkept_sum=pf2.double().sum((1, 2)))
+    # gradients of encode(): d/dparams of <res_feat, w1> + <pair_feat, w2> with hash weights w (training path of the reference)
+    m.zero_grad()
+    rfg, pfg, _, _ = m.encode({k: v.clone() for k, v in batch.items()}, True, True)
+    w1, w2 = synth.hash_tensor(tuple(rfg.shape), 71, scale=1.0), synth.hash_tensor(tuple(pfg.shape), 72, scale=1.0)
+    ((rfg * w1).sum() + (pfg * w2).sum()).backward()
+    P = dict(m.named_parameters())
+    grads = {'grad_' + k.replace('.', '__'): P[k].grad for k in (
+        'pair_embed.aa_pair_embed.weight', 'pair_embed.relpos_embed.weight', 'pair_embed.aapair_to_distcoef.weight',
+        'pair_embed.distance_embed.0.weight', 'pair_embed.distance_embed.2.bias', 'pair_embed.out_mlp.0.weight', 'pair_embed.out_mlp.4.weight',
+        'residue_embed.aatype_embed.weight', 'residue_embed.mlp.6.weight')}
+    grads['grad_residue_embed__mlp__0__weight_sub'] = P['residue_embed.mlp.0.weight'].grad[::4, ::7]
+    save('encode_small', res_feat=rf, pair_feat=pf, R0=R0, p0=p0, res_feat_seqkept=rf2, pair_feat_seqkept_sum=pf2.double().sum((1, 2)), **grads)
 
 
 def case_reconstruct():

@@ -253,6 +253,23 @@ def test_encode_small():
         prf, ppf, pR, pp = [t.detach() for t in m.encode({k: v.clone() for k, v in batch.items()}, True, True)]
     with torch.no_grad(), pytest.raises(RuntimeError, match='no CPU path'):
         m.encode({k: v.clone() for k, v in batch.items()}, True, True)
+    # ... and its gradients (structured embedding / tall-linear backward helpers of ab_opt_amd/embed.py) against the reference's
+    m.zero_grad()
+    b2 = {k: v.clone() for k, v in batch.items()}
+    rfg, pfg, _, _ = m.encode(b2, True, True)
+    w1, w2 = synth.hash_tensor(tuple(rfg.shape), 71, scale=1.0), synth.hash_tensor(tuple(pfg.shape), 72, scale=1.0)
+    ((rfg * w1).sum() + (pfg * w2).sum()).backward()
+    P = dict(m.named_parameters())
+    checked = 0
+    for k in g:
+        if not k.startswith('grad_'):
+            continue
+        name = k[len('grad_'):].replace('__', '.')
+        got = P['residue_embed.mlp.0.weight'].grad[::4, ::7] if name.endswith('_sub') else P[name].grad
+        assert max_abs(got, g[k]) <= 2e-4 * max(1e-6, g[k].abs().max().item()), name
+        checked += 1
+    assert checked == 10
+    m.zero_grad()
     assert max_abs(prf, g['res_feat']) < 2e-5 and max_abs(ppf, g['pair_feat']) < 2e-5 and max_abs(pR, g['R0']) < 1e-6
 
 
