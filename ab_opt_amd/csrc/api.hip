@@ -118,6 +118,17 @@ extern "C" int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abo
     return launch_pair_embed(in, w, pair_feat, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" size_t abopt_pair_gauss_workspace_bytes(int N, int L) { return pair_gauss_ws_bytes(N, L); }
+
+extern "C" int abopt_pair_gauss_features(const abopt_encode_inputs* in, const float* aapair_to_distcoef, float* G, float* T,
+                                         void* ws, size_t ws_bytes, abopt_stream stream) {
+    int rc;
+    if ((rc = check_encode_inputs(in, "pair_gauss_features"))) return rc;
+    if ((int64_t)in->N * in->L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(aapair_to_distcoef && G && ws, "pair_gauss_features: NULL argument");
+    return launch_pair_gauss_features(in, aapair_to_distcoef, G, T, ws, ws_bytes, (hipStream_t)stream);
+}
+
 extern "C" int abopt_reconstruct_backbone_partially(const float* pos_ctx, const float* R_new, const float* t_new, const int64_t* aa,
                                                     const int64_t* chain_nb, const int64_t* res_nb, const uint8_t* mask_atoms,
                                                     const uint8_t* mask_recons, const float* bb_table, const float* o_table,

@@ -410,6 +410,66 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
     }
 }
 
+static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct PackBufs { f32x4* atoms4; int* aa_eff; int* resnb; int* chain; uint8_t* flags; char* end; };
+static PackBufs carve_pack(char* p, int64_t rows) {
+    PackBufs b;
+    b.atoms4 = (f32x4*)p; p += al256((size_t)rows * 16 * sizeof(f32x4));
+    b.aa_eff = (int*)p; p += al256((size_t)rows * 4);
+    b.resnb = (int*)p; p += al256((size_t)rows * 4);
+    b.chain = (int*)p; p += al256((size_t)rows * 4);
+    b.flags = (uint8_t*)p; p += al256((size_t)rows);
+    b.end = p;
+    return b;
+}
+static size_t pack_bytes(int64_t rows) { return al256(rows * 16 * sizeof(f32x4)) + 3 * al256(rows * 4) + al256(rows); }
+
+// ------------------------------------------------------------------------------------------------ training side: Gaussian features
+// G[n,i,j,a*A+b] = exp(-softplus(coef[aa_i*22+aa_j][a*A+b]) d_ab^2) * mask_a_i * mask_b_j,  d_ab = |x_ia - x_jb| / 10  (pair.py:62-73),
+// and T = dG/d softplus(coef) = -d_ab^2 G for the backward (the coefficient table is the only trainable input).  One
+// workgroup per query residue (n, i); thread ab < A*A walks the keys j, so every j writes one contiguous A*A row.
+__global__ __launch_bounds__(256) void pair_gauss_features_kernel(const f32x4* __restrict__ atoms4, const int* __restrict__ aa_eff,
+                                                                  const float* __restrict__ coef, int A, int L,
+                                                                  float* __restrict__ G, float* __restrict__ T) {
+    const int64_t row = blockIdx.x;                                        // n * L + i
+    const int64_t base = (row / L) * L;
+    const int ab = threadIdx.x, AA = A * A;
+    if (ab >= AA) return;
+    const int a = ab / A, b = ab % A;
+    const f32x4 pi = atoms4[row * 16 + a];
+    const int aa_i = aa_eff[row];
+    float* g = G + row * (int64_t)L * AA + ab;
+    float* t = T ? T + row * (int64_t)L * AA + ab : nullptr;
+    for (int j = 0; j < L; ++j) {
+        const f32x4 pj = atoms4[(base + j) * 16 + b];
+        const float x = coef[(int64_t)(aa_i * AAT + aa_eff[base + j]) * AA + ab];
+        const float c = (x > 20.f) ? x : log1pf(expf(x));
+        const float dx = pi[0] - pj[0], dy = pi[1] - pj[1], dz = pi[2] - pj[2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz) / 10.f;
+        const float gv = (pi[3] != 0.f && pj[3] != 0.f) ? expf(-1.f * c * (d * d)) : 0.f;
+        g[(int64_t)j * AA] = gv;
+        if (t) t[(int64_t)j * AA] = -(d * d) * gv;
+    }
+}
+
+size_t pair_gauss_ws_bytes(int N, int L) { return pack_bytes((int64_t)N * L) + 1024; }
+
+int launch_pair_gauss_features(const abopt_encode_inputs* in, const float* coef, float* G, float* T, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int N = in->N, L = in->L, A = in->atoms;
+    ABOPT_CHECK_ARG(A >= 3 && A <= 15 && A <= in->atoms_in, "pair_gauss_features: atoms=%d must be in [3, min(15, atoms_in=%d)]", A, in->atoms_in);
+    const int64_t rows = (int64_t)N * L;
+    if (rows == 0) return ABOPT_OK;
+    if (ws_bytes < pair_gauss_ws_bytes(N, L)) { set_error("pair_gauss_features: workspace too small"); return ABOPT_EWORKSPACE; }
+    PackBufs pb = carve_pack((char*)ws, rows);
+    hipLaunchKernelGGL(residue_pack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(64), 0, st, in->aa, in->res_nb, in->chain_nb, in->pos_atoms, in->mask_atoms,
+                       in->structure_mask, in->sequence_mask, in->atoms_in, A, rows, pb.atoms4, pb.aa_eff, pb.resnb, pb.chain, pb.flags, (float*)nullptr, (float*)nullptr);
+    ABOPT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pair_gauss_features_kernel, dim3((unsigned)rows), dim3(256), 0, st, pb.atoms4, pb.aa_eff, coef, A, L, G, T);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ backbone reconstruction
 // reconstruct_backbone_partially (AbDock/src/modules/common/geometry.py:404-480): the step right after the sampler
 // (design_for_pdb.py:166-223).  One thread per residue: N, CA, C = R l + t with l the ideal local coordinates of the residue
@@ -469,21 +529,6 @@ int launch_reconstruct_backbone(const float* pos_ctx, const float* R_new, const 
 }
 
 // ------------------------------------------------------------------------------------------------ host
-static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
-
-struct PackBufs { f32x4* atoms4; int* aa_eff; int* resnb; int* chain; uint8_t* flags; char* end; };
-static PackBufs carve_pack(char* p, int64_t rows) {
-    PackBufs b;
-    b.atoms4 = (f32x4*)p; p += al256((size_t)rows * 16 * sizeof(f32x4));
-    b.aa_eff = (int*)p; p += al256((size_t)rows * 4);
-    b.resnb = (int*)p; p += al256((size_t)rows * 4);
-    b.chain = (int*)p; p += al256((size_t)rows * 4);
-    b.flags = (uint8_t*)p; p += al256((size_t)rows);
-    b.end = p;
-    return b;
-}
-static size_t pack_bytes(int64_t rows) { return al256(rows * 16 * sizeof(f32x4)) + 3 * al256(rows * 4) + al256(rows); }
-
 static int residue_in_dim(int A, bool hotspot) { return EF + AAT * A * 3 + 39 + EF + (hotspot ? EF : 0); }
 
 size_t residue_embed_ws_bytes(int N, int L, int A, int hotspot) {

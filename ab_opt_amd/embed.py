@@ -90,6 +90,27 @@ class _SmallTableLookup(torch.autograd.Function):
         return _splitk_tn(oh, dout.reshape(-1, dout.shape[-1])), None
 
 
+class _GaussFeatures(torch.autograd.Function):
+    """Gaussian atom-pair features (pair.py:62-73) from the HIP kernel `abopt_pair_gauss_features`: the torch statement spends
+    ~10 elementwise kernels on (N,L,L,15,15[,3]) tensors here.  Only the coefficient table carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, coef_table, aa, res_nb, chain_nb, pos, matom, n_types):
+        inp, keep = hip.encode_inputs(aa, res_nb, chain_nb, pos, matom, pos.shape[2])
+        G, T = hip.pair_gauss_features(inp, coef_table.detach(), want_T=True)
+        ctx.save_for_backward(coef_table, aa, T)
+        ctx.n_types = n_types
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        coef_table, aa, T = ctx.saved_tensors
+        oh = F.one_hot(aa, ctx.n_types).to(dG.dtype)
+        tmp = torch.einsum('njb,nijc->nibc', oh, dG * T)                            # T = dG/d softplus(coef)
+        dtab = torch.einsum('nia,nibc->abc', oh, tmp).reshape(ctx.n_types ** 2, -1) * torch.sigmoid(coef_table)
+        return dtab, None, None, None, None, None, None
+
+
 class AngularEncoding(nn.Module):
     def __init__(self, num_funcs=3):
         super().__init__()
@@ -243,11 +264,13 @@ class PairEmbedding(nn.Module):
         same = chain_nb[:, :, None] == chain_nb[:, None, :]
         rel = torch.clamp(res_nb[:, :, None] - res_nb[:, None, :], min=-self.max_relpos, max=self.max_relpos)
         f_rel = _SmallTableLookup.apply(self.relpos_embed.weight, rel + self.max_relpos) * same[:, :, :, None]
-        d = (torch.linalg.norm(pos[:, :, None, :, None] - pos[:, None, :, None, :], dim=-1, ord=2) / 10).reshape(N, L, L, -1)
-        c = F.softplus(_AAPairLookup.apply(self.aapair_to_distcoef.weight, aa, self.max_aa_types))
-        g = torch.exp(-1 * c * d ** 2)
-        map_ = (matom[:, :, None, :, None] * matom[:, None, :, None, :]).reshape(N, L, L, -1)
-        f_dist = _tall_mlp(self.distance_embed, g * map_)
+        if pos.is_cuda and pos.dtype == torch.float32:
+            gm = _GaussFeatures.apply(self.aapair_to_distcoef.weight, aa, res_nb, chain_nb, pos, matom, self.max_aa_types)
+        else:       # plain statement (CPU, or the float64 yardstick of the parity tests)
+            d = (torch.linalg.norm(pos[:, :, None, :, None] - pos[:, None, :, None, :], dim=-1, ord=2) / 10).reshape(N, L, L, -1)
+            c = F.softplus(_AAPairLookup.apply(self.aapair_to_distcoef.weight, aa, self.max_aa_types))
+            gm = torch.exp(-1 * c * d ** 2) * (matom[:, :, None, :, None] * matom[:, None, :, None, :]).reshape(N, L, L, -1)
+        f_dist = _tall_mlp(self.distance_embed, gm)
         if pstruct is not None:
             f_dist = f_dist * pstruct[:, :, :, None]
         n, ca, cc = pos[:, :, ATOM_N], pos[:, :, ATOM_CA], pos[:, :, ATOM_C]

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,7 +73,7 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
            'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect',
-           'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_pair_backward',
+           'abopt_pair_gauss_workspace_bytes', 'abopt_pair_gauss_features', 'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward']
 
 _lib = None
@@ -122,6 +122,9 @@ def lib():
                                       c_f, c_f, c_i64, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_prof_enable.argtypes = [C.c_int]
         L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.abopt_pair_gauss_workspace_bytes.restype = C.c_size_t
+        L.abopt_pair_gauss_workspace_bytes.argtypes = [C.c_int] * 2
+        L.abopt_pair_gauss_features.argtypes = [C.POINTER(EncodeInputs), c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_reconstruct_backbone_partially.argtypes = [c_f, c_f, c_f, c_i64, c_i64, c_i64, c_u8, c_u8, c_f, c_f, c_f, c_u8] + [C.c_int] * 3 + [C.c_void_p]
         L.abopt_ipa_train_workspace_bytes.restype = C.c_size_t
         L.abopt_ipa_train_workspace_bytes.argtypes = [C.c_int] * 2
@@ -382,6 +385,19 @@ def residue_embed_forward(inp, weights, has_hotspot):
     buf = Workspace.get(nb, dev)
     _check(lib().abopt_residue_embed_forward(C.byref(inp), C.byref(weights), ptr(res_feat), ptr(R), ptr(p), ptr(buf), buf.numel(), stream()))
     return res_feat, R, p
+
+
+def pair_gauss_features(inp, coef_table, want_T):
+    """Gaussian atom-pair features of PairEmbedding (and their derivative wrt softplus(coef)) -> G, T (N,L,L,A*A)."""
+    N, L, AA = inp.N, inp.L, inp.atoms * inp.atoms
+    dev = coef_table.device
+    G = torch.empty(N, L, L, AA, device=dev)
+    T = torch.empty(N, L, L, AA, device=dev) if want_T else None
+    nb = lib().abopt_pair_gauss_workspace_bytes(N, L)
+    buf = Workspace.get(nb, dev)
+    _check(lib().abopt_pair_gauss_features(C.byref(inp), ptr(coef_table.contiguous(), torch.float32), ptr(G), ptr(T, optional=True),
+                                           ptr(buf), buf.numel(), stream()))
+    return G, T
 
 
 def pair_embed_forward(inp, weights):

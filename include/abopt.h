@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 5
+#define ABOPT_ABI_VERSION 6
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -253,6 +253,12 @@ size_t abopt_pair_embed_workspace_bytes(int N, int L, int atoms);
 /* -> pair_feat [N,L,L,64] */
 int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat,
                              void* ws, size_t ws_bytes, abopt_stream stream);
+
+/* Training side of PairEmbedding (pair.py:62-73): the Gaussian atom-pair features G [N,L,L,atoms*atoms] that feed
+ * distance_embed, and T = dG / d softplus(coef) [same shape, NULL to skip] for the backward of aapair_to_distcoef. */
+size_t abopt_pair_gauss_workspace_bytes(int N, int L);
+int abopt_pair_gauss_features(const abopt_encode_inputs* in, const float* aapair_to_distcoef, float* G, float* T,
+                              void* ws, size_t ws_bytes, abopt_stream stream);
 
 /* ---- reconstruct_backbone_partially: D/modules/common/geometry.py:404-480 (called on every saved frame right after the
  * sampler, D/tools/runner/design_for_pdb.py:166-223).  pos_ctx/pos_new [N,L,A,3], mask_atoms/mask_new [N,L,A], R_new [N,L,3,3],
