@@ -441,7 +441,8 @@ __global__ __launch_bounds__(256) void pair_gauss_features_kernel(const f32x4* _
     const int aa_i = aa_eff[row];
     float* g = G + row * (int64_t)L * AA + ab;
     float* t = T ? T + row * (int64_t)L * AA + ab : nullptr;
-    for (int j = 0; j < L; ++j) {
+#pragma unroll 8
+    for (int j = 0; j < L; ++j) {                                          // unrolled: 8 independent load chains in flight per thread
         const f32x4 pj = atoms4[(base + j) * 16 + b];
         const float x = coef[(int64_t)(aa_i * AAT + aa_eff[base + j]) * AA + ab];
         const float c = (x > 20.f) ? x : log1pf(expf(x));
