@@ -91,11 +91,10 @@ __global__ __launch_bounds__(256) void points_to_global_frags_kernel(float* __re
             for (int k = 0; k < P * 3; ++k) pts[r][(set - 1) * NPT + h * (P * 3) + k] = f[k];
             if (set == 1) pts[r][2 * NPT + h] = nrm;
         }
-        if (j < L) {                                               // rows past the end are clamped copies: transform them in LDS only
-#pragma unroll
+        if (j < L && set == 0) {                                   // only the query points are read back from proj (the wave-specialised kernel
+#pragma unroll                                                     // takes key/value points from kvfrag); rows past the end are clamped copies
             for (int q = 0; q < 6; ++q) reinterpret_cast<float4*>(p)[q] = v[q];
-            if (set == 0) proj[row * NP + OFF_NQ + h] = nrm;
-            if (set == 1) proj[row * NP + OFF_NK + h] = nrm;
+            proj[row * NP + OFF_NQ + h] = nrm;
         }
     }
     __syncthreads();
