@@ -12,7 +12,9 @@ int launch_linear(const float* X, int ldx, const float* W, int ldw, const float*
                   int M, int N, int K, bool relu, hipStream_t st, int ksplit = 1, int64_t slab_stride = 0);
 
 // ipa.hip -------------------------------------------------------------------------------------
-// proj [N*L, NP = 2048]: q|k|v|qp|kp|vp (2016) with the three point sets in the global frame, then |q_pts|^2, |k_pts|^2 per head.
+// proj [N*L, NP = 2048]: q|k|v|qp|kp|vp (2016) with the point sets in the global frame, then |q_pts|^2, |k_pts|^2 per head.
+// When the fragment copy is written (kvfrag != NULL) only the QUERY points/norms are updated in proj: the key/value points
+// and |k_pts|^2 then live in kvfrag alone.
 // kvfrag != NULL (and the wave-specialised kernel in use): also emits its key/value operands in MFMA fragment order
 bool ipa_uses_kvfrag(int L);
 size_t ipa_kvfrag_floats(int N, int L);
