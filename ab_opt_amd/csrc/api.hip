@@ -108,14 +108,14 @@ extern "C" int abopt_residue_embed_forward(const abopt_encode_inputs* in, const 
     return launch_residue_embed(in, w, res_feat, R, p, ws, ws_bytes, (hipStream_t)stream);
 }
 
-extern "C" int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat,
+extern "C" int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* activations,
                                         void* ws, size_t ws_bytes, abopt_stream stream) {
     int rc;
     if ((rc = check_encode_inputs(in, "pair_embed_forward"))) return rc;
     if ((int64_t)in->N * in->L == 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(w && w->aa_pair_embed && w->relpos_embed && w->aapair_to_distcoef && w->freq_bands && w->wd0 && w->bd0 && w->wd1 && w->bd1 &&
                     w->wo0 && w->bo0 && w->wo1 && w->bo1 && w->wo2 && w->bo2 && pair_feat && ws, "pair_embed_forward: NULL argument");
-    return launch_pair_embed(in, w, pair_feat, ws, ws_bytes, (hipStream_t)stream);
+    return launch_pair_embed(in, w, pair_feat, activations, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" size_t abopt_pair_gauss_workspace_bytes(int N, int L) { return pair_gauss_ws_bytes(N, L); }

@@ -227,7 +227,9 @@ struct PairArgs {
     const f32x4* wd0; const float* bd0; const f32x4* wd1; const float* bd1;
     const f32x4* wo0; const float* bo0; const f32x4* wo1; const float* bo1; const f32x4* wo2; const float* bo2;
     float* out; int N, L, A, has_struct;
+    float* acts;          // training: per pair [relu(D0) 64 | f_dist 64 | f_dih 32 | relu(O0) 64 | relu(O1) 64] (PAIR_ACT floats), NULL for inference
 };
+constexpr int PAIR_ACT = 288;
 
 constexpr int PMT = 4;        // 16-pair tiles per wave
 
@@ -240,6 +242,17 @@ constexpr int PMT = 4;        // 16-pair tiles per wave
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                              \
                 _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt)                                                        \
                     DST[mt][nt] = mfma4e(w_[nt][q], SRC[mt][blk][q], DST[mt][nt]);                                        \
+    }
+// training: dump a 64-wide activation tile (lane = pair fm of tile mt, features 16 nt + 4 kq ..) at float offset OFF of the pair's record
+#define PAIR_SAVE(TILE, OFF)                                                                                              \
+    if (a.acts) {                                                                                                         \
+        _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt) {                                                              \
+            const int j_ = j0 + mt * 16 + fm;                                                                             \
+            if (j_ < L) {                                                                                                 \
+                float* d_ = a.acts + ((row_i * L) + j_) * PAIR_ACT + (OFF) + kq * 4;                                      \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(d_ + nt * 16) = TILE[mt][nt];  \
+            }                                                                                                             \
+        }                                                                                                                 \
     }
 #define SEL4(ARR, I) ((I) == 0 ? ARR[0] : (I) == 1 ? ARR[1] : (I) == 2 ? ARR[2] : ARR[3])
 
@@ -312,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
             for (int r = 0; r < 4; ++r) h0[mt][nt][r] = fmaxf(h0[mt][nt][r], 0.f);
             h1[mt][nt] = bv;
         }
+    PAIR_SAVE(h0, 0)
     // ---- distance_embed.2 + ReLU, structure mask (pair.py:74-76)
     PAIR_DENSE(h1, h0, a.wd1)
     float ps[PMT], same[PMT], mp[PMT];
@@ -328,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) h1[mt][nt][r] = fmaxf(h1[mt][nt][r], 0.f) * ps[mt];
     }
+    PAIR_SAVE(h1, 64)
     // ---- out_mlp.0: folded embedding tables + f_dist block + dihedral block
 #pragma unroll
     for (int mt = 0; mt < PMT; ++mt)
@@ -366,6 +381,16 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
             if (mt == 0) { dh[0][0] = d0; dh[0][1] = d1; } else if (mt == 1) { dh[1][0] = d0; dh[1][1] = d1; }
             else if (mt == 2) { dh[2][0] = d0; dh[2][1] = d1; } else { dh[3][0] = d0; dh[3][1] = d1; }
         }
+        if (a.acts) {
+#pragma unroll
+            for (int mt = 0; mt < PMT; ++mt) {
+                const int j_ = j0 + mt * 16 + fm;
+                if (j_ < L) {
+                    float* d_ = a.acts + ((row_i * L) + j_) * PAIR_ACT + 128 + kq * 4;
+                    *reinterpret_cast<f32x4*>(d_) = dh[mt][0]; *reinterpret_cast<f32x4*>(d_ + 16) = dh[mt][1];
+                }
+            }
+        }
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             f32x4 w_[4];
@@ -388,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
             for (int r = 0; r < 4; ++r) h0[mt][nt][r] = fmaxf(h0[mt][nt][r], 0.f);
             h1[mt][nt] = bv;
         }
+    PAIR_SAVE(h0, 160)
     PAIR_DENSE(h1, h0, a.wo1)
 #pragma unroll
     for (int mt = 0; mt < PMT; ++mt)
@@ -398,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
             for (int r = 0; r < 4; ++r) h1[mt][nt][r] = fmaxf(h1[mt][nt][r], 0.f);
             h0[mt][nt] = bv;
         }
+    PAIR_SAVE(h1, 224)
     PAIR_DENSE(h0, h1, a.wo2)
     // ---- pair mask, store (pair.py:100): a lane owns features 16 nt + 4 kq .. +3 of pair (i, j0 + 16 mt + fm)
 #pragma unroll
@@ -584,7 +611,7 @@ size_t pair_embed_ws_bytes(int N, int L, int A) {
     return pack_bytes((int64_t)N * L) + al256(pair_weight_floats(A) * 4) + 4096;
 }
 
-int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, void* ws, size_t ws_bytes, hipStream_t st) {
+int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* acts, void* ws, size_t ws_bytes, hipStream_t st) {
     const int N = in->N, L = in->L, A = in->atoms;
     ABOPT_CHECK_ARG(A >= 3 && A <= 15 && A <= in->atoms_in, "pair_embed: atoms=%d must be in [3, min(15, atoms_in=%d)]", A, in->atoms_in);
     const int64_t rows = (int64_t)N * L;
@@ -623,7 +650,7 @@ int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weig
     a.atoms4 = pb.atoms4; a.aa_eff = pb.aa_eff; a.res_nb = pb.resnb; a.chain_nb = pb.chain; a.flags = pb.flags;
     a.t_aap = t_aap; a.t_rel = t_rel; a.sp = sp; a.freq = w->freq_bands;
     a.wd0 = wd0; a.bd0 = w->bd0; a.wd1 = wd1; a.bd1 = w->bd1; a.wo0 = wo0; a.bo0 = w->bo0; a.wo1 = wo1; a.bo1 = w->bo1; a.wo2 = wo2; a.bo2 = w->bo2;
-    a.out = pair_feat; a.N = N; a.L = L; a.A = A; a.has_struct = in->structure_mask ? 1 : 0;
+    a.out = pair_feat; a.N = N; a.L = L; a.A = A; a.has_struct = in->structure_mask ? 1 : 0; a.acts = acts;
     const int jblocks = (L + 16 * PMT - 1) / (16 * PMT);
     const int64_t units = rows * jblocks;
     hipLaunchKernelGGL(pair_embed_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, a);

@@ -57,7 +57,7 @@ size_t residue_embed_ws_bytes(int N, int L, int A, int hotspot);
 int launch_residue_embed(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* res_feat, float* R, float* p,
                          void* ws, size_t ws_bytes, hipStream_t st);
 size_t pair_embed_ws_bytes(int N, int L, int A);
-int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* acts, void* ws, size_t ws_bytes, hipStream_t st);
 
 size_t pair_gauss_ws_bytes(int N, int L);
 int launch_pair_gauss_features(const abopt_encode_inputs* in, const float* coef, float* G, float* T, void* ws, size_t ws_bytes, hipStream_t st);

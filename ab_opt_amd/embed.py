@@ -111,6 +111,57 @@ class _GaussFeatures(torch.autograd.Function):
         return dtab, None, None, None, None, None, None
 
 
+class _PairEmbedFn(torch.autograd.Function):
+    """PairEmbedding on the training path: forward is the fused HIP kernel (`abopt_pair_embed_forward` with its activation dump,
+    plus `abopt_pair_gauss_features` for the Gaussian features and their derivative); backward is the chain rule over the
+    saved activations as tall library GEMMs (split-K weight gradients, structured sums for the two amino-acid-pair tables).
+    Only the parameters carry gradients (positions, masks and indices do not)."""
+
+    @staticmethod
+    def forward(ctx, aa, res_nb, chain_nb, pos, matom, structure_mask, n_types, max_relpos,
+                E_aap, E_rel, coef, freq, wd0, bd0, wd1, bd1, wo0, bo0, wo1, bo1, wo2, bo2):
+        inp, keep = hip.encode_inputs(aa, res_nb, chain_nb, pos, matom, pos.shape[2], structure_mask=structure_mask)
+        t = [x.detach().contiguous() for x in (E_aap, E_rel, coef, freq, wd0, bd0, wd1, bd1, wo0, bo0, wo1, bo1, wo2, bo2)]
+        w = hip.PairEmbedWeights(*[hip.ptr(x, torch.float32) for x in t])
+        out, acts = hip.pair_embed_forward(inp, w, save_activations=True)
+        G, T = hip.pair_gauss_features(inp, t[2], want_T=True)
+        ctx.save_for_backward(aa, res_nb, chain_nb, matom, acts, G, T, E_aap, E_rel, coef, wd0, wd1, wo0, wo1, wo2)
+        ctx.n_types, ctx.max_relpos = n_types, max_relpos
+        return out
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, dout):
+        aa, res_nb, chain_nb, matom, acts, G, T, E_aap, E_rel, coef, wd0, wd1, wo0, wo1, wo2 = ctx.saved_tensors
+        N, L = aa.shape
+        M, C, nt = N * L * L, dout.shape[-1], ctx.n_types
+        a2 = acts.view(M, -1)
+        h0, h1, dih, o0, o1 = a2[:, :64], a2[:, 64:128], a2[:, 128:154], a2[:, 160:224], a2[:, 224:288]
+        mres = matom[:, :, ATOM_CA]
+        do2 = (dout * (mres[:, :, None] & mres[:, None, :]).unsqueeze(-1)).reshape(M, C)
+        dwo2, dbo2 = _splitk_tn(do2, o1), do2.sum(0)
+        do1 = (do2 @ wo2) * (o1 > 0)
+        dwo1, dbo1 = _splitk_tn(do1, o0), do1.sum(0)
+        do0 = (do1 @ wo1) * (o0 > 0)
+        dbo0 = do0.sum(0)
+        # out_mlp.0 columns: [aa-pair embedding | relpos embedding x same-chain | f_dist | f_dih]
+        oh = F.one_hot(aa, nt).to(dout.dtype)
+        s_aap = torch.einsum('nia,nibc->abc', oh, torch.einsum('njb,nijc->nibc', oh, do0.view(N, L, L, C))).reshape(nt * nt, C)
+        rel = torch.clamp(res_nb[:, :, None] - res_nb[:, None, :], min=-ctx.max_relpos, max=ctx.max_relpos) + ctx.max_relpos
+        same = (chain_nb[:, :, None] == chain_nb[:, None, :]).reshape(M, 1)
+        s_rel = _splitk_tn(F.one_hot(rel.reshape(M), 2 * ctx.max_relpos + 1).to(dout.dtype) * same, do0)
+        dwo0 = torch.cat([s_aap.t() @ E_aap, s_rel.t() @ E_rel, _splitk_tn(do0, h1), _splitk_tn(do0, dih)], dim=1)
+        dE_aap, dE_rel = s_aap @ wo0[:, :C], s_rel @ wo0[:, C:2 * C]
+        dh1 = (do0 @ wo0[:, 2 * C:3 * C]) * (h1 > 0)                                # f_dist = relu(.) x structure mask: zero where masked
+        dwd1, dbd1 = _splitk_tn(dh1, h0), dh1.sum(0)
+        dh0 = (dh1 @ wd1) * (h0 > 0)
+        G2 = G.view(M, -1)
+        dwd0, dbd0 = _splitk_tn(dh0, G2), dh0.sum(0)
+        dS = ((dh0 @ wd0) * T.view(M, -1)).view(N, L, L, -1)                         # d / d softplus(coef)
+        dcoef = torch.einsum('nia,nibc->abc', oh, torch.einsum('njb,nijc->nibc', oh, dS)).reshape(nt * nt, -1) * torch.sigmoid(coef)
+        return (None,) * 8 + (dE_aap, dE_rel, dcoef, None, dwd0, dbd0, dwd1, dbd1, dwo0, dbo0, dwo1, dbo1, dwo2, dbo2)
+
+
 class AngularEncoding(nn.Module):
     def __init__(self, num_funcs=3):
         super().__init__()
@@ -260,6 +311,13 @@ class PairEmbedding(nn.Module):
         pstruct = structure_mask[:, :, None] * structure_mask[:, None, :] if structure_mask is not None else None
         if sequence_mask is not None:
             aa = torch.where(sequence_mask, aa, torch.full_like(aa, AA_UNK))
+        if pos.is_cuda and pos.dtype == torch.float32 and self.aa_pair_embed.weight.shape[1] == 64:
+            # training on the device: fused HIP forward + GEMM backward.  Everything below is the plain statement of the same
+            # maths (CPU checks against the reference's fixtures, and the float64 yardstick of the parity tests).
+            lin = [m for m in list(self.distance_embed) + list(self.out_mlp) if isinstance(m, nn.Linear)]
+            return _PairEmbedFn.apply(aa, res_nb, chain_nb, pos, matom, structure_mask, self.max_aa_types, self.max_relpos,
+                                      self.aa_pair_embed.weight, self.relpos_embed.weight, self.aapair_to_distcoef.weight,
+                                      self.dihedral_embed.freq_bands, *[p for m in lin for p in (m.weight, m.bias)])
         f_aap = _AAPairLookup.apply(self.aa_pair_embed.weight, aa, self.max_aa_types)
         same = chain_nb[:, :, None] == chain_nb[:, None, :]
         rel = torch.clamp(res_nb[:, :, None] - res_nb[:, None, :], min=-self.max_relpos, max=self.max_relpos)

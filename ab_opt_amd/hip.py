@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -135,7 +135,7 @@ def lib():
         L.abopt_pair_embed_workspace_bytes.restype = C.c_size_t
         L.abopt_pair_embed_workspace_bytes.argtypes = [C.c_int] * 3
         L.abopt_residue_embed_forward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(ResidueEmbedWeights), c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
-        L.abopt_pair_embed_forward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_pair_embed_forward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         for name in EXPORTS:
             getattr(L, name)          # AttributeError here = a symbol of include/abopt.h is missing
         if L.abopt_abi_version() != ABI_VERSION:
@@ -400,14 +400,19 @@ def pair_gauss_features(inp, coef_table, want_T):
     return G, T
 
 
-def pair_embed_forward(inp, weights):
+PAIR_ACT = 288
+
+
+def pair_embed_forward(inp, weights, save_activations=False):
+    """-> pair_feat (N,L,L,64) [, activations (N,L,L,288) for the training backward]."""
     N, L = inp.N, inp.L
     dev = torch.device('cuda', torch.cuda.current_device())
     pair_feat = torch.empty(N, L, L, 64, device=dev)
+    acts = torch.empty(N, L, L, PAIR_ACT, device=dev) if save_activations else None
     nb = lib().abopt_pair_embed_workspace_bytes(N, L, inp.atoms)
     buf = Workspace.get(nb, dev)
-    _check(lib().abopt_pair_embed_forward(C.byref(inp), C.byref(weights), ptr(pair_feat), ptr(buf), buf.numel(), stream()))
-    return pair_feat
+    _check(lib().abopt_pair_embed_forward(C.byref(inp), C.byref(weights), ptr(pair_feat), ptr(acts, optional=True), ptr(buf), buf.numel(), stream()))
+    return (pair_feat, acts) if save_activations else pair_feat
 
 
 _BB_TABLES = {}

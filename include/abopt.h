@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 6
+#define ABOPT_ABI_VERSION 7
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -250,8 +250,11 @@ size_t abopt_residue_embed_workspace_bytes(int N, int L, int atoms, int hotspot)
 int abopt_residue_embed_forward(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* res_feat, float* R, float* p,
                                 void* ws, size_t ws_bytes, abopt_stream stream);
 size_t abopt_pair_embed_workspace_bytes(int N, int L, int atoms);
-/* -> pair_feat [N,L,L,64] */
-int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat,
+/* -> pair_feat [N,L,L,64].  activations: NULL for inference; for training a [N,L,L,ABOPT_PAIR_ACT] buffer that receives, per
+ * pair, relu(distance_embed.0) (64) | f_dist = relu(distance_embed.2) x structure mask (64) | f_dih (26, padded to 32) |
+ * relu(out_mlp.0) (64) | relu(out_mlp.2) (64): what the backward of the five linears needs (pair.py:74-99). */
+enum { ABOPT_PAIR_ACT = 288 };
+int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* activations,
                              void* ws, size_t ws_bytes, abopt_stream stream);
 
 /* Training side of PairEmbedding (pair.py:62-73): the Gaussian atom-pair features G [N,L,L,atoms*atoms] that feed
