@@ -98,7 +98,7 @@ def test_ga_block_L128_vs_reference():
     assert max_abs(out.cpu(), g['out']) < 3e-5
 
 
-@pytest.mark.parametrize('N,L,lengths', [(1, 1, [1]), (3, 7, [7, 1, 4]), (2, 65, [65, 64]), (1, 200, [200]), (2, 256, [256, 250])])
+@pytest.mark.parametrize('N,L,lengths', [(1, 1, [1]), (3, 7, [7, 1, 4]), (2, 65, [65, 64]), (1, 200, [200]), (2, 256, [256, 250]), (1, 521, [521])])
 def test_ga_block_ragged_vs_oracle(N, L, lengths):
     from oracle import ipa
     blk = _block_on_device(seed=5)
