@@ -114,19 +114,28 @@ class IpaCore(torch.autograd.Function):
             + (hm(dfn) * feat[..., H * 64:o].reshape(N, L, H, D)).sum(-1) + (dag_l * ag).sum(-1)
         dag = hm(dag_l)
         T = lambda a: a.transpose(-1, -2)
-        da_node = dfn @ T(v) + dag @ T(vg)                                          # (N,H,L,L)
+        # every (N,12,L,L) matrix is multiplied ONCE from each side, against concatenated right-hand sides:
+        dout_cat = torch.cat([dfn, dag], dim=-1)                                    # (N,H,L,56): d feat_node | d aggregated points
+        da_node = dout_cat @ T(torch.cat([v, vg], dim=-1))                          # (N,H,L,L)
         g, dz = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb)          # the z-streaming part
         del da_node
-        dv, dvg = T(alpha) @ dfn, T(alpha) @ dag
+        ones = torch.ones_like(q[..., :1])
+        P1 = g @ torch.cat([k, kg, ones], dim=-1)                                   # sum_j g_ij [k_j | kg_j | 1]
+        P2 = T(g) @ torch.cat([q, qg, ones], dim=-1)                                # sum_i g_ij [q_i | qg_i | 1]
+        P3 = T(alpha) @ dout_cat                                                    # sum_i alpha_ij [dfn_i | dag_i]
         sc = 1.0 / math.sqrt(D)
-        dq, dk = (g @ k) * sc, (T(g) @ q) * sc
+        dq, g_kg, g_rows = P1[..., :D] * sc, P1[..., D:D + P * 3], P1[..., D + P * 3:]
+        dk, g_qg, g_cols = P2[..., :D] * sc, P2[..., D:D + P * 3], P2[..., D + P * 3:]
+        dv, dvg = P3[..., :D], P3[..., D:]
         gam = gamma_raw.reshape(-1)
         cfac = math.sqrt(2 / (9 * P)) / 2
         coef = (-F.softplus(gam) * cfac).view(1, H, 1, 1)
-        dqg = 2 * coef * (qg * g.sum(-1, keepdim=True) - g @ kg)
-        dkg = 2 * coef * (kg * g.sum(-2).unsqueeze(-1) - T(g) @ qg)
-        d2 = (qg ** 2).sum(-1, keepdim=True) + (kg ** 2).sum(-1).unsqueeze(-2) - 2 * (qg @ T(kg))
-        dgamma = ((g * d2).sum((0, 2, 3)) * (-torch.sigmoid(gam) * cfac)).reshape(gamma_raw.shape)
+        dqg = 2 * coef * (qg * g_rows - g_kg)
+        dkg = 2 * coef * (kg * g_cols - g_qg)
+        # sum_ij g_ij |qg_i - kg_j|^2 without forming the distance matrix
+        gd2 = ((qg ** 2).sum(-1, keepdim=True) * g_rows).sum((0, 2, 3)) + ((kg ** 2).sum(-1, keepdim=True) * g_cols).sum((0, 2, 3)) \
+            - 2 * (qg * g_kg).sum((0, 2, 3))
+        dgamma = (gd2 * (-torch.sigmoid(gam) * cfac)).reshape(gamma_raw.shape)
         dWb = (g.reshape(N, H, L * L) @ z.reshape(N, L * L, -1)).sum(0)
         loc_grad = lambda d: torch.einsum('nlba,nlkb->nlka', R, hm(d).reshape(N, L, HP, 3)).reshape(N, L, HP * 3)     # R^T d
         dproj = torch.cat([hm(dq).reshape(N, L, HD), hm(dk).reshape(N, L, HD), hm(dv).reshape(N, L, HD), loc_grad(dqg), loc_grad(dkg), loc_grad(dvg)], dim=-1)
