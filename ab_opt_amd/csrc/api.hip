@@ -31,15 +31,12 @@ struct Carver {
 constexpr int F = 128, FI = F + 4;
 constexpr int OUT_KSPLIT = 4;     // out_transform (K = 1824, N = 128) has only M/64 * 2 tiles: split K so it fills the chip
 
-struct GaScratch { float *proj, *feat, *u, *y, *h1, *h2, *kvf; };
+struct GaScratch { float *proj, *feat, *u, *kvf; };
 static GaScratch carve_ga(Carver& cv, int64_t M, int N, int L) {
     GaScratch s;
     s.proj = cv.f((size_t)M * NP);
     s.feat = cv.f((size_t)M * ABOPT_IPA_FEAT);
     s.u = cv.f((size_t)M * F * OUT_KSPLIT);
-    s.y = cv.f((size_t)M * F);
-    s.h1 = cv.f((size_t)M * F);
-    s.h2 = cv.f((size_t)M * F);
     s.kvf = cv.f(ipa_kvfrag_floats(N, L));
     return s;
 }

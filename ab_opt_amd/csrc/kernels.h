@@ -26,9 +26,6 @@ int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, cons
 // rows.hip ------------------------------------------------------------------------------------
 int launch_so3_exp(const float* w, float* R, int64_t n, hipStream_t st);
 int launch_so3_log(const float* R, float* w, int64_t n, int grad_mode, hipStream_t st);
-// y = LN(x + (mask ? u : 0)), u = sum of `nslab` slabs (stride slab_stride floats) + ubias (may be NULL); mask may be NULL. F == 128.
-int launch_residual_layernorm(const float* x, const float* u, const uint8_t* mask, const float* gamma, const float* beta,
-                              float* y, int64_t rows, hipStream_t st, int nslab = 1, int64_t slab_stride = 0, const float* ubias = nullptr);
 // mlp.hip: out = LN2(y + MLP(y)), y = LN1(x + mask*(sum of u slabs + ubias))  -- the tail of a GABlock in one launch
 int launch_fused_ln_mlp(const float* x, const float* u, int nslab, int64_t slab_stride, const float* ubias, const uint8_t* mask,
                         const float* g1, const float* be1, const float* W0, const float* b0, const float* W1, const float* b1,

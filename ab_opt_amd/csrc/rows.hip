@@ -39,42 +39,6 @@ int launch_so3_log(const float* R, float* w, int64_t n, int grad_mode, hipStream
     return ABOPT_OK;
 }
 
-// y = LN(x + (mask ? u : 0)) with the reference's LayerNorm (biased variance, sqrt(var + 1e-10)): one wave per
-// row, two features per lane (F = 128).  ga.py:175-177.
-__global__ __launch_bounds__(256) void residual_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ u,
-                                                                 const uint8_t* __restrict__ mask, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, float* __restrict__ y, int64_t rows,
-                                                                 int nslab, int64_t slab_stride, const float* __restrict__ ubias) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int lane = threadIdx.x & 63;
-    const bool keep = mask ? (mask[row] != 0) : true;
-    const float2 xv = reinterpret_cast<const float2*>(x + row * F)[lane];
-    float2 uv = reinterpret_cast<const float2*>(u + row * F)[lane];
-    for (int sl = 1; sl < nslab; ++sl) {                      // split-K partial slabs, summed in slab order
-        const float2 w = reinterpret_cast<const float2*>(u + sl * slab_stride + row * F)[lane];
-        uv.x += w.x; uv.y += w.y;
-    }
-    if (ubias) { const float2 bb = reinterpret_cast<const float2*>(ubias)[lane]; uv.x += bb.x; uv.y += bb.y; }
-    if (!keep) uv = make_float2(0.f, 0.f);
-    const float a = xv.x + uv.x, b = xv.y + uv.y;
-    const float mean = wave_sum(a + b) * (1.f / F);
-    const float da = a - mean, db = b - mean;
-    const float var = wave_sum(da * da + db * db) * (1.f / F);
-    const float sd = sqrtf(var + 1e-10f);
-    const float2 g = reinterpret_cast<const float2*>(gamma)[lane], bt = reinterpret_cast<const float2*>(beta)[lane];
-    reinterpret_cast<float2*>(y + row * F)[lane] = make_float2(da / sd * g.x + bt.x, db / sd * g.y + bt.y);
-}
-
-int launch_residual_layernorm(const float* x, const float* u, const uint8_t* mask, const float* gamma, const float* beta,
-                              float* y, int64_t rows, hipStream_t st, int nslab, int64_t slab_stride, const float* ubias) {
-    if (rows == 0) return ABOPT_OK;
-    hipLaunchKernelGGL(residual_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, u, mask, gamma, beta, y, rows,
-                       nslab, slab_stride, ubias);
-    ABOPT_LAUNCH_CHECK();
-    return ABOPT_OK;
-}
-
 // cat = [res_feat | Embedding(s_t)]  (dpm_full.py:89)
 __global__ __launch_bounds__(256) void embed_concat_kernel(const float* __restrict__ res_feat, const int64_t* __restrict__ s_t,
                                                            const float* __restrict__ embed, float* __restrict__ cat, int64_t rows) {
