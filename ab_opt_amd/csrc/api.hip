@@ -42,7 +42,7 @@ static GaScratch carve_ga(Carver& cv, int64_t M, int N, int L) {
 }
 
 static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, const float* x, const float* z, const uint8_t* mask,
-                    float* x_out, int N, int L, const abopt_ga_debug* dbg, const GaScratch& s, hipStream_t st, const float* pbc = nullptr) {
+                    float* x_out, int N, int L, const abopt_ga_debug* dbg, const GaScratch& s, hipStream_t st, const float* pbc = nullptr, int z_shared = 0) {
     const int64_t M = (int64_t)N * L;
     int rc;
     // node projections: q|k|v|qp|kp|vp in one GEMM, then points to the global frame
@@ -50,7 +50,7 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     if ((rc = launch_points_to_global(s.proj, R, t, M, st, s.kvf, N, L))) return rc;
     float* feat = (dbg && dbg->feat) ? dbg->feat : s.feat;
     if ((rc = launch_ipa_core(s.proj, z, mask, R, t, w->w_pair_bias, w->spatial_coef, feat,
-                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, s.kvf, N, L, st))) return rc;
+                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, s.kvf, N, L, st, z_shared))) return rc;
     // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
     if ((rc = launch_linear(feat, ABOPT_IPA_FEAT, w->w_out, ABOPT_IPA_FEAT, nullptr, s.u, F, (int)M, F, ABOPT_IPA_FEAT, false, st,
                             OUT_KSPLIT, M * F))) return rc;
@@ -205,13 +205,13 @@ static size_t pair_bias_layer_floats(int N, int L) { return (size_t)N * L * ((L 
 
 static int ga_encoder(const abopt_ga_weights* blocks, int num_layers, const float* R, const float* t, const float* x, const float* z,
                       const uint8_t* mask, float* x_out, int N, int L, const GaScratch& s, float* pong, hipStream_t st,
-                      const float* pair_bias_cache = nullptr) {
+                      const float* pair_bias_cache = nullptr, int z_shared = 0) {
     // ga.py:190-193: the same R, t, z feed every block.  Ping-pong so the last block writes x_out.
     const float* cur = x;
     for (int i = 0; i < num_layers; ++i) {
         float* dst = ((num_layers - 1 - i) % 2 == 0) ? x_out : pong;
         int rc = ga_block(&blocks[i], R, t, cur, z, mask, dst, N, L, nullptr, s, st,
-                          pair_bias_cache ? pair_bias_cache + (size_t)i * pair_bias_layer_floats(N, L) : nullptr);
+                          pair_bias_cache ? pair_bias_cache + (size_t)i * pair_bias_layer_floats(z_shared ? 1 : N, L) : nullptr, z_shared);
         if (rc) return rc;
         cur = dst;
     }
@@ -285,7 +285,7 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
                                      const float* res_feat, const float* pair_feat, const float* beta,
                                      const uint8_t* mask_generate, const uint8_t* mask_res,
                                      float* v_next, float* R_next, float* eps_pos, float* c_denoised, float* prmsd_logits,
-                                     int N, int L, int Fd, int Cd, int grad_mode, const float* pair_bias_cache,
+                                     int N, int L, int Fd, int Cd, int grad_mode, const float* pair_bias_cache, int pair_feat_shared,
                                      void* ws, size_t ws_bytes, abopt_stream stream) {
     int rc;
     if ((rc = check_dims(N, L, Fd, Cd))) return rc;
@@ -313,7 +313,7 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
     if ((rc = launch_linear(e.cat, 2 * F, w->w_mix0, 2 * F, w->b_mix0, e.x0, F, (int)M, F, 2 * F, true, st))) return rc;
     if ((rc = launch_linear(e.x0, F, w->w_mix1, F, w->b_mix1, e.cat, F, (int)M, F, F, false, st))) return rc;   // reuse cat[:, :F] as x (ld = F)
     // dpm_full.py:90  encoder
-    if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st, pair_bias_cache))) return rc;
+    if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st, pair_bias_cache, pair_feat_shared ? 1 : 0))) return rc;
     // dpm_full.py:92-93 time features
     if ((rc = launch_build_infeat(e.xe, beta, e.infeat, w->prmsd_ln_gamma, w->prmsd_ln_beta, has_prmsd ? e.infeat_ln : nullptr, N, L, st))) return rc;
     // three heads, first layers fused (shared input): [M,132] x [384,132]^T

@@ -583,8 +583,9 @@ void end(hipStream_t st) {
 
 int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
                     const float* w_pair_bias, const float* spatial_coef, float* feat,
-                    float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache, const float* kvfrag, int N, int L, hipStream_t st) {
+                    float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache, const float* kvfrag, int N, int L, hipStream_t st, int z_shared) {
     if (N == 0 || L == 0) return ABOPT_OK;
+    if (z_shared && !ipa_uses_kvfrag(L)) { set_error("ipa_core: a shared pair_feat needs the wave-specialised kernel (L <= 2048, default variant)"); return ABOPT_EUNSUPPORTED; }
     const int variant = ipa_variant();
     if (variant == 0) {                                          // row-per-workgroup VALU kernel kept for A/B runs (L <= 480)
         const size_t lds = ((size_t)L * (ZLD + H) + 1440) * sizeof(float);
@@ -601,7 +602,7 @@ int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, cons
     ABOPT_CHECK_ARG((int64_t)N * nib < (1ll << 31), "ipa_core: grid too large");
     if (ipa_uses_kvfrag(L)) {
         ABOPT_CHECK_ARG(kvfrag != nullptr, "ipa_core: the wave-specialised kernel needs the key/value fragment buffer");
-        int rc = launch_ipa_core_ws(proj, z, mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, kvfrag, N, L, st);
+        int rc = launch_ipa_core_ws(proj, z, mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, kvfrag, N, L, st, z_shared);
         if (rc) return rc;
         if (dbg_alpha) {
             ABOPT_CHECK_ARG(dbg_logits != nullptr, "ipa_core: alpha dump needs the logits dump");

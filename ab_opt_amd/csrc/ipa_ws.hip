@@ -67,7 +67,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                                                              const uint8_t* __restrict__ mask, const float* __restrict__ R,
                                                              const float* __restrict__ t, const float* __restrict__ Wb,
                                                              const float* __restrict__ spatial_coef, float* __restrict__ feat,
-                                                             float* __restrict__ dbg_logits, const float* __restrict__ pbc, const float* __restrict__ kvfrag, int N, int L, int nib, int xcd_remap) {
+                                                             float* __restrict__ dbg_logits, const float* __restrict__ pbc, const float* __restrict__ kvfrag, int N, int L, int nib, int xcd_remap, int z_shared) {
     __shared__ __attribute__((aligned(16))) WsSmem sm;
     int n, ib;
     {   // all i-blocks of a sample on one XCD when N % 8 == 0 (L2 locality of its k/v tiles; speed only)
@@ -131,7 +131,7 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
         f32x4 ringb[4];                                                     // CACHED: the row chunk's precomputed pair bias, lane (head fm, keys 4 kq ..)
 #define WS_ISSUE_Z(SLOT, ROW, CH)                                                                                        \
     {                                                                                                                    \
-        const int64_t zrow_ = rowbase + min(i0 + w4 * RPW + (ROW), L - 1);                            \
+        const int64_t zrow_ = (z_shared ? 0 : rowbase) + min(i0 + w4 * RPW + (ROW), L - 1);   /* z_shared: one pair_feat for the whole batch */ \
         const float* zi_ = z + (zrow_ * (int64_t)L) * C;                                                                 \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                              \
             ring[SLOT][r_] = *(reinterpret_cast<const f32x4*>(zi_ + (int64_t)min((CH) * JC + kq * 4 + r_, L - 1) * C) + fm); \
@@ -435,12 +435,12 @@ int launch_pair_bias_cache(const float* z, const float* const* wb, int num_layer
 
 int launch_ipa_core_ws(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
                        const float* w_pair_bias, const float* spatial_coef, float* feat, float* dbg_logits,
-                       const float* pair_bias_cache, const float* kvfrag, int N, int L, hipStream_t st) {
+                       const float* pair_bias_cache, const float* kvfrag, int N, int L, hipStream_t st, int z_shared) {
     const int nib = (L + BI - 1) / BI;
     const int remap = (N % 8 == 0) ? 1 : 0;
     prof::begin(st);
 #define WS_LAUNCH(DBGV, NPWV, CV) hipLaunchKernelGGL((ipa_core_ws_kernel<DBGV, NPWV, CV>), dim3((unsigned)(N * nib)), dim3((NPWV + 4) * 64), 0, st, proj, z, \
-                                                     mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, kvfrag, N, L, nib, remap)
+                                                     mask, R, t, w_pair_bias, spatial_coef, feat, dbg_logits, pair_bias_cache, kvfrag, N, L, nib, remap, z_shared)
     if (pair_bias_cache) { if (dbg_logits) WS_LAUNCH(true, 4, true); else WS_LAUNCH(false, 4, true); }
     else if (dbg_logits) WS_LAUNCH(true, 4, false);
     else                 WS_LAUNCH(false, 4, false);

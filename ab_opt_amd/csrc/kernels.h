@@ -21,7 +21,8 @@ size_t ipa_kvfrag_floats(int N, int L);
 int launch_points_to_global(float* proj, const float* R, const float* t, int64_t rows, hipStream_t st, float* kvfrag, int N, int L);
 int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
                     const float* w_pair_bias, const float* spatial_coef, float* feat,
-                    float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache, const float* kvfrag, int N, int L, hipStream_t st);
+                    float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache, const float* kvfrag, int N, int L, hipStream_t st,
+                    int z_shared = 0 /* 1: z (and the pair-bias cache) hold ONE sample that every batch entry shares */);
 
 // rows.hip ------------------------------------------------------------------------------------
 int launch_so3_exp(const float* w, float* R, int64_t n, hipStream_t st);

@@ -103,6 +103,14 @@ class FullDPM(nn.Module):
         tpr = torch.zeros(T0 + 1, N, **f32) if self.abdock else None
         tpp = torch.zeros(T0 + 1, N, **f32) if self.abdock else None
 
+        # Replicated-complex batches (one crop, N samples: design_for_pdb.py:141-147) may pass the context ONCE: res_feat
+        # (1,L,F) / pair_feat (1,L,L,C) are then shared by all N samples -- the kernels index pair_feat and its bias cache
+        # with batch stride 0, so the 100 x 6 passes over it are served from L2/MALL instead of HBM.
+        shared = pair_feat.shape[0] == 1 and N > 1
+        if shared and not use_bias_cache:
+            raise ValueError('a shared pair_feat requires the pair-bias cache')
+        if res_feat.shape[0] == 1 and N > 1:
+            res_feat = res_feat.expand(N, -1, -1)
         res_feat, pair_feat = res_feat.contiguous().float(), pair_feat.contiguous().float()
         mask_generate, mask_res = mask_generate.contiguous(), mask_res.contiguous()
         ew = self.eps_net.packed()
@@ -128,7 +136,7 @@ class FullDPM(nn.Module):
             torch.div(torch.sub(tp[t], mean), scale, out=p_norm)
             beta = betas[t].expand([N]).contiguous()
             hip.eps_net_forward(ew, tv[t], p_norm, ts[t], res_feat, pair_feat, beta, mask_generate, mask_res,
-                                self.abdock, self.num_bins, False, out=net, pair_bias_cache=pbc)
+                                self.abdock, self.num_bins, False, out=net, pair_bias_cache=pbc, pair_feat_shared=shared)
             sp = self._step_params(t, sample_structure, sample_sequence, ppl_masked, optimize_mode)
             out = dict(v=tv[t - 1], p=tp[t - 1], s=ts[t - 1])
             if self.abdock:

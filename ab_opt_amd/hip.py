@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -106,7 +106,7 @@ def lib():
         L.abopt_ga_encoder_forward.argtypes = [C.POINTER(GaWeights), C.c_int, c_f, c_f, c_f, c_f, c_u8, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_eps_net_forward.argtypes = [C.POINTER(EpsWeights), c_f, c_f, c_i64, c_f, c_f, c_f, c_u8, c_u8,
-                                            c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f,
+                                            c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f, C.c_int,
                                             C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_pair_bias_cache_bytes.restype = C.c_size_t
         L.abopt_pair_bias_cache_bytes.argtypes = [C.c_int] * 3
@@ -246,7 +246,7 @@ def ga_encoder_forward(ws_array, num_layers, R, t, x, z, mask):
 
 
 def eps_net_forward(ew, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res, has_prmsd, num_bins, grad_mode=False, out=None,
-                    pair_bias_cache=None):
+                    pair_bias_cache=None, pair_feat_shared=False):
     N, L = mask_res.shape
     F, Cd = res_feat.shape[-1], pair_feat.shape[-1]
     dev = res_feat.device
@@ -262,7 +262,7 @@ def eps_net_forward(ew, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate,
                                        ptr(mask_generate.contiguous(), torch.bool), ptr(mask_res.contiguous(), torch.bool),
                                        ptr(out['v_next']), ptr(out['R_next']), ptr(out['eps_pos']), ptr(out['c']),
                                        ptr(out['prmsd_logits'], optional=True), N, L, F, Cd, int(grad_mode),
-                                       ptr(pair_bias_cache, torch.float32, optional=True), ptr(buf), buf.numel(), stream()))
+                                       ptr(pair_bias_cache, torch.float32, optional=True), int(pair_feat_shared), ptr(buf), buf.numel(), stream()))
     return out
 
 

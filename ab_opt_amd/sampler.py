@@ -76,3 +76,27 @@ def sample_sharded(model, batch, sample_opt, k=1, group=None, seed=None):
         cand = all_gather_candidates(cand, counts, group)
     top = rank_commoness(cand, min(k, cand.shape[0]))
     return traj, (a, b), top, cand
+
+
+@torch.no_grad()
+def sample_replicated(model, complex_batch, num_samples, sample_opt=None, optimize_step=None):
+    """N samples of ONE complex without replicating it.
+
+    The reference's runners build the batch by repeating one crop `num_samples` times on the host
+    (AbDock/src/tools/runner/design_for_pdb.py:141-147), so encode() runs N times and N identical copies of pair_feat
+    (17 MB each at L=256) are streamed from HBM at every step.  Here `complex_batch` holds the complex once (batch dim 1):
+    it is encoded once and the sampler shares res_feat / pair_feat across the N samples.  Returns the same trajectory
+    dict as `model.sample` (batch dim `num_samples`).  `optimize_step` selects `model.optimize`-style partial denoising."""
+    from . import hip
+    sample_opt = dict(sample_opt or {'sample_structure': True, 'sample_sequence': True})
+    sample_opt.pop('contig', None)
+    one = {k: (v[:1] if torch.is_tensor(v) else v) for k, v in complex_batch.items()}
+    res_feat, pair_feat, R_0, p_0 = model.encode(one, remove_structure=sample_opt.get('sample_structure', True),
+                                                remove_sequence=sample_opt.get('sample_sequence', True))
+    rep = lambda a: a.expand(num_samples, *a.shape[1:]).contiguous()
+    v_0 = rep(hip.so3_log(R_0, grad_mode=False))
+    args = (v_0, rep(p_0), rep(one['aa']))
+    masks = (rep(one['generate_flag']), rep(one['mask']))
+    if optimize_step is None:
+        return model.diffusion.sample(*args, res_feat, pair_feat, *masks, **sample_opt)
+    return model.diffusion.optimize(*args, optimize_step, res_feat, pair_feat, *masks, **sample_opt)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 7
+#define ABOPT_ABI_VERSION 8
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -112,6 +112,9 @@ int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_t, const fl
                           float* v_next, float* R_next, float* eps_pos, float* c_denoised, float* prmsd_logits,
                           int N, int L, int F, int C, int grad_mode,
                           const float* pair_bias_cache /* NULL: compute the pair bias inside the step */,
+                          int pair_feat_shared /* 1: pair_feat is [1,L,L,C] (and the cache was built with N = 1) and is shared by
+                                                  all N samples -- the replicated-complex batches of the reference's runners,
+                                                  D/tools/runner/design_for_pdb.py:141-147 */,
                           void* ws, size_t ws_bytes, abopt_stream stream);
 
 /* ---- Per-step transitions: D/modules/diffusion/transition.py:42-50,80-101 (position), :146-160

@@ -347,6 +347,25 @@ def test_reconstruct_backbone_partially_vs_reference():
     assert torch.equal(p0[~gen], bb['pos_heavyatom'][~gen])
 
 
+def test_replicated_complex_shares_context_bit_identically():
+    """sampler.sample_replicated (context encoded once, pair_feat shared with batch stride 0 in the kernels) must give exactly
+    the trajectory of model.sample on the host-replicated batch the reference's runner builds (design_for_pdb.py:141-147)."""
+    from ab_opt_amd import sampler
+    m = build_model(10, 3, device=DEV)
+    one = {k: dev(v) for k, v in synth.make_batch(1, synth.LAYOUT_128, seed=12, lengths=[101]).items()}
+    n = 5
+    repl = {k: v.expand(n, *v.shape[1:]).contiguous() for k, v in one.items()}
+    opt = {'sample_structure': True, 'sample_sequence': True, 'contig': '', 'seed': 321}
+    ref = m.sample(repl, dict(opt))
+    got = sampler.sample_replicated(m, one, n, dict(opt))
+    assert sorted(ref) == sorted(got)
+    for t in ref:
+        for a, b in zip(ref[t], got[t]):
+            assert torch.equal(a.cpu(), b.cpu()), t
+    # and the samples differ from each other (distinct Philox counters per sample)
+    assert not torch.equal(got[0][1][0], got[0][1][1])
+
+
 def test_sample_init_vs_reference():
     from ab_opt_amd import hip
     g = load_golden('trajectory_abdock_T10')

@@ -18,3 +18,12 @@ for flavour in ('abdesign', 'abdock'):
     traj = model.sample(dict(batch), opt)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f'{flavour}: model.sample N={N} L={L} T=100: {dt * 1e3:.1f} ms end to end = {N * 100 / dt:.0f} sample-steps/s; traj[0][1] {tuple(traj[0][1].shape)} on {traj[0][1].device}, traj[50][1] on {traj[50][1].device}')
+
+    # the same N samples of ONE complex: host-replicated batch (the reference runner's way) vs shared context
+    from ab_opt_amd import sampler
+    one = {k: v[:1].contiguous() for k, v in batch.items()}
+    repl = {k: v.expand(N, *v.shape[1:]).contiguous() for k, v in one.items()}
+    for name, fn in (('replicated batch', lambda: model.sample(dict(repl), opt)), ('shared context', lambda: sampler.sample_replicated(model, one, N, opt))):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f'{flavour}: one complex x {N} samples, {name}: {dt * 1e3:.1f} ms = {N * 100 / dt:.0f} sample-steps/s')
