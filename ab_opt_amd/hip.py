@@ -160,6 +160,10 @@ def ptr(t, dtype=None, optional=False):
         raise ValueError('required tensor is None')
     if not t.is_cuda:
         raise RuntimeError('ab_opt_amd kernels run on a HIP device only; got a CPU tensor (there is no CPU path)')
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f'tensor lives on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}: kernels launch on '
+                           'the current device/stream -- call torch.cuda.set_device() (one process per GPU) or wrap the call in '
+                           '`with torch.cuda.device(tensor.device):`')
     if not t.is_contiguous():
         raise ValueError('tensor must be contiguous')
     if dtype is not None and t.dtype != dtype:
