@@ -261,13 +261,8 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
                 const int h = w4 * 3 + hh;
                 const float coefh = sm.coef[h];
                 // A operand: row = query fm, K-permuted: step s <-> channel 8 kq + s (same permutation on the key side)
-#ifndef WS_Q_GLOBAL
                 const float4 q0 = *reinterpret_cast<const float4*>(&sm.q[fm][h * D + kq * 8]);
                 const float4 q1 = *reinterpret_cast<const float4*>(&sm.q[fm][h * D + kq * 8 + 4]);
-#else
-                const float* qrow = projn + (int64_t)min(i0 + fm, L - 1) * NP + OFF_Q + kq * 8;
-                const float4 q0 = reinterpret_cast<const float4*>(qrow + h * D)[0], q1 = reinterpret_cast<const float4*>(qrow + h * D)[1];
-#endif
                 f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;                 // two chains (dependent-MFMA latency)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) { acc0 = mfma4(f4get(q0, s), f4get(kf[hh].k0, s), acc0); acc1 = mfma4(f4get(q1, s), f4get(kf[hh].k1, s), acc1); }
