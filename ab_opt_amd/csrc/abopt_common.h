@@ -26,14 +26,23 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)
+// All-reduce over the 64 lanes without touching the LDS crossbar (ds_bpermute costs ~60 cycles per step): two gfx950 row
+// swaps fold the four 16-lane rows, four DPP row rotations (row_ror:8,4,2,1) finish inside a row.
+#define ABOPT_DPP_ROR(x, n) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x120 + (n), 0xf, 0xf, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    v += ABOPT_DPP_ROR(v, 8); v += ABOPT_DPP_ROR(v, 4); v += ABOPT_DPP_ROR(v, 2); v += ABOPT_DPP_ROR(v, 1);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    v = fmaxf(v, ABOPT_DPP_ROR(v, 8)); v = fmaxf(v, ABOPT_DPP_ROR(v, 4)); v = fmaxf(v, ABOPT_DPP_ROR(v, 2)); v = fmaxf(v, ABOPT_DPP_ROR(v, 1));
     return v;
 }
 
