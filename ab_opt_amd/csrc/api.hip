@@ -29,7 +29,7 @@ struct Carver {
 };
 
 constexpr int F = 128, FI = F + 4;
-constexpr int OUT_KSPLIT = 4;     // out_transform (K = 1824, N = 128) has only M/64 * 2 tiles: split K so it fills the chip
+constexpr int OUT_KSPLIT = 2;     // out_transform (K = 1824, N = 128) has only M/64 * 2 tiles: split K so it fills the chip
 
 struct GaScratch { float *proj, *feat, *u, *kvf; };
 static GaScratch carve_ga(Carver& cv, int64_t M, int N, int L) {
