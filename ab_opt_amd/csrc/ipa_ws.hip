@@ -129,13 +129,16 @@ __global__ __launch_bounds__((NPW + 4) * 64, (NPW + 4) / 4) void ipa_core_ws_ker
         // that ~12 KB per pair wave (48 KB per CU) is always in flight: HBM latency under load is ~2 us.
         f32x4 ring[4][4];
         f32x4 ringb[4];                                                     // CACHED: the row chunk's precomputed pair bias, lane (head fm, keys 4 kq ..)
+        // wave-uniform row base in SGPRs + 32-bit per-lane byte offsets: three VALU per load instead of five 64-bit ones
+        const int w4u = __builtin_amdgcn_readfirstlane(w4);
+        const unsigned lane_b = (unsigned)fm * 16u;
 #define WS_ISSUE_Z(SLOT, ROW, CH)                                                                                        \
     {                                                                                                                    \
-        const int64_t zrow_ = (z_shared ? 0 : rowbase) + min(i0 + w4 * RPW + (ROW), L - 1);   /* z_shared: one pair_feat for the whole batch */ \
-        const float* zi_ = z + (zrow_ * (int64_t)L) * C;                                                                 \
+        const int64_t zrow_ = (z_shared ? 0 : rowbase) + min(i0 + w4u * RPW + (ROW), L - 1);   /* z_shared: one pair_feat for the whole batch */ \
+        const char* zi_ = reinterpret_cast<const char*>(z + (zrow_ * (int64_t)L) * C);                                  \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                              \
-            ring[SLOT][r_] = *(reinterpret_cast<const f32x4*>(zi_ + (int64_t)min((CH) * JC + kq * 4 + r_, L - 1) * C) + fm); \
-        if (CACHED) ringb[SLOT] = *(reinterpret_cast<const f32x4*>(pbc + (zrow_ * nchunk + min((CH), nchunk - 1)) * 256) + lane);  \
+            ring[SLOT][r_] = *reinterpret_cast<const f32x4*>(zi_ + ((unsigned)min((CH) * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b)); \
+        if (CACHED) ringb[SLOT] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(pbc + (zrow_ * nchunk + min((CH), nchunk - 1)) * 256) + (unsigned)lane * 16u);  \
     }
         // ring position p = c * RPW + ii (c = chunk within the revolution) is also the slot; requests run 3 positions ahead
         WS_ISSUE_Z(0, 0 % RPW, 0 / RPW) WS_ISSUE_Z(1, 1 % RPW, 1 / RPW) WS_ISSUE_Z(2, 2 % RPW, 2 / RPW)
