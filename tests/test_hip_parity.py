@@ -366,6 +366,20 @@ def test_replicated_complex_shares_context_bit_identically():
     assert not torch.equal(got[0][1][0], got[0][1][1])
 
 
+def test_sampling_is_deterministic_for_a_seed():
+    """Race detector: every kernel on the path is free of atomics and cross-workgroup ordering, so a seeded run must repeat
+    bit for bit (a missing wave-level LDS fence in the IPA core once broke this silently)."""
+    m = build_model(10, 3, device=DEV)
+    batch = {k: dev(v) for k, v in synth.make_batch(6, synth.LAYOUT_256, seed=5, lengths=[256, 256, 243, 256, 256, 200]).items()}
+    opt = {'sample_structure': True, 'sample_sequence': True, 'contig': '', 'seed': 77}
+    ref = m.sample(dict(batch), dict(opt))
+    for _ in range(4):
+        got = m.sample(dict(batch), dict(opt))
+        for t in ref:
+            for a, b in zip(ref[t], got[t]):
+                assert torch.equal(a.cpu(), b.cpu()), t
+
+
 def test_sample_init_vs_reference():
     from ab_opt_amd import hip
     g = load_golden('trajectory_abdock_T10')
