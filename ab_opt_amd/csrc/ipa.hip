@@ -572,11 +572,11 @@ void begin(hipStream_t st) {
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_on = false; return; }
         g_pool.emplace_back(a, b);
     }
-    hipEventRecord(g_pool[g_used].first, st);
+    (void)hipEventRecord(g_pool[g_used].first, st);
 }
 void end(hipStream_t st) {
     if (!g_on) return;
-    hipEventRecord(g_pool[g_used].second, st);
+    (void)hipEventRecord(g_pool[g_used].second, st);
     ++g_used;
 }
 }  // namespace prof
