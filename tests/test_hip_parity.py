@@ -380,6 +380,38 @@ def test_sampling_is_deterministic_for_a_seed():
                 assert torch.equal(a.cpu(), b.cpu()), t
 
 
+def test_structure_only_sampling_and_contig_mask():
+    """BASELINE config 3 mode (AbDock pose diffusion: obj = pred_x0, sample_sequence=False): the sequence never changes and
+    the start state matches the reference's recorded initial draw; with a contig the generated set is restricted to it
+    (diffab.py:125-127,184-205)."""
+    g = load_golden('trajectory_abdock_T10_structonly')
+    _, m, batch = _traj_setup()
+    b = {k: dev(v) for k, v in batch.items()}
+    nz = noise_dict(g, 10)
+    nzd = {t: {k: (dev(v) if v is not None else None) for k, v in d.items()} for t, d in nz.items()}
+    traj = m.sample(dict(b), sample_opt=dict(sample_structure=True, sample_sequence=False, contig='', noise=nzd))
+    from oracle import geometry as G
+    # context frames within 0.03 rad of pi sit on the log map's ill-conditioned branch (DESIGN 4.1): 5e-4 on R there
+    assert max_abs(G.so3_exp(traj[10][0].cpu()), G.so3_exp(g['traj10_v'])) < 5e-4 and max_abs(traj[10][1].cpu(), g['traj10_p']) < 1e-4
+    for t in range(10, -1, -1):
+        assert torch.equal(traj[t][2].cpu(), batch['aa']), t                # sample_sequence=False: s_next = s_t everywhere (dpm_full.py:296-297)
+        assert torch.isfinite(traj[t][1]).all()
+    # contig: only residues 31..36 (1-based, inclusive) of the generated segment may change
+    b2 = {k: dev(v) for k, v in batch.items()}
+    gen0 = b2['generate_flag'].clone()
+    traj2 = m.sample(b2, sample_opt=dict(sample_structure=True, sample_sequence=True, contig='31-36', seed=5))
+    allowed = gen0.clone()
+    allowed[:] = False
+    allowed[:, 30:36] = True
+    allowed &= gen0
+    assert torch.equal(b2['generate_flag'], allowed)                       # the reference narrows batch['generate_flag'] in place
+    moved = (traj2[0][1] - traj2[10][1].to(traj2[0][1].device)).abs().sum(-1) > 0
+    assert not moved[~allowed].any() and moved[allowed].any()
+    # (padded positions, aa = 21, have an all-zero one-hot, so the reference re-draws them uniformly at every step: transition.py:202-245)
+    keep = (~allowed & b2['mask']).cpu()
+    assert torch.equal(traj2[0][2].cpu()[keep], batch['aa'][keep])
+
+
 def test_sample_init_vs_reference():
     from ab_opt_amd import hip
     g = load_golden('trajectory_abdock_T10')
