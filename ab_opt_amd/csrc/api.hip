@@ -176,6 +176,14 @@ extern "C" int abopt_ipa_core_train_forward(const float* proj_local, const float
     return launch_ipa_train_forward(proj_local, R, t, pair_feat, mask, w_pair_bias, spatial_coef, feat, alpha, N, L, (float*)ws, (hipStream_t)stream);
 }
 
+extern "C" int abopt_ipa_points_backward(const float* dfeat, int ld_dfeat, const float* feat, const float* R, const float* t,
+                                         float* dout_cat, float* delta, int N, int L, abopt_stream stream) {
+    ABOPT_CHECK_ARG(N >= 0 && L >= 0, "ipa_points_backward: negative dims");
+    if ((int64_t)N * L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(dfeat && feat && R && t && dout_cat && delta && ld_dfeat >= ABOPT_IPA_FEAT, "ipa_points_backward: bad argument");
+    return launch_ipa_points_backward(dfeat, ld_dfeat, feat, R, t, dout_cat, delta, N, L, (hipStream_t)stream);
+}
+
 extern "C" int abopt_ipa_pair_backward(const float* pair_feat, const float* alpha, const float* dalpha_node, const float* delta,
                                        const float* dfeat, int ld_dfeat, const float* w_pair_bias, float* g, float* dpair_feat,
                                        int N, int L, int Cd, abopt_stream stream) {

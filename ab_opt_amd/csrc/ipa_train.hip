@@ -123,6 +123,60 @@ __global__ __launch_bounds__(256) void alpha_head_major_kernel(const float* __re
     }
 }
 
+// Backward of the points epilogue (ga.py:133-139: loc = R^T (agg - t), dist = |loc|, dir = loc / (dist + 1e-4)) and the
+// flash-attention delta, one workgroup per query row, thread = (head, point):
+//   dout_cat[n, h, i, 0:32]  = d feat_node_ih                      (head-major copy for the batched GEMMs)
+//   dout_cat[n, h, i, 32:56] = d agg_pts_ih = R_i . d loc
+//   delta[n, i, h]           = <d feat_p2n, feat_p2n>_h + <d feat_node, feat_node>_h + <d agg_pts, agg_pts>_h,  agg_pts = R loc + t
+__global__ __launch_bounds__(128) void ipa_points_backward_kernel(const float* __restrict__ dfeat, int ld_dfeat, const float* __restrict__ feat,
+                                                                  const float* __restrict__ R, const float* __restrict__ t,
+                                                                  float* __restrict__ dout_cat, float* __restrict__ delta, int L) {
+    const int64_t row = blockIdx.x;
+    const int64_t n = row / L;
+    const int i = (int)(row % L), tid = threadIdx.x;
+    if (tid >= H * P) return;
+    const int h = tid / P, p = tid % P;
+    const float* df = dfeat + row * ld_dfeat;
+    const float* ff = feat + row * FEAT;
+    constexpr int o = H * C + H * D;                             // start of the point features
+    const float* Rr = R + row * 9;
+    const float* tr = t + row * 3;
+    const int hp = h * P + p;
+    const float lx = ff[o + hp * 3], ly = ff[o + hp * 3 + 1], lz = ff[o + hp * 3 + 2];
+    const float nrm = sqrtf(lx * lx + ly * ly + lz * lz);
+    const float ux = nrm > 0.f ? lx / nrm : 0.f, uy = nrm > 0.f ? ly / nrm : 0.f, uz = nrm > 0.f ? lz / nrm : 0.f;
+    const float inv = 1.f / (nrm + 1e-4f);
+    const float dd = df[o + NPT + hp];                           // d dist
+    const float* ddir = df + o + NPT + H * P + hp * 3;
+    const float* dloc = df + o + hp * 3;
+    const float k = dd - (ddir[0] * lx + ddir[1] * ly + ddir[2] * lz) * inv * inv;
+    const float dlx = dloc[0] + ddir[0] * inv + k * ux, dly = dloc[1] + ddir[1] * inv + k * uy, dlz = dloc[2] + ddir[2] * inv + k * uz;
+    const float gx = Rr[0] * dlx + Rr[1] * dly + Rr[2] * dlz, gy = Rr[3] * dlx + Rr[4] * dly + Rr[5] * dlz, gz = Rr[6] * dlx + Rr[7] * dly + Rr[8] * dlz;
+    const float ax = Rr[0] * lx + Rr[1] * ly + Rr[2] * lz + tr[0], ay = Rr[3] * lx + Rr[4] * ly + Rr[5] * lz + tr[1], az = Rr[6] * lx + Rr[7] * ly + Rr[8] * lz + tr[2];
+    float* oc = dout_cat + ((n * H + h) * (int64_t)L + i) * (D + P * 3);
+    oc[D + p * 3] = gx; oc[D + p * 3 + 1] = gy; oc[D + p * 3 + 2] = gz;
+    float part = gx * ax + gy * ay + gz * az;
+    // this thread's slice of the head's pair (8 of 64 channels) and node (4 of 32 channels) dot products; d feat_node copied head-major
+#pragma unroll
+    for (int c = 0; c < 8; ++c) part = fmaf(df[h * C + p * 8 + c], ff[h * C + p * 8 + c], part);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float v = df[H * C + h * D + p * 4 + d];
+        oc[p * 4 + d] = v;
+        part = fmaf(v, ff[H * C + h * D + p * 4 + d], part);
+    }
+    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);      // the 8 point-threads of a head are adjacent lanes
+    if (p == 0) delta[row * H + h] = part;
+}
+
+int launch_ipa_points_backward(const float* dfeat, int ld_dfeat, const float* feat, const float* R, const float* t, float* dout_cat, float* delta,
+                               int N, int L, hipStream_t st) {
+    if ((int64_t)N * L == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(ipa_points_backward_kernel, dim3((unsigned)((int64_t)N * L)), dim3(128), 0, st, dfeat, ld_dfeat, feat, R, t, dout_cat, delta, L);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
 int launch_ipa_pair_backward(const float* z, const float* alpha, const float* dalpha_node, const float* delta, const float* dfeat, int ld_dfeat,
                              const float* Wb, float* g_out, float* dz, int N, int L, hipStream_t st) {
     if ((int64_t)N * L == 0) return ABOPT_OK;

@@ -47,6 +47,8 @@ int launch_mean_over_L(const float* in, float* out, int N, int L, int B, hipStre
 size_t ipa_train_ws_floats(int N, int L);
 int launch_ipa_train_forward(const float* proj_local, const float* R, const float* t, const float* z, const uint8_t* mask,
                              const float* Wb, const float* spatial_coef, float* feat, float* alpha, int N, int L, float* ws, hipStream_t st);
+int launch_ipa_points_backward(const float* dfeat, int ld_dfeat, const float* feat, const float* R, const float* t, float* dout_cat, float* delta,
+                               int N, int L, hipStream_t st);
 int launch_ipa_pair_backward(const float* z, const float* alpha, const float* dalpha_node, const float* delta, const float* dfeat, int ld_dfeat,
                              const float* Wb, float* g_out, float* dz, int N, int L, hipStream_t st);
 

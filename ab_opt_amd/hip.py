@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,7 +73,7 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
            'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect',
-           'abopt_pair_gauss_workspace_bytes', 'abopt_pair_gauss_features', 'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_pair_backward',
+           'abopt_pair_gauss_workspace_bytes', 'abopt_pair_gauss_features', 'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward']
 
 _lib = None
@@ -129,6 +129,7 @@ def lib():
         L.abopt_ipa_train_workspace_bytes.restype = C.c_size_t
         L.abopt_ipa_train_workspace_bytes.argtypes = [C.c_int] * 2
         L.abopt_ipa_core_train_forward.argtypes = [c_f, c_f, c_f, c_f, c_u8, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_ipa_points_backward.argtypes = [c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_ipa_pair_backward.argtypes = [c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.abopt_residue_embed_workspace_bytes.restype = C.c_size_t
         L.abopt_residue_embed_workspace_bytes.argtypes = [C.c_int] * 4
@@ -354,6 +355,17 @@ def ipa_core_train_forward(proj_local, R, t, z, mask, w_pair_bias, spatial_coef)
                                               ptr(w_pair_bias.contiguous(), torch.float32), ptr(spatial_coef.contiguous(), torch.float32),
                                               ptr(feat), ptr(alpha), N, L, z.shape[-1], ptr(buf), buf.numel(), stream()))
     return feat, alpha
+
+
+def ipa_points_backward(dfeat, feat, R, t):
+    """-> dout_cat (N,12,L,56) = [d feat_node | d aggregated points] head-major, delta (N,L,12)  (abopt_ipa_points_backward)."""
+    N, L = feat.shape[:2]
+    dout_cat = torch.empty(N, 12, L, 56, device=feat.device)
+    delta = torch.empty(N, L, 12, device=feat.device)
+    dfeat = dfeat.contiguous()
+    _check(lib().abopt_ipa_points_backward(ptr(dfeat, torch.float32), dfeat.shape[-1], ptr(feat.contiguous(), torch.float32),
+                                           ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32), ptr(dout_cat), ptr(delta), N, L, stream()))
+    return dout_cat, delta
 
 
 def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias):

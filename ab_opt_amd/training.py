@@ -98,24 +98,10 @@ class IpaCore(torch.autograd.Function):
         pts = [proj[..., 3 * HD + i * HP * 3: 3 * HD + (i + 1) * HP * 3].reshape(N, L, HP, 3) for i in range(3)]
         qg, kg, vg = (hm(_to_global(R, t, p).reshape(N, L, H, P * 3)) for p in pts)
         dfeat = dfeat.contiguous()
-        dfn = hm(dfeat[..., H * 64: H * 64 + HD].reshape(N, L, H, D))
-        o = H * 64 + HD
-        dloc, ddist, ddir = dfeat[..., o:o + HP * 3].reshape(N, L, HP, 3), dfeat[..., o + HP * 3:o + HP * 4], dfeat[..., o + HP * 4:].reshape(N, L, HP, 3)
-        loc = feat[..., o:o + HP * 3].reshape(N, L, HP, 3)
-        # points epilogue (ga.py:136-139): loc = R^T (agg - t), dist = |loc|, dir = loc / (dist + 1e-4)
-        n = loc.norm(dim=-1, keepdim=True)
-        unit = torch.where(n > 0, loc / n.clamp_min(1e-30), torch.zeros_like(loc))
-        inv = 1.0 / (n + 1e-4)
-        dl = dloc + ddir * inv + (ddist.unsqueeze(-1) - (ddir * loc).sum(-1, keepdim=True) * inv * inv) * unit
-        dag_l = torch.einsum('nlab,nlkb->nlka', R, dl).reshape(N, L, H, P * 3)
-        ag = _to_global(R, t, loc).reshape(N, L, H, P * 3)
-        # delta_ih = sum_j alpha dalpha = <dfeat, feat> over the three aggregated outputs
-        delta = (dfeat[..., :H * 64] * feat[..., :H * 64]).reshape(N, L, H, 64).sum(-1) \
-            + (hm(dfn) * feat[..., H * 64:o].reshape(N, L, H, D)).sum(-1) + (dag_l * ag).sum(-1)
-        dag = hm(dag_l)
+        # points epilogue backward (ga.py:136-139), head-major [d feat_node | d agg_pts] and delta_ih = <dfeat, feat>: one kernel
+        dout_cat, delta = hip.ipa_points_backward(dfeat, feat, R, t)
         T = lambda a: a.transpose(-1, -2)
         # every (N,12,L,L) matrix is multiplied ONCE from each side, against concatenated right-hand sides:
-        dout_cat = torch.cat([dfn, dag], dim=-1)                                    # (N,H,L,56): d feat_node | d aggregated points
         da_node = dout_cat @ T(torch.cat([v, vg], dim=-1))                          # (N,H,L,L)
         g, dz = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb)          # the z-streaming part
         del da_node

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 8
+#define ABOPT_ABI_VERSION 9
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -202,6 +202,10 @@ size_t abopt_ipa_train_workspace_bytes(int N, int L);
 int abopt_ipa_core_train_forward(const float* proj_local, const float* R, const float* t, const float* pair_feat, const uint8_t* mask,
                                  const float* w_pair_bias, const float* spatial_coef, float* feat, float* alpha,
                                  int N, int L, int C, void* ws, size_t ws_bytes, abopt_stream stream);
+/* prologue of the backward: the points epilogue (ga.py:133-139) differentiated, d feat_node re-laid out head-major next to
+ * it (dout_cat [N,12,L,32+24]) and delta [N,L,12] = sum_j alpha dalpha (see above). */
+int abopt_ipa_points_backward(const float* dfeat, int ld_dfeat, const float* feat, const float* R, const float* t,
+                              float* dout_cat, float* delta, int N, int L, abopt_stream stream);
 int abopt_ipa_pair_backward(const float* pair_feat, const float* alpha, const float* dalpha_node, const float* delta,
                             const float* dfeat, int ld_dfeat, const float* w_pair_bias, float* g, float* dpair_feat,
                             int N, int L, int C, abopt_stream stream);
