@@ -184,6 +184,22 @@ extern "C" int abopt_ipa_points_backward(const float* dfeat, int ld_dfeat, const
     return launch_ipa_points_backward(dfeat, ld_dfeat, feat, R, t, dout_cat, delta, N, L, (hipStream_t)stream);
 }
 
+extern "C" int abopt_ipa_backward_operands(const float* proj_local, const float* R, const float* t, float* Aq, float* Ak, float* Av,
+                                           int N, int L, abopt_stream stream) {
+    ABOPT_CHECK_ARG(N >= 0 && L >= 0, "ipa_backward_operands: negative dims");
+    if ((int64_t)N * L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(proj_local && R && t && Aq && Ak && Av, "ipa_backward_operands: NULL argument");
+    return launch_ipa_backward_operands(proj_local, R, t, Aq, Ak, Av, N, L, (hipStream_t)stream);
+}
+
+extern "C" int abopt_ipa_backward_assemble(const float* P1, const float* P2, const float* P3, const float* Aq, const float* Ak, const float* R,
+                                           const float* spatial_coef, float* dproj, float* e, int N, int L, abopt_stream stream) {
+    ABOPT_CHECK_ARG(N >= 0 && L >= 0, "ipa_backward_assemble: negative dims");
+    if ((int64_t)N * L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(P1 && P2 && P3 && Aq && Ak && R && spatial_coef && dproj && e, "ipa_backward_assemble: NULL argument");
+    return launch_ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, spatial_coef, dproj, e, N, L, (hipStream_t)stream);
+}
+
 extern "C" int abopt_ipa_pair_backward(const float* pair_feat, const float* alpha, const float* dalpha_node, const float* delta,
                                        const float* dfeat, int ld_dfeat, const float* w_pair_bias, float* g, float* dpair_feat,
                                        int N, int L, int Cd, abopt_stream stream) {

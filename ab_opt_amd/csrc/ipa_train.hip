@@ -177,6 +177,97 @@ int launch_ipa_points_backward(const float* dfeat, int ld_dfeat, const float* fe
     return ABOPT_OK;
 }
 
+// Head-major GEMM operands of the backward from the (local-frame) projections: one workgroup per residue, thread = (head, point)
+//   Aq[n,h,i,:] = [q_ih (32) | q_pts global (24) | 1],  Ak likewise from k,  Av[n,h,i,:] = [v_ih (32) | v_pts global (24)]
+__global__ __launch_bounds__(128) void ipa_backward_operands_kernel(const float* __restrict__ proj, const float* __restrict__ R, const float* __restrict__ t,
+                                                                    float* __restrict__ Aq, float* __restrict__ Ak, float* __restrict__ Av, int L) {
+    const int64_t row = blockIdx.x;
+    const int64_t n = row / L;
+    const int i = (int)(row % L), tid = threadIdx.x;
+    if (tid >= H * P) return;
+    const int h = tid / P, p = tid % P;
+    const float* pr = proj + row * ABOPT_NODE_PROJ;
+    const float* Rr = R + row * 9;
+    const float* tr = t + row * 3;
+    const int64_t hb = (n * H + h) * (int64_t)L + i;
+    float* outs[3] = {Aq + hb * 57, Ak + hb * 57, Av + hb * 56};
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        float* o = outs[s3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[p * 4 + d] = pr[s3 * H * D + h * D + p * 4 + d];
+        const float* lp = pr + 3 * H * D + s3 * NPT + (h * P + p) * 3;
+        o[D + p * 3 + 0] = Rr[0] * lp[0] + Rr[1] * lp[1] + Rr[2] * lp[2] + tr[0];
+        o[D + p * 3 + 1] = Rr[3] * lp[0] + Rr[4] * lp[1] + Rr[5] * lp[2] + tr[1];
+        o[D + p * 3 + 2] = Rr[6] * lp[0] + Rr[7] * lp[1] + Rr[8] * lp[2] + tr[2];
+        if (s3 < 2 && p == 0) o[D + P * 3] = 1.f;
+    }
+}
+
+// d proj [N,L,2016] (gradients wrt q|k|v and the LOCAL-frame points) from the three batched products
+//   P1 = g Ak = [sum_j g k_j | sum_j g kg_j | sum_j g],  P2 = g^T Aq,  P3 = alpha^T [d feat_node | d agg_pts]      (head-major, 57/57/56 wide)
+// and e[n,i,h] = |qg|^2 rowsum + |kg|^2 colsum - 2 <qg, sum_j g kg_j>, whose sum over (n, i) is d loss / d coef_h (ga.py:108-111)
+__global__ __launch_bounds__(128) void ipa_backward_assemble_kernel(const float* __restrict__ P1, const float* __restrict__ P2, const float* __restrict__ P3,
+                                                                    const float* __restrict__ Aq, const float* __restrict__ Ak, const float* __restrict__ R,
+                                                                    const float* __restrict__ spatial_coef, float* __restrict__ dproj, float* __restrict__ e, int L) {
+    const int64_t row = blockIdx.x;
+    const int64_t n = row / L;
+    const int i = (int)(row % L), tid = threadIdx.x;
+    if (tid >= H * P) return;
+    const int h = tid / P, p = tid % P;
+    const int64_t hb = (n * H + h) * (int64_t)L + i;
+    const float* p1 = P1 + hb * 57; const float* p2 = P2 + hb * 57; const float* p3 = P3 + hb * 56;
+    const float* aq = Aq + hb * 57; const float* ak = Ak + hb * 57;
+    const float* Rr = R + row * 9;
+    float* dp = dproj + row * ABOPT_NODE_PROJ;
+    const float sc = 0.17677669529663687f;                       // 1 / sqrt(32)
+    const float scv = spatial_coef[h];
+    const float gam = (scv > 20.f) ? scv : log1pf(expf(scv));
+    const float c2 = 2.f * ((-1.f * gam * 0.16666666666666666f) / 2.f);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        dp[h * D + p * 4 + d] = p1[p * 4 + d] * sc;
+        dp[H * D + h * D + p * 4 + d] = p2[p * 4 + d] * sc;
+        dp[2 * H * D + h * D + p * 4 + d] = p3[p * 4 + d];
+    }
+    const float grow = p1[D + P * 3], gcol = p2[D + P * 3];
+    float gq[3], gk[3], gv[3], part = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float qg = aq[D + p * 3 + a], kg = ak[D + p * 3 + a], gkg = p1[D + p * 3 + a], gqg = p2[D + p * 3 + a];
+        gq[a] = c2 * (qg * grow - gkg);
+        gk[a] = c2 * (kg * gcol - gqg);
+        gv[a] = p3[D + p * 3 + a];
+        part += qg * qg * grow + kg * kg * gcol - 2.f * qg * gkg;
+    }
+    float* outs[3] = {dp + 3 * H * D + (h * P + p) * 3, dp + 3 * H * D + NPT + (h * P + p) * 3, dp + 3 * H * D + 2 * NPT + (h * P + p) * 3};
+    const float* gs[3] = {gq, gk, gv};
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {                             // R^T d
+        const float* gvec = gs[s3];
+        outs[s3][0] = Rr[0] * gvec[0] + Rr[3] * gvec[1] + Rr[6] * gvec[2];
+        outs[s3][1] = Rr[1] * gvec[0] + Rr[4] * gvec[1] + Rr[7] * gvec[2];
+        outs[s3][2] = Rr[2] * gvec[0] + Rr[5] * gvec[1] + Rr[8] * gvec[2];
+    }
+    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+    if (p == 0) e[row * H + h] = part;
+}
+
+int launch_ipa_backward_operands(const float* proj, const float* R, const float* t, float* Aq, float* Ak, float* Av, int N, int L, hipStream_t st) {
+    if ((int64_t)N * L == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(ipa_backward_operands_kernel, dim3((unsigned)((int64_t)N * L)), dim3(128), 0, st, proj, R, t, Aq, Ak, Av, L);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+int launch_ipa_backward_assemble(const float* P1, const float* P2, const float* P3, const float* Aq, const float* Ak, const float* R,
+                                 const float* spatial_coef, float* dproj, float* e, int N, int L, hipStream_t st) {
+    if ((int64_t)N * L == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(ipa_backward_assemble_kernel, dim3((unsigned)((int64_t)N * L)), dim3(128), 0, st, P1, P2, P3, Aq, Ak, R, spatial_coef, dproj, e, L);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
 int launch_ipa_pair_backward(const float* z, const float* alpha, const float* dalpha_node, const float* delta, const float* dfeat, int ld_dfeat,
                              const float* Wb, float* g_out, float* dz, int N, int L, hipStream_t st) {
     if ((int64_t)N * L == 0) return ABOPT_OK;

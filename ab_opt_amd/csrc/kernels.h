@@ -49,6 +49,9 @@ int launch_ipa_train_forward(const float* proj_local, const float* R, const floa
                              const float* Wb, const float* spatial_coef, float* feat, float* alpha, int N, int L, float* ws, hipStream_t st);
 int launch_ipa_points_backward(const float* dfeat, int ld_dfeat, const float* feat, const float* R, const float* t, float* dout_cat, float* delta,
                                int N, int L, hipStream_t st);
+int launch_ipa_backward_operands(const float* proj, const float* R, const float* t, float* Aq, float* Ak, float* Av, int N, int L, hipStream_t st);
+int launch_ipa_backward_assemble(const float* P1, const float* P2, const float* P3, const float* Aq, const float* Ak, const float* R,
+                                 const float* spatial_coef, float* dproj, float* e, int N, int L, hipStream_t st);
 int launch_ipa_pair_backward(const float* z, const float* alpha, const float* dalpha_node, const float* delta, const float* dfeat, int ld_dfeat,
                              const float* Wb, float* g_out, float* dz, int N, int L, hipStream_t st);
 

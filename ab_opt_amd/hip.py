@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,7 +73,7 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
            'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect',
-           'abopt_pair_gauss_workspace_bytes', 'abopt_pair_gauss_features', 'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_pair_backward',
+           'abopt_pair_gauss_workspace_bytes', 'abopt_pair_gauss_features', 'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward']
 
 _lib = None
@@ -130,6 +130,8 @@ def lib():
         L.abopt_ipa_train_workspace_bytes.argtypes = [C.c_int] * 2
         L.abopt_ipa_core_train_forward.argtypes = [c_f, c_f, c_f, c_f, c_u8, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_ipa_points_backward.argtypes = [c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
+        L.abopt_ipa_backward_operands.argtypes = [c_f] * 6 + [C.c_int, C.c_int, C.c_void_p]
+        L.abopt_ipa_backward_assemble.argtypes = [c_f] * 9 + [C.c_int, C.c_int, C.c_void_p]
         L.abopt_ipa_pair_backward.argtypes = [c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.abopt_residue_embed_workspace_bytes.restype = C.c_size_t
         L.abopt_residue_embed_workspace_bytes.argtypes = [C.c_int] * 4
@@ -366,6 +368,27 @@ def ipa_points_backward(dfeat, feat, R, t):
     _check(lib().abopt_ipa_points_backward(ptr(dfeat, torch.float32), dfeat.shape[-1], ptr(feat.contiguous(), torch.float32),
                                            ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32), ptr(dout_cat), ptr(delta), N, L, stream()))
     return dout_cat, delta
+
+
+def ipa_backward_operands(proj_local, R, t):
+    """-> Aq, Ak (N,12,L,57), Av (N,12,L,56): head-major GEMM operands of the IPA backward (abopt_ipa_backward_operands)."""
+    N, L = proj_local.shape[:2]
+    dev = proj_local.device
+    Aq, Ak, Av = torch.empty(N, 12, L, 57, device=dev), torch.empty(N, 12, L, 57, device=dev), torch.empty(N, 12, L, 56, device=dev)
+    _check(lib().abopt_ipa_backward_operands(ptr(proj_local.contiguous(), torch.float32), ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32),
+                                             ptr(Aq), ptr(Ak), ptr(Av), N, L, stream()))
+    return Aq, Ak, Av
+
+
+def ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, spatial_coef):
+    """-> d proj_local (N,L,2016), e (N,L,12)  (abopt_ipa_backward_assemble)."""
+    N, _, L, _ = P1.shape
+    dproj = torch.empty(N, L, 2016, device=P1.device)
+    e = torch.empty(N, L, 12, device=P1.device)
+    _check(lib().abopt_ipa_backward_assemble(ptr(P1.contiguous(), torch.float32), ptr(P2.contiguous(), torch.float32), ptr(P3.contiguous(), torch.float32),
+                                             ptr(Aq, torch.float32), ptr(Ak, torch.float32), ptr(R.contiguous(), torch.float32),
+                                             ptr(spatial_coef.contiguous(), torch.float32), ptr(dproj), ptr(e), N, L, stream()))
+    return dproj, e
 
 
 def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias):

@@ -92,39 +92,24 @@ class IpaCore(torch.autograd.Function):
         from . import hip
         proj, z, R, t, Wb, gamma_raw, feat, alpha = ctx.saved_tensors
         N, L = proj.shape[:2]
-        HD, HP = H * D, H * P
-        hm = lambda a: a.permute(0, 2, 1, 3)                                        # (N,L,H,*) <-> (N,H,L,*): head-major views for batched GEMMs
-        q, k, v = (hm(proj[..., i * HD:(i + 1) * HD].reshape(N, L, H, D)) for i in range(3))
-        pts = [proj[..., 3 * HD + i * HP * 3: 3 * HD + (i + 1) * HP * 3].reshape(N, L, HP, 3) for i in range(3)]
-        qg, kg, vg = (hm(_to_global(R, t, p).reshape(N, L, H, P * 3)) for p in pts)
+        # head-major operands [q | q_pts global | 1], [k | k_pts | 1], [v | v_pts] for the batched GEMMs: one kernel
+        Aq, Ak, Av = hip.ipa_backward_operands(proj, R, t)
         dfeat = dfeat.contiguous()
         # points epilogue backward (ga.py:136-139), head-major [d feat_node | d agg_pts] and delta_ih = <dfeat, feat>: one kernel
         dout_cat, delta = hip.ipa_points_backward(dfeat, feat, R, t)
         T = lambda a: a.transpose(-1, -2)
-        # every (N,12,L,L) matrix is multiplied ONCE from each side, against concatenated right-hand sides:
-        da_node = dout_cat @ T(torch.cat([v, vg], dim=-1))                          # (N,H,L,L)
+        da_node = dout_cat @ T(Av)                                                  # (N,H,L,L)
         g, dz = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb)          # the z-streaming part
         del da_node
-        ones = torch.ones_like(q[..., :1])
-        P1 = g @ torch.cat([k, kg, ones], dim=-1)                                   # sum_j g_ij [k_j | kg_j | 1]
-        P2 = T(g) @ torch.cat([q, qg, ones], dim=-1)                                # sum_i g_ij [q_i | qg_i | 1]
+        # every (N,12,L,L) matrix is multiplied ONCE from each side:
+        P1 = g @ Ak                                                                 # sum_j g_ij [k_j | kg_j | 1]
+        P2 = T(g) @ Aq                                                              # sum_i g_ij [q_i | qg_i | 1]
         P3 = T(alpha) @ dout_cat                                                    # sum_i alpha_ij [dfn_i | dag_i]
-        sc = 1.0 / math.sqrt(D)
-        dq, g_kg, g_rows = P1[..., :D] * sc, P1[..., D:D + P * 3], P1[..., D + P * 3:]
-        dk, g_qg, g_cols = P2[..., :D] * sc, P2[..., D:D + P * 3], P2[..., D + P * 3:]
-        dv, dvg = P3[..., :D], P3[..., D:]
+        # scale, spatial-term chain rule, rotation back to the residue frames, re-layout to (N,L,2016): one kernel
+        dproj, e = hip.ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, gamma_raw.reshape(-1))
         gam = gamma_raw.reshape(-1)
-        cfac = math.sqrt(2 / (9 * P)) / 2
-        coef = (-F.softplus(gam) * cfac).view(1, H, 1, 1)
-        dqg = 2 * coef * (qg * g_rows - g_kg)
-        dkg = 2 * coef * (kg * g_cols - g_qg)
-        # sum_ij g_ij |qg_i - kg_j|^2 without forming the distance matrix
-        gd2 = ((qg ** 2).sum(-1, keepdim=True) * g_rows).sum((0, 2, 3)) + ((kg ** 2).sum(-1, keepdim=True) * g_cols).sum((0, 2, 3)) \
-            - 2 * (qg * g_kg).sum((0, 2, 3))
-        dgamma = (gd2 * (-torch.sigmoid(gam) * cfac)).reshape(gamma_raw.shape)
+        dgamma = (e.sum((0, 1)) * (-torch.sigmoid(gam) * (math.sqrt(2 / (9 * P)) / 2))).reshape(gamma_raw.shape)
         dWb = (g.reshape(N, H, L * L) @ z.reshape(N, L * L, -1)).sum(0)
-        loc_grad = lambda d: torch.einsum('nlba,nlkb->nlka', R, hm(d).reshape(N, L, HP, 3)).reshape(N, L, HP * 3)     # R^T d
-        dproj = torch.cat([hm(dq).reshape(N, L, HD), hm(dk).reshape(N, L, HD), hm(dv).reshape(N, L, HD), loc_grad(dqg), loc_grad(dkg), loc_grad(dvg)], dim=-1)
         return dproj, dz, None, None, None, dWb, dgamma
 
 

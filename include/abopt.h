@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 9
+#define ABOPT_ABI_VERSION 10
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -206,6 +206,13 @@ int abopt_ipa_core_train_forward(const float* proj_local, const float* R, const 
  * it (dout_cat [N,12,L,32+24]) and delta [N,L,12] = sum_j alpha dalpha (see above). */
 int abopt_ipa_points_backward(const float* dfeat, int ld_dfeat, const float* feat, const float* R, const float* t,
                               float* dout_cat, float* delta, int N, int L, abopt_stream stream);
+/* head-major operands of the backward's batched GEMMs: Aq/Ak [N,12,L,57] = [q|k (32) | points in the global frame (24) | 1],
+ * Av [N,12,L,56] = [v | v points]; and the final assembly of d proj_local [N,L,2016] (+ e [N,L,12], whose sum is
+ * d loss / d(-softplus(spatial_coef) sqrt(2/(9P))/2)) from P1 = g Ak, P2 = g^T Aq, P3 = alpha^T dout_cat. */
+int abopt_ipa_backward_operands(const float* proj_local, const float* R, const float* t, float* Aq, float* Ak, float* Av,
+                                int N, int L, abopt_stream stream);
+int abopt_ipa_backward_assemble(const float* P1, const float* P2, const float* P3, const float* Aq, const float* Ak, const float* R,
+                                const float* spatial_coef, float* dproj, float* e, int N, int L, abopt_stream stream);
 int abopt_ipa_pair_backward(const float* pair_feat, const float* alpha, const float* dalpha_node, const float* delta,
                             const float* dfeat, int ld_dfeat, const float* w_pair_bias, float* g, float* dpair_feat,
                             int N, int L, int C, abopt_stream stream);
