@@ -106,24 +106,27 @@ extern "C" int abopt_residue_embed_forward(const abopt_encode_inputs* in, const 
 }
 
 extern "C" int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* activations,
-                                        void* ws, size_t ws_bytes, abopt_stream stream) {
+                                        float* gauss, float* dgauss, void* ws, size_t ws_bytes, abopt_stream stream) {
     int rc;
     if ((rc = check_encode_inputs(in, "pair_embed_forward"))) return rc;
     if ((int64_t)in->N * in->L == 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(w && w->aa_pair_embed && w->relpos_embed && w->aapair_to_distcoef && w->freq_bands && w->wd0 && w->bd0 && w->wd1 && w->bd1 &&
                     w->wo0 && w->bo0 && w->wo1 && w->bo1 && w->wo2 && w->bo2 && pair_feat && ws, "pair_embed_forward: NULL argument");
-    return launch_pair_embed(in, w, pair_feat, activations, ws, ws_bytes, (hipStream_t)stream);
+    ABOPT_CHECK_ARG((gauss == nullptr) == (dgauss == nullptr), "pair_embed_forward: gauss and dgauss go together");
+    return launch_pair_embed(in, w, pair_feat, activations, gauss, dgauss, ws, ws_bytes, (hipStream_t)stream);
 }
 
-extern "C" size_t abopt_pair_gauss_workspace_bytes(int N, int L) { return pair_gauss_ws_bytes(N, L); }
+extern "C" size_t abopt_pair_embed_backward_workspace_bytes(int N, int L, int atoms) { return pair_embed_backward_ws_bytes(N, L, atoms); }
 
-extern "C" int abopt_pair_gauss_features(const abopt_encode_inputs* in, const float* aapair_to_distcoef, float* G, float* T,
+extern "C" int abopt_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dpair_feat,
+                                         const float* activations, const float* dgauss, float* dys, float* dsoftplus,
                                          void* ws, size_t ws_bytes, abopt_stream stream) {
     int rc;
-    if ((rc = check_encode_inputs(in, "pair_gauss_features"))) return rc;
+    if ((rc = check_encode_inputs(in, "pair_embed_backward"))) return rc;
     if ((int64_t)in->N * in->L == 0) return ABOPT_OK;
-    ABOPT_CHECK_ARG(aapair_to_distcoef && G && ws, "pair_gauss_features: NULL argument");
-    return launch_pair_gauss_features(in, aapair_to_distcoef, G, T, ws, ws_bytes, (hipStream_t)stream);
+    ABOPT_CHECK_ARG(w && w->wd0 && w->wd1 && w->wo0 && w->wo1 && w->wo2 && dpair_feat && activations && dgauss && dys && dsoftplus && ws,
+                    "pair_embed_backward: NULL argument");
+    return launch_pair_embed_backward(in, w, dpair_feat, activations, dgauss, dys, dsoftplus, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int abopt_reconstruct_backbone_partially(const float* pos_ctx, const float* R_new, const float* t_new, const int64_t* aa,

@@ -207,6 +207,28 @@ __global__ void pair_tables_kernel(const float* __restrict__ e_aap, const float*
 
 // out[(blk*4 + nt)*64 + lane] = (W[nt*16 + fm][col(blk, 4 kq + q)])_{q<4};  col(blk, c) = col0 + blk*stride + c, valid while
 // c < width and blk*stride + c < kreal (else 0): the MFMA A-operand fragment order of a [64, K] weight matrix.
+// A-operand fragments of W^T restricted to columns [col0, col0 + 64) of W [64, ldw]: rows of the operand = input features
+// (what the backward multiplies by), K = the 64 output features.  out[(blk * 4 + nt) * 64 + lane][q] = W[16 blk + 4 kq + q][col0 + 16 nt + fm]
+__global__ void swizzle_transposed_kernel(const float* __restrict__ W, int ldw, int col0, f32x4* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4 * 4 * 64) return;
+    const int lane = idx & 63, nt = (idx >> 6) & 3, blk = idx >> 8, fm = lane & 15, kq = lane >> 4;
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = W[(blk * 16 + kq * 4 + q) * ldw + col0 + nt * 16 + fm];
+    out[idx] = v;
+}
+// same for distance_embed.0 [64, A*A]: operand rows = (a, b padded to 16): out[(blk * A + a) * 64 + lane][q] = W[16 blk + 4 kq + q][a * A + fm] (0 for fm >= A)
+__global__ void swizzle_wd0_transposed_kernel(const float* __restrict__ W, int A, f32x4* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4 * A * 64) return;
+    const int lane = idx & 63, a = (idx >> 6) % A, blk = (idx >> 6) / A, fm = lane & 15, kq = lane >> 4;
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (fm < A) ? W[(blk * 16 + kq * 4 + q) * A * A + a * A + fm] : 0.f;
+    out[idx] = v;
+}
+
 __global__ void swizzle_weights_kernel(const float* __restrict__ W, int ldw, int col0, int stride, int width, int kreal, int nblk, f32x4* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nblk * 4 * 64) return;
@@ -227,6 +249,7 @@ struct PairArgs {
     const f32x4* wd0; const float* bd0; const f32x4* wd1; const float* bd1;
     const f32x4* wo0; const float* bo0; const f32x4* wo1; const float* bo1; const f32x4* wo2; const float* bo2;
     float* out; int N, L, A, has_struct;
+    float* gsave; float* tsave;   // training: Gaussian features and d/d softplus(coef), [pair][A][16] (b padded to 16), NULL for inference
     float* acts;          // training: per pair [relu(D0) 64 | f_dist 64 | f_dih 32 | relu(O0) 64 | relu(O1) 64] (PAIR_ACT floats), NULL for inference
 };
 constexpr int PAIR_ACT = 288;
@@ -300,12 +323,22 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
 #pragma unroll
             for (int mt = 0; mt < PMT; ++mt) {
                 const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.sp + ((int64_t)aap[mt] * A + at) * 16 + kq * 4);
+                f32x4 tq;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float dx = pi[0] - pj[mt][q][0], dy = pi[1] - pj[mt][q][1], dz = pi[2] - pj[mt][q][2];
                     const float d = sqrtf(dx * dx + dy * dy + dz * dz) / 10.f;                  // pair.py:64
                     const float gv = expf(-1.f * c4[q] * (d * d));                              // pair.py:67
                     g[mt][q] = (pi[3] != 0.f && pj[mt][q][3] != 0.f) ? gv : 0.f;               // pair.py:69-73
+                    tq[q] = -(d * d) * g[mt][q];
+                }
+                if (a.gsave) {
+                    const int j_ = j0 + mt * 16 + fm;
+                    if (j_ < L) {
+                        const int64_t o_ = (((row_i * L) + j_) * A + at) * 16 + kq * 4;
+                        *reinterpret_cast<f32x4*>(a.gsave + o_) = g[mt];
+                        *reinterpret_cast<f32x4*>(a.tsave + o_) = tq;
+                    }
                 }
             }
 #pragma unroll
@@ -452,48 +485,135 @@ static PackBufs carve_pack(char* p, int64_t rows) {
 }
 static size_t pack_bytes(int64_t rows) { return al256(rows * 16 * sizeof(f32x4)) + 3 * al256(rows * 4) + al256(rows); }
 
-// ------------------------------------------------------------------------------------------------ training side: Gaussian features
-// G[n,i,j,a*A+b] = exp(-softplus(coef[aa_i*22+aa_j][a*A+b]) d_ab^2) * mask_a_i * mask_b_j,  d_ab = |x_ia - x_jb| / 10  (pair.py:62-73),
-// and T = dG/d softplus(coef) = -d_ab^2 G for the backward (the coefficient table is the only trainable input).  One
-// workgroup per query residue (n, i); thread ab < A*A walks the keys j, so every j writes one contiguous A*A row.
-__global__ __launch_bounds__(256) void pair_gauss_features_kernel(const f32x4* __restrict__ atoms4, const int* __restrict__ aa_eff,
-                                                                  const float* __restrict__ coef, int A, int L,
-                                                                  float* __restrict__ G, float* __restrict__ T) {
-    const int64_t row = blockIdx.x;                                        // n * L + i
-    const int64_t base = (row / L) * L;
-    const int ab = threadIdx.x, AA = A * A;
-    if (ab >= AA) return;
-    const int a = ab / A, b = ab % A;
-    const f32x4 pi = atoms4[row * 16 + a];
-    const int aa_i = aa_eff[row];
-    float* g = G + row * (int64_t)L * AA + ab;
-    float* t = T ? T + row * (int64_t)L * AA + ab : nullptr;
-#pragma unroll 8
-    for (int j = 0; j < L; ++j) {                                          // unrolled: 8 independent load chains in flight per thread
-        const f32x4 pj = atoms4[(base + j) * 16 + b];
-        const float x = coef[(int64_t)(aa_i * AAT + aa_eff[base + j]) * AA + ab];
-        const float c = (x > 20.f) ? x : log1pf(expf(x));
-        const float dx = pi[0] - pj[0], dy = pi[1] - pj[1], dz = pi[2] - pj[2];
-        const float d = sqrtf(dx * dx + dy * dy + dz * dz) / 10.f;
-        const float gv = (pi[3] != 0.f && pj[3] != 0.f) ? expf(-1.f * c * (d * d)) : 0.f;
-        g[(int64_t)j * AA] = gv;
-        if (t) t[(int64_t)j * AA] = -(d * d) * gv;
+// ------------------------------------------------------------------------------------------------ pair embedding: backward chain
+// d(out) -> gradients w.r.t. the pre-activation of every layer, for the 64-pair strip of a wave, in registers exactly like the
+// forward (the accumulator of W^T . dY is the B operand of the next W^T): per pair it writes
+//   dys[0:64] = d out x pair mask (= dY of out_mlp.4)   dys[64:128] = dY of out_mlp.2   dys[128:192] = dY of out_mlp.0
+//   dys[192:256] = dY of distance_embed.2                dys[256:320] = dY of distance_embed.0
+//   ds [A][16]  = d loss / d softplus(coef) per atom pair (= (Wd0^T dY_d0) x T)
+// The weight gradients are then tall GEMMs of these against the saved activations (host side).
+struct PairBwdArgs {
+    const float* dout; const float* acts; const float* tsave; const uint8_t* flags;
+    const f32x4* wo2t; const f32x4* wo1t; const f32x4* wo0dt; const f32x4* wd1t; const f32x4* wd0t;
+    float* dys; float* ds; int N, L, A, has_struct;
+};
+constexpr int PAIR_DY = 320;
+
+#define PAIR_LOAD_ACT(DST, OFF)                                                                                           \
+    _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt) {                                                                  \
+        const float* s_ = b.acts + ((row_i * L) + jc[mt]) * PAIR_ACT + (OFF) + kq * 4;                                    \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = *reinterpret_cast<const f32x4*>(s_ + nt * 16);     \
+    }
+#define PAIR_STORE_DY(SRC, OFF)                                                                                           \
+    _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt) {                                                                  \
+        if (j0 + mt * 16 + fm < L) {                                                                                      \
+            float* d_ = b.dys + ((row_i * L) + jc[mt]) * PAIR_DY + (OFF) + kq * 4;                                        \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(d_ + nt * 16) = SRC[mt][nt];       \
+        }                                                                                                                 \
+    }
+// DST = (W^T . SRC) masked by ACT > 0
+#define PAIR_BACK(DST, SRC, WT, ACT)                                                                                      \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt)                                                                \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};                   \
+        _Pragma("unroll") for (int blk = 0; blk < 4; ++blk) {                                                             \
+            f32x4 w_[4];                                                                                                 \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) w_[nt] = (WT)[(blk * 4 + nt) * 64 + lane];                   \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                 \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
+                    _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt)                                                    \
+                        DST[mt][nt] = mfma4e(w_[nt][q], SRC[mt][blk][q], DST[mt][nt]);                                    \
+        }                                                                                                                \
+        _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt)                                                                \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                              \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) DST[mt][nt][r] = (ACT[mt][nt][r] > 0.f) ? DST[mt][nt][r] : 0.f; \
+    }
+
+__global__ __launch_bounds__(256, 2) void pair_embed_backward_kernel(PairBwdArgs b) {
+    const int lane = threadIdx.x & 63, fm = lane & 15, kq = lane >> 4;
+    const int L = b.L, A = b.A;
+    const int jblocks = (L + 16 * PMT - 1) / (16 * PMT);
+    const int64_t unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (unit >= (int64_t)b.N * L * jblocks) return;
+    const int64_t row_i = unit / jblocks;
+    const int j0 = (int)(unit % jblocks) * 16 * PMT;
+    const int64_t base = (row_i / L) * L;
+    const uint8_t fl_i = b.flags[row_i];
+    int jc[PMT];
+#pragma unroll
+    for (int mt = 0; mt < PMT; ++mt) jc[mt] = min(j0 + mt * 16 + fm, L - 1);
+    f32x4 da[PMT][4], db[PMT][4], act[PMT][4];
+    // d out x pair mask (pair.py:100)
+#pragma unroll
+    for (int mt = 0; mt < PMT; ++mt) {
+        const float mp = ((fl_i & 1) && (b.flags[base + jc[mt]] & 1)) ? 1.f : 0.f;
+        const float* s_ = b.dout + ((row_i * L) + jc[mt]) * EC + kq * 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) da[mt][nt] = *reinterpret_cast<const f32x4*>(s_ + nt * 16) * mp;
+    }
+    PAIR_STORE_DY(da, 0)
+    PAIR_LOAD_ACT(act, 224)                      // relu(out_mlp.2 pre-activation)
+    PAIR_BACK(db, da, b.wo2t, act)
+    PAIR_STORE_DY(db, 64)
+    PAIR_LOAD_ACT(act, 160)                      // relu(out_mlp.0)
+    PAIR_BACK(da, db, b.wo1t, act)
+    PAIR_STORE_DY(da, 128)
+    PAIR_LOAD_ACT(act, 64)                       // f_dist = relu(distance_embed.2) x structure mask: zero where masked
+    PAIR_BACK(db, da, b.wo0dt, act)
+    PAIR_STORE_DY(db, 192)
+    PAIR_LOAD_ACT(act, 0)                        // relu(distance_embed.0)
+    PAIR_BACK(da, db, b.wd1t, act)
+    PAIR_STORE_DY(da, 256)
+    // d G = Wd0^T dY_d0 per atom block a (operand rows = the 16 padded b), times T = dG / d softplus(coef)
+#pragma unroll 1
+    for (int at = 0; at < A; ++at) {
+        f32x4 acc[PMT];
+#pragma unroll
+        for (int mt = 0; mt < PMT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const f32x4 w_ = b.wd0t[(blk * A + at) * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mt = 0; mt < PMT; ++mt) acc[mt] = mfma4e(w_[q], da[mt][blk][q], acc[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < PMT; ++mt) {
+            if (j0 + mt * 16 + fm < L) {
+                const int64_t o_ = (((row_i * L) + jc[mt]) * A + at) * 16 + kq * 4;
+                *reinterpret_cast<f32x4*>(b.ds + o_) = acc[mt] * *reinterpret_cast<const f32x4*>(b.tsave + o_);
+            }
+        }
     }
 }
 
-size_t pair_gauss_ws_bytes(int N, int L) { return pack_bytes((int64_t)N * L) + 1024; }
+size_t pair_embed_backward_ws_bytes(int N, int L, int A) { return pack_bytes((int64_t)N * L) + al256((size_t)(4 * 4 + 4 * A) * 1024 * 4 + 4096); }
 
-int launch_pair_gauss_features(const abopt_encode_inputs* in, const float* coef, float* G, float* T, void* ws, size_t ws_bytes, hipStream_t st) {
+int launch_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dout, const float* acts, const float* tsave,
+                               float* dys, float* ds, void* ws, size_t ws_bytes, hipStream_t st) {
     const int N = in->N, L = in->L, A = in->atoms;
-    ABOPT_CHECK_ARG(A >= 3 && A <= 15 && A <= in->atoms_in, "pair_gauss_features: atoms=%d must be in [3, min(15, atoms_in=%d)]", A, in->atoms_in);
+    ABOPT_CHECK_ARG(A >= 3 && A <= 15 && A <= in->atoms_in, "pair_embed_backward: atoms=%d must be in [3, min(15, atoms_in=%d)]", A, in->atoms_in);
     const int64_t rows = (int64_t)N * L;
     if (rows == 0) return ABOPT_OK;
-    if (ws_bytes < pair_gauss_ws_bytes(N, L)) { set_error("pair_gauss_features: workspace too small"); return ABOPT_EWORKSPACE; }
+    if (ws_bytes < pair_embed_backward_ws_bytes(N, L, A)) { set_error("pair_embed_backward: workspace too small"); return ABOPT_EWORKSPACE; }
     PackBufs pb = carve_pack((char*)ws, rows);
+    f32x4* wt = (f32x4*)pb.end;
+    f32x4 *wo2t = wt, *wo1t = wt + 1024, *wo0dt = wt + 2048, *wd1t = wt + 3072, *wd0t = wt + 4096;
     hipLaunchKernelGGL(residue_pack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(64), 0, st, in->aa, in->res_nb, in->chain_nb, in->pos_atoms, in->mask_atoms,
                        in->structure_mask, in->sequence_mask, in->atoms_in, A, rows, pb.atoms4, pb.aa_eff, pb.resnb, pb.chain, pb.flags, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(swizzle_transposed_kernel, dim3(4), dim3(256), 0, st, w->wo2, EC, 0, wo2t);
+    hipLaunchKernelGGL(swizzle_transposed_kernel, dim3(4), dim3(256), 0, st, w->wo1, EC, 0, wo1t);
+    hipLaunchKernelGGL(swizzle_transposed_kernel, dim3(4), dim3(256), 0, st, w->wo0, 3 * EC + 26, 2 * EC, wo0dt);
+    hipLaunchKernelGGL(swizzle_transposed_kernel, dim3(4), dim3(256), 0, st, w->wd1, EC, 0, wd1t);
+    hipLaunchKernelGGL(swizzle_wd0_transposed_kernel, dim3(A), dim3(256), 0, st, w->wd0, A, wd0t);
     ABOPT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(pair_gauss_features_kernel, dim3((unsigned)rows), dim3(256), 0, st, pb.atoms4, pb.aa_eff, coef, A, L, G, T);
+    PairBwdArgs b;
+    b.dout = dout; b.acts = acts; b.tsave = tsave; b.flags = pb.flags;
+    b.wo2t = wo2t; b.wo1t = wo1t; b.wo0dt = wo0dt; b.wd1t = wd1t; b.wd0t = wd0t;
+    b.dys = dys; b.ds = ds; b.N = N; b.L = L; b.A = A; b.has_struct = in->structure_mask ? 1 : 0;
+    const int jblocks = (L + 16 * PMT - 1) / (16 * PMT);
+    hipLaunchKernelGGL(pair_embed_backward_kernel, dim3((unsigned)((rows * jblocks + 3) / 4)), dim3(256), 0, st, b);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }
@@ -611,7 +731,8 @@ size_t pair_embed_ws_bytes(int N, int L, int A) {
     return pack_bytes((int64_t)N * L) + al256(pair_weight_floats(A) * 4) + 4096;
 }
 
-int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* acts, void* ws, size_t ws_bytes, hipStream_t st) {
+int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* acts, float* gsave, float* tsave,
+                      void* ws, size_t ws_bytes, hipStream_t st) {
     const int N = in->N, L = in->L, A = in->atoms;
     ABOPT_CHECK_ARG(A >= 3 && A <= 15 && A <= in->atoms_in, "pair_embed: atoms=%d must be in [3, min(15, atoms_in=%d)]", A, in->atoms_in);
     const int64_t rows = (int64_t)N * L;
@@ -650,7 +771,7 @@ int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weig
     a.atoms4 = pb.atoms4; a.aa_eff = pb.aa_eff; a.res_nb = pb.resnb; a.chain_nb = pb.chain; a.flags = pb.flags;
     a.t_aap = t_aap; a.t_rel = t_rel; a.sp = sp; a.freq = w->freq_bands;
     a.wd0 = wd0; a.bd0 = w->bd0; a.wd1 = wd1; a.bd1 = w->bd1; a.wo0 = wo0; a.bo0 = w->bo0; a.wo1 = wo1; a.bo1 = w->bo1; a.wo2 = wo2; a.bo2 = w->bo2;
-    a.out = pair_feat; a.N = N; a.L = L; a.A = A; a.has_struct = in->structure_mask ? 1 : 0; a.acts = acts;
+    a.out = pair_feat; a.N = N; a.L = L; a.A = A; a.has_struct = in->structure_mask ? 1 : 0; a.acts = acts; a.gsave = gsave; a.tsave = tsave;
     const int jblocks = (L + 16 * PMT - 1) / (16 * PMT);
     const int64_t units = rows * jblocks;
     hipLaunchKernelGGL(pair_embed_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, a);

@@ -60,10 +60,12 @@ size_t residue_embed_ws_bytes(int N, int L, int A, int hotspot);
 int launch_residue_embed(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* res_feat, float* R, float* p,
                          void* ws, size_t ws_bytes, hipStream_t st);
 size_t pair_embed_ws_bytes(int N, int L, int A);
-int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* acts, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* acts, float* gsave, float* tsave,
+                      void* ws, size_t ws_bytes, hipStream_t st);
+size_t pair_embed_backward_ws_bytes(int N, int L, int A);
+int launch_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dout, const float* acts, const float* tsave,
+                               float* dys, float* ds, void* ws, size_t ws_bytes, hipStream_t st);
 
-size_t pair_gauss_ws_bytes(int N, int L);
-int launch_pair_gauss_features(const abopt_encode_inputs* in, const float* coef, float* G, float* T, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_reconstruct_backbone(const float* pos_ctx, const float* R_new, const float* t_new, const int64_t* aa, const int64_t* chain_nb,
                                 const int64_t* res_nb, const uint8_t* mask_atoms, const uint8_t* mask_recons, const float* bb_table,
                                 const float* o_table, float* pos_new, uint8_t* mask_new, int N, int L, int A, hipStream_t st);

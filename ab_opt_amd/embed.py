@@ -90,32 +90,12 @@ class _SmallTableLookup(torch.autograd.Function):
         return _splitk_tn(oh, dout.reshape(-1, dout.shape[-1])), None
 
 
-class _GaussFeatures(torch.autograd.Function):
-    """Gaussian atom-pair features (pair.py:62-73) from the HIP kernel `abopt_pair_gauss_features`: the torch statement spends
-    ~10 elementwise kernels on (N,L,L,15,15[,3]) tensors here.  Only the coefficient table carries a gradient."""
-
-    @staticmethod
-    def forward(ctx, coef_table, aa, res_nb, chain_nb, pos, matom, n_types):
-        inp, keep = hip.encode_inputs(aa, res_nb, chain_nb, pos, matom, pos.shape[2])
-        G, T = hip.pair_gauss_features(inp, coef_table.detach(), want_T=True)
-        ctx.save_for_backward(coef_table, aa, T)
-        ctx.n_types = n_types
-        return G
-
-    @staticmethod
-    def backward(ctx, dG):
-        coef_table, aa, T = ctx.saved_tensors
-        oh = F.one_hot(aa, ctx.n_types).to(dG.dtype)
-        tmp = torch.einsum('njb,nijc->nibc', oh, dG * T)                            # T = dG/d softplus(coef)
-        dtab = torch.einsum('nia,nibc->abc', oh, tmp).reshape(ctx.n_types ** 2, -1) * torch.sigmoid(coef_table)
-        return dtab, None, None, None, None, None, None
-
-
 class _PairEmbedFn(torch.autograd.Function):
-    """PairEmbedding on the training path: forward is the fused HIP kernel (`abopt_pair_embed_forward` with its activation dump,
-    plus `abopt_pair_gauss_features` for the Gaussian features and their derivative); backward is the chain rule over the
-    saved activations as tall library GEMMs (split-K weight gradients, structured sums for the two amino-acid-pair tables).
-    Only the parameters carry gradients (positions, masks and indices do not)."""
+    """PairEmbedding on the training path.  Forward: the fused HIP kernel with its activation dump (`abopt_pair_embed_forward`:
+    five 64-wide activation tiles, the Gaussian features g and T = dg / d softplus(coef)).  Backward: `abopt_pair_embed_backward`
+    chains d(out) back through the five linears in registers and writes d loss / d pre-activation of every layer; the weight
+    gradients are then tall library GEMMs against the saved activations (split over K), and the gradients of the two
+    amino-acid-pair tables are structured sums (one-hot contractions).  Only the parameters carry gradients."""
 
     @staticmethod
     def forward(ctx, aa, res_nb, chain_nb, pos, matom, structure_mask, n_types, max_relpos,
@@ -123,42 +103,42 @@ class _PairEmbedFn(torch.autograd.Function):
         inp, keep = hip.encode_inputs(aa, res_nb, chain_nb, pos, matom, pos.shape[2], structure_mask=structure_mask)
         t = [x.detach().contiguous() for x in (E_aap, E_rel, coef, freq, wd0, bd0, wd1, bd1, wo0, bo0, wo1, bo1, wo2, bo2)]
         w = hip.PairEmbedWeights(*[hip.ptr(x, torch.float32) for x in t])
-        out, acts = hip.pair_embed_forward(inp, w, save_activations=True)
-        G, T = hip.pair_gauss_features(inp, t[2], want_T=True)
-        ctx.save_for_backward(aa, res_nb, chain_nb, matom, acts, G, T, E_aap, E_rel, coef, wd0, wd1, wo0, wo1, wo2)
+        out, acts, G, T = hip.pair_embed_forward(inp, w, save_activations=True)
+        ctx.save_for_backward(aa, res_nb, chain_nb, pos, matom, acts, G, T, *t)
+        ctx.structure_mask = structure_mask
         ctx.n_types, ctx.max_relpos = n_types, max_relpos
         return out
 
     @staticmethod
     @torch.no_grad()
     def backward(ctx, dout):
-        aa, res_nb, chain_nb, matom, acts, G, T, E_aap, E_rel, coef, wd0, wd1, wo0, wo1, wo2 = ctx.saved_tensors
+        aa, res_nb, chain_nb, pos, matom, acts, G, T = ctx.saved_tensors[:8]
+        t = list(ctx.saved_tensors[8:])
+        E_aap, E_rel, coef, wo0 = t[0], t[1], t[2], t[8]
         N, L = aa.shape
+        A = pos.shape[2]
         M, C, nt = N * L * L, dout.shape[-1], ctx.n_types
-        a2 = acts.view(M, -1)
+        inp, keep = hip.encode_inputs(aa, res_nb, chain_nb, pos, matom, A, structure_mask=ctx.structure_mask)
+        w = hip.PairEmbedWeights(*[hip.ptr(x, torch.float32) for x in t])
+        dys, ds = hip.pair_embed_backward(inp, w, dout, acts, T)
+        y, a2 = dys.view(M, -1), acts.view(M, -1)
+        do2, do1, do0, dh1, dh0 = (y[:, 64 * k:64 * (k + 1)] for k in range(5))
         h0, h1, dih, o0, o1 = a2[:, :64], a2[:, 64:128], a2[:, 128:154], a2[:, 160:224], a2[:, 224:288]
-        mres = matom[:, :, ATOM_CA]
-        do2 = (dout * (mres[:, :, None] & mres[:, None, :]).unsqueeze(-1)).reshape(M, C)
-        dwo2, dbo2 = _splitk_tn(do2, o1), do2.sum(0)
-        do1 = (do2 @ wo2) * (o1 > 0)
-        dwo1, dbo1 = _splitk_tn(do1, o0), do1.sum(0)
-        do0 = (do1 @ wo1) * (o0 > 0)
-        dbo0 = do0.sum(0)
+        db = y.sum(0)                                                               # the five bias gradients at once
+        dbo2, dbo1, dbo0, dbd1, dbd0 = (db[64 * k:64 * (k + 1)] for k in range(5))
+        dwo2, dwo1, dwd1 = _splitk_tn(do2, o1), _splitk_tn(do1, o0), _splitk_tn(dh1, h0)
         # out_mlp.0 columns: [aa-pair embedding | relpos embedding x same-chain | f_dist | f_dih]
         oh = F.one_hot(aa, nt).to(dout.dtype)
-        s_aap = torch.einsum('nia,nibc->abc', oh, torch.einsum('njb,nijc->nibc', oh, do0.view(N, L, L, C))).reshape(nt * nt, C)
+        pair_sum = lambda x4: torch.einsum('nia,nibc->abc', oh, torch.einsum('njb,nijc->nibc', oh, x4)).reshape(nt * nt, -1)
+        s_aap = pair_sum(do0.reshape(N, L, L, C))
         rel = torch.clamp(res_nb[:, :, None] - res_nb[:, None, :], min=-ctx.max_relpos, max=ctx.max_relpos) + ctx.max_relpos
         same = (chain_nb[:, :, None] == chain_nb[:, None, :]).reshape(M, 1)
         s_rel = _splitk_tn(F.one_hot(rel.reshape(M), 2 * ctx.max_relpos + 1).to(dout.dtype) * same, do0)
         dwo0 = torch.cat([s_aap.t() @ E_aap, s_rel.t() @ E_rel, _splitk_tn(do0, h1), _splitk_tn(do0, dih)], dim=1)
         dE_aap, dE_rel = s_aap @ wo0[:, :C], s_rel @ wo0[:, C:2 * C]
-        dh1 = (do0 @ wo0[:, 2 * C:3 * C]) * (h1 > 0)                                # f_dist = relu(.) x structure mask: zero where masked
-        dwd1, dbd1 = _splitk_tn(dh1, h0), dh1.sum(0)
-        dh0 = (dh1 @ wd1) * (h0 > 0)
-        G2 = G.view(M, -1)
-        dwd0, dbd0 = _splitk_tn(dh0, G2), dh0.sum(0)
-        dS = ((dh0 @ wd0) * T.view(M, -1)).view(N, L, L, -1)                         # d / d softplus(coef)
-        dcoef = torch.einsum('nia,nibc->abc', oh, torch.einsum('njb,nijc->nibc', oh, dS)).reshape(nt * nt, -1) * torch.sigmoid(coef)
+        unpad = lambda m: m.reshape(m.shape[0], A, 16)[:, :, :A].reshape(m.shape[0], A * A)          # [.., a, 16] -> [.., a*A + b]
+        dwd0 = unpad(_splitk_tn(dh0, G.view(M, -1)))
+        dcoef = unpad(pair_sum(ds)) * torch.sigmoid(coef)
         return (None,) * 8 + (dE_aap, dE_rel, dcoef, None, dwd0, dbd0, dwd1, dbd1, dwo0, dbo0, dwo1, dbo1, dwo2, dbo2)
 
 
@@ -322,12 +302,9 @@ class PairEmbedding(nn.Module):
         same = chain_nb[:, :, None] == chain_nb[:, None, :]
         rel = torch.clamp(res_nb[:, :, None] - res_nb[:, None, :], min=-self.max_relpos, max=self.max_relpos)
         f_rel = _SmallTableLookup.apply(self.relpos_embed.weight, rel + self.max_relpos) * same[:, :, :, None]
-        if pos.is_cuda and pos.dtype == torch.float32:
-            gm = _GaussFeatures.apply(self.aapair_to_distcoef.weight, aa, res_nb, chain_nb, pos, matom, self.max_aa_types)
-        else:       # plain statement (CPU, or the float64 yardstick of the parity tests)
-            d = (torch.linalg.norm(pos[:, :, None, :, None] - pos[:, None, :, None, :], dim=-1, ord=2) / 10).reshape(N, L, L, -1)
-            c = F.softplus(_AAPairLookup.apply(self.aapair_to_distcoef.weight, aa, self.max_aa_types))
-            gm = torch.exp(-1 * c * d ** 2) * (matom[:, :, None, :, None] * matom[:, None, :, None, :]).reshape(N, L, L, -1)
+        d = (torch.linalg.norm(pos[:, :, None, :, None] - pos[:, None, :, None, :], dim=-1, ord=2) / 10).reshape(N, L, L, -1)
+        c = F.softplus(_AAPairLookup.apply(self.aapair_to_distcoef.weight, aa, self.max_aa_types))
+        gm = torch.exp(-1 * c * d ** 2) * (matom[:, :, None, :, None] * matom[:, None, :, None, :]).reshape(N, L, L, -1)
         f_dist = _tall_mlp(self.distance_embed, gm)
         if pstruct is not None:
             f_dist = f_dist * pstruct[:, :, :, None]

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,8 +73,9 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
            'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect',
-           'abopt_pair_gauss_workspace_bytes', 'abopt_pair_gauss_features', 'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
-           'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward']
+           'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
+           'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
+           'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward']
 
 _lib = None
 _lock = threading.Lock()
@@ -122,9 +123,6 @@ def lib():
                                       c_f, c_f, c_i64, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_prof_enable.argtypes = [C.c_int]
         L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
-        L.abopt_pair_gauss_workspace_bytes.restype = C.c_size_t
-        L.abopt_pair_gauss_workspace_bytes.argtypes = [C.c_int] * 2
-        L.abopt_pair_gauss_features.argtypes = [C.POINTER(EncodeInputs), c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_reconstruct_backbone_partially.argtypes = [c_f, c_f, c_f, c_i64, c_i64, c_i64, c_u8, c_u8, c_f, c_f, c_f, c_u8] + [C.c_int] * 3 + [C.c_void_p]
         L.abopt_ipa_train_workspace_bytes.restype = C.c_size_t
         L.abopt_ipa_train_workspace_bytes.argtypes = [C.c_int] * 2
@@ -138,7 +136,10 @@ def lib():
         L.abopt_pair_embed_workspace_bytes.restype = C.c_size_t
         L.abopt_pair_embed_workspace_bytes.argtypes = [C.c_int] * 3
         L.abopt_residue_embed_forward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(ResidueEmbedWeights), c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
-        L.abopt_pair_embed_forward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_pair_embed_forward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_pair_embed_backward_workspace_bytes.restype = C.c_size_t
+        L.abopt_pair_embed_backward_workspace_bytes.argtypes = [C.c_int] * 3
+        L.abopt_pair_embed_backward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, c_f, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         for name in EXPORTS:
             getattr(L, name)          # AttributeError here = a symbol of include/abopt.h is missing
         if L.abopt_abi_version() != ABI_VERSION:
@@ -426,32 +427,39 @@ def residue_embed_forward(inp, weights, has_hotspot):
     return res_feat, R, p
 
 
-def pair_gauss_features(inp, coef_table, want_T):
-    """Gaussian atom-pair features of PairEmbedding (and their derivative wrt softplus(coef)) -> G, T (N,L,L,A*A)."""
-    N, L, AA = inp.N, inp.L, inp.atoms * inp.atoms
-    dev = coef_table.device
-    G = torch.empty(N, L, L, AA, device=dev)
-    T = torch.empty(N, L, L, AA, device=dev) if want_T else None
-    nb = lib().abopt_pair_gauss_workspace_bytes(N, L)
-    buf = Workspace.get(nb, dev)
-    _check(lib().abopt_pair_gauss_features(C.byref(inp), ptr(coef_table.contiguous(), torch.float32), ptr(G), ptr(T, optional=True),
-                                           ptr(buf), buf.numel(), stream()))
-    return G, T
-
-
 PAIR_ACT = 288
 
 
 def pair_embed_forward(inp, weights, save_activations=False):
-    """-> pair_feat (N,L,L,64) [, activations (N,L,L,288) for the training backward]."""
+    """-> pair_feat (N,L,L,64) [, activations (N,L,L,288), G, T (N,L,L,atoms*16) for the training backward]."""
     N, L = inp.N, inp.L
     dev = torch.device('cuda', torch.cuda.current_device())
     pair_feat = torch.empty(N, L, L, 64, device=dev)
-    acts = torch.empty(N, L, L, PAIR_ACT, device=dev) if save_activations else None
+    acts = G = T = None
+    if save_activations:
+        acts = torch.empty(N, L, L, PAIR_ACT, device=dev)
+        G, T = torch.empty(N, L, L, inp.atoms * 16, device=dev), torch.empty(N, L, L, inp.atoms * 16, device=dev)
     nb = lib().abopt_pair_embed_workspace_bytes(N, L, inp.atoms)
     buf = Workspace.get(nb, dev)
-    _check(lib().abopt_pair_embed_forward(C.byref(inp), C.byref(weights), ptr(pair_feat), ptr(acts, optional=True), ptr(buf), buf.numel(), stream()))
-    return (pair_feat, acts) if save_activations else pair_feat
+    _check(lib().abopt_pair_embed_forward(C.byref(inp), C.byref(weights), ptr(pair_feat), ptr(acts, optional=True), ptr(G, optional=True),
+                                          ptr(T, optional=True), ptr(buf), buf.numel(), stream()))
+    return (pair_feat, acts, G, T) if save_activations else pair_feat
+
+
+PAIR_DY = 320
+
+
+def pair_embed_backward(inp, weights, dpair_feat, acts, T):
+    """-> dys (N,L,L,320), ds (N,L,L,atoms*16)  (include/abopt.h: abopt_pair_embed_backward)."""
+    N, L = inp.N, inp.L
+    dev = acts.device
+    dys = torch.empty(N, L, L, PAIR_DY, device=dev)
+    ds = torch.empty(N, L, L, inp.atoms * 16, device=dev)
+    nb = lib().abopt_pair_embed_backward_workspace_bytes(N, L, inp.atoms)
+    buf = Workspace.get(nb, dev)
+    _check(lib().abopt_pair_embed_backward(C.byref(inp), C.byref(weights), ptr(dpair_feat.contiguous(), torch.float32), ptr(acts, torch.float32),
+                                           ptr(T, torch.float32), ptr(dys), ptr(ds), ptr(buf), buf.numel(), stream()))
+    return dys, ds
 
 
 _BB_TABLES = {}

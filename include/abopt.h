@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 10
+#define ABOPT_ABI_VERSION 11
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -268,13 +268,18 @@ size_t abopt_pair_embed_workspace_bytes(int N, int L, int atoms);
  * pair, relu(distance_embed.0) (64) | f_dist = relu(distance_embed.2) x structure mask (64) | f_dih (26, padded to 32) |
  * relu(out_mlp.0) (64) | relu(out_mlp.2) (64): what the backward of the five linears needs (pair.py:74-99). */
 enum { ABOPT_PAIR_ACT = 288 };
+/* gauss / dgauss (both or neither, training): [N,L,L,atoms,16] -- the Gaussian atom-pair features g (pair.py:62-73, atom b of
+ * residue j padded to 16) and T = dg / d softplus(coef) = -d^2 g. */
 int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* activations,
-                             void* ws, size_t ws_bytes, abopt_stream stream);
-
-/* Training side of PairEmbedding (pair.py:62-73): the Gaussian atom-pair features G [N,L,L,atoms*atoms] that feed
- * distance_embed, and T = dG / d softplus(coef) [same shape, NULL to skip] for the backward of aapair_to_distcoef. */
-size_t abopt_pair_gauss_workspace_bytes(int N, int L);
-int abopt_pair_gauss_features(const abopt_encode_inputs* in, const float* aapair_to_distcoef, float* G, float* T,
+                             float* gauss, float* dgauss, void* ws, size_t ws_bytes, abopt_stream stream);
+/* Backward chain of the five linears for the training path: from dpair_feat [N,L,L,64] and the saved activations writes, per pair,
+ * dys [N,L,L,ABOPT_PAIR_DY] = d loss / d pre-activation of out_mlp.4 | out_mlp.2 | out_mlp.0 | distance_embed.2 |
+ * distance_embed.0 (64 each), and dsoftplus [N,L,L,atoms,16] = d loss / d softplus(aapair_to_distcoef) per atom pair.  The
+ * weight gradients are tall GEMMs of dys against the activations (host side). */
+enum { ABOPT_PAIR_DY = 320 };
+size_t abopt_pair_embed_backward_workspace_bytes(int N, int L, int atoms);
+int abopt_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dpair_feat,
+                              const float* activations, const float* dgauss, float* dys, float* dsoftplus,
                               void* ws, size_t ws_bytes, abopt_stream stream);
 
 /* ---- reconstruct_backbone_partially: D/modules/common/geometry.py:404-480 (called on every saved frame right after the
