@@ -120,7 +120,7 @@ class FullDPM(nn.Module):
         h = self._sched_host()
         inv = self.trans_rot.angular_distrib_inv
         X, cdf = inv.X, (inv.cdf() if noise is None else None)
-        betas = self.trans_pos.var_sched.betas
+        beta_rows = self.trans_pos.var_sched.betas[:T0 + 1, None].expand(T0 + 1, N).contiguous()    # beta_t per sample, one row per step
         net = dict(v_next=torch.empty(N, L, 3, **f32), R_next=torch.empty(N, L, 3, 3, **f32), eps_pos=torch.empty(N, L, 3, **f32),
                    c=torch.empty(N, L, 20, **f32), prmsd_logits=torch.empty(N, self.num_bins, **f32) if self.abdock else None)
         p_norm = torch.empty(N, L, 3, **f32)
@@ -133,8 +133,8 @@ class FullDPM(nn.Module):
             if stop_after is not None and T0 - t >= stop_after:
                 break
             # dpm_full.py:276: p_t = normalize(traj[t].p)
-            torch.div(torch.sub(tp[t], mean), scale, out=p_norm)
-            beta = betas[t].expand([N]).contiguous()
+            torch.sub(tp[t], mean, out=p_norm).div_(scale)
+            beta = beta_rows[t]
             hip.eps_net_forward(ew, tv[t], p_norm, ts[t], res_feat, pair_feat, beta, mask_generate, mask_res,
                                 self.abdock, self.num_bins, False, out=net, pair_bias_cache=pbc, pair_feat_shared=shared)
             sp = self._step_params(t, sample_structure, sample_sequence, ppl_masked, optimize_mode)
