@@ -17,80 +17,105 @@ namespace abopt {
 
 // alpha, dalpha_node and g use the head-major layout (N, 12, L, L): every (n, h) slice is then a plain row-major L x L
 // matrix for the batched library GEMMs the host runs on them.
-constexpr int TJ = 256;                                                    // keys per LDS tile
+// One workgroup per query row (n, i), four waves; wave w takes the 16-key chunks w, w+4, ...  Same tiling as the pair waves of
+// the forward kernel (ipa_ws.hip), all three contractions on the matrix cores:
+//   dalpha_pair[j, h] = z[j, :] . dfp[h, :]          A = z chunk transposed through a wave-private LDS tile, B = dfp (LDS)
+//   dz[j, c]          = sum_h alpha[h,j] dfp[h,c] + g[h,j] Wb[h,c]     A = [dfp^T | Wb^T] (LDS), B = [alpha ; g] transposed through LDS
+// g is produced in lanes (h = lane & 15, keys 4 (lane >> 4) + r): the accumulator layout of the first product and the
+// 16-byte store layout of the head-major output.
+struct PairBwdSmem {
+    float dfp[16][C + 4];            // rows h (12..15 zero): B operand of the first product
+    float at[C][36];                 // [c][0:16] = dfp^T, [16:32] = Wb^T (heads 12..15 zero): A operand of the dz product
+    float zst[4][JC][ZSLD];          // per wave: z chunk, [key][channel]
+    float ag[4][JC][36];             // per wave: [key][0:16] = alpha over heads, [16:32] = g over heads
+};
 
-// One workgroup per query row (n, i): 4 waves, each handles 4 keys per iteration (lane = (jl, x)): x = head in phase 1
-// (dalpha, g), x = group of 4 channels in phase 2 (dz).  The two phases exchange (alpha, g) through a wave-private LDS tile.
 __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __restrict__ z, const float* __restrict__ alpha,
                                                                 const float* __restrict__ dalpha_node, const float* __restrict__ delta,
                                                                 const float* __restrict__ dfeat, int ld_dfeat, const float* __restrict__ Wb,
                                                                 float* __restrict__ g_out, float* __restrict__ dz, int L) {
-    __shared__ __attribute__((aligned(16))) float zs[4][4][C + 4];       // per wave: 4 key rows of z
-    __shared__ __attribute__((aligned(16))) float ag[4][4][2][16];        // per wave: alpha, g of 4 keys x 12 heads
-    __shared__ float as[H][TJ + 4], ns[H][TJ + 4], gs[H][TJ + 4];         // row i of alpha / dalpha_node / g for one key tile, all heads
+    __shared__ __attribute__((aligned(16))) PairBwdSmem sm;
     const int64_t row = blockIdx.x;                                        // n * L + i
     const int64_t n = row / L;
     const int i = (int)(row % L);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, jl = lane >> 4, x = lane & 15;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
     const float* dfp = dfeat + row * ld_dfeat;                             // [12][64]
-    // phase-1 operand: dfp[h = x][0:64];  phase-2 operands: dfp[0:12][4x .. 4x+3], Wb[0:12][4x .. 4x+3]
-    float4 d1[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) d1[q] = (x < H) ? reinterpret_cast<const float4*>(dfp + x * C)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 d2[H], w2[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) { d2[h] = reinterpret_cast<const float4*>(dfp + h * C)[x]; w2[h] = reinterpret_cast<const float4*>(Wb + h * C)[x]; }
-    const float del = (x < H) ? delta[row * H + x] : 0.f;
+    for (int e = tid; e < 16 * C; e += 256) {
+        const int h = e / C, c = e % C;
+        const float d = (h < H) ? dfp[h * C + c] : 0.f, w = (h < H) ? Wb[h * C + c] : 0.f;
+        sm.dfp[h][c] = d; sm.at[c][h] = d; sm.at[c][16 + h] = w;
+    }
+    __syncthreads();
+    const float del = (fm < H) ? delta[row * H + fm] : 0.f;
     const float* zrow = z + row * (int64_t)L * C;
     float* dzrow = dz + row * (int64_t)L * C;
-    const int64_t hm = ((n * H) * (int64_t)L + i) * L;                     // (n, h = 0, i, j = 0); heads are L*L apart
-    const int64_t hstride = (int64_t)L * L;
-    for (int jt = 0; jt < L; jt += TJ) {
-        __syncthreads();                                                   // previous tile's g has been written out
+    const int64_t hm = ((n * H + fm) * (int64_t)L + i) * L;                // (n, h = fm, i, j = 0) of the head-major arrays
+    const int nchunk = (L + JC - 1) / JC;
+    f32x4 zr[4];
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const int j = jt + tid;
-            as[h][tid] = (j < L) ? alpha[hm + h * hstride + j] : 0.f;
-            ns[h][tid] = (j < L) ? dalpha_node[hm + h * hstride + j] : 0.f;
+    for (int r = 0; r < 4; ++r) zr[r] = *(reinterpret_cast<const f32x4*>(zrow + (int64_t)min(wave * JC + kq * 4 + r, L - 1) * C) + fm);
+    for (int ch = wave; ch < nchunk; ch += 4) {
+        const int j0 = ch * JC;
+        // ---- z chunk -> LDS (transpose), next chunk's rows requested
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&sm.zst[wave][kq * 4 + r][fm * 4]) = zr[r];
+        if (ch + 4 < nchunk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zr[r] = *(reinterpret_cast<const f32x4*>(zrow + (int64_t)min((ch + 4) * JC + kq * 4 + r, L - 1) * C) + fm);
         }
-        __syncthreads();
-        // the wave's 4 z rows per iteration: lane (jl, x) loads channels 4x..4x+3 of key j (1 KB per wave, coalesced), one iteration ahead
-        float4 znext = reinterpret_cast<const float4*>(zrow + (int64_t)min(jt + wave * 4 + jl, L - 1) * C)[x];
-        for (int jj = wave * 4; jj < TJ && jt + jj < L; jj += 16) {
-            const int j = jt + jj + jl;
-            const bool ok = j < L;
-            const float4 zv = znext;
-            znext = reinterpret_cast<const float4*>(zrow + (int64_t)min(j + 16, L - 1) * C)[x];
-            wave_lds_sync();
-            *reinterpret_cast<float4*>(&zs[wave][jl][x * 4]) = zv;
-            const float a = (x < H) ? as[x][jj + jl] : 0.f, dn = (x < H) ? ns[x][jj + jl] : 0.f;
-            wave_lds_sync();
-            // phase 1: dalpha for (key jl, head x)
-            float acc = 0.f;
+        // alpha / dalpha_node of (head fm, keys j0 + 4 kq ..): 16 B per lane from the head-major rows
+        f32x4 a4 = (f32x4){0.f, 0.f, 0.f, 0.f}, n4 = a4;
+        const int jq = j0 + kq * 4;
+        if (fm < H) {
+            if (jq + 3 < L && (L % 4) == 0) {
+                a4 = *reinterpret_cast<const f32x4*>(alpha + hm + jq);
+                n4 = *reinterpret_cast<const f32x4*>(dalpha_node + hm + jq);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float4 zz = *reinterpret_cast<const float4*>(&zs[wave][jl][q * 4]);
-                acc = fmaf(d1[q].x, zz.x, acc); acc = fmaf(d1[q].y, zz.y, acc); acc = fmaf(d1[q].z, zz.z, acc); acc = fmaf(d1[q].w, zz.w, acc);
+                for (int r = 0; r < 4; ++r) if (jq + r < L) { a4[r] = alpha[hm + jq + r]; n4[r] = dalpha_node[hm + jq + r]; }
             }
-            const float gv = a * ((dn + acc) - del) * 0.5773502691896258f;
-            if (x < H) gs[x][jj + jl] = gv;
-            ag[wave][jl][0][x] = a; ag[wave][jl][1][x] = gv;
-            wave_lds_sync();
-            // phase 2: dz for (key jl, channels 4x..4x+3)
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const float ah = ag[wave][jl][0][h], gh = ag[wave][jl][1][h];
-                o.x = fmaf(ah, d2[h].x, o.x); o.y = fmaf(ah, d2[h].y, o.y); o.z = fmaf(ah, d2[h].z, o.z); o.w = fmaf(ah, d2[h].w, o.w);
-                o.x = fmaf(gh, w2[h].x, o.x); o.y = fmaf(gh, w2[h].y, o.y); o.z = fmaf(gh, w2[h].z, o.z); o.w = fmaf(gh, w2[h].w, o.w);
-            }
-            if (ok) reinterpret_cast<float4*>(dzrow + (int64_t)j * C)[x] = o;
         }
-        __syncthreads();
+        wave_lds_sync();
+        // ---- dalpha_pair = z . dfp^T on the matrix cores, then g
+        f32x4 acc4[4];
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const int j = jt + tid;
-            if (j < L) g_out[hm + h * hstride + j] = gs[h][tid];
+        for (int q = 0; q < 4; ++q) {
+            const float4 za = *reinterpret_cast<const float4*>(&sm.zst[wave][fm][kq * 16 + q * 4]);
+            const float4 dv = *reinterpret_cast<const float4*>(&sm.dfp[fm][kq * 16 + q * 4]);
+            acc4[q] = mfma4(za.x, dv.x, (f32x4){0.f, 0.f, 0.f, 0.f});
+            acc4[q] = mfma4(za.y, dv.y, acc4[q]); acc4[q] = mfma4(za.z, dv.z, acc4[q]); acc4[q] = mfma4(za.w, dv.w, acc4[q]);
+        }
+        const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+        f32x4 g4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g4[r] = a4[r] * ((n4[r] + acc[r]) - del) * 0.5773502691896258f;
+        if (fm < H) {
+            if (jq + 3 < L && (L % 4) == 0) *reinterpret_cast<f32x4*>(g_out + hm + jq) = g4;
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (jq + r < L) g_out[hm + jq + r] = g4[r];
+        }
+        // ---- [alpha ; g] -> LDS transposed ([key][head]) for the dz product
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sm.ag[wave][kq * 4 + r][fm] = a4[r]; sm.ag[wave][kq * 4 + r][16 + fm] = g4[r]; }
+        wave_lds_sync();
+        // ---- dz[j, c]: rows = channels of tile ct, cols = keys
+        const bool jok = (j0 + fm) < L;
+        float* dzj = dzrow + (int64_t)(j0 + fm) * C + kq * 4;
+        f32x4 bq[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) bq[blk] = *reinterpret_cast<const f32x4*>(&sm.ag[wave][fm][blk * 16 + kq * 4]);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const f32x4 aq = *reinterpret_cast<const f32x4*>(&sm.at[ct * 16 + fm][blk * 16 + kq * 4]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) o = mfma4(aq[s], bq[blk][s], o);
+            }
+            if (jok) *reinterpret_cast<f32x4*>(dzj + ct * 16) = o;
         }
     }
 }
