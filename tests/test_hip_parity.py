@@ -412,6 +412,35 @@ def test_structure_only_sampling_and_contig_mask():
     assert torch.equal(traj2[0][2].cpu()[keep], batch['aa'][keep])
 
 
+def test_c_abi_error_paths():
+    """Error behaviour of the boundary: bad arguments come back as error codes with a message (raised as RuntimeError by the
+    binding), never as a crash or a silent fallback."""
+    import ctypes as C
+    from ab_opt_amd import hip
+    L_ = hip.lib()
+    blk = _block_on_device()
+    _, ws = blk.packed()
+    R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(1, 16, [16])]
+    out = torch.empty_like(x)
+    small = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    args = lambda F, Cd, buf: (C.byref(ws), hip.ptr(R), hip.ptr(t), hip.ptr(x), hip.ptr(z), hip.ptr(mask), hip.ptr(out), 1, 16, F, Cd, None,
+                               hip.ptr(buf), buf.numel(), hip.stream())
+    assert L_.abopt_ga_block_forward(*args(128, 64, small)) == 4                      # ABOPT_EWORKSPACE
+    assert b'workspace too small' in L_.abopt_last_error()
+    big = torch.empty(L_.abopt_ga_workspace_bytes(1, 16, 128, 64), dtype=torch.uint8, device=DEV)
+    assert L_.abopt_ga_block_forward(*args(256, 64, big)) == 3                        # ABOPT_EUNSUPPORTED: res_feat_dim != 128
+    assert L_.abopt_ga_block_forward(*args(128, 64, big)) == 0
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        hip.so3_exp(torch.zeros(4, 3))
+    with pytest.raises(TypeError):
+        hip.so3_exp(torch.zeros(4, 3, dtype=torch.float64, device=DEV))
+    with pytest.raises(RuntimeError, match='atoms'):                                   # resolution outside [3, 15]
+        b = {k: dev(v) for k, v in synth.make_batch(1, synth.LAYOUT_128, seed=1, lengths=[20]).items()}
+        inp, keep = hip.encode_inputs(b['aa'], b['res_nb'], b['chain_nb'], b['pos_heavyatom'], b['mask_heavyatom'], 2, fragment_type=b['fragment_type'])
+        m = build_model(10, 3, device=DEV)
+        hip.pair_embed_forward(inp, m.pair_embed._hip_weights())
+
+
 def test_sample_init_vs_reference():
     from ab_opt_amd import hip
     g = load_golden('trajectory_abdock_T10')
