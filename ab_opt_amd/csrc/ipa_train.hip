@@ -33,7 +33,7 @@ struct PairBwdSmem {
 __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __restrict__ z, const float* __restrict__ alpha,
                                                                 const float* __restrict__ dalpha_node, const float* __restrict__ delta,
                                                                 const float* __restrict__ dfeat, int ld_dfeat, const float* __restrict__ Wb,
-                                                                float* __restrict__ g_out, float* __restrict__ dz, int L) {
+                                                                float* __restrict__ g_out, float* __restrict__ dz, float* __restrict__ dwb_part, int L) {
     __shared__ __attribute__((aligned(16))) PairBwdSmem sm;
     const int64_t row = blockIdx.x;                                        // n * L + i
     const int64_t n = row / L;
@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
     float* dzrow = dz + row * (int64_t)L * C;
     const int64_t hm = ((n * H + fm) * (int64_t)L + i) * L;                // (n, h = fm, i, j = 0) of the head-major arrays
     const int nchunk = (L + JC - 1) / JC;
-    f32x4 zr[4];
+    f32x4 zr[4], zc[4], accW[4];                                          // accW: this wave's share of sum_j g[h,j] z[j,c] (d proj_pair_bias.weight)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) accW[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) zr[r] = *(reinterpret_cast<const f32x4*>(zrow + (int64_t)min(wave * JC + kq * 4 + r, L - 1) * C) + fm);
     for (int ch = wave; ch < nchunk; ch += 4) {
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
         // ---- z chunk -> LDS (transpose), next chunk's rows requested
         wave_lds_sync();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&sm.zst[wave][kq * 4 + r][fm * 4]) = zr[r];
+        for (int r = 0; r < 4; ++r) { zc[r] = zr[r]; *reinterpret_cast<f32x4*>(&sm.zst[wave][kq * 4 + r][fm * 4]) = zr[r]; }
         if (ch + 4 < nchunk) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) zr[r] = *(reinterpret_cast<const f32x4*>(zrow + (int64_t)min((ch + 4) * JC + kq * 4 + r, L - 1) * C) + fm);
@@ -96,6 +98,11 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (jq + r < L) g_out[hm + jq + r] = g4[r];
         }
+        // ---- d Wb[h, c] += sum_j g[h, j] z[j, c]: z rows are already the A operand, g the B operand (keys past L carry g = 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) accW[mt] = mfma4(zc[r][mt], g4[r], accW[mt]);
         // ---- [alpha ; g] -> LDS transposed ([key][head]) for the dz product
 #pragma unroll
         for (int r = 0; r < 4; ++r) { sm.ag[wave][kq * 4 + r][fm] = a4[r]; sm.ag[wave][kq * 4 + r][16 + fm] = g4[r]; }
@@ -117,6 +124,18 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
             }
             if (jok) *reinterpret_cast<f32x4*>(dzj + ct * 16) = o;
         }
+    }
+    // ---- the row's d Wb partial: accumulator tile mt holds channels 4 fm' + mt (rows 4 kq + r = fm') of head fm
+    __syncthreads();
+    float (*red)[16][C + 4] = reinterpret_cast<float (*)[16][C + 4]>(&sm.zst[0][0][0]);          // 4 x [16 heads][64 channels], reuses the z tiles
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][fm][(kq * 4 + r) * 4 + mt] = accW[mt][r];
+    __syncthreads();
+    for (int e = tid; e < H * C; e += 256) {
+        const int h = e / C, c = e % C;
+        dwb_part[row * (H * C) + e] = (red[0][h][c] + red[1][h][c]) + (red[2][h][c] + red[3][h][c]);
     }
 }
 
@@ -294,9 +313,9 @@ int launch_ipa_backward_assemble(const float* P1, const float* P2, const float* 
 }
 
 int launch_ipa_pair_backward(const float* z, const float* alpha, const float* dalpha_node, const float* delta, const float* dfeat, int ld_dfeat,
-                             const float* Wb, float* g_out, float* dz, int N, int L, hipStream_t st) {
+                             const float* Wb, float* g_out, float* dz, float* dwb_part, int N, int L, hipStream_t st) {
     if ((int64_t)N * L == 0) return ABOPT_OK;
-    hipLaunchKernelGGL(ipa_pair_backward_kernel, dim3((unsigned)((int64_t)N * L)), dim3(256), 0, st, z, alpha, dalpha_node, delta, dfeat, ld_dfeat, Wb, g_out, dz, L);
+    hipLaunchKernelGGL(ipa_pair_backward_kernel, dim3((unsigned)((int64_t)N * L)), dim3(256), 0, st, z, alpha, dalpha_node, delta, dfeat, ld_dfeat, Wb, g_out, dz, dwb_part, L);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

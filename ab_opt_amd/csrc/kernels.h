@@ -53,7 +53,8 @@ int launch_ipa_backward_operands(const float* proj, const float* R, const float*
 int launch_ipa_backward_assemble(const float* P1, const float* P2, const float* P3, const float* Aq, const float* Ak, const float* R,
                                  const float* spatial_coef, float* dproj, float* e, int N, int L, hipStream_t st);
 int launch_ipa_pair_backward(const float* z, const float* alpha, const float* dalpha_node, const float* delta, const float* dfeat, int ld_dfeat,
-                             const float* Wb, float* g_out, float* dz, int N, int L, hipStream_t st);
+                             const float* Wb, float* g_out, float* dz, float* dwb_part /* [N*L, 12*C] per-row partials of d proj_pair_bias.weight */,
+                             int N, int L, hipStream_t st);
 
 // embed.hip: encode() ----------------------------------------------------------------------------
 size_t residue_embed_ws_bytes(int N, int L, int A, int hotspot);

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -130,7 +130,7 @@ def lib():
         L.abopt_ipa_points_backward.argtypes = [c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_ipa_backward_operands.argtypes = [c_f] * 6 + [C.c_int, C.c_int, C.c_void_p]
         L.abopt_ipa_backward_assemble.argtypes = [c_f] * 9 + [C.c_int, C.c_int, C.c_void_p]
-        L.abopt_ipa_pair_backward.argtypes = [c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.abopt_ipa_pair_backward.argtypes = [c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.abopt_residue_embed_workspace_bytes.restype = C.c_size_t
         L.abopt_residue_embed_workspace_bytes.argtypes = [C.c_int] * 4
         L.abopt_pair_embed_workspace_bytes.restype = C.c_size_t
@@ -393,15 +393,16 @@ def ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, spatial_coef):
 
 
 def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias):
-    """alpha, dalpha_node head-major (N,12,L,L) -> g (N,12,L,L), dz (N,L,L,C)  (include/abopt.h: abopt_ipa_pair_backward)."""
+    """alpha, dalpha_node head-major (N,12,L,L) -> g (N,12,L,L), dz (N,L,L,C), dWb (12,C)  (include/abopt.h: abopt_ipa_pair_backward)."""
     N, L = z.shape[:2]
     g = torch.empty_like(alpha)
     dz = torch.empty_like(z)
+    dwb_rows = torch.empty(N * L, 12 * z.shape[-1], device=z.device)
     dfeat = dfeat.contiguous()
     _check(lib().abopt_ipa_pair_backward(ptr(z.contiguous(), torch.float32), ptr(alpha.contiguous(), torch.float32), ptr(dalpha_node.contiguous(), torch.float32),
                                          ptr(delta.contiguous(), torch.float32), ptr(dfeat, torch.float32), dfeat.shape[-1],
-                                         ptr(w_pair_bias.contiguous(), torch.float32), ptr(g), ptr(dz), N, L, z.shape[-1], stream()))
-    return g, dz
+                                         ptr(w_pair_bias.contiguous(), torch.float32), ptr(g), ptr(dz), ptr(dwb_rows), N, L, z.shape[-1], stream()))
+    return g, dz, dwb_rows.sum(0).view(12, z.shape[-1])
 
 
 def encode_inputs(aa, res_nb, chain_nb, pos_atoms, mask_atoms, atoms, fragment_type=None, hotspot=None, structure_mask=None, sequence_mask=None):

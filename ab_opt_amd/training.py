@@ -99,7 +99,7 @@ class IpaCore(torch.autograd.Function):
         dout_cat, delta = hip.ipa_points_backward(dfeat, feat, R, t)
         T = lambda a: a.transpose(-1, -2)
         da_node = dout_cat @ T(Av)                                                  # (N,H,L,L)
-        g, dz = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb)          # the z-streaming part
+        g, dz, dWb = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb)     # the z-streaming part (incl. d proj_pair_bias.weight)
         del da_node
         # every (N,12,L,L) matrix is multiplied ONCE from each side:
         P1 = g @ Ak                                                                 # sum_j g_ij [k_j | kg_j | 1]
@@ -109,7 +109,6 @@ class IpaCore(torch.autograd.Function):
         dproj, e = hip.ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, gamma_raw.reshape(-1))
         gam = gamma_raw.reshape(-1)
         dgamma = (e.sum((0, 1)) * (-torch.sigmoid(gam) * (math.sqrt(2 / (9 * P)) / 2))).reshape(gamma_raw.shape)
-        dWb = (g.reshape(N, H, L * L) @ z.reshape(N, L * L, -1)).sum(0)
         return dproj, dz, None, None, None, dWb, dgamma
 
 

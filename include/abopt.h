@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 11
+#define ABOPT_ABI_VERSION 12
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -215,6 +215,7 @@ int abopt_ipa_backward_assemble(const float* P1, const float* P2, const float* P
                                 const float* spatial_coef, float* dproj, float* e, int N, int L, abopt_stream stream);
 int abopt_ipa_pair_backward(const float* pair_feat, const float* alpha, const float* dalpha_node, const float* delta,
                             const float* dfeat, int ld_dfeat, const float* w_pair_bias, float* g, float* dpair_feat,
+                            float* dw_pair_bias_rows /* [N*L, 12*C]: per-query-row partials of d proj_pair_bias.weight (sum over rows) */,
                             int N, int L, int C, abopt_stream stream);
 
 /* ---- encode(): D/models/diffab.py:39-83.  ResidueEmbedding.forward (D/modules/encoders/residue.py:26-92; the AbDesign
