@@ -412,6 +412,27 @@ def test_structure_only_sampling_and_contig_mask():
     assert torch.equal(traj2[0][2].cpu()[keep], batch['aa'][keep])
 
 
+def test_design_pipeline_end_to_end():
+    """The runner's sequence (design_for_pdb.py:141-336) on the device: shared-context sampling -> backbone rebuild -> commonness
+    ranking.  Integration check: shapes, finiteness, masks, ranking indices."""
+    from ab_opt_amd import sampler, geometry
+    m = build_model(10, 3, device=DEV)
+    one = {k: dev(v) for k, v in synth.make_batch(1, synth.LAYOUT_128, seed=9).items()}
+    n = 6
+    traj = sampler.sample_replicated(m, one, n, {'sample_structure': True, 'sample_sequence': True, 'seed': 3})
+    v, p, s, prmsd, ppl = traj[0]
+    rep = lambda a: a.expand(n, *a.shape[1:]).contiguous()
+    pos, mask = geometry.reconstruct_backbone_partially(rep(one['pos_heavyatom']), geometry.so3vec_to_rotation(v), p, s, rep(one['chain_nb']),
+                                                        rep(one['res_nb']), rep(one['mask_heavyatom']), rep(one['generate_flag']))
+    gen = rep(one['generate_flag'])
+    assert pos.shape == (n, 128, 15, 3) and torch.isfinite(pos).all() and mask[gen][:, :4].all() and not mask[gen][:, 4:].any()
+    assert torch.equal(pos[~gen], rep(one['pos_heavyatom'])[~gen])
+    assert max_abs(pos[gen][:, 1], p[gen]) < 1e-4                               # CA sits at the frame origin
+    cand = pos[gen][:, :3].reshape(n, -1, 3)
+    top = sampler.rank_commoness(cand, k=3)
+    assert top.shape == (3,) and len(set(top.tolist())) == 3 and prmsd.shape == (n,) and ppl.shape == (n,)
+
+
 def test_c_abi_error_paths():
     """Error behaviour of the boundary: bad arguments come back as error codes with a message (raised as RuntimeError by the
     binding), never as a crash or a silent fallback."""
