@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const int64_t* __restric
                                                         const uint8_t* __restrict__ mask_generate, float scale, float m0, float m1, float m2,
                                                         int noise_structure, int noise_sequence, int grad_mode,
                                                         float* __restrict__ v_noisy, float* __restrict__ p_noisy, int64_t* __restrict__ s_noisy,
-                                                        float* __restrict__ eps_p, int L, int64_t rows) {
+                                                        float* __restrict__ eps_p, float* __restrict__ c_noisy, int L, int64_t rows) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     const int64_t tt = t[i / L];
@@ -271,16 +271,18 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const int64_t* __restric
     const int64_t s0 = s_0[i];
     int64_t sn = s0;
     if (noise_sequence) {
+        const bool ok = s0 >= 0 && s0 < KAA;
+        float tot = 0.f, c[KAA];
+#pragma unroll
+        for (int k = 0; k < KAA; ++k) {
+            const float oh = (ok && s0 == k) ? 1.f : 0.f;
+            const float ck = gen ? (abar * oh) + ((1.f - abar) / (float)KAA) : oh;       // c_t, transition.py:196-198
+            if (c_noisy) c_noisy[i * KAA + k] = ck;
+            c[k] = ck + 1e-8f;                                                             // _sample adds 1e-8 (transition.py:179)
+            tot += c[k];
+        }
         if (nz.axis) sn = nz.s_noisy[i];
         else {
-            const bool ok = s0 >= 0 && s0 < KAA;
-            float tot = 0.f, c[KAA];
-#pragma unroll
-            for (int k = 0; k < KAA; ++k) {
-                const float oh = (ok && s0 == k) ? 1.f : 0.f;
-                c[k] = (gen ? (abar * oh) + ((1.f - abar) / (float)KAA) : oh) + 1e-8f;
-                tot += c[k];
-            }
             const float target = useq * tot;
             float cum = 0.f;
             sn = KAA - 1;
@@ -353,7 +355,7 @@ extern "C" int abopt_add_noise(const int64_t* t, const float* alpha_bars, const 
                                const abopt_addnoise_noise* noise, uint64_t seed, uint64_t offset,
                                const float* v_0, const float* p_0, const int64_t* s_0, const uint8_t* mask_generate,
                                float position_scale, const float* position_mean, int noise_structure, int noise_sequence, int grad_mode,
-                               float* v_noisy, float* p_noisy, int64_t* s_noisy, float* eps_p, int N, int L, abopt_stream stream) {
+                               float* v_noisy, float* p_noisy, int64_t* s_noisy, float* eps_p, float* c_noisy, int N, int L, abopt_stream stream) {
     ABOPT_CHECK_ARG(t && alpha_bars && fwd_stddevs && fwd_approx && fwd_X && v_0 && p_0 && s_0 && mask_generate && position_mean &&
                     v_noisy && p_noisy && s_noisy && bins >= 2 && num_sched >= 1, "add_noise: bad arguments");
     abopt_addnoise_noise nz = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -367,7 +369,7 @@ extern "C" int abopt_add_noise(const int64_t* t, const float* alpha_bars, const 
     if (rows == 0) return ABOPT_OK;
     hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, alpha_bars, fwd_stddevs, fwd_approx,
                        fwd_X, fwd_cdf, bins, nz, seed, offset, v_0, p_0, s_0, mask_generate, position_scale, position_mean[0], position_mean[1],
-                       position_mean[2], noise_structure, noise_sequence, grad_mode, v_noisy, p_noisy, s_noisy, eps_p, L, rows);
+                       position_mean[2], noise_structure, noise_sequence, grad_mode, v_noisy, p_noisy, s_noisy, eps_p, c_noisy, L, rows);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

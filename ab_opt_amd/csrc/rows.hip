@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256) void embed_concat_kernel(const float* __restri
     const int lane = threadIdx.x & 63;
     const int64_t s = s_t[row];
     const float2 a = reinterpret_cast<const float2*>(res_feat + row * F)[lane];
-    const float2 b = reinterpret_cast<const float2*>(embed + s * F)[lane];
+    // nn.Embedding(25, F) raises on an index outside [0, 25) (dpm_full.py:89); a kernel cannot raise, so the row is poisoned with
+    // NaN instead of reading out of bounds: every output of the step then comes back NaN (never a silently wrong number)
+    const bool ok = s >= 0 && s < 25;
+    const float qnan = __int_as_float(0x7fc00000);
+    const float2 b = ok ? reinterpret_cast<const float2*>(embed + s * F)[lane] : make_float2(qnan, qnan);
     reinterpret_cast<float2*>(cat + row * 2 * F)[lane] = a;
     reinterpret_cast<float2*>(cat + row * 2 * F + F)[lane] = b;
 }

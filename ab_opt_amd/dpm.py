@@ -90,7 +90,7 @@ class FullDPM(nn.Module):
 
     # ------------------------------------------------------------------ sampling
     def _run(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
-             ppl_masked, noise, seed, rng_offset, pbar, stop_after=None, optimize_mode=False, use_bias_cache=True):
+             ppl_masked, noise, seed, rng_offset, pbar, stop_after=None, optimize_mode=False, use_bias_cache=None):
         """Denoise from step t_start down to 0.  state = (v, p_angstrom, s) on device."""
         dev = res_feat.device
         N, L = mask_res.shape
@@ -107,6 +107,11 @@ class FullDPM(nn.Module):
         # (1,L,F) / pair_feat (1,L,L,C) are then shared by all N samples -- the kernels index pair_feat and its bias cache
         # with batch stride 0, so the 100 x 6 passes over it are served from L2/MALL instead of HBM.
         shared = pair_feat.shape[0] == 1 and N > 1
+        if use_bias_cache is None:
+            # the cache costs num_layers * N * L^2 * 48 B next to pair_feat's N * L^2 * 256 B: take it when it fits comfortably,
+            # otherwise the kernels compute the pair bias in place (bit-identical, test_pair_bias_cache_is_bit_identical)
+            need = hip.pair_bias_cache_bytes(pair_feat.shape[0], L, len(self.eps_net.encoder.blocks))
+            use_bias_cache = shared or (L <= 2048 and need <= torch.cuda.mem_get_info(dev)[0] // 2)
         if shared and not use_bias_cache:
             raise ValueError('a shared pair_feat requires the pair-bias cache')
         if res_feat.shape[0] == 1 and N > 1:
@@ -165,7 +170,7 @@ class FullDPM(nn.Module):
 
     @torch.no_grad()
     def sample(self, v, p, s, res_feat, pair_feat, mask_generate, mask_res, sample_structure=True, sample_sequence=True,
-               pbar=False, noise=None, seed=None, rng_offset=0, **kwargs):
+               pbar=False, noise=None, seed=None, rng_offset=0, use_bias_cache=None, **kwargs):
         """dpm_full.py:236-302.  `noise` (optional) = {'init': {q4,p,s}, t: {axis,bin,ubin,gauss,z,s_next}} replays
         recorded draws; otherwise a Philox stream seeded from torch's CPU generator is used."""
         hip.lib()
@@ -175,13 +180,13 @@ class FullDPM(nn.Module):
                                 h['scale'], h['mean'], sample_structure, sample_sequence)
         T = self.num_steps
         out = self._run(state, T, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, True,
-                        noise, seed, rng_offset, pbar)
+                        noise, seed, rng_offset, pbar, use_bias_cache=use_bias_cache)
         # dpm_full.py:269: the first entry carries zeros_like(s) / ones_like(s) in the two extra slots
         return self._to_traj(T, *out, first_extra=lambda s_: (torch.zeros_like(s_), torch.ones_like(s_)))
 
     @torch.no_grad()
     def optimize(self, v, p, s, opt_step, res_feat, pair_feat, mask_generate, mask_res, sample_structure=True,
-                 sample_sequence=True, pbar=False, noise=None, seed=None, rng_offset=0):
+                 sample_sequence=True, pbar=False, noise=None, seed=None, rng_offset=0, use_bias_cache=None):
         """dpm_full.py:304-367: noise the input to step `opt_step`, then denoise."""
         hip.lib()
         seed = self._new_seed() if seed is None else int(seed)
@@ -197,6 +202,6 @@ class FullDPM(nn.Module):
         # dpm_full.py:351-358: the loop feeds the net's third output to the position update as noise whatever `obj` is,
         # and averages the perplexity over all residues (calc_perplexity(logits) without a mask)
         out = self._run(state, opt_step, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, False,
-                        noise, seed, rng_offset + N * v.shape[1], pbar, optimize_mode=True)
+                        noise, seed, rng_offset + N * v.shape[1], pbar, optimize_mode=True, use_bias_cache=use_bias_cache)
         traj = self._to_traj(opt_step, *out, first_extra=lambda s_: (torch.zeros_like(s_), torch.ones_like(s_)))
         return {k: tuple(e) for k, e in traj.items()}

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -120,7 +120,7 @@ def lib():
         L.abopt_commonness_score.argtypes = [c_f, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_add_noise.argtypes = [c_i64, c_f, c_f, c_u8, c_f, c_f, C.c_int, C.c_int, C.POINTER(AddNoiseNoise), C.c_uint64, C.c_uint64,
                                       c_f, c_f, c_i64, c_u8, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,
-                                      c_f, c_f, c_i64, c_f, C.c_int, C.c_int, C.c_void_p]
+                                      c_f, c_f, c_i64, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_prof_enable.argtypes = [C.c_int]
         L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.abopt_reconstruct_backbone_partially.argtypes = [c_f, c_f, c_f, c_i64, c_i64, c_i64, c_u8, c_u8, c_f, c_f, c_f, c_u8] + [C.c_int] * 3 + [C.c_void_p]
@@ -179,6 +179,13 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _contig(*ts):
+    """Contiguous versions of the arguments, returned as objects the CALLER binds to locals: a temporary
+    `x.contiguous()` inside an argument list is freed as soon as its address is taken, and the caching allocator hands
+    the same block to the next temporary -- two kernel arguments would then alias."""
+    return [t if (t is None or t.is_contiguous()) else t.contiguous() for t in ts]
+
+
 class Workspace:
     """Grow-only scratch buffer per (device, stream)."""
     _bufs = {}
@@ -234,9 +241,9 @@ def ga_block_forward(ws, R, t, x, z, mask, debug=False):
         dbg = GaDebug(ptr(extras['logits']), ptr(extras['alpha']), ptr(extras['feat']))
     nb = lib().abopt_ga_workspace_bytes(N, L, F, Cd)
     buf = Workspace.get(nb, x.device)
-    _check(lib().abopt_ga_block_forward(C.byref(ws), ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32),
-                                        ptr(x.contiguous(), torch.float32), ptr(z.contiguous(), torch.float32),
-                                        ptr(mask.contiguous(), torch.bool), ptr(out), N, L, F, Cd,
+    R, t, x, z, mask = _contig(R, t, x, z, mask)      # copies (if any) stay alive until the launch is enqueued
+    _check(lib().abopt_ga_block_forward(C.byref(ws), ptr(R, torch.float32), ptr(t, torch.float32), ptr(x, torch.float32), ptr(z, torch.float32),
+                                        ptr(mask, torch.bool), ptr(out), N, L, F, Cd,
                                         C.byref(dbg) if dbg is not None else None, ptr(buf), buf.numel(), stream()))
     return (out, extras) if debug else out
 
@@ -247,9 +254,9 @@ def ga_encoder_forward(ws_array, num_layers, R, t, x, z, mask):
     out = torch.empty_like(x)
     nb = lib().abopt_ga_workspace_bytes(N, L, F, Cd)
     buf = Workspace.get(nb, x.device)
-    _check(lib().abopt_ga_encoder_forward(ws_array, num_layers, ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32),
-                                          ptr(x.contiguous(), torch.float32), ptr(z.contiguous(), torch.float32),
-                                          ptr(mask.contiguous(), torch.bool), ptr(out), N, L, F, Cd, ptr(buf), buf.numel(), stream()))
+    R, t, x, z, mask = _contig(R, t, x, z, mask)
+    _check(lib().abopt_ga_encoder_forward(ws_array, num_layers, ptr(R, torch.float32), ptr(t, torch.float32), ptr(x, torch.float32),
+                                          ptr(z, torch.float32), ptr(mask, torch.bool), ptr(out), N, L, F, Cd, ptr(buf), buf.numel(), stream()))
     return out
 
 
@@ -264,14 +271,17 @@ def eps_net_forward(ew, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate,
                    prmsd_logits=torch.empty(N, num_bins, device=dev) if has_prmsd else None)
     nb = lib().abopt_eps_workspace_bytes(N, L, F, Cd)
     buf = Workspace.get(nb, dev)
-    _check(lib().abopt_eps_net_forward(C.byref(ew), ptr(v_t.contiguous(), torch.float32), ptr(p_t.contiguous(), torch.float32),
-                                       ptr(s_t.contiguous(), torch.int64), ptr(res_feat.contiguous(), torch.float32),
-                                       ptr(pair_feat.contiguous(), torch.float32), ptr(beta.contiguous(), torch.float32),
-                                       ptr(mask_generate.contiguous(), torch.bool), ptr(mask_res.contiguous(), torch.bool),
+    v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res = _contig(v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res)
+    _check(lib().abopt_eps_net_forward(C.byref(ew), ptr(v_t, torch.float32), ptr(p_t, torch.float32), ptr(s_t, torch.int64), ptr(res_feat, torch.float32),
+                                       ptr(pair_feat, torch.float32), ptr(beta, torch.float32), ptr(mask_generate, torch.bool), ptr(mask_res, torch.bool),
                                        ptr(out['v_next']), ptr(out['R_next']), ptr(out['eps_pos']), ptr(out['c']),
                                        ptr(out['prmsd_logits'], optional=True), N, L, F, Cd, int(grad_mode),
                                        ptr(pair_bias_cache, torch.float32, optional=True), int(pair_feat_shared), ptr(buf), buf.numel(), stream()))
     return out
+
+
+def pair_bias_cache_bytes(N, L, num_layers):
+    return lib().abopt_pair_bias_cache_bytes(N, L, num_layers)
 
 
 def pair_bias_cache(blocks_array, num_layers, pair_feat):
@@ -279,7 +289,8 @@ def pair_bias_cache(blocks_array, num_layers, pair_feat):
     N, L = pair_feat.shape[:2]
     nb = lib().abopt_pair_bias_cache_bytes(N, L, num_layers)
     cache = torch.empty(nb // 4, dtype=torch.float32, device=pair_feat.device)
-    _check(lib().abopt_pair_bias_cache(blocks_array, num_layers, ptr(pair_feat.contiguous(), torch.float32), ptr(cache), N, L,
+    pair_feat, = _contig(pair_feat)
+    _check(lib().abopt_pair_bias_cache(blocks_array, num_layers, ptr(pair_feat, torch.float32), ptr(cache), N, L,
                                        pair_feat.shape[-1], stream()))
     return cache
 
@@ -309,32 +320,36 @@ def sample_init(v, p, s, mask_generate, init_noise, seed, offset, scale, mean, s
     if init_noise is not None:
         q4, pn, sr = init_noise.get('q4'), init_noise.get('p'), init_noise.get('s')
     mean_arr = (C.c_float * 3)(*[float(m) for m in mean])
-    _check(lib().abopt_sample_init(ptr(v.contiguous(), torch.float32), ptr(p.contiguous(), torch.float32), ptr(s.contiguous(), torch.int64),
-                                   ptr(mask_generate.contiguous(), torch.bool), ptr(q4, optional=True), ptr(pn, optional=True),
+    v, p, s, mask_generate = _contig(v, p, s, mask_generate)
+    _check(lib().abopt_sample_init(ptr(v, torch.float32), ptr(p, torch.float32), ptr(s, torch.int64),
+                                   ptr(mask_generate, torch.bool), ptr(q4, optional=True), ptr(pn, optional=True),
                                    ptr(sr, optional=True), seed, offset, float(scale), mean_arr, int(sample_structure), int(sample_sequence),
                                    ptr(v_i), ptr(p_i), ptr(s_i), N, L, stream()))
     return v_i, p_i, s_i
 
 
 def add_noise(t, alpha_bars, fwd, noise, seed, offset, v_0, p_0, s_0, mask_generate, scale, mean,
-              noise_structure=True, noise_sequence=True, grad_mode=False, want_eps=False):
+              noise_structure=True, noise_sequence=True, grad_mode=False, want_eps=False, want_probs=False):
     """fwd: ApproxAngularDistribution of the forward process (buffers stddevs, approx_flag, X + cdf())."""
     N, L = mask_generate.shape
     v_n, p_n, s_n = torch.empty_like(v_0), torch.empty_like(p_0), torch.empty_like(s_0)
     eps = torch.empty_like(p_0) if want_eps else None
+    probs = torch.empty(N, L, 20, dtype=torch.float32, device=p_0.device) if want_probs else None
     nz = None
     if noise is not None:
         nz = AddNoiseNoise(ptr(noise['axis'], torch.float32), ptr(noise['bin'], torch.int64), ptr(noise['ubin'], torch.float32),
                            ptr(noise['gauss'], torch.float32), ptr(noise['pos'], torch.float32), ptr(noise.get('s_noisy'), torch.int64, optional=True))
     mean_arr = (C.c_float * 3)(*[float(m) for m in mean])
     cdf = fwd.cdf() if noise is None else None
-    _check(lib().abopt_add_noise(ptr(t.contiguous(), torch.int64), ptr(alpha_bars, torch.float32), ptr(fwd.stddevs, torch.float32),
+    t, v_0, p_0, s_0, mask_generate = _contig(t, v_0, p_0, s_0, mask_generate)
+    _check(lib().abopt_add_noise(ptr(t, torch.int64), ptr(alpha_bars, torch.float32), ptr(fwd.stddevs, torch.float32),
                                  ptr(fwd.approx_flag, torch.bool), ptr(fwd.X, torch.float32), ptr(cdf, optional=True), fwd.X.shape[1], fwd.X.shape[0],
                                  C.byref(nz) if nz is not None else None, seed, offset,
-                                 ptr(v_0.contiguous(), torch.float32), ptr(p_0.contiguous(), torch.float32), ptr(s_0.contiguous(), torch.int64),
-                                 ptr(mask_generate.contiguous(), torch.bool), float(scale), mean_arr, int(noise_structure), int(noise_sequence),
-                                 int(grad_mode), ptr(v_n), ptr(p_n), ptr(s_n), ptr(eps, optional=True), N, L, stream()))
-    return (v_n, p_n, s_n, eps) if want_eps else (v_n, p_n, s_n)
+                                 ptr(v_0, torch.float32), ptr(p_0, torch.float32), ptr(s_0, torch.int64),
+                                 ptr(mask_generate, torch.bool), float(scale), mean_arr, int(noise_structure), int(noise_sequence),
+                                 int(grad_mode), ptr(v_n), ptr(p_n), ptr(s_n), ptr(eps, optional=True), ptr(probs, optional=True), N, L, stream()))
+    out = (v_n, p_n, s_n) + ((eps,) if want_eps else ()) + ((probs,) if want_probs else ())
+    return out
 
 
 def commonness_score(structs):
@@ -353,9 +368,10 @@ def ipa_core_train_forward(proj_local, R, t, z, mask, w_pair_bias, spatial_coef)
     alpha = torch.empty(N, 12, L, L, device=dev)
     nb = lib().abopt_ipa_train_workspace_bytes(N, L)
     buf = Workspace.get(nb, dev)
-    _check(lib().abopt_ipa_core_train_forward(ptr(proj_local.contiguous(), torch.float32), ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32),
-                                              ptr(z.contiguous(), torch.float32), ptr(mask.contiguous(), torch.bool),
-                                              ptr(w_pair_bias.contiguous(), torch.float32), ptr(spatial_coef.contiguous(), torch.float32),
+    proj_local, R, t, z, mask, w_pair_bias, spatial_coef = _contig(proj_local, R, t, z, mask, w_pair_bias, spatial_coef)
+    _check(lib().abopt_ipa_core_train_forward(ptr(proj_local, torch.float32), ptr(R, torch.float32), ptr(t, torch.float32),
+                                              ptr(z, torch.float32), ptr(mask, torch.bool),
+                                              ptr(w_pair_bias, torch.float32), ptr(spatial_coef, torch.float32),
                                               ptr(feat), ptr(alpha), N, L, z.shape[-1], ptr(buf), buf.numel(), stream()))
     return feat, alpha
 
@@ -365,9 +381,9 @@ def ipa_points_backward(dfeat, feat, R, t):
     N, L = feat.shape[:2]
     dout_cat = torch.empty(N, 12, L, 56, device=feat.device)
     delta = torch.empty(N, L, 12, device=feat.device)
-    dfeat = dfeat.contiguous()
-    _check(lib().abopt_ipa_points_backward(ptr(dfeat, torch.float32), dfeat.shape[-1], ptr(feat.contiguous(), torch.float32),
-                                           ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32), ptr(dout_cat), ptr(delta), N, L, stream()))
+    dfeat, feat, R, t = _contig(dfeat, feat, R, t)
+    _check(lib().abopt_ipa_points_backward(ptr(dfeat, torch.float32), dfeat.shape[-1], ptr(feat, torch.float32),
+                                           ptr(R, torch.float32), ptr(t, torch.float32), ptr(dout_cat), ptr(delta), N, L, stream()))
     return dout_cat, delta
 
 
@@ -376,7 +392,8 @@ def ipa_backward_operands(proj_local, R, t):
     N, L = proj_local.shape[:2]
     dev = proj_local.device
     Aq, Ak, Av = torch.empty(N, 12, L, 57, device=dev), torch.empty(N, 12, L, 57, device=dev), torch.empty(N, 12, L, 56, device=dev)
-    _check(lib().abopt_ipa_backward_operands(ptr(proj_local.contiguous(), torch.float32), ptr(R.contiguous(), torch.float32), ptr(t.contiguous(), torch.float32),
+    proj_local, R, t = _contig(proj_local, R, t)
+    _check(lib().abopt_ipa_backward_operands(ptr(proj_local, torch.float32), ptr(R, torch.float32), ptr(t, torch.float32),
                                              ptr(Aq), ptr(Ak), ptr(Av), N, L, stream()))
     return Aq, Ak, Av
 
@@ -386,9 +403,10 @@ def ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, spatial_coef):
     N, _, L, _ = P1.shape
     dproj = torch.empty(N, L, 2016, device=P1.device)
     e = torch.empty(N, L, 12, device=P1.device)
-    _check(lib().abopt_ipa_backward_assemble(ptr(P1.contiguous(), torch.float32), ptr(P2.contiguous(), torch.float32), ptr(P3.contiguous(), torch.float32),
-                                             ptr(Aq, torch.float32), ptr(Ak, torch.float32), ptr(R.contiguous(), torch.float32),
-                                             ptr(spatial_coef.contiguous(), torch.float32), ptr(dproj), ptr(e), N, L, stream()))
+    P1, P2, P3, R, spatial_coef = _contig(P1, P2, P3, R, spatial_coef)
+    _check(lib().abopt_ipa_backward_assemble(ptr(P1, torch.float32), ptr(P2, torch.float32), ptr(P3, torch.float32),
+                                             ptr(Aq, torch.float32), ptr(Ak, torch.float32), ptr(R, torch.float32),
+                                             ptr(spatial_coef, torch.float32), ptr(dproj), ptr(e), N, L, stream()))
     return dproj, e
 
 
@@ -398,10 +416,10 @@ def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias):
     g = torch.empty_like(alpha)
     dz = torch.empty_like(z)
     dwb_rows = torch.empty(N * L, 12 * z.shape[-1], device=z.device)
-    dfeat = dfeat.contiguous()
-    _check(lib().abopt_ipa_pair_backward(ptr(z.contiguous(), torch.float32), ptr(alpha.contiguous(), torch.float32), ptr(dalpha_node.contiguous(), torch.float32),
-                                         ptr(delta.contiguous(), torch.float32), ptr(dfeat, torch.float32), dfeat.shape[-1],
-                                         ptr(w_pair_bias.contiguous(), torch.float32), ptr(g), ptr(dz), ptr(dwb_rows), N, L, z.shape[-1], stream()))
+    z, alpha, dalpha_node, delta, dfeat, w_pair_bias = _contig(z, alpha, dalpha_node, delta, dfeat, w_pair_bias)
+    _check(lib().abopt_ipa_pair_backward(ptr(z, torch.float32), ptr(alpha, torch.float32), ptr(dalpha_node, torch.float32),
+                                         ptr(delta, torch.float32), ptr(dfeat, torch.float32), dfeat.shape[-1],
+                                         ptr(w_pair_bias, torch.float32), ptr(g), ptr(dz), ptr(dwb_rows), N, L, z.shape[-1], stream()))
     return g, dz, dwb_rows.sum(0).view(12, z.shape[-1])
 
 
@@ -458,7 +476,8 @@ def pair_embed_backward(inp, weights, dpair_feat, acts, T):
     ds = torch.empty(N, L, L, inp.atoms * 16, device=dev)
     nb = lib().abopt_pair_embed_backward_workspace_bytes(N, L, inp.atoms)
     buf = Workspace.get(nb, dev)
-    _check(lib().abopt_pair_embed_backward(C.byref(inp), C.byref(weights), ptr(dpair_feat.contiguous(), torch.float32), ptr(acts, torch.float32),
+    dpair_feat, = _contig(dpair_feat)
+    _check(lib().abopt_pair_embed_backward(C.byref(inp), C.byref(weights), ptr(dpair_feat, torch.float32), ptr(acts, torch.float32),
                                            ptr(T, torch.float32), ptr(dys), ptr(ds), ptr(buf), buf.numel(), stream()))
     return dys, ds
 
@@ -477,10 +496,11 @@ def reconstruct_backbone_partially(pos_ctx, R_new, t_new, aa, chain_nb, res_nb, 
     N, L, A = mask_atoms.shape
     pos_new = torch.empty(N, L, A, 3, device=dev)
     mask_new = torch.empty(N, L, A, dtype=torch.bool, device=dev)
-    _check(lib().abopt_reconstruct_backbone_partially(ptr(pos_ctx.contiguous(), torch.float32), ptr(R_new.contiguous(), torch.float32),
-                                                      ptr(t_new.contiguous(), torch.float32), ptr(aa.contiguous(), torch.int64),
-                                                      ptr(chain_nb.contiguous(), torch.int64), ptr(res_nb.contiguous(), torch.int64),
-                                                      ptr(mask_atoms.contiguous(), torch.bool), ptr(mask_recons.contiguous(), torch.bool),
+    pos_ctx, R_new, t_new, aa, chain_nb, res_nb, mask_atoms, mask_recons = _contig(pos_ctx, R_new, t_new, aa, chain_nb, res_nb, mask_atoms, mask_recons)
+    _check(lib().abopt_reconstruct_backbone_partially(ptr(pos_ctx, torch.float32), ptr(R_new, torch.float32),
+                                                      ptr(t_new, torch.float32), ptr(aa, torch.int64),
+                                                      ptr(chain_nb, torch.int64), ptr(res_nb, torch.int64),
+                                                      ptr(mask_atoms, torch.bool), ptr(mask_recons, torch.bool),
                                                       ptr(bb), ptr(ot), ptr(pos_new), ptr(mask_new), N, L, A, stream()))
     return pos_new, mask_new
 

@@ -100,7 +100,8 @@ class _DiffabBase(nn.Module):
             batch['generate_flag'] = mask_generate
         mask_res = batch['mask']
         res_feat, pair_feat, R_0, p_0 = self.encode(batch, remove_structure=g('train_structure', True), remove_sequence=g('train_sequence', True))
-        v_0 = hip.so3_log(R_0.detach(), grad_mode=True)          # frames come from input coordinates: no gradient flows here
+        v_0 = hip.so3_log(R_0.detach(), grad_mode=torch.is_grad_enabled())     # frames come from input coordinates: no gradient flows here;
+        # the clamp follows autograd state like the reference's log_rotation (so3.py:12-16): validation runs under no_grad
         return self.diffusion(v_0, p_0, batch['aa'], res_feat, pair_feat, mask_generate, mask_res,
                               denoise_structure=g('train_structure', True), denoise_sequence=g('train_sequence', True))
 

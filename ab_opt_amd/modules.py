@@ -95,6 +95,9 @@ class GABlock(nn.Module):
         self._pack = (snap, t, s)
         return t, s
 
+    def invalidate_packed(self):
+        self._pack = None
+
     @torch.no_grad()
     def forward(self, R, t, x, z, mask, return_parts=False):
         """(N,L,3,3), (N,L,3), (N,L,F), (N,L,L,C), (N,L) bool -> (N,L,F)   [ga.py:149-178]"""
@@ -180,6 +183,20 @@ class EpsilonNet(nn.Module):
         if no_bins is not None:
             self.prmsd_predictor = PerResidueRMSDCaPredictor(no_bins, F + 3, F)
         self._pack = None
+        # packed (kernel-layout) weight copies are keyed on (data_ptr, _version, device) of their sources; writes that bypass the
+        # version counter (`p.data.copy_(ema)`) are invisible to that key, so the usual entry points drop the packs outright
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+
+    def invalidate_packed(self):
+        """Forget the kernel-layout weight copies (rebuilt at the next call).  Call after writing parameters through `.data`
+        (EMA swaps); `load_state_dict`, `train()` and `eval()` call it for you."""
+        self._pack = None
+        for b in self.encoder.blocks:
+            b.invalidate_packed()
+
+    def train(self, mode=True):
+        self.invalidate_packed()
+        return super().train(mode)
 
     def _sources(self):
         ps = [p for n, p in self.named_parameters() if not n.startswith('encoder.')]

@@ -69,8 +69,13 @@ def sample_sharded(model, batch, sample_opt, k=1, group=None, seed=None):
     opt.setdefault('rng_offset', a * batch['aa'].shape[1])      # distinct Philox counters per global sample index
     if seed is not None:
         opt['seed'] = seed
-    traj = model.sample(sub, sample_opt=opt)
-    cand = candidates_from_positions(traj[0][1], sub['generate_flag'])
+    n_gen = int(batch['generate_flag'][0].sum()) if n > 0 else 0
+    if b > a:
+        traj = model.sample(sub, sample_opt=opt)
+        cand = candidates_from_positions(traj[0][1], sub['generate_flag'])
+    else:                                   # more ranks than samples: nothing to denoise here, but every rank still joins the gather
+        traj = {}
+        cand = batch['pos_heavyatom'].new_zeros((0, n_gen, 3))
     if world > 1:
         counts = [shard_range(n, world, r)[1] - shard_range(n, world, r)[0] for r in range(world)]
         cand = all_gather_candidates(cand, counts, group)

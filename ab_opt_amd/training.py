@@ -38,8 +38,11 @@ def so3_exp(w):
     return eye + b[..., None, None] * S + c[..., None, None] * (S @ S)
 
 
-def so3_log(R, min_cos=-0.999):
-    """rotation_to_so3vec under autograd: the reference clamps the cosine at -0.999 when grad is enabled (so3.py:12-16)."""
+def so3_log(R, min_cos=None):
+    """rotation_to_so3vec: the reference clamps the cosine at -0.999 when grad is enabled, at -1.0 under no_grad, e.g. in its
+    validation passes (so3.py:12-16)."""
+    if min_cos is None:
+        min_cos = -0.999 if torch.is_grad_enabled() else -1.0
     tr = R[..., 0, 0] + R[..., 1, 1] + R[..., 2, 2]
     ct = ((tr - 1) / 2).clamp_min(min_cos)
     st = torch.sqrt(1 - ct ** 2)
@@ -206,7 +209,7 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
     with torch.no_grad():                       # noising has no learnable parameters; native kernel (transition.py:62-78,120-144,179-200)
         v_n, p_n_ang, s_n, eps_p = hip.add_noise(t, vs.alpha_bars, dpm.trans_rot.angular_distrib_fwd, noise, seed, 0,
                                                  v_0.detach().float(), p_0.detach().float(), s_0, mask_generate, h['scale'], h['mean'],
-                                                 noise_structure=denoise_structure, noise_sequence=denoise_sequence, grad_mode=True, want_eps=True)
+                                                 noise_structure=denoise_structure, noise_sequence=denoise_sequence, grad_mode=torch.is_grad_enabled(), want_eps=True)
     p0n = dpm._normalize_position(p_0)
     p_n = dpm._normalize_position(p_n_ang)
     R_0 = so3_exp(v_0)

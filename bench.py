@@ -13,6 +13,10 @@ region; encode() and PDB I/O are outside the metric.  val
 Samples are independent, so ranks share nothing during the loop (weak scaling, 32 samples per GPU); the only
 exchange is the candidate all_gather of the batched-sampling reduction after the last step, which is inside the
 timed region at N>1.
+
+Roofline accounting: the dominant kernel is the IPA core; its ALGORITHMIC bytes
+per launch are N*(256*L^2 + 1076*L) (pair features once + node features in/out + frames/mask), its duration is measured
+live with HIP events recorded on the launch stream around every launch inside the timed region.
 """
 import argparse
 import json
@@ -27,24 +31,49 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy ceiling)
-# HBM bytes per ipa_core launch from the PMC counters (separate rocprofv3 --pmc passes on this command, FETCH_SIZE doubled per
-# the gfx950 correction): profiles/r01_g_pmc_ipa_core.txt.  745 MB read + 60 MB written; 142 MB above the algorithmic
-# bytes = the per-call pair-bias cache stream that replaces the in-kernel pair-bias contraction.
-MEASURED_TRAFFIC = {(32, 256): 363911.5 * 1024 * 2 + 58368.1 * 1024}
+FP32_PEAK_TFLOPS = 157.3   # fp32 vector == fp32 MFMA peak (same guide)
+NUM_LAYERS = 6
+# HBM bytes per ipa_core launch from the PMC counters of the committed profile (separate rocprofv3 --pmc passes on this
+# command; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md section HBM).  A constant from that profile,
+# not something this run measured: `traffic_source` names the file.
+MEASURED_TRAFFIC = {}
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'ipa_core_traffic.json')
+if os.path.exists(TRAFFIC_JSON):
+    with open(TRAFFIC_JSON) as fh:
+        for rec in json.load(fh):
+            MEASURED_TRAFFIC[(rec['N'], rec['L'])] = (rec['bytes_per_launch'], rec['source'])
 
 
-def ipa_core_bytes(N, L, C=64):
-    """Algorithmic HBM bytes of ONE launch of the IPA-core kernel (DESIGN.md 'Roofline accounting'):
-    z once + node projections in (2016 floats/residue) + features out (1824) + frames/mask (52 B)."""
+def ipa_algorithmic_bytes(N, L):
+    """per sample-layer 4*C*L^2 (z once) + 2*4*F*L (x in/out) + 52*L (R, t, mask) = 256 L^2 + 1076 L."""
+    return N * (256 * L * L + 1076 * L)
+
+
+def ipa_kernel_io_bytes(N, L, C=64):
+    """What the IPA-core KERNEL itself must move (its own operands, not the survey's per-layer figure): z once + node
+    projections in (2016 floats/residue) + features out (1824) + frames/mask (52 B).  Reported next to the survey figure."""
     return N * (4 * C * L * L + (2016 * 4 + 1824 * 4 + 52) * L)
 
 
-def build_workload(dev, N, L, T, seed):
-    from conftest import AttrDict
-    import cases
+def step_algorithmic_bytes(N, L):
+    """6*N*(256 L^2 + 1076 L) + 13.0e6 (weights once per step)."""
+    return NUM_LAYERS * ipa_algorithmic_bytes(N, L) + 13.0e6
+
+
+def step_flops(N, L):
+    """per sample-layer node GEMMs (2*L*128*(2016+128*3) + 2*L*1824*128) + pairwise terms
+    2*L^2*12*(64 + 32 + 24 + 64 + 32 + 24) + softmax ~ 4 flops per logit; + mixer/heads ~0.09 GF per sample."""
+    node = 2 * L * 128 * (2016 + 3 * 128) + 2 * L * 1824 * 128
+    pair = 2 * L * L * 12 * (64 + 32 + 24 + 64 + 32 + 24) + 4 * L * L * 12
+    return N * (NUM_LAYERS * (node + pair) + 0.09e9 * L / 256)
+
+
+def build_workload(dev, N, L, T, seed, abdesign=True):
+    import cases  # noqa: F401
     from ab_opt_amd.dpm import FullDPM
     from ab_opt_amd.utils import synth
-    dpm = FullDPM(128, 64, num_steps=T, eps_net_opt=dict(num_layers=6), _abdesign=True).eval()
+    kw = dict(_abdesign=True) if abdesign else dict(obj='pred_x0', num_bins=40, dist_min=0.5, dist_max=19.5)
+    dpm = FullDPM(128, 64, num_steps=T, eps_net_opt=dict(num_layers=NUM_LAYERS), **kw).eval()
     synth.fill_module_(dpm, seed=2)
     dpm = dpm.to(dev)
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -61,17 +90,35 @@ def build_workload(dev, N, L, T, seed):
     return dpm, (v, p, s), res_feat, pair_feat, gen, mres
 
 
-def cpu_baseline(L, T, budget_s=45.0):
+def cpu_baseline(L, T, budget_s=45.0, check=None):
     """The oracle ('port' of the reference, test infrastructure) on the host cores: a bounded sample of the same
     workload.  Threads are capped at 32: the op mix is elementwise/bandwidth bound and slows down badly beyond that on
-    many-core hosts; `cores` reports the threads actually used."""
+    many-core hosts; `cores` reports the threads actually used.
+
+    `check` (optional): (dpm, t, state, res_feat, pair_feat, gen, mres, gpu_out, sample_ids) -- the oracle also recomputes
+    EpsilonNet for a few samples of the bench batch at the bench's first step and the caller's GPU outputs are compared with
+    it (the bench launch geometry, N % 8 == 0, is the one under test)."""
     from oracle import dpm as odpm
     from ab_opt_amd.dpm import FullDPM
     from ab_opt_amd.utils import synth
     import cases
     threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
-    m = FullDPM(128, 64, num_steps=10, eps_net_opt=dict(num_layers=6), _abdesign=True).eval()
+    out = {}
+    if check is not None:
+        dpm_gpu, t, state, res_feat, pair_feat, gen, mres, gpu_out, ids = check
+        sd = {k: v.detach().cpu() for k, v in dpm_gpu.state_dict().items()}
+        idx = torch.tensor(ids)
+        v, p, s = [a[idx.to(a.device)].cpu() for a in state]
+        beta = dpm_gpu.trans_pos.var_sched.betas[t].cpu().expand([len(ids)])
+        ref = odpm.eps_net(sd, 'eps_net.', v, (p - 0.0) / 10.0, s, res_feat[idx.to(res_feat.device)].cpu(), pair_feat[idx.to(pair_feat.device)].cpu(), beta,
+                           gen[idx.to(gen.device)].cpu(), mres[idx.to(mres.device)].cpu(), num_layers=NUM_LAYERS, prmsd_head=False, mode='mm')
+        errs = {}
+        for name, k in (('R_next', 1), ('eps_pos', 2), ('c', 3)):
+            errs[name] = float((gpu_out[name][idx.to(gpu_out[name].device)].cpu() - ref[k]).abs().max())
+        out['parity_first_step'] = dict(samples=list(ids), max_abs_err=errs, tol=5e-5, ok=all(e < 5e-5 for e in errs.values()))
+        assert out['parity_first_step']['ok'], out['parity_first_step']
+    m = FullDPM(128, 64, num_steps=10, eps_net_opt=dict(num_layers=NUM_LAYERS), _abdesign=True).eval()
     synth.fill_module_(m, seed=2)
     sch = odpm.variance_schedule(10)
     den = odpm.Denoiser(m.state_dict(), num_steps=10, variant='abdesign', pre='', mode='ref',
@@ -96,10 +143,67 @@ def cpu_baseline(L, T, budget_s=45.0):
         rate = N * done / (time.perf_counter() - t0)
         detail[f'{mode}_N{N}'] = round(rate, 3)
         best = max(best, rate)
-    return dict(value=round(best, 3), unit='sample-steps/s', cores=threads, kind='port',
-                sample=f'oracle Denoiser.step (EpsilonNet + transitions) at L={L}, {threads} threads: N=1 with matmul contractions, '
-                       f'N=1 in the reference op order, N=4 with matmul contractions (a few steps each, {budget_s:.0f}s budget); '
-                       f'best rate reported; per-variant: {detail}')
+    out.update(value=round(best, 3), unit='sample-steps/s', cores=threads, kind='port',
+               sample=f'oracle Denoiser.step (EpsilonNet + transitions) at L={L}, {threads} threads: N=1 with matmul contractions, '
+                      f'N=1 in the reference op order, N=4 with matmul contractions (a few steps each, {budget_s:.0f}s budget); '
+                      f'best rate reported; per-variant: {detail}')
+    return out
+
+
+def secondary_measurements(dev, L):
+    """The other BASELINE.json configs that fit one GPU, each as a single number so the driver's record carries them
+    (they are not the headline metric):
+      train_step_ms               config 5: AbDesign flavour model(batch) -> losses -> backward -> Adam, N=16, L=256
+      sample_e2e_ms               config 2 end to end: model.sample(batch) incl. encode(), the pair-bias cache and the trajectory hand-over, N=32
+      config3_sample_steps_per_s  config 3: AbDock pose sampling (prmsd head, pred_x0, sample_sequence=False), N=64, the sampling loop alone"""
+    from conftest import build_model
+    from ab_opt_amd.utils.synth import make_batch, LAYOUT_256, LAYOUT_128
+    layout = LAYOUT_256 if L == 256 else LAYOUT_128
+    res = {}
+    # ---- config 2 end to end
+    model = build_model(100, 7, flavour='abdesign', device=dev).eval()
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(32, layout).items()}
+    opt = {'sample_structure': True, 'sample_sequence': True, 'contig': ''}
+    model.sample(dict(batch), dict(opt))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    model.sample(dict(batch), dict(opt))
+    torch.cuda.synchronize()
+    res['sample_e2e_ms'] = round((time.perf_counter() - t0) * 1e3, 2)
+    res['sample_e2e_config'] = f'model.sample, AbDesign flavour, N=32, L={L}, T=100, encode + cache + 100 steps + D2H of the trajectory'
+    # ---- config 5 training step
+    model.train()
+    tb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(16, layout).items()}
+    adam = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+    def step():
+        adam.zero_grad(set_to_none=True)
+        loss = sum(model(dict(tb)).values())
+        loss.backward()
+        adam.step()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    iters = 5
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    res['train_step_ms'] = round((time.perf_counter() - t0) / iters * 1e3, 2)
+    res['train_step_config'] = f'AbDesign flavour model(batch) fwd + bwd + Adam, N=16, L={L} (encode() inside, as train.py runs it)'
+    model.zero_grad(set_to_none=True)
+    model.eval()
+    del adam, tb
+    torch.cuda.empty_cache()
+    # ---- config 3: AbDock poses
+    N3, T, K3 = 64, 100, 20
+    dpm, state, res_feat, pair_feat, gen, mres = build_workload(dev, N3, L, T, seed=77, abdesign=False)
+    run = lambda n: dpm._run(state, T, res_feat, pair_feat, gen, mres, True, False, True, None, 99, 0, False, stop_after=n)
+    run(3)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    run(K3)
+    torch.cuda.synchronize()
+    res['config3_sample_steps_per_s'] = round(N3 * K3 / (time.perf_counter() - t0), 1)
+    res['config3_config'] = f'AbDock dock_single model block (prmsd head, pred_x0), structure-only sampling, N={N3} poses, L={L}, {K3} timed steps'
+    return res
 
 
 def log(*a):
@@ -117,6 +221,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='samples per GPU')
     ap.add_argument('--length', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip train_step_ms / sample_e2e_ms / config3 (N=1 only)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -140,6 +245,13 @@ def main():
     log('workload ready')
     run = lambda n: dpm._run(state, T, res_feat, pair_feat, gen, mres, True, True, True, None, 1234 + rank, rank * N * L, False, stop_after=n)
 
+    # the network outputs of the first step (same launch geometry as the timed steps), kept for the oracle check below
+    first = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        beta = dpm.trans_pos.var_sched.betas[T].expand([N]).contiguous()
+        first = hip.eps_net_forward(dpm.eps_net.packed(), state[0], state[1] / 10.0, state[2], res_feat, pair_feat, beta, gen, mres, False, 0, False,
+                                    pair_bias_cache=hip.pair_bias_cache(dpm.eps_net.encoder.packed_array(), NUM_LAYERS, pair_feat))
+        first = {k: (v.clone() if v is not None else None) for k, v in first.items()}
     if W > 0:
         run(W)
     torch.cuda.synchronize()
@@ -171,21 +283,38 @@ def main():
         dt = float(tmax.item())
     if rank == 0:
         per_launch_ms = ipa_ms / max(launches, 1)
-        ach = ipa_core_bytes(N, L) / (per_launch_ms * 1e-3) / 1e9 if launches else 0.0
+        alg = ipa_algorithmic_bytes(N, L)
+        ach = alg / (per_launch_ms * 1e-3) / 1e9 if launches else 0.0
+        step_s = dt / K
+        traffic, traffic_src = MEASURED_TRAFFIC.get((N, L), (None, None))
         line = {
             'metric': 'denoising steps/sec (256-res complex, 100-step sampler)', 'value': round(world * N * K / dt, 2),
-            'unit': 'sample-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(dt / K * 1e3, 4),
+            'unit': 'sample-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(step_s * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'AbDesign codesign_single model block (F=128, C=64, 6 IPA layers, T=100), L={L}, 6 CDR segments, '
                                    f'batch {N} per GPU, distinct pair features per sample, device Philox RNG',
                        'samples_per_gpu': N, 'residues': L, 'sampler_steps': T, 'parallelism': f'independent samples x{world}'},
             'roofline': {'bound': 'hbm', 'kernel': 'ipa_core', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': MEASURED_TRAFFIC.get((N, L)), 'launches': launches,
-                         'avg_launch_ms': round(per_launch_ms, 4), 'algorithmic_bytes_per_launch': ipa_core_bytes(N, L)},
+                         'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src, 'launches': launches,
+                         'avg_launch_ms': round(per_launch_ms, 4), 'algorithmic_bytes_per_launch': alg,
+                         'algorithmic_bytes_formula': 'N*(256*L^2 + 1076*L)  [SURVEY 8(d)]',
+                         'kernel_io_bytes_per_launch': ipa_kernel_io_bytes(N, L),
+                         'kernel_io_frac': round(ipa_kernel_io_bytes(N, L) / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if launches else 0.0,
+                         'step': {'algorithmic_bytes': step_algorithmic_bytes(N, L), 'hbm_frac': round(step_algorithmic_bytes(N, L) / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                                  'flops': step_flops(N, L), 'tflops': round(step_flops(N, L) / step_s / 1e12, 2),
+                                  'fp32_peak_tflops': FP32_PEAK_TFLOPS, 'flop_frac': round(step_flops(N, L) / step_s / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                  'ipa_core_share_of_step': round(per_launch_ms * launches / K / (step_s * 1e3), 4) if launches else None}},
         }
         if world == 1 and not args.no_cpu_baseline:
             log('cpu baseline on', os.cpu_count(), 'cores ...')
-            line['cpu_baseline'] = cpu_baseline(L, T)
+            check = (dpm, T, state, res_feat, pair_feat, gen, mres, first, [0, N // 2 + 1] if N > 2 else [0]) if first is not None else None
+            line['cpu_baseline'] = cpu_baseline(L, T, check=check)
+        if world == 1 and not args.no_secondary:
+            log('secondary configs ...')
+            try:
+                line['secondary'] = secondary_measurements(dev, L)
+            except Exception as e:           # never lose the headline line to a secondary measurement
+                line['secondary'] = {'error': repr(e)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 12
+#define ABOPT_ABI_VERSION 13
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -174,7 +174,9 @@ int abopt_sample_init(const float* v, const float* p, const int64_t* s, const ui
  * (:62-78), AminoacidCategoricalTransition.add_noise (:179-200); used by FullDPM.optimize (dpm_full.py:320-339) and by the
  * training loss (dpm_full.py:162-178).  t [N] is per sample; alpha_bars/fwd_* are the schedule buffers ([T+1], [T+1,bins]);
  * fwd_cdf [T+1,bins-1] only for the device-RNG path.  p_0 / p_noisy in Angstrom.  noise: reference draw order
- * randn(N,L,3) axis, multinomial bin, rand ubin, randn gauss | randn(N,L,3) pos | multinomial s_noisy; all NULL => Philox. */
+ * randn(N,L,3) axis, multinomial bin, rand ubin, randn gauss | randn(N,L,3) pos | multinomial s_noisy; all NULL => Philox.
+ * c_noisy (optional, [N,L,20]): the categorical c_t the sequence sample is drawn from (transition.py:196-198), whether or not
+ * the sample itself is injected. */
 typedef struct {
     const float* axis; const int64_t* bin; const float* ubin; const float* gauss;   /* rotation (so3.py:141-146) */
     const float* pos;                                                               /* e_rand (transition.py:75) */
@@ -186,7 +188,7 @@ int abopt_add_noise(const int64_t* t, const float* alpha_bars, const float* fwd_
                     const abopt_addnoise_noise* noise, uint64_t seed, uint64_t offset,
                     const float* v_0, const float* p_0, const int64_t* s_0, const uint8_t* mask_generate,
                     float position_scale, const float* position_mean, int noise_structure, int noise_sequence, int grad_mode,
-                    float* v_noisy, float* p_noisy, int64_t* s_noisy, float* eps_p, int N, int L, abopt_stream stream);
+                    float* v_noisy, float* p_noisy, int64_t* s_noisy, float* eps_p, float* c_noisy, int N, int L, abopt_stream stream);
 
 /* ---- Batched-sampling reduction: D/tools/runner/design_for_testset.py:556-589 (calc_per_rmsd +
  * rank_commoness score).  structs [B,n,3] -> score [B] = mean_{b'} RMSD(b,b') * B/(B-1). */

@@ -50,6 +50,7 @@ class Tape:
 
     def __init__(self):
         self.log = []
+        self.cat_probs = []        # inputs of every 20-class torch.multinomial call (the categorical the reference samples from)
 
     @contextlib.contextmanager
     def recording(self):
@@ -59,6 +60,8 @@ class Tape:
             def f(*a, **k):
                 out = orig[n](*a, **k)
                 self.log.append((n, out.clone()))
+                if n == 'multinomial' and a[0].shape[-1] == 20:
+                    self.cat_probs.append(a[0].detach().clone())
                 return out
             return f
         with contextlib.ExitStack() as st:
@@ -235,26 +238,6 @@ def case_trajectory():
     out.update(res_feat=rf, pair_feat_sub=pf[:, ::7, ::5], pair_feat_sum=pf.double().sum((1, 2)), R0=R0, p0=p0)
     save('trajectory_abdock_T10', **out)
 
-    # structure-only sampling (AbDock docking mode: sample_sequence=False), 4 steps worth is enough
-    torch.manual_seed(7)
-    tape = Tape()
-    with tape.recording():
-        traj = m.sample({k: v.clone() for k, v in batch.items()},
-                        sample_opt=dict(sample_structure=True, sample_sequence=False, contig=''))
-    n2 = {}
-    n2['init_q4'] = tape.pop('randn'); n2['init_p'] = tape.pop('randn_like')
-    for t in range(T, 0, -1):
-        n2[f't{t}_axis'] = tape.pop('randn')
-        n2[f't{t}_bin'] = tape.pop('multinomial').reshape(2, 128)
-        n2[f't{t}_ubin'] = tape.pop('rand_like').reshape(2, 128)
-        n2[f't{t}_gauss'] = tape.pop('randn_like').reshape(2, 128)
-        n2[f't{t}_z'] = tape.pop('randn_like')
-        n2[f't{t}_s_next'] = tape.pop('multinomial').reshape(2, 128)
-    for t in (T, 5, 0):
-        e = traj[t]
-        n2[f'traj{t}_v'], n2[f'traj{t}_p'], n2[f'traj{t}_s'] = e[0], e[1], e[2]
-    save('trajectory_abdock_T10_structonly', **n2)
-
     # optimize(): noise to step 4 then denoise
     torch.manual_seed(11)
     tape = Tape()
@@ -270,6 +253,65 @@ def case_trajectory():
         e = traj[t]
         o[f'traj{t}_v'], o[f'traj{t}_p'], o[f'traj{t}_s'] = e[0], e[1], e[2]
     save('optimize_abdock_T10_k4', **o)
+
+
+def case_structonly():
+    """BASELINE config 3 mode: AbDock pose diffusion, sample_sequence=False (structure-only), every step recorded."""
+    T = 10
+    m = abdock_model(T, seed=3)
+    batch = synth.make_batch(2, synth.LAYOUT_128, seed=2022, lengths=[128, 117])
+    torch.manual_seed(7)
+    tape = Tape()
+    with tape.recording():
+        traj = m.sample({k: v.clone() for k, v in batch.items()},
+                        sample_opt=dict(sample_structure=True, sample_sequence=False, contig=''))
+    n2 = {}
+    n2['init_q4'] = tape.pop('randn'); n2['init_p'] = tape.pop('randn_like')
+    for t in range(T, 0, -1):
+        n2[f't{t}_axis'] = tape.pop('randn')
+        n2[f't{t}_bin'] = tape.pop('multinomial').reshape(2, 128)
+        n2[f't{t}_ubin'] = tape.pop('rand_like').reshape(2, 128)
+        n2[f't{t}_gauss'] = tape.pop('randn_like').reshape(2, 128)
+        n2[f't{t}_z'] = tape.pop('randn_like')
+        n2[f't{t}_s_next'] = tape.pop('multinomial').reshape(2, 128)
+    for t in range(T, -1, -1):
+        e = traj[t]
+        n2[f'traj{t}_v'], n2[f'traj{t}_p'], n2[f'traj{t}_s'] = e[0], e[1], e[2]
+        if t < T:
+            n2[f'traj{t}_prmsd'], n2[f'traj{t}_ppl'] = e[3], e[4]
+    with torch.no_grad():      # sample_sequence=False keeps the sequence in encode() (diffab.py:128-131)
+        rf, pf, _, _ = m.encode({k: v.clone() for k, v in batch.items()}, True, False)
+    n2['res_feat'] = rf
+    save('trajectory_abdock_T10_structonly', **n2)
+
+
+def case_posterior():
+    """The categorical distributions the reference samples from (AminoacidCategoricalTransition._sample input = post + 1e-8,
+    transition.py:171-181,202-245): the 10 denoising posteriors of the config-1 trajectory and, for optimize(), the forward
+    categorical c_t of add_noise plus its 4 posteriors.  Same models / seeds as case_trajectory, so the runs are replayed and
+    asserted equal to the committed trajectories before anything is written."""
+    T = 10
+    m = abdock_model(T, seed=3)
+    batch = synth.make_batch(2, synth.LAYOUT_128, seed=2022, lengths=[128, 117])
+    old = np.load(os.path.join(HERE, 'trajectory_abdock_T10.npz'))
+    torch.manual_seed(2022)
+    tape = Tape()
+    with tape.recording():
+        traj = m.sample({k: v.clone() for k, v in batch.items()}, sample_opt=dict(sample_structure=True, sample_sequence=True, contig=''))
+    assert np.array_equal(traj[0][1].numpy(), old['traj0_p']) and np.array_equal(traj[3][2].numpy(), old['traj3_s'])
+    assert len(tape.cat_probs) == T
+    out = {f't{t}_probs': tape.cat_probs[T - t].reshape(2, 128, 20) for t in range(T, 0, -1)}
+    old = np.load(os.path.join(HERE, 'optimize_abdock_T10_k4.npz'))
+    torch.manual_seed(11)
+    tape = Tape()
+    with tape.recording():
+        traj = m.optimize({k: v.clone() for k, v in batch.items()}, 4, optimize_opt=dict(sample_structure=True, sample_sequence=True))
+    assert np.array_equal(traj[0][1].numpy(), old['traj0_p'])
+    assert len(tape.cat_probs) == 5
+    out['opt_addnoise_probs'] = tape.cat_probs[0].reshape(2, 128, 20)
+    for i, t in enumerate(range(4, 0, -1)):
+        out[f'opt_t{t}_probs'] = tape.cat_probs[1 + i].reshape(2, 128, 20)
+    save('posterior_abdock_T10', **out)
 
 
 def case_abdesign_sample():
@@ -392,8 +434,8 @@ if __name__ == '__main__':
     assert os.path.isdir(REF), 'reference mount not present: goldens can only be generated in the build container'
     sys.path.insert(0, os.path.join(REF, 'AbDock'))
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['so3', 'ga_block', 'eps_net', 'schedule_tables', 'trajectory', 'abdesign_sample',
-                             'training', 'encode', 'rank', 'reconstruct']
+    which = sys.argv[1:] or ['so3', 'ga_block', 'eps_net', 'schedule_tables', 'trajectory', 'structonly', 'abdesign_sample',
+                             'training', 'encode', 'rank', 'reconstruct', 'posterior']
     for w in which:
         print('==', w)
         globals()['case_' + w]()

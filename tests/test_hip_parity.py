@@ -734,3 +734,222 @@ def test_commonness_score_vs_reference():
     score = hip.commonness_score(dev(structs))
     assert torch.equal(torch.topk(score, 5, largest=False)[1].cpu(), g['rank'])
     assert abs(score.sum().item() / 16 - g['avg_rmsd'].item()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ categorical transition, pinned directly
+def _device_step_with_posterior(d, t, state, res_feat, pair_feat, gen, mres, noise_t, optimize_mode=False, sample_sequence=True):
+    """eps_net + abopt_denoise_step(want_post) for step t from `state` (v, p_angstrom, s); returns (post, out dict)."""
+    from ab_opt_amd import hip
+    N, L = mres.shape
+    h = d._sched_host()
+    p_norm = (state[1] - d.position_mean) / d.position_scale
+    beta = d.trans_pos.var_sched.betas[t].expand([N]).contiguous()
+    net = hip.eps_net_forward(d.eps_net.packed(), state[0], p_norm, state[2], res_feat, pair_feat, beta, gen, mres, d.abdock, d.num_bins, False)
+    sp = d._step_params(t, True, sample_sequence, not optimize_mode, optimize_mode)
+    out = dict(v=torch.empty(N, L, 3, device=DEV), p=torch.empty(N, L, 3, device=DEV), s=torch.empty(N, L, dtype=torch.int64, device=DEV),
+               prmsd=torch.empty(N, device=DEV), ppl=torch.empty(N, device=DEV))
+    inv = d.trans_rot.angular_distrib_inv
+    post = hip.denoise_step(sp, noise_t, 0, 0, state[0], state[1], state[2], net['v_next'], net['eps_pos'], net['c'], net['prmsd_logits'], gen,
+                            inv.X[t], None, d.num_bins, out, want_post=True)
+    return post, out
+
+
+def test_categorical_posterior_on_device_vs_reference():
+    """abopt_denoise_step's posterior (post_out) against the distribution the reference sampled from at every recorded step
+    (golden posterior_abdock_T10 = the input of AminoacidCategoricalTransition._sample, transition.py:171-181,202-245),
+    generated and context residues, padded rows included; same for optimize() and for add_noise's forward categorical.
+    The sequences in the trajectory fixtures are injected draws: THIS is the check that pins the sequence transition."""
+    from ab_opt_amd import hip
+    g, gp, go = load_golden('trajectory_abdock_T10'), load_golden('posterior_abdock_T10'), load_golden('optimize_abdock_T10_k4')
+    _, m, batch = _traj_setup()
+    d = m.diffusion
+    b = {k: dev(v) for k, v in batch.items()}
+    with torch.no_grad():
+        _, pf, _, _ = m.encode(dict(b), True, True)
+    rf, gen, mres = dev(g['res_feat']), b['generate_flag'], b['mask']
+    nz = noise_dict(g, 10)
+    worst = 0.0
+    for t in range(10, 0, -1):
+        state = (dev(g[f'traj{t}_v']), dev(g[f'traj{t}_p']), dev(g[f'traj{t}_s']))
+        post, out = _device_step_with_posterior(d, t, state, rf, pf, gen, mres, {k: dev(v) for k, v in nz[t].items()})
+        err = max_abs(post.cpu() + 1e-8, gp[f't{t}_probs'])
+        worst = max(worst, err)
+        assert err < 2e-6, (t, err)
+        genc = batch['generate_flag']
+        assert max_abs((post.cpu() + 1e-8)[genc], gp[f't{t}_probs'][genc]) < 2e-6 and genc.any()
+        assert torch.equal(post.cpu()[~genc], (gp[f't{t}_probs'] - 1e-8)[~genc].round())      # context / padding: the one-hot of s_t (all-zero for padding)
+    for t in range(4, 0, -1):                                                                  # optimize(): unmasked perplexity, net output as noise
+        state = (dev(go[f'traj{t}_v']), dev(go[f'traj{t}_p']), dev(go[f'traj{t}_s']))
+        noise_t = {k: dev(go[f't{t}_{k}']) for k in ('axis', 'bin', 'ubin', 'gauss', 'z', 's_next')}
+        post, _ = _device_step_with_posterior(d, t, state, rf, pf, gen, mres, noise_t, optimize_mode=True)
+        assert max_abs(post.cpu() + 1e-8, gp[f'opt_t{t}_probs']) < 2e-6, t
+    # forward categorical of add_noise (transition.py:183-200) at step 4, with and without injected draws
+    tt = torch.full([2], 4, dtype=torch.long, device=DEV)
+    v0 = hip.so3_log(dev(g['R0']), False)
+    init = dict(axis=dev(go['rot_axis']), bin=dev(go['rot_bin']), ubin=dev(go['rot_ubin']), gauss=dev(go['rot_gauss']), pos=dev(go['pos']), s_noisy=dev(go['s_noisy']))
+    for noise in (init, None):
+        *_, probs = hip.add_noise(tt, d.trans_pos.var_sched.alpha_bars, d.trans_rot.angular_distrib_fwd, noise, 5, 0, v0, dev(g['p0']), b['aa'], gen,
+                                  10.0, [0.0, 0.0, 0.0], want_probs=True)
+        assert max_abs(probs.cpu() + 1e-8, gp['opt_addnoise_probs']) < 1e-7
+    print('worst posterior error vs reference:', worst)
+
+
+def test_sequence_sampler_draws_from_the_posterior():
+    """Device RNG path: the sampled s_next follows post_out (the distribution pinned above) -- per-class chi-square over many
+    residues with a skewed posterior, generated residues only; context residues keep s_t exactly."""
+    from ab_opt_amd import hip
+    m = build_model(100, 2, device=DEV)
+    d = m.diffusion
+    N, L, t = 64, 256, 30
+    sp = d._step_params(t, True, True, True)
+    inv = d.trans_rot.angular_distrib_inv
+    z3 = torch.zeros(N, L, 3, device=DEV)
+    c_net = torch.softmax(dev(synth.hash_tensor((1, 1, 20), 9, scale=6.0)), -1).expand(N, L, 20).contiguous()     # one skewed prediction everywhere
+    s_t = torch.full((N, L), 7, dtype=torch.int64, device=DEV)
+    gen = torch.ones(N, L, dtype=torch.bool, device=DEV)
+    gen[:, ::5] = False
+    out = dict(v=torch.empty(N, L, 3, device=DEV), p=torch.empty(N, L, 3, device=DEV), s=torch.empty(N, L, dtype=torch.int64, device=DEV),
+               prmsd=torch.empty(N, device=DEV), ppl=torch.empty(N, device=DEV))
+    post = hip.denoise_step(sp, None, 99, 0, z3, z3, s_t, z3, z3, c_net, torch.zeros(N, 40, device=DEV), gen, inv.X[t], inv.cdf()[t], 40, out, want_post=True)
+    assert torch.equal(out['s'][~gen], s_t[~gen])
+    pg = post[gen][0].cpu().double()                                  # identical posterior for every generated residue
+    n = int(gen.sum())
+    freq = torch.zeros(20, dtype=torch.float64).scatter_add_(0, out['s'][gen].cpu(), torch.ones(n, dtype=torch.float64))
+    exp = pg * n
+    keep = exp > 10
+    chi2 = (((freq - exp) ** 2 / exp)[keep]).sum().item()
+    assert chi2 < 3 * int(keep.sum()), (chi2, int(keep.sum()))
+    assert freq[~keep].sum() <= 10 * (~keep).sum() + 20
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 3 mode, every step
+def test_structure_only_steps_teacher_forced_vs_reference():
+    """AbDock pose diffusion (sample_sequence=False, obj=pred_x0): every one of the 10 recorded reference steps, state reset to
+    the reference's each step (golden trajectory_abdock_T10_structonly, all steps)."""
+    from oracle import dpm, geometry as G
+    g = load_golden('trajectory_abdock_T10_structonly')
+    m_cpu, m, batch = _traj_setup()
+    d = m.diffusion
+    b = {k: dev(v) for k, v in batch.items()}
+    with torch.no_grad():
+        rf, pf, _, _ = m.encode(dict(b), True, False)                       # remove_sequence=False in this mode (diffab.py:128-131)
+    assert max_abs(rf.cpu(), g['res_feat']) < 2e-4 * g['res_feat'].abs().max().item()
+    rf = dev(g['res_feat'])
+    gen, mres = b['generate_flag'], b['mask']
+    nz = noise_dict(g, 10)
+    inv = m_cpu.diffusion.trans_rot.angular_distrib_inv
+    den = dpm.Denoiser(m_cpu.state_dict(), num_steps=10, variant='abdock', obj='pred_x0', mode='mm',
+                       tables=(None, dict(stddevs=inv.stddevs, approx_flag=inv.approx_flag, X=inv.X, Y=None)))
+    for t in range(10, 0, -1):
+        state = (dev(g[f'traj{t}_v']), dev(g[f'traj{t}_p']), dev(g[f'traj{t}_s']))
+        noise_t = {k: dev(v) for k, v in nz[t].items()}
+        tv, tp, ts, tpr, tpp = d._run(tuple(s.clone() for s in state), t, rf, pf, gen, mres, True, False, True, {t: noise_t}, 0, 0, False, stop_after=1)
+        e = dpm.so3_noise(den.tab_inv, torch.full((2, 128), t), nz[t])
+        if t <= 1:
+            e = torch.zeros_like(e)
+        o = den._eps(g[f'traj{t}_v'], den.norm(g[f'traj{t}_p']), g[f'traj{t}_s'], g['res_feat'], pf.cpu(), den.sch['betas'][t].expand([2]),
+                     batch['generate_flag'], batch['mask'], False)
+        n, worst = rot_close(tv[t - 1].cpu(), g[f'traj{t - 1}_v'], G.so3_exp(e) @ G.so3_exp(o[0]), R_upstream=o[1])
+        assert n >= 230 and worst < 1.0, (t, n, worst)
+        assert max_abs(tp[t - 1].cpu(), g[f'traj{t - 1}_p']) < 1e-4, t
+        assert torch.equal(ts[t - 1].cpu(), g[f'traj{t}_s']) and torch.equal(ts[t - 1].cpu(), batch['aa'])      # s_next = s_t in this mode
+        assert max_abs(tpr[t - 1].cpu(), g[f'traj{t - 1}_prmsd']) < 1e-4, t
+        assert max_abs(tpp[t - 1].cpu(), g[f'traj{t - 1}_ppl']) < 1e-5, t       # perplexity comes from the posterior, not from the injected draw
+
+
+# ------------------------------------------------------------------------------------------ the launch geometry bench.py times
+def _rand_eps_inputs(N, L, lengths, seed, gen_ranges):
+    gtor = torch.Generator(device=DEV).manual_seed(seed)
+    r = lambda *shape, s=1.0: torch.randn(*shape, device=DEV, generator=gtor) * s
+    mres = dev(cases.mask_from_lengths(lengths, L))
+    gen = dev(cases.gen_from_ranges(N, L, gen_ranges)) & mres
+    s = torch.randint(0, 20, (N, L), device=DEV, generator=gtor)
+    s = torch.where(mres, s, torch.full_like(s, 21))
+    return r(N, L, 3, s=1.5), r(N, L, 3, s=2.0), s, r(N, L, 128), r(N, L, L, 64), gen, mres
+
+
+@pytest.mark.parametrize('N', [8, 32])
+def test_ga_block_bench_geometry_vs_oracle(N):
+    """GABlock at the batch sizes that switch on the XCD-aware block mapping (N % 8 == 0), L = 256 with ragged lengths,
+    against the oracle.  N = 32, L = 256 is the launch bench.py times; the oracle is run on a subset of the (independent)
+    samples at N = 32."""
+    from oracle import ipa, geometry as G
+    L = 256
+    blk = _block_on_device(seed=5)
+    sd = {k: v.cpu() for k, v in blk.state_dict().items()}
+    lengths = [256, 250, 256, 231, 256, 256, 17, 256] * (N // 8)
+    v, t, _, x, z, _, mask = _rand_eps_inputs(N, L, lengths, 1000 + N, [(25, 33)])
+    R = dev(G.so3_exp(v.cpu()))
+    out = blk(R, t, x, z, mask)
+    ids = list(range(8)) if N == 8 else [0, 6, 9, 17, 23, 31]
+    ix = torch.tensor(ids, device=DEV)
+    ref = ipa.ga_block(sd, '', R[ix].cpu(), t[ix].cpu(), x[ix].cpu(), z[ix].cpu(), mask[ix].cpu(), mode='mm')
+    assert max_abs(out[ix].cpu(), ref) < 3e-5
+
+
+@pytest.mark.parametrize('flavour,N', [('abdesign', 32), ('abdock', 64)])
+def test_eps_net_bench_geometry_vs_oracle(flavour, N):
+    """EpsilonNet through the SAMPLER's launch path (per-call pair-bias cache, N % 8 == 0) at the BASELINE config-2 shape
+    (AbDesign flavour, N=32, L=256) and the config-3 shape (AbDock flavour, N=64 poses, L=256), against the oracle on a subset of
+    the independent samples; then one full denoising step (transitions with injected draws) at the same shape."""
+    from ab_opt_amd import hip
+    from oracle import dpm, geometry as G
+    L, T, t = 256, 100, 63
+    if flavour == 'abdesign':
+        d_cpu = standalone_abdesign_dpm(T, 2)
+        d = standalone_abdesign_dpm(T, 2).to(DEV)
+        pre = ''
+    else:
+        d_cpu = build_model(T, 2).diffusion
+        d = build_model(T, 2, device=DEV).diffusion
+        pre = ''
+    sd = {k: v.cpu() for k, v in d_cpu.state_dict().items()}
+    lengths = ([256] * 5 + [243, 256, 200]) * (N // 8)
+    v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lengths, 2000 + N, [(25, 33), (51, 57), (94, 106), (133, 144), (159, 166), (198, 207)])
+    beta = d.trans_pos.var_sched.betas[t].expand([N]).contiguous()
+    pbc = hip.pair_bias_cache(d.eps_net.encoder.packed_array(), 6, pf)
+    net = hip.eps_net_forward(d.eps_net.packed(), v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc)
+    ids = [0, 5, N // 2 + 1, N - 1]
+    ix = torch.tensor(ids, device=DEV)
+    c = lambda a: a[ix].cpu()
+    inv = d_cpu.trans_rot.angular_distrib_inv
+    den = dpm.Denoiser(sd, num_steps=T, variant=flavour, obj='pred_x0', mode='mm', pre=pre,
+                       tables=(None, dict(stddevs=inv.stddevs, approx_flag=inv.approx_flag, X=inv.X, Y=None)))
+    ref = den._eps(c(v), c(p), c(s), c(rf), c(pf), c(beta), c(gen), c(mres), False)
+    assert max_abs(c(net['R_next']), ref[1]) < 3e-5
+    assert max_abs(c(net['eps_pos']), ref[2]) < 3e-5
+    assert max_abs(c(net['c']), ref[3]) < 1e-5
+    if d.abdock:
+        assert max_abs(c(net['prmsd_logits']), ref[4]) < 3e-5
+    # one whole step of the sampling loop at this shape, draws injected; config 3 runs structure-only
+    gtor = torch.Generator(device=DEV).manual_seed(7)
+    nz = dict(axis=torch.randn(N, L, 3, device=DEV, generator=gtor), bin=torch.randint(0, 8191, (N, L), device=DEV, generator=gtor),
+              ubin=torch.rand(N, L, device=DEV, generator=gtor), gauss=torch.randn(N, L, device=DEV, generator=gtor),
+              z=torch.randn(N, L, 3, device=DEV, generator=gtor), s_next=torch.randint(0, 20, (N, L), device=DEV, generator=gtor))
+    seq = flavour == 'abdesign'
+    tv, tp, ts, tpr, tpp = d._run((v.clone(), p * 10, s.clone()), t, rf, pf, gen, mres, True, seq, True, {t: nz}, 0, 0, False, stop_after=1)
+    v_n, p_n, s_n, ex = den.step(t, c(v), c(p * 10) / 10, c(s), c(rf), c(pf), c(gen), c(mres), {k: c(a) for k, a in nz.items()}, sample_sequence=seq)
+    assert max_abs(tp[t - 1][ix].cpu(), p_n * 10) < 1e-4
+    e = dpm.so3_noise(den.tab_inv, torch.full((len(ids), L), t), {k: c(a) for k, a in nz.items()})
+    n, worst = rot_close(tv[t - 1][ix].cpu(), v_n, G.so3_exp(e) @ G.so3_exp(ex['eps_out'][0]), R_upstream=ex['eps_out'][1])
+    assert n >= 0.9 * len(ids) * L and worst < 1.0, (n, worst)
+    assert torch.equal(ts[t - 1][ix].cpu(), s_n)
+    if d.abdock:
+        assert max_abs(tpr[t - 1][ix].cpu(), ex['prmsd']) < 1e-4 and max_abs(tpp[t - 1][ix].cpu(), ex['ppl']) < 1e-5
+
+
+def test_non_contiguous_inputs_keep_their_copies_alive():
+    """Sliced / transposed inputs: the binding makes contiguous copies that must outlive the launch (two temporaries freed
+    early would alias in the caching allocator).  Results must equal the contiguous call bit for bit."""
+    blk = _block_on_device()
+    R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(2, 40, [40, 33], salt=900)]
+    base = blk(R, t, x, z, mask)
+    pad = lambda a: torch.stack([a, a + 1], dim=-1)[..., 0]                       # same values, non-contiguous view
+    assert not pad(t).is_contiguous()
+    assert torch.equal(blk(pad(R), pad(t), pad(x), z, mask), base)
+    m = build_model(100, 2, device=DEV)
+    args = [dev(a) for a in cases.eps_inputs(2, 40, [40, 33], [(5, 14), (22, 30)])]
+    ref = m.diffusion.eps_net(*args)
+    args2 = [pad(a) if a.dtype == torch.float32 and a.dim() >= 2 and a.dim() < 4 else a for a in args]
+    got = m.diffusion.eps_net(*args2)
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))

@@ -180,10 +180,13 @@ def test_trajectory_structure_only_and_optimize():
     # sample_sequence=False => encode keeps the sequence (remove_sequence=False)
     rf2, pf2, _, _ = embed.encode(sd, batch, True, False)
     traj = den.sample(G.so3_log(R0), p0, batch['aa'], rf2, pf2, batch['generate_flag'], batch['mask'], nz, sample_sequence=False)
-    for t in (10, 5, 0):
-        assert max_abs(G.so3_exp(traj[t][0]), G.so3_exp(g[f'traj{t}_v'])) < 1e-6
-        assert max_abs(traj[t][1], g[f'traj{t}_p']) < 1e-6
-        assert torch.equal(traj[t][2], g[f'traj{t}_s'])
+    assert max_abs(rf2, g['res_feat']) < 2e-5
+    for t in range(10, -1, -1):                   # every step of the structure-only run (BASELINE config 3 mode)
+        assert max_abs(G.so3_exp(traj[t][0]), G.so3_exp(g[f'traj{t}_v'])) < 1e-6, t
+        assert max_abs(traj[t][1], g[f'traj{t}_p']) < 1e-6, t
+        assert torch.equal(traj[t][2], g[f'traj{t}_s']), t
+        if t < 10:
+            assert max_abs(traj[t][3], g[f'traj{t}_prmsd']) < 1e-4 and max_abs(traj[t][4], g[f'traj{t}_ppl']) < 1e-5, t
     g = load_golden('optimize_abdock_T10_k4')
     init = den.optimize_init(G.so3_log(R0), p0, batch['aa'], batch['generate_flag'], 4,
                              dict(rot=dict(axis=g['rot_axis'], bin=g['rot_bin'], ubin=g['rot_ubin'], gauss=g['rot_gauss']),
@@ -191,6 +194,30 @@ def test_trajectory_structure_only_and_optimize():
     traj = den.sample(None, None, None, rf, pf, batch['generate_flag'], batch['mask'], noise_dict(g, 4, with_init=False),
                       t_start=4, init_state=init)
     _traj_check(traj, g, 4, False, tol_R=1e-6, tol_p=1e-6)
+
+
+def test_categorical_distributions_vs_reference():
+    """The categorical the reference SAMPLES from (input of AminoacidCategoricalTransition._sample, transition.py:171-181) at
+    every recorded step: denoising posterior (transition.py:202-245) from the reference's own states, and the forward
+    categorical of add_noise (transition.py:183-200).  The sampled sequences in the trajectory fixtures are injected draws, so
+    this is what pins the sequence transition."""
+    g = load_golden('trajectory_abdock_T10')
+    gp = load_golden('posterior_abdock_T10')
+    m = build_model(10, 3)
+    batch, sd, rf, pf, R0, p0 = _encode_traj_case(m)
+    gen, mres = batch['generate_flag'], batch['mask']
+    den = dpm.Denoiser(sd, num_steps=10, variant='abdock', obj='pred_x0', mode='ref')
+    nz = noise_dict(g, 10)
+    for t in (10, 7, 4, 1):
+        _, _, _, ex = den.step(t, g[f'traj{t}_v'], den.norm(g[f'traj{t}_p']), g[f'traj{t}_s'], rf, pf, gen, mres, nz[t])
+        assert max_abs(ex['post'] + 1e-8, gp[f't{t}_probs']) < 1e-7, t
+        assert ex['post'][gen].sum(-1).sub(1).abs().max() < 1e-5
+    go = load_golden('optimize_abdock_T10_k4')
+    tt = torch.full([2], 4, dtype=torch.long)
+    assert max_abs(dpm.seq_add_noise_probs(den.sch, batch['aa'], gen, tt) + 1e-8, gp['opt_addnoise_probs']) < 1e-7
+    _, _, _, ex = den.step(3, go['traj3_v'], den.norm(go['traj3_p']), go['traj3_s'], rf, pf, gen, mres,
+                           {k: go[f't3_{k}'] for k in ('axis', 'bin', 'ubin', 'gauss', 'z', 's_next')}, optimize_mode=True)
+    assert max_abs(ex['post'] + 1e-8, gp['opt_t3_probs']) < 1e-7
 
 
 def test_trajectory_abdesign_T10():
