@@ -31,13 +31,14 @@ struct Carver {
 constexpr int F = 128, FI = F + 4;
 constexpr int OUT_KSPLIT = 2;     // out_transform (K = 1824, N = 128) has only M/64 * 2 tiles: split K so it fills the chip
 
-struct GaScratch { float *proj, *feat, *u, *kvf; };
+struct GaScratch { float *proj, *feat, *u, *kvf, *qf; };
 static GaScratch carve_ga(Carver& cv, int64_t M, int N, int L) {
     GaScratch s;
     s.proj = cv.f((size_t)M * NP);
     s.feat = cv.f((size_t)M * ABOPT_IPA_FEAT);
     s.u = cv.f((size_t)M * F * OUT_KSPLIT);
     s.kvf = cv.f(ipa_kvfrag_floats(N, L));
+    s.qf = cv.f(ipa_qfrag_floats(N, L));
     return s;
 }
 
@@ -47,10 +48,10 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     int rc;
     // node projections: q|k|v|qp|kp|vp in one GEMM, then points to the global frame
     if ((rc = launch_linear(x, F, w->w_node, F, nullptr, s.proj, NP, (int)M, ABOPT_NODE_PROJ, F, false, st))) return rc;
-    if ((rc = launch_points_to_global(s.proj, R, t, M, st, s.kvf, N, L))) return rc;
+    if ((rc = launch_ipa_frags(s.proj, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st))) return rc;
     float* feat = (dbg && dbg->feat) ? dbg->feat : s.feat;
-    if ((rc = launch_ipa_core(s.proj, z, mask, R, t, w->w_pair_bias, w->spatial_coef, feat,
-                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, s.kvf, N, L, st, z_shared))) return rc;
+    if ((rc = launch_ipa_core(s.qf, s.kvf, z, mask, R, t, w->w_pair_bias, feat,
+                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, N, L, st, z_shared))) return rc;
     // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
     if ((rc = launch_linear(feat, ABOPT_IPA_FEAT, w->w_out, ABOPT_IPA_FEAT, nullptr, s.u, F, (int)M, F, ABOPT_IPA_FEAT, false, st,
                             OUT_KSPLIT, M * F))) return rc;
@@ -227,8 +228,6 @@ extern "C" int abopt_ga_block_forward(const abopt_ga_weights* w, const float* R,
     if (!cv.ok) { set_error("ga_block_forward: workspace too small (%zu bytes given)", ws_bytes); return ABOPT_EWORKSPACE; }
     return ga_block(w, R, t, x, z, mask, x_out, N, L, dbg, s, (hipStream_t)stream);
 }
-
-static size_t pair_bias_layer_floats(int N, int L) { return (size_t)N * L * ((L + JC - 1) / JC) * 256; }
 
 static int ga_encoder(const abopt_ga_weights* blocks, int num_layers, const float* R, const float* t, const float* x, const float* z,
                       const uint8_t* mask, float* x_out, int N, int L, const GaScratch& s, float* pong, hipStream_t st,

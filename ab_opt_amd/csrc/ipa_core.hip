@@ -1,0 +1,515 @@
+// IPA core for CDNA4 (gfx950): invariant point attention between the node projections and out_transform, fused in ONE pass
+// over the pair features z.  Reference semantics: AbDock/src/modules/encoders/ga.py
+//   _node_logits :81-86   _pair_logits :88-90   _spatial_logits :92-112   _alpha_from_logits :11-26
+//   _pair_aggregation :114-118   _node_aggregation :120-125   _spatial_aggregation :127-147
+// The reference materialises (N,L,L,12,{24,32,64}) temporaries; here z[n,i,:,:] is read from HBM exactly once per (n,i) and
+// everything else stays on chip.  All contractions are v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).
+//
+// One 1024-thread workgroup = 16 query residues of one sample; keys are consumed 16 at a time with an online softmax (any L).
+// The 16 waves (4 per SIMD, <= 128 VGPRs each) have three roles, pipelined one key chunk apart through a triple-buffered
+// S/P tile in LDS, one barrier per chunk:
+//
+//   8 "pair" waves  (2 query rows each)   chunk t  : stream z[i, chunk] through a 3-deep register ring, logits = (S + pair bias)
+//                                                    sqrt(1/3), mask, online softmax, pair aggregation  fp[c,h] += z[j,c] P[j,h]
+//                                                    (M = channel, N = head, K = key); P back to LDS in place of S
+//   4 "A" waves     (3 heads each)        chunk t+1: S^T[j,i] = k'_j . q'_i  -- ONE 15-step MFMA chain per head: the operands are
+//                                                    augmented so that q.k/sqrt(D), the point cross term and both squared norms
+//                                                    of  -gamma sqrt(2/(9P))/2 |q_pts - k_pts|^2  are K-slices of the same product
+//                                                    (no epilogue arithmetic); adds the cached pair bias; writes S as 16-byte rows
+//   4 "C" waves     (3 heads each)        chunk t-1: fn[d,i] += v[j,d] P[i,j], pts[e,i] += v_pts[j,e] P[i,j]  (M = channel, N = query)
+//
+// Each SIMD hosts 2 pair waves + 1 A + 1 C wave: four independent instruction streams share its matrix pipe (157 MFMAs per
+// chunk per SIMD), so the pipe stays fed while individual waves wait for HBM (pair waves) or L2 (A / C waves).
+// Operands arrive pre-arranged in MFMA fragment order (ipa.hip: ipa_frags_kernel): every global load of the A / C waves and
+// every LDS access of the S/P tile is a conflict-free, fully coalesced 16 bytes per lane.
+#include "ipa_common.h"
+#include "kernels.h"
+
+// Developer ablations (never in the shipped build): make CXXEXTRA=-DCORE_ABL=<bits>.  bit 0: pair waves load z only once;
+// bit 1: A/C waves load their fragments only once; bit 2: pair waves skip the aggregation MFMAs; bit 3: A waves skip their MFMAs;
+// bit 4: C waves skip their MFMAs; bit 5: pair waves skip the softmax arithmetic.  Results are wrong by construction.
+#ifndef CORE_ABL
+#define CORE_ABL 0
+#endif
+
+#ifdef CORE_TIMING   // developer build (make CXXEXTRA=-DCORE_TIMING): s_memtime section timers of one workgroup, printed by the launcher
+#include <cstdio>
+#define TSTAMP(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
+#define TSYNC(kw, kb) { TSTAMP(kw) __syncthreads(); TSTAMP(kb) }
+__device__ long long g_core_timing[3][8];
+#else
+#define TSTAMP(k)
+#define TSYNC(kw, kb) __syncthreads();
+#endif
+
+namespace abopt {
+
+constexpr int NPW = 8, RPW = BI / NPW;          // pair waves, query rows per pair wave
+constexpr int NTH = 1024;
+constexpr int SROW = 16 * JC + 4;               // one query row of the S/P tile: [16 head slots][16 keys] + 4 (rows 4 banks apart)
+constexpr int SCLD = 17;                        // row stride of the per-(row, head) scalars
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kSqrt13 = 0.5773502691896258f;   // sqrt(1/3), ga.py:165
+constexpr float kScale2 = kSqrt13 * kLog2e;            // logits are kept in base-2 units: p = exp2(l2 - m2)
+constexpr float kMask2 = 1e5f * kLog2e;           // the reference's additive -1e5 on masked pairs (ga.py:20-23), same units
+
+// position of key group kq (keys 4 kq .. 4 kq + 3) inside head h's 16-key row of the S/P tile.  The rotation by h >> 1 makes the
+// pair waves' 16-byte reads AND writes (lane = (head, key group)) bank-conflict free; see DESIGN.md section 3.1.
+__device__ __forceinline__ int sp_off(int h, int kq) { return h * JC + 4 * ((kq + (h >> 1)) & 3); }
+
+struct CoreLds {
+    float* sp;      // [3][BI][SROW]
+    f32x4* qf;      // [H][4][64]        query-side operands of the block, fragment order
+    float* scl;     // [2][BI][SCLD]     rescale factor of the chunk (by chunk parity)
+    float* lsum;    // [BI][SCLD]        softmax denominators
+    float* zst;     // [NPW][JC][ZSLD]   in-kernel pair bias only: per-wave transpose tile
+    float* wbs;     // [16][C + 4]       in-kernel pair bias only: proj_pair_bias weights, rows 12..15 zero
+    uint8_t* mk;    // [nchunk * JC]     key mask of the sample, 0 past the end
+};
+template <bool CACHED>
+__host__ __device__ constexpr size_t core_lds_fixed_bytes() {
+    return sizeof(float) * (3 * BI * SROW + H * 4 * 64 * 4 + 2 * BI * SCLD + BI * SCLD + (CACHED ? 0 : NPW * JC * ZSLD + 16 * (C + 4)));
+}
+
+template <bool DBG, bool CACHED>
+__global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__ qfrag, const float* __restrict__ kvfrag, const float* __restrict__ z,
+                                                       const uint8_t* __restrict__ mask, const float* __restrict__ R, const float* __restrict__ t,
+                                                       const float* __restrict__ Wb, float* __restrict__ feat, float* __restrict__ dbg_logits,
+                                                       const float* __restrict__ pbc, int N, int L, int nib, int xcd_remap, int z_shared) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    CoreLds sm;
+    {
+        float* p = reinterpret_cast<float*>(smem_raw);
+        sm.sp = p; p += 3 * BI * SROW;
+        sm.qf = reinterpret_cast<f32x4*>(p); p += H * 4 * 64 * 4;
+        sm.scl = p; p += 2 * BI * SCLD;
+        sm.lsum = p; p += BI * SCLD;
+        sm.zst = p; if (!CACHED) p += NPW * JC * ZSLD;
+        sm.wbs = p; if (!CACHED) p += 16 * (C + 4);
+        sm.mk = reinterpret_cast<uint8_t*>(p);
+    }
+    int n, ib;
+    {   // all i-blocks of a sample on one XCD when N % 8 == 0 (blocks are dealt round-robin to the 8 XCDs): its key/value fragments stay
+        // in that XCD's L2.  Speed only, never correctness.
+        const int b = blockIdx.x;
+        if (xcd_remap) { const int xcd = b & 7, k = b >> 3; n = xcd + 8 * (k / nib); ib = k % nib; }
+        else { n = b / nib; ib = b % nib; }
+    }
+    const int tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunk = (L + JC - 1) / JC;
+    const int i0 = ib * BI;
+    const int64_t rowbase = (int64_t)n * L;
+    const int64_t zbase = z_shared ? 0 : rowbase;                      // z_shared: one pair_feat (and bias cache) for the whole batch
+    // Key chunks are visited in natural order by every query block of a sample: the 16 blocks then read the same 96 KB of key/value
+    // fragments at about the same time and all but the first hit in the XCD's L2.  (A per-block rotated order was measured: L2 hit
+    // rate of the fragments fell from ~90 % to ~25 %, FETCH_SIZE 0.75 -> 1.16 GB per launch, kernel 185 -> 199 us.)
+    const int c0 = (CORE_ABL & 512) ? ib % nchunk : 0;
+    auto chunk_of = [&](int it) { const int c = it + c0; return c < nchunk ? c : c - nchunk; };      // iteration -> key chunk
+#ifdef CORE_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();   // 0 prologue | 1 work | 2 barrier wait | 3 epilogue own | 4 F1/F2 waits | 5 common epilogue
+#endif
+
+    // ---------------------------------------------------------------- prologue (every role first puts its own global loads in flight)
+    auto fill_lds = [&]() {
+        const f32x4* qg = reinterpret_cast<const f32x4*>(qfrag) + ((int64_t)n * nib + ib) * (H * 4 * 64);
+#pragma unroll
+        for (int e = 0; e < H * 4 * 64 / NTH; ++e) sm.qf[e * NTH + tid] = qg[e * NTH + tid];
+        // (head slots 12..15 of the S/P tile are never written by the A waves: whatever they hold stays in MFMA columns / lanes
+        //  12..15 of the pair waves, which are never stored)
+        for (int e = tid; e < nchunk * JC; e += NTH) sm.mk[e] = (e < L) ? mask[rowbase + e] : 0;
+        if (!CACHED) {
+            for (int e = tid; e < 16 * (C / 4); e += NTH) {
+                const int h = e / (C / 4), c4 = e % (C / 4);
+                f32x4 w4v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (h < H) w4v = reinterpret_cast<const f32x4*>(Wb + h * C)[c4];
+                *reinterpret_cast<f32x4*>(&sm.wbs[h * (C + 4) + c4 * 4]) = w4v;
+            }
+        }
+    };
+
+    if (wave < NPW) {
+        // =========================================================================================== pair waves
+        const int il0 = wave * RPW;
+        const char* zrow[RPW];
+#pragma unroll
+        for (int ii = 0; ii < RPW; ++ii)
+            zrow[ii] = reinterpret_cast<const char*>(z + ((zbase + min(i0 + il0 + ii, L - 1)) * (int64_t)L) * C);
+        const unsigned lane_b = (unsigned)fm * 16u;
+        f32x4 ring[3][4];                                                // z ring: one row chunk per slot (4 x 16 B per lane), requests run 2 positions ahead
+        f32x4 ringb[3];                                                  // CACHED: the row chunk's pair bias, lane = (head fm, keys 4 kq ..): 768 contiguous bytes per wave load
+        const char* pbrow[RPW];                                          // wave-uniform row bases (SGPRs) + one per-lane byte offset
+#pragma unroll
+        for (int ii = 0; ii < RPW; ++ii)
+            pbrow[ii] = CACHED ? reinterpret_cast<const char*>(pbc + ((zbase + min(i0 + il0 + ii, L - 1)) * (int64_t)nchunk) * (H * JC)) : nullptr;
+        const unsigned pb_lane = (unsigned)(min(fm, H - 1) * JC + kq * 4) * 4u;
+#define PW_ISSUE(SLOT, II, CH)                                                                                          \
+    {                                                                                                                    \
+        const int ch_ = chunk_of(min((CH), nchunk - 1));                       /* past the end: harmless re-read */      \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                \
+            ring[SLOT][r_] = ZLOAD(reinterpret_cast<const f32x4*>(zrow[II] + ((unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b))); \
+        if (CACHED && !(CORE_ABL & 64)) ringb[SLOT] = ZLOAD(reinterpret_cast<const f32x4*>(pbrow[II] + ((unsigned)ch_ * (unsigned)(H * JC * 4) + pb_lane))); \
+    }
+// z and its bias cache are read once per launch: non-temporal loads (measured 182 -> 174 us per launch at N=32, L=256)
+#ifdef CORE_NO_NT
+#define ZLOAD(p) (*(p))
+#else
+#define ZLOAD(p) __builtin_nontemporal_load(p)
+#endif
+        PW_ISSUE(0, 0, 0) PW_ISSUE(1, 1, 0)
+        fill_lds();
+        float m_run[RPW], l_run[RPW];
+        f32x4 accP[RPW][4];
+#pragma unroll
+        for (int ii = 0; ii < RPW; ++ii) {
+            m_run[ii] = -INFINITY; l_run[ii] = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) accP[ii][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int spo = sp_off(fm, kq);
+        __syncthreads();                                                    // LDS tile visible
+        bool mi_b[RPW];
+#pragma unroll
+        for (int ii = 0; ii < RPW; ++ii) mi_b[ii] = (i0 + il0 + ii < L) && sm.mk[min(i0 + il0 + ii, L - 1)] != 0;
+        __syncthreads();                                                    // barrier #0: S(0) ready
+        TSTAMP(0)
+
+        // one (query row, chunk) position: ring slot SLOT holds its z; BUF = chunk % 3
+#define PW_POS(SLOT, II, CH, BUF)                                                                                        \
+    {                                                                                                                    \
+        if (!(CORE_ABL & 1)) PW_ISSUE(((SLOT) + 2) % 3, II, (CH) + 1)       /* two positions ahead = same row, next chunk */ \
+        const int il_ = il0 + (II);                                                                                      \
+        float* spp_ = sm.sp + ((BUF) * BI + il_) * SROW + spo;                                                           \
+        f32x4 sv_ = *reinterpret_cast<const f32x4*>(spp_);                                                               \
+        if (CACHED) sv_ += ringb[SLOT];                                                                                  \
+        if (!CACHED) {                                                      /* pair bias in place: z chunk transposed through a wave-private LDS tile */ \
+            float* zt_ = sm.zst + wave * (JC * ZSLD);                                                                    \
+            wave_lds_sync();                                                                                             \
+            _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) *reinterpret_cast<f32x4*>(&zt_[(kq * 4 + r_) * ZSLD + fm * 4]) = ring[SLOT][r_]; \
+            wave_lds_sync();                                                                                             \
+            f32x4 a4_[4];                                                                                                \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                           \
+                const f32x4 za_ = *reinterpret_cast<const f32x4*>(&zt_[fm * ZSLD + kq * 16 + q_ * 4]);                   \
+                const f32x4 wv_ = *reinterpret_cast<const f32x4*>(&sm.wbs[fm * (C + 4) + kq * 16 + q_ * 4]);            \
+                a4_[q_] = mfma4(za_[0], wv_[0], (f32x4){0.f, 0.f, 0.f, 0.f});                                            \
+                a4_[q_] = mfma4(za_[1], wv_[1], a4_[q_]); a4_[q_] = mfma4(za_[2], wv_[2], a4_[q_]); a4_[q_] = mfma4(za_[3], wv_[3], a4_[q_]); \
+            }                                                                                                            \
+            sv_ += (a4_[0] + a4_[1]) + (a4_[2] + a4_[3]);                                                                \
+        }                                                                                                                \
+        float l2_[4];                                                                                                    \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                               \
+            if (DBG) {                                                                                                   \
+                const int j_ = chunk_of(CH) * JC + kq * 4 + r_;                                                          \
+                if (j_ < L && fm < H && (i0 + il_) < L) dbg_logits[((rowbase + i0 + il_) * L + j_) * H + fm] = sv_[r_] * kSqrt13; \
+            }                                                                                                            \
+            const float x_ = sv_[r_] * kScale2;                                                                               \
+            l2_[r_] = ((mk4_ >> (8 * r_)) & 0xffu) ? x_ : x_ - kMask2;      /* ga.py:20-23 (masked QUERY rows are zeroed at the end instead) */ \
+        }                                                                                                                \
+        f32x4 pv_; float sc_;                                                                                            \
+        if (CORE_ABL & 32) { sc_ = 1.f; pv_ = (f32x4){l2_[0], l2_[1], l2_[2], l2_[3]}; l_run[II] += l2_[0]; }           \
+        else {                                                                                                           \
+        const float mx_ = rows_max(fmaxf(fmaxf(l2_[0], l2_[1]), fmaxf(l2_[2], l2_[3])));                                 \
+        const float mn_ = fmaxf(m_run[II], mx_);                                                                         \
+        sc_ = __builtin_amdgcn_exp2f(m_run[II] - mn_);                                                                   \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) pv_[r_] = __builtin_amdgcn_exp2f(l2_[r_] - mn_);                \
+        const float ps_ = rows_sum((pv_[0] + pv_[1]) + (pv_[2] + pv_[3]));                                               \
+        l_run[II] = l_run[II] * sc_ + ps_;                                                                               \
+        m_run[II] = mn_;                                                                                                 \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[II][mt_] *= sc_;                                        \
+        }                                                                                                                \
+        if (CORE_ABL & 4) { _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) accP[II][r_] += ring[SLOT][r_] * pv_[r_]; } \
+        else                                                                                                             \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                 \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[II][mt_] = mfma4(ring[SLOT][r_][mt_], pv_[r_], accP[II][mt_]); \
+        *reinterpret_cast<f32x4*>(spp_) = pv_;                                                                           \
+        if (kq == 0) sm.scl[(((CH) & 1) * BI + il_) * SCLD + fm] = sc_;                                                  \
+    }
+        // one chunk = positions (row 0, row 1); K = chunk index within the 3-chunk revolution of the ring
+#define PW_CHUNK(K, CH)                                                                                                  \
+    {                                                                                                                    \
+        const uint32_t mk4_ = *reinterpret_cast<const uint32_t*>(&sm.mk[chunk_of(CH) * JC + kq * 4]);                    \
+        PW_POS((2 * (K)) % 3, 0, CH, K)                                                                                  \
+        PW_POS((2 * (K) + 1) % 3, 1, CH, K)                                                                              \
+        TSYNC(1, 2)                                                         /* barrier #(CH + 1) */                       \
+    }
+        int ch = 0;
+        for (; ch + 3 <= nchunk; ch += 3) { PW_CHUNK(0, ch) PW_CHUNK(1, ch + 1) PW_CHUNK(2, ch + 2) }
+        if (ch < nchunk) {
+            PW_CHUNK(0, ch)
+            if (ch + 1 < nchunk) PW_CHUNK(1, ch + 1)
+        }
+        // alpha = P / l, zero for masked queries (ga.py:24-25); pair features out
+#pragma unroll
+        for (int ii = 0; ii < RPW; ++ii) {
+            const int il = il0 + ii, i = i0 + il;
+            if (kq == 0) sm.lsum[il * SCLD + fm] = l_run[ii];
+            if (i < L && fm < H) {
+                const float inv = mi_b[ii] ? 1.f / l_run[ii] : 0.f;
+                float* fo = feat + (rowbase + i) * FEAT + fm * C + kq * 16;        // accumulator row 4 kq + r of tile mt <-> channel 16 kq + 4 r + mt
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    reinterpret_cast<f32x4*>(fo)[r] = (f32x4){accP[ii][0][r] * inv, accP[ii][1][r] * inv, accP[ii][2][r] * inv, accP[ii][3][r] * inv};
+            }
+        }
+        TSYNC(3, 4)                                                         // F1: lsum visible, C waves done with the last chunk
+        TSYNC(3, 4)                                                         // F2: aggregated points in LDS
+    } else if (wave < NPW + 4) {
+        // =========================================================================================== A waves: S(t + 1)
+        const int h0 = (wave - NPW) * 3;
+        const f32x4* kvn = reinterpret_cast<const f32x4*>(kvfrag) + (int64_t)n * nchunk * H * 512;
+        f32x4 kf[3][4];
+        // per head: operands of the NEXT chunk are requested as soon as this chunk's MFMAs have consumed the registers, so every
+        // load has a whole chunk period to arrive (no conditional loads: the compiler keeps exact vmcnt counts)
+#define AW_ISSUE(HH, CH)                                                                                                 \
+    {                                                                                                                    \
+        const int c_ = chunk_of(min((CH), nchunk - 1));                                                                  \
+        const f32x4* fr_ = kvn + ((int64_t)c_ * H + h0 + (HH)) * 512 + lane;                                             \
+        if (!(CORE_ABL & 128)) { _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) kf[HH][s_] = fr_[s_ * 64]; }           \
+    }
+#define AW_ISSUE0(HH) { const f32x4* fr_ = kvn + ((int64_t)chunk_of(0) * H + h0 + (HH)) * 512 + lane;                   \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) kf[HH][s_] = fr_[s_ * 64]; }
+        auto produce = [&](int c, int buf) {                                // S(c) -> sp[buf], then request chunk c + 1
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) {
+                const int h = h0 + hh;
+                const f32x4* qh = sm.qf + (h * 4) * 64 + lane;
+                const f32x4 q0 = qh[0], q1 = qh[64], q2 = qh[128], q3 = qh[192];
+                // rows = keys (A operand k'), columns = queries (B operand q'); two chains hide the 40-cycle dependent-MFMA latency
+                f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                if (CORE_ABL & 8) { acc0 = kf[hh][0] * q0 + kf[hh][1] * q1; acc1 = kf[hh][2] * q2 + kf[hh][3] * q3; }
+                else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { acc0 = mfma4(kf[hh][0][s], q0[s], acc0); acc1 = mfma4(kf[hh][2][s], q2[s], acc1); }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { acc0 = mfma4(kf[hh][1][s], q1[s], acc0); if (s < 3) acc1 = mfma4(kf[hh][3][s], q3[s], acc1); }
+                }
+                const f32x4 sres = acc0 + acc1;
+                if (!(CORE_ABL & 2) && (!(CORE_ABL & 1024) || (c & 1))) { if (hh == 0) AW_ISSUE(0, c + 1) else if (hh == 1) AW_ISSUE(1, c + 1) else AW_ISSUE(2, c + 1) }
+                *reinterpret_cast<f32x4*>(sm.sp + (buf * BI + fm) * SROW + sp_off(h, kq)) = sres;      // accumulator row 4 kq + r = key, column fm = query
+                __builtin_amdgcn_sched_barrier(0);                          // keep the per-head order: hipcc otherwise sinks all reloads to the end of the iteration
+            }
+        };
+        AW_ISSUE0(0) AW_ISSUE0(1) AW_ISSUE0(2)
+        fill_lds();
+        __syncthreads();
+        produce(0, 0);
+        __syncthreads();                                                    // barrier #0
+        TSTAMP(0)
+        int buf = 1;
+        for (int c = 1; c < nchunk; ++c) {
+            produce(c, buf);
+            buf = (buf == 2) ? 0 : buf + 1;
+            TSYNC(1, 2)                                                     // barrier #c
+        }
+        TSYNC(1, 2)                                                         // barrier #nchunk
+        TSYNC(3, 4)                                                         // F1
+        TSYNC(3, 4)                                                         // F2
+    } else {
+        // =========================================================================================== C waves: node / point aggregation of chunk t - 1
+        const int h0 = (wave - NPW - 4) * 3;
+        const f32x4* kvn = reinterpret_cast<const f32x4*>(kvfrag) + (int64_t)n * nchunk * H * 512;
+        f32x4 vf[3][4];
+        f32x4 accV[3][2], accT[3][2];
+#pragma unroll
+        for (int hh = 0; hh < 3; ++hh)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { accV[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; accT[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#define CW_ISSUE(HH, CH)                                                                                                 \
+    {                                                                                                                    \
+        const f32x4* fr_ = kvn + ((int64_t)chunk_of(min((CH), nchunk - 1)) * H + h0 + (HH)) * 512 + 4 * 64 + lane;       \
+        if (!(CORE_ABL & 256)) { _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) vf[HH][s_] = fr_[s_ * 64]; }           \
+    }
+#define CW_ISSUE0(HH) { const f32x4* fr_ = kvn + ((int64_t)chunk_of(0) * H + h0 + (HH)) * 512 + 4 * 64 + lane;          \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) vf[HH][s_] = fr_[s_ * 64]; }
+        auto consume = [&](int c, int buf) {                                // P(c) in sp[buf]; then request chunk c + 1 (same per-head pipeline as the A waves)
+            const int par = c & 1;
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) {
+                const int h = h0 + hh;
+                const float sc = sm.scl[(par * BI + fm) * SCLD + h];                                   // rescale of (query fm, head h)
+                const f32x4 pa = *reinterpret_cast<const f32x4*>(sm.sp + (buf * BI + fm) * SROW + sp_off(h, kq));   // B: column = query fm, step s <-> key 4 kq + s
+                accV[hh][0] *= sc; accV[hh][1] *= sc; accT[hh][0] *= sc; accT[hh][1] *= sc;
+                if (CORE_ABL & 16) { accV[hh][0] += vf[hh][0] * pa; accV[hh][1] += vf[hh][1] * pa; accT[hh][0] += vf[hh][2] * pa; accT[hh][1] += vf[hh][3] * pa; }
+                else
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {                                                          // A: row fm <-> value channels 2 fm (+1) / point coordinates 2 fm (+1)
+                    accV[hh][0] = mfma4(vf[hh][s][0], pa[s], accV[hh][0]);
+                    accV[hh][1] = mfma4(vf[hh][s][1], pa[s], accV[hh][1]);
+                    accT[hh][0] = mfma4(vf[hh][s][2], pa[s], accT[hh][0]);
+                    accT[hh][1] = mfma4(vf[hh][s][3], pa[s], accT[hh][1]);
+                }
+                if (!(CORE_ABL & 2) && (!(CORE_ABL & 1024) || (c & 1))) { if (hh == 0) CW_ISSUE(0, c + 1) else if (hh == 1) CW_ISSUE(1, c + 1) else CW_ISSUE(2, c + 1) }
+                __builtin_amdgcn_sched_barrier(0);                          // keep the per-head order (see the A waves)
+            }
+        };
+        CW_ISSUE0(0) CW_ISSUE0(1) CW_ISSUE0(2)
+        fill_lds();
+        __syncthreads();
+        const bool mi_c = (i0 + fm < L) && sm.mk[min(i0 + fm, L - 1)] != 0;
+        __syncthreads();                                                    // barrier #0
+        TSTAMP(0)
+        TSYNC(1, 2)                                                         // barrier #1: P(0) ready
+        int buf = 0;                                                        // buffer of the chunk being consumed
+        for (int c = 1; c < nchunk; ++c) {
+            consume(c - 1, buf);
+            buf = (buf == 2) ? 0 : buf + 1;
+            TSYNC(1, 2)                                                     // barrier #(c + 1)
+        }
+        consume(nchunk - 1, buf);
+        TSYNC(3, 4)                                                         // F1
+        float* pts = sm.sp;                                                 // [BI][H][24] aggregated global-frame points; the S/P tile is free now
+        const int i = i0 + fm;
+#pragma unroll
+        for (int hh = 0; hh < 3; ++hh) {
+            const int h = h0 + hh;
+            const float inv = mi_c ? 1.f / sm.lsum[fm * SCLD + h] : 0.f;
+            // accumulator row 4 kq + r of tile k <-> channel 2 (4 kq + r) + k: a lane owns 8 consecutive channels of query fm
+            if (i < L) {
+                float* fo = feat + (rowbase + i) * FEAT + H * C + h * D + kq * 8;
+                reinterpret_cast<f32x4*>(fo)[0] = (f32x4){accV[hh][0][0] * inv, accV[hh][1][0] * inv, accV[hh][0][1] * inv, accV[hh][1][1] * inv};
+                reinterpret_cast<f32x4*>(fo)[1] = (f32x4){accV[hh][0][2] * inv, accV[hh][1][2] * inv, accV[hh][0][3] * inv, accV[hh][1][3] * inv};
+            }
+            if (kq < 3) {
+                float* po = pts + (fm * H + h) * (P * 3) + kq * 8;
+                reinterpret_cast<f32x4*>(po)[0] = (f32x4){accT[hh][0][0] * inv, accT[hh][1][0] * inv, accT[hh][0][1] * inv, accT[hh][1][1] * inv};
+                reinterpret_cast<f32x4*>(po)[1] = (f32x4){accT[hh][0][2] * inv, accT[hh][1][2] * inv, accT[hh][0][3] * inv, accT[hh][1][3] * inv};
+            }
+        }
+        TSYNC(3, 4)                                                         // F2
+    }
+
+    // ---------------------------------------------------------------- all waves: local frame, norm, direction of the aggregated points (ga.py:136-139)
+    // one thread per 4 consecutive points of a residue: 16-byte LDS reads and global stores
+    const float* pts = sm.sp;
+    for (int e = tid; e < BI * (H * P / 4); e += NTH) {
+        const int il = e / (H * P / 4), g = e % (H * P / 4), i = i0 + il;
+        if (i >= L) continue;
+        const float* Rr = R + (rowbase + i) * 9;
+        const float* tr = t + (rowbase + i) * 3;
+        const float r0 = Rr[0], r1 = Rr[1], r2 = Rr[2], r3 = Rr[3], r4 = Rr[4], r5 = Rr[5], r6 = Rr[6], r7 = Rr[7], r8 = Rr[8];
+        const float t0 = tr[0], t1 = tr[1], t2 = tr[2];
+        f32x4 a[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const f32x4*>(pts + (il * H * P + 4 * g) * 3 + 4 * q);
+        float loc[12], dir[12];
+        f32x4 dist;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dx = a[(3 * k) >> 2][(3 * k) & 3] - t0, dy = a[(3 * k + 1) >> 2][(3 * k + 1) & 3] - t1, dz = a[(3 * k + 2) >> 2][(3 * k + 2) & 3] - t2;
+            const float lx = r0 * dx + r3 * dy + r6 * dz;                // R^T (a - t), geometry.py:94-117
+            const float ly = r1 * dx + r4 * dy + r7 * dz;
+            const float lz = r2 * dx + r5 * dy + r8 * dz;
+            const float d = sqrtf(lx * lx + ly * ly + lz * lz);
+            const float inv = 1.f / (d + 1e-4f);                         // ga.py:138-139
+            loc[3 * k] = lx; loc[3 * k + 1] = ly; loc[3 * k + 2] = lz;
+            dir[3 * k] = lx * inv; dir[3 * k + 1] = ly * inv; dir[3 * k + 2] = lz * inv;
+            dist[k] = d;
+        }
+        float* fpnt = feat + (rowbase + i) * FEAT + H * C + H * D;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            reinterpret_cast<f32x4*>(fpnt + 12 * g)[q] = (f32x4){loc[4 * q], loc[4 * q + 1], loc[4 * q + 2], loc[4 * q + 3]};
+            reinterpret_cast<f32x4*>(fpnt + H * P * 3 + H * P + 12 * g)[q] = (f32x4){dir[4 * q], dir[4 * q + 1], dir[4 * q + 2], dir[4 * q + 3]};
+        }
+        *reinterpret_cast<f32x4*>(fpnt + H * P * 3 + 4 * g) = dist;
+    }
+#ifdef CORE_TIMING
+    TSTAMP(5)
+    if (blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == NPW || wave == NPW + 4))
+        for (int k = 0; k < 8; ++k) g_core_timing[wave == 0 ? 0 : (wave == NPW ? 1 : 2)][k] = tacc[k];
+#endif
+}
+
+// Pair-bias cache: lp[l][n,i,j,h] = z[n,i,j,:] . Wb_l[h,:] for every layer l in ONE pass over z (ga.py:88-90).  z and the weights do
+// not change during the 100 steps of FullDPM.sample, so the sampler builds this once per call and the per-step kernel reads 48
+// bytes per (i,j) instead of spending 64 more MFMAs per (row, chunk) and an LDS transpose on it.
+// Layout per layer: [N*L (query row)][nchunk][12 (head)][16 (key in chunk)] -- the float4 (head, 4 keys) an A wave adds to its
+// S tile.  Same MFMA chain order as the in-kernel path => bit-identical logits.
+struct WbList { const float* w[8]; };
+
+__global__ __launch_bounds__(256) void pair_bias_cache_kernel(const float* __restrict__ z, WbList wl, int num_layers, float* __restrict__ cache,
+                                                              int64_t rows, int L, int nchunk) {
+    __shared__ __attribute__((aligned(16))) float zst[4][JC][ZSLD];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fm = lane & 15, kq = lane >> 4;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + wave;                  // (query row, chunk)
+    if (unit >= rows * nchunk) return;
+    const int64_t row = unit / nchunk;
+    const int ch = (int)(unit % nchunk);
+    const float* zi = z + (row * (int64_t)L) * C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x4*>(&zst[wave][kq * 4 + r][fm * 4]) = *(reinterpret_cast<const f32x4*>(zi + (int64_t)min(ch * JC + kq * 4 + r, L - 1) * C) + fm);
+    wave_lds_sync();                                                      // cross-lane transpose through LDS
+    f32x4 za[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) za[q] = *reinterpret_cast<const f32x4*>(&zst[wave][fm][kq * 16 + q * 4]);
+    for (int l = 0; l < num_layers; ++l) {
+        f32x4 acc4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 wv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (fm < H) wv = reinterpret_cast<const f32x4*>(wl.w[l] + fm * C + kq * 16)[q];
+            acc4[q] = mfma4(za[q][0], wv[0], (f32x4){0.f, 0.f, 0.f, 0.f});
+            acc4[q] = mfma4(za[q][1], wv[1], acc4[q]); acc4[q] = mfma4(za[q][2], wv[2], acc4[q]); acc4[q] = mfma4(za[q][3], wv[3], acc4[q]);
+        }
+        const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);       // accumulator row 4 kq + r = key, column fm = head
+        if (fm < H) *reinterpret_cast<f32x4*>(cache + ((int64_t)l * rows * nchunk + unit) * (H * JC) + fm * JC + kq * 4) = acc;
+    }
+}
+
+size_t pair_bias_layer_floats(int N, int L) { return (size_t)N * L * ((L + JC - 1) / JC) * (H * JC); }
+
+int launch_pair_bias_cache(const float* z, const float* const* wb, int num_layers, float* cache, int N, int L, hipStream_t st) {
+    ABOPT_CHECK_ARG(num_layers >= 1 && num_layers <= 8, "pair_bias_cache: 1..8 layers supported (got %d)", num_layers);
+    WbList wl;
+    for (int l = 0; l < 8; ++l) wl.w[l] = l < num_layers ? wb[l] : nullptr;
+    const int nchunk = (L + JC - 1) / JC;
+    const int64_t units = (int64_t)N * L * nchunk;
+    if (units == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(pair_bias_cache_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, z, wl, num_layers, cache, (int64_t)N * L, L, nchunk);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+template <bool DBG, bool CACHED>
+static int launch_core_variant(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
+                               const float* Wb, float* feat, float* dbg_logits, const float* pbc, int N, int L, hipStream_t st, int z_shared) {
+    const int nib = (L + BI - 1) / BI, nchunk = (L + JC - 1) / JC;
+    const size_t lds = core_lds_fixed_bytes<CACHED>() + (size_t)nchunk * JC;
+    ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core: L=%d needs %zu bytes of LDS for the key mask (max 163840)", L, lds);
+    static size_t configured = 0;                                           // per instantiation
+    if (lds > configured) {
+        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_core_kernel<DBG, CACHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    prof::begin(st);
+    hipLaunchKernelGGL((ipa_core_kernel<DBG, CACHED>), dim3((unsigned)(N * nib)), dim3(NTH), lds, st, qfrag, kvfrag, z, mask, R, t, Wb, feat, dbg_logits, pbc,
+                       N, L, nib, (N % 8 == 0) ? 1 : 0, z_shared);
+    prof::end(st);
+    ABOPT_LAUNCH_CHECK();
+#ifdef CORE_TIMING
+    {
+        long long h[3][8];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_core_timing), sizeof(h));
+        static int calls = 0;
+        if (++calls == 8)
+            for (int r = 0; r < 3; ++r)
+                fprintf(stderr, "[core timing, cycles of WG 17] %s: prologue %lld | work %lld | barrier wait %lld | own epilogue %lld | F1/F2 wait %lld | common epilogue %lld\n",
+                        r == 0 ? "pair" : (r == 1 ? "A   " : "C   "), h[r][0], h[r][1], h[r][2], h[r][3], h[r][4], h[r][5]);
+    }
+#endif
+    return ABOPT_OK;
+}
+
+int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
+                           const float* w_pair_bias, float* feat, float* dbg_logits, const float* pair_bias_cache, int N, int L, hipStream_t st, int z_shared) {
+    if (pair_bias_cache) {
+        if (dbg_logits) return launch_core_variant<true, true>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dbg_logits, pair_bias_cache, N, L, st, z_shared);
+        return launch_core_variant<false, true>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dbg_logits, pair_bias_cache, N, L, st, z_shared);
+    }
+    if (dbg_logits) return launch_core_variant<true, false>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dbg_logits, nullptr, N, L, st, z_shared);
+    return launch_core_variant<false, false>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dbg_logits, nullptr, N, L, st, z_shared);
+}
+
+}  // namespace abopt

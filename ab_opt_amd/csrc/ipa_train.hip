@@ -320,7 +320,7 @@ int launch_ipa_pair_backward(const float* z, const float* alpha, const float* da
     return ABOPT_OK;
 }
 
-size_t ipa_train_ws_floats(int N, int L) { return (size_t)N * L * NP + ipa_kvfrag_floats(N, L) + (size_t)N * L * L * H + 64; }
+size_t ipa_train_ws_floats(int N, int L) { return (size_t)N * L * NP + ipa_kvfrag_floats(N, L) + ipa_qfrag_floats(N, L) + (size_t)N * L * L * H + 64; }
 
 // proj_local [N*L, 2016] (points in the residue frames, as the six projections produce them) -> feat [N*L, 1824], alpha [N, 12, L, L]
 int launch_ipa_train_forward(const float* proj_local, const float* R, const float* t, const float* z, const uint8_t* mask,
@@ -332,9 +332,10 @@ int launch_ipa_train_forward(const float* proj_local, const float* R, const floa
     ABOPT_HIP(hipMemcpy2DAsync(proj, (size_t)NP * sizeof(float), proj_local, (size_t)ABOPT_NODE_PROJ * sizeof(float),
                                (size_t)ABOPT_NODE_PROJ * sizeof(float), (size_t)M, hipMemcpyDeviceToDevice, st));
     int rc;
-    if ((rc = launch_points_to_global(proj, R, t, M, st, kvf, N, L))) return rc;
-    float* logits = kvf + ipa_kvfrag_floats(N, L);
-    if ((rc = launch_ipa_core(proj, z, mask, R, t, Wb, spatial_coef, feat, logits, nullptr, nullptr, kvf, N, L, st))) return rc;
+    float* qf = kvf + ipa_kvfrag_floats(N, L);
+    if ((rc = launch_ipa_frags(proj, R, t, spatial_coef, qf, kvf, N, L, st))) return rc;
+    float* logits = qf + ipa_qfrag_floats(N, L);
+    if ((rc = launch_ipa_core(qf, kvf, z, mask, R, t, Wb, feat, logits, nullptr, nullptr, N, L, st))) return rc;
     const size_t lds = (size_t)L * H * sizeof(float);
     ABOPT_CHECK_ARG(lds <= 96 * 1024, "ipa_core_train_forward: L=%d too long (max 2048)", L);
     ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha_head_major_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -11,18 +11,17 @@ namespace abopt {
 int launch_linear(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
                   int M, int N, int K, bool relu, hipStream_t st, int ksplit = 1, int64_t slab_stride = 0);
 
-// ipa.hip -------------------------------------------------------------------------------------
-// proj [N*L, NP = 2048]: q|k|v|qp|kp|vp (2016) with the point sets in the global frame, then |q_pts|^2, |k_pts|^2 per head.
-// When the fragment copy is written (kvfrag != NULL) only the QUERY points/norms are updated in proj: the key/value points
-// and |k_pts|^2 then live in kvfrag alone.
-// kvfrag != NULL (and the wave-specialised kernel in use): also emits its key/value operands in MFMA fragment order
-bool ipa_uses_kvfrag(int L);
+// ipa.hip / ipa_core.hip ----------------------------------------------------------------------
+// proj [N*L, NP = 2048]: q|k|v|qp|kp|vp (2016 used), points still in the residue frames (the six bias-free projections of ga.py:54-66).
+// launch_ipa_frags moves the point sets to the global frame and lays the IPA core's operands out in MFMA fragment order:
+// qfrag (queries, pre-scaled, spatial_coef folded in) and kvfrag (keys / values); the core never reads proj.
 size_t ipa_kvfrag_floats(int N, int L);
-int launch_points_to_global(float* proj, const float* R, const float* t, int64_t rows, hipStream_t st, float* kvfrag, int N, int L);
-int launch_ipa_core(const float* proj, const float* z, const uint8_t* mask, const float* R, const float* t,
-                    const float* w_pair_bias, const float* spatial_coef, float* feat,
-                    float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache, const float* kvfrag, int N, int L, hipStream_t st,
-                    int z_shared = 0 /* 1: z (and the pair-bias cache) hold ONE sample that every batch entry shares */);
+size_t ipa_qfrag_floats(int N, int L);
+size_t pair_bias_layer_floats(int N, int L);
+int launch_ipa_frags(const float* proj, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag, int N, int L, hipStream_t st);
+int launch_ipa_core(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
+                    const float* w_pair_bias, float* feat, float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache,
+                    int N, int L, hipStream_t st, int z_shared = 0 /* 1: z and the pair-bias cache hold ONE sample that every batch entry shares */);
 
 // rows.hip ------------------------------------------------------------------------------------
 int launch_so3_exp(const float* w, float* R, int64_t n, hipStream_t st);

@@ -35,5 +35,5 @@ dt = (time.perf_counter() - t0) / iters
 n, ms = hip.prof_collect()
 hip.prof_enable(False)
 per = ms / n
-gbs = bench.ipa_core_bytes(N, L) / (per * 1e-3) / 1e9
+gbs = bench.ipa_algorithmic_bytes(N, L) / (per * 1e-3) / 1e9
 print(f'N={N} L={L}: ipa_core {per*1e3:.1f} us/launch = {gbs:.0f} GB/s algorithmic ({gbs/80:.1f}% of 8 TB/s); whole GABlock {dt*1e3:.3f} ms; checksum {out.double().sum().item():.6f}')

@@ -19,4 +19,4 @@ run(2); torch.cuda.synchronize()
 hip.prof_enable(True)
 run(K); torch.cuda.synchronize()
 n, ms = hip.prof_collect()
-print(f'cached path: ipa_core {ms / n * 1e3:.1f} us/launch = {bench.ipa_core_bytes(N, L) / (ms / n * 1e-3) / 1e9 / 80:.1f}% of 8 TB/s over {n} launches')
+print(f'cached path: ipa_core {ms / n * 1e3:.1f} us/launch = {bench.ipa_algorithmic_bytes(N, L) / (ms / n * 1e-3) / 1e9 / 80:.1f}% of 8 TB/s (SURVEY 8d bytes) over {n} launches')
