@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -75,7 +75,7 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
-           'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward']
+           'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite']
 
 _lib = None
 _lock = threading.Lock()
@@ -140,6 +140,9 @@ def lib():
         L.abopt_pair_embed_backward_workspace_bytes.restype = C.c_size_t
         L.abopt_pair_embed_backward_workspace_bytes.argtypes = [C.c_int] * 3
         L.abopt_pair_embed_backward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, c_f, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_dockq_workspace_bytes.restype = C.c_size_t
+        L.abopt_dockq_workspace_bytes.argtypes = [C.c_int]
+        L.abopt_dockq_lite.argtypes = [c_f, c_u8, C.c_int, c_f, c_u8, C.c_void_p, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         for name in EXPORTS:
             getattr(L, name)          # AttributeError here = a symbol of include/abopt.h is missing
         if L.abopt_abi_version() != ABI_VERSION:
@@ -503,6 +506,21 @@ def reconstruct_backbone_partially(pos_ctx, R_new, t_new, aa, chain_nb, res_nb, 
                                                       ptr(mask_atoms, torch.bool), ptr(mask_recons, torch.bool),
                                                       ptr(bb), ptr(ot), ptr(pos_new), ptr(mask_new), N, L, A, stream()))
     return pos_new, mask_new
+
+
+def dockq_lite(model_pos, model_mask, native_pos, native_mask, group):
+    """DockQ of S candidates against one native (include/abopt.h: abopt_dockq_lite) -> (S, 4) = fnat, irms, Lrms, DockQ.
+    model_pos (S,L,A,3); model_mask (S,L,A) or (L,A) shared; native_pos (L,A,3); native_mask (L,A); group (L,) int {0,1,2}."""
+    S, L, A, _ = model_pos.shape
+    shared = model_mask.dim() == 2
+    model_pos, model_mask, native_pos, native_mask = _contig(model_pos.float(), model_mask, native_pos.float(), native_mask)
+    group = group.to(torch.int32).contiguous()
+    out = torch.empty(S, 4, dtype=torch.float32, device=model_pos.device)
+    nb = lib().abopt_dockq_workspace_bytes(L)
+    buf = Workspace.get(nb, model_pos.device)
+    _check(lib().abopt_dockq_lite(ptr(model_pos, torch.float32), ptr(model_mask, torch.bool), int(shared), ptr(native_pos, torch.float32),
+                                  ptr(native_mask, torch.bool), ptr(group, torch.int32), S, L, A, ptr(out), ptr(buf), buf.numel(), stream()))
+    return out
 
 
 def prof_enable(on=True):

@@ -41,9 +41,13 @@ def all_gather_candidates(cand, counts=None, group=None):
     pad = cand
     if cand.shape[0] < nmax:
         pad = torch.cat([cand, cand.new_zeros((nmax - cand.shape[0],) + tuple(cand.shape[1:]))], 0)
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad.contiguous(), group=group)
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+    pad = pad.contiguous()
+    staged = pad.is_cuda and dist.get_backend(group) == 'gloo'          # gloo: the gather goes through host memory
+    src = pad.cpu() if staged else pad
+    bufs = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(bufs, src, group=group)
+    out = torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+    return out.to(cand.device) if staged else out
 
 
 def commonness_score(structs, score_fn=None):
@@ -57,6 +61,20 @@ def commonness_score(structs, score_fn=None):
 def rank_commoness(structs, k, score_fn=None):
     """Indices of the k most common structures (design_for_testset.py:575-589)."""
     return torch.topk(commonness_score(structs, score_fn), k=k, largest=False)[1]
+
+
+def dockq_scores(model_pos, model_mask, native_pos, native_mask, fragment_type=None, group=None):
+    """DockQ of candidate structures against the native complex, on the device (the reference writes every candidate to a PDB
+    file and shells out: AbDock/src/tools/runner/design_for_pdb.py:316-321, AbDock/DockQ/DockQ.py:98-385).
+
+    model_pos (S,L,A,3), model_mask (S,L,A) or (L,A), native_pos (L,A,3), native_mask (L,A).  The two chains are given either as
+    `group` (L,) in {0: not scored, 1, 2} or through `fragment_type` (antibody chains 1/2 -> group 1, antigen 3 -> group 2).
+    -> dict of (S,) tensors: fnat, irms, Lrms, DockQ."""
+    from . import hip
+    if group is None:
+        group = torch.where(fragment_type == 3, 2, torch.where(fragment_type > 0, 1, 0))
+    out = hip.dockq_lite(model_pos, model_mask, native_pos, native_mask, group)
+    return dict(fnat=out[:, 0], irms=out[:, 1], Lrms=out[:, 2], DockQ=out[:, 3])
 
 
 @torch.no_grad()
@@ -105,3 +123,52 @@ def sample_replicated(model, complex_batch, num_samples, sample_opt=None, optimi
     if optimize_step is None:
         return model.diffusion.sample(*args, res_feat, pair_feat, *masks, **sample_opt)
     return model.diffusion.optimize(*args, optimize_step, res_feat, pair_feat, *masks, **sample_opt)
+
+
+def complexes_of_rank(n_complexes, world_size, rank):
+    """By-complex partition of a test set (BASELINE config 4): complex c runs on rank c % world, so every
+    sample of a complex -- and therefore its whole commonness ranking -- stays on one GPU and nothing is exchanged per complex."""
+    return list(range(rank, n_complexes, world_size))
+
+
+@torch.no_grad()
+def design_testset_sharded(model, complexes, samples_per_complex, sample_opt=None, k=1, group=None, seed=0, optimize_step=None):
+    """BASELINE config 4: a test set of complexes x `samples_per_complex` samples over the ranks of `group`, partitioned BY COMPLEX.
+
+    The reference fans this out as one subprocess per structure through Ray and collects files
+    (AbDock/optimize_ab.py:21-31,66-72; AbDock/src/tools/runner/design_for_testset.py:556-589 ranks each structure's samples).
+    Here every rank designs its own complexes with the shared-context sampler (`sample_replicated`: the complex is encoded once,
+    N samples share its pair features), ranks each complex's candidates locally with the commonness score, and the per-complex
+    summaries (a few hundred bytes each) are exchanged once at the end with all_gather_object.
+
+    complexes: list of batch dicts with batch dim 1.  Seeds depend on the complex index only, so results do not depend on the
+    number of ranks.  -> list (one entry per complex, in input order, identical on every rank) of
+    dict(complex=index, rank=owner, top=LongTensor(k), score=Tensor(S), ca=final CA positions of the generated residues (S, n_gen, 3))."""
+    world, rank = (dist.get_world_size(group), dist.get_rank(group)) if dist.is_initialized() else (1, 0)
+    sample_opt = dict(sample_opt or {'sample_structure': True, 'sample_sequence': True})
+    mine = []
+    for c in complexes_of_rank(len(complexes), world, rank):
+        one = complexes[c]
+        opt = dict(sample_opt, seed=int(seed) + 1000003 * c, rng_offset=0)
+        traj = sample_replicated(model, one, samples_per_complex, opt, optimize_step=optimize_step)
+        gen = one['generate_flag'][:1].expand(samples_per_complex, -1)
+        cand = candidates_from_positions(traj[0][1], gen)
+        score = commonness_score(cand)
+        top = torch.topk(score, k=min(k, samples_per_complex), largest=False)[1]
+        mine.append(dict(complex=c, rank=rank, top=top.cpu(), score=score.cpu(), ca=cand.cpu()))
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine, group=group)
+        mine = [e for part in everyone for e in part]
+    return sorted(mine, key=lambda e: e['complex'])
+
+
+def wrap_ddp(model, device=None, **kw):
+    """Data-parallel training (BASELINE config 5 at N GPUs): one process per GPU, gradients averaged by bucketed all-reduce over
+    RCCL (backend 'nccl') overlapped with backward.  The reference's train.py (AbDock/train.py:70-114) is single-process; this is
+    the wrapper a multi-GPU launch adds around `get_model(cfg)`.  The custom autograd functions of the training path are ordinary
+    torch.autograd.Function nodes, so DistributedDataParallel's hooks see their parameter gradients like any other."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+    kw.setdefault('find_unused_parameters', True)      # the prmsd loss touches no parameter when mask_generate[:, 0] is all False
+    return DDP(model.to(dev), device_ids=[dev.index], **kw)

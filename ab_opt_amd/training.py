@@ -206,10 +206,11 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
         t = torch.randint(0, dpm.num_steps, (N,), dtype=torch.long, device=dev)
     h = dpm._sched_host()
     seed = dpm._new_seed() if seed is None else int(seed)
+    grad_mode = torch.is_grad_enabled()         # so3.py:12-16: the log map clamps at -0.999 under autograd, -1.0 in no_grad validation passes
     with torch.no_grad():                       # noising has no learnable parameters; native kernel (transition.py:62-78,120-144,179-200)
         v_n, p_n_ang, s_n, eps_p = hip.add_noise(t, vs.alpha_bars, dpm.trans_rot.angular_distrib_fwd, noise, seed, 0,
                                                  v_0.detach().float(), p_0.detach().float(), s_0, mask_generate, h['scale'], h['mean'],
-                                                 noise_structure=denoise_structure, noise_sequence=denoise_sequence, grad_mode=torch.is_grad_enabled(), want_eps=True)
+                                                 noise_structure=denoise_structure, noise_sequence=denoise_sequence, grad_mode=grad_mode, want_eps=True)
     p0n = dpm._normalize_position(p_0)
     p_n = dpm._normalize_position(p_n_ang)
     R_0 = so3_exp(v_0)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 13
+#define ABOPT_ABI_VERSION 14
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -189,6 +189,17 @@ int abopt_add_noise(const int64_t* t, const float* alpha_bars, const float* fwd_
                     const float* v_0, const float* p_0, const int64_t* s_0, const uint8_t* mask_generate,
                     float position_scale, const float* position_mean, int noise_structure, int noise_sequence, int grad_mode,
                     float* v_noisy, float* p_noisy, int64_t* s_noisy, float* eps_p, float* c_noisy, int N, int L, abopt_stream stream);
+
+/* ---- DockQ scoring of docked candidates: D/tools/runner/design_for_pdb.py:316-321 calls calc_DockQ(model, native, use_CA_only=True)
+ * (AbDock/DockQ/DockQ.py:98-385) per candidate, which runs the `fnat` program twice (DockQ/src/fnat.c:100-252: residue contacts over
+ * all heavy atoms, 5 A for Fnat, 10 A for the interface) and superimposes CA atoms twice (interface -> iRMS; receptor -> LRMS).
+ * Structures are tensors with the batch's residue indexing: pos [L,A,3] Angstrom, mask [L,A], group [L] (0 = not in the file,
+ * 1 / 2 = the two chains); atom slot 1 = CA.  model_pos [S,L,A,3]; model_mask [S,L,A], or [L,A] with model_mask_shared = 1.
+ * out [S,4] = (fnat, irms, Lrms, DockQ).  ws: abopt_dockq_workspace_bytes(L). */
+size_t abopt_dockq_workspace_bytes(int L);
+int abopt_dockq_lite(const float* model_pos, const uint8_t* model_mask, int model_mask_shared, const float* native_pos,
+                     const uint8_t* native_mask, const int32_t* group, int S, int L, int A, float* out,
+                     void* ws, size_t ws_bytes, abopt_stream stream);
 
 /* ---- Batched-sampling reduction: D/tools/runner/design_for_testset.py:556-589 (calc_per_rmsd +
  * rank_commoness score).  structs [B,n,3] -> score [B] = mean_{b'} RMSD(b,b') * B/(B-1). */

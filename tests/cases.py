@@ -71,3 +71,27 @@ def reconstruct_batch():
     batch['generate_flag'][:, 20:25] = True
     batch['generate_flag'] &= batch['mask']
     return batch
+
+
+def dockq_case(S=6, seed=31):
+    """Native complex (64 antibody + 64 antigen residues, backbone + CB, a few residues with missing atoms / absent) and S docked
+    candidates: the antibody moved rigidly by growing amounts plus coordinate noise.  -> native_pos (L,A,3), mask (L,A) bool,
+    group (L,) int {0 absent, 1 antibody, 2 antigen}, model_pos (S,L,A,3); coordinates rounded to the PDB's 3 decimals."""
+    from oracle.geometry import so3_exp
+    c = synth.make_complex(synth.LAYOUT_128, seed=seed)
+    pos, mask = c['pos_heavyatom'].clone(), c['mask_heavyatom'].clone()
+    group = torch.where(c['fragment_type'] == 1, 1, torch.where(c['fragment_type'] == 3, 2, 0)).int()
+    group[5] = 0; group[100] = 0                       # residues that are not in the files at all
+    mask[7, 1] = False; mask[70, 4] = False            # a missing CA, a missing CB
+    mask[group == 0] = False
+    pos = (pos * 1000).round() / 1000
+    ab = group == 1
+    cen = pos[ab][:, 1].mean(0)
+    models = []
+    for k in range(S):
+        rot = so3_exp(synth.hash_tensor((1, 3), 900 + k, scale=0.08 * k))[0]
+        shift = synth.hash_tensor((3,), 950 + k, scale=1.5 * k)
+        m = pos.clone()
+        m[ab] = (pos[ab] - cen) @ rot.T + cen + shift + synth.hash_tensor(tuple(pos[ab].shape), 970 + k, scale=0.15 * k)
+        models.append((m * 1000).round() / 1000)
+    return pos, mask, group, torch.stack(models, 0)

@@ -365,6 +365,43 @@ def case_training():
     save('training_abdock', **o)
 
 
+def case_training_abdesign():
+    """AbDesign FullDPM.forward (BASELINE config 5 flavour: rot, pos(eps), seq losses; A/modules/diffusion/dpm_full.py:138-191) with
+    fixed t and recorded noise; losses + a few parameter gradients + input gradients."""
+    T = 100
+    dpm = abdesign_fulldpm(T, seed=2).train()
+    N, L = 2, 48
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(N, L, [48, 41], [(6, 17), (30, 37)], salt=300)
+    s = s.clamp(max=19)
+    t = torch.tensor([37, 80])
+    res_feat = res_feat.clone().requires_grad_(True)
+    pair_feat = pair_feat.clone().requires_grad_(True)
+    torch.manual_seed(17)
+    tape = Tape()
+    with tape.recording():
+        loss = dpm(v, p * 10, s, res_feat, pair_feat, gen, mres, denoise_structure=True, denoise_sequence=True, t=t)
+    o = {}
+    o['rot_axis'] = tape.pop('randn'); o['rot_bin'] = tape.pop('multinomial').reshape(N, L)
+    o['rot_ubin'] = tape.pop('rand_like').reshape(N, L); o['rot_gauss'] = tape.pop('randn_like').reshape(N, L)
+    o['pos'] = tape.pop('randn_like'); o['s_noisy'] = tape.pop('multinomial').reshape(N, L)
+    assert not tape.log
+    assert set(loss) == {'rot', 'pos', 'seq'}
+    sum(loss.values()).backward()
+    for k, val in loss.items():
+        o['loss_' + k] = val
+    names = ['eps_net.encoder.blocks.0.proj_pair_bias.weight', 'eps_net.encoder.blocks.0.spatial_coef',
+             'eps_net.encoder.blocks.5.out_transform.weight', 'eps_net.encoder.blocks.3.proj_key_point.weight',
+             'eps_net.encoder.blocks.2.mlp_transition.2.weight', 'eps_net.encoder.blocks.4.layer_norm_1.gamma',
+             'eps_net.res_feat_mixer.0.weight', 'eps_net.eps_crd_net.4.weight', 'eps_net.eps_seq_net.0.weight', 'eps_net.current_sequence_embedding.weight']
+    params = dict(dpm.named_parameters())
+    for n_ in names:
+        g_ = params[n_].grad
+        o['grad_' + n_] = g_[::3, ::5] if g_.numel() > 50000 else g_            # big matrices: strided sample (tests use the same stride)
+    o['grad_res_feat'] = res_feat.grad
+    o['grad_pair_feat_sub'] = pair_feat.grad[:, ::5, ::3]
+    save('training_abdesign', **o)
+
+
 def case_encode():
     m = abdock_model(10, seed=3)
     batch = synth.make_batch(2, synth.LAYOUT_128, seed=99, lengths=[24, 19])
@@ -430,12 +467,56 @@ def case_rank():
     save('rank_commoness', rank=rank, avg_rmsd=ns['calc_avg_rmsd'](structs))
 
 
+def case_dockq():
+    """DockQ scoring of docked candidates (design_for_pdb.py:316-321).  Fnat / contact counts / interface residues come from the
+    REFERENCE's own scorer: its `fnat` C program built from /root/reference/AbDock/DockQ/src (oracle/Makefile -> oracle/_ref/fnat) and
+    run on PDB files written from the case tensors.  iRMS / LRMS follow DockQ.py:296-366; Biopython is absent here, so they are
+    computed with the oracle's SVD fit and cross-checked against scipy.spatial.transform.Rotation.align_vectors."""
+    import subprocess, tempfile
+    from scipy.spatial.transform import Rotation
+    from oracle import dockq as DQ
+    subprocess.run(['make', '-C', os.path.join(ROOT, 'oracle')], check=True)
+    fnat_bin = os.path.join(ROOT, 'oracle', '_ref', 'fnat')
+    pos, mask, group, models = cases.dockq_case()
+    pos, mask, group, models = pos.numpy().astype(np.float64), mask.numpy(), group.numpy(), models.numpy().astype(np.float64)
+    out = dict(fnat=[], nat_correct=[], nat_total=[], irms=[], Lrms=[], DockQ=[])
+    with tempfile.TemporaryDirectory() as d:
+        DQ.write_pdb(d + '/native.pdb', pos, mask, group)
+        for k in range(models.shape[0]):
+            DQ.write_pdb(d + '/model.pdb', models[k], mask, group)
+            run = lambda cut: DQ.parse_reference_fnat(subprocess.run([fnat_bin, d + '/model.pdb', d + '/native.pdb', cut, '-all'],
+                                                                     capture_output=True, text=True, check=True).stdout)
+            r5, r10 = run('5'), run('10')
+            o = DQ.dockq(models[k], mask, pos, mask, group)
+            inter = set((i + 1, 'AB'[group[i] - 1]) for i in np.nonzero(o['interface'])[0])
+            assert inter == r10['inter'] and (o['nat_correct'], o['nat_total']) == (r5['nat_correct'], r5['nat_total'])
+            # independent superposition check (scipy): interface fit and receptor fit
+            both = mask[:, 1] & (group > 0)
+            sel = o['interface'] & both
+            x, y = pos[:, 1], models[k][:, 1]
+            cx, cy = x[sel].mean(0), y[sel].mean(0)
+            _, rssd = Rotation.align_vectors(x[sel] - cx, y[sel] - cy)
+            assert abs(rssd / np.sqrt(sel.sum()) - o['irms']) < 1e-6, (rssd / np.sqrt(sel.sum()), o['irms'])
+            n1, n2 = (both & (group == 1)).sum(), (both & (group == 2)).sum()
+            rec, lig = (1, 2) if n1 > n2 else (2, 1)
+            rs, ls = both & (group == rec), both & (group == lig)
+            cx, cy = x[rs].mean(0), y[rs].mean(0)
+            Rm, _ = Rotation.align_vectors(x[rs] - cx, y[rs] - cy)
+            lr = np.sqrt((((Rm.apply(y[ls] - cy) + cx) - x[ls]) ** 2).sum(-1).mean())
+            assert abs(lr - o['Lrms']) < 1e-6, (lr, o['Lrms'])
+            out['fnat'].append(r5['fnat']); out['nat_correct'].append(r5['nat_correct']); out['nat_total'].append(r5['nat_total'])
+            out['irms'].append(o['irms']); out['Lrms'].append(o['Lrms'])
+            out['DockQ'].append((r5['nat_correct'] / r5['nat_total'] + 1 / (1 + (o['irms'] / 1.5) ** 2) + 1 / (1 + (o['Lrms'] / 8.5) ** 2)) / 3)
+        out['interface'] = o['interface']
+    save('dockq_small', **{k: np.asarray(v) for k, v in out.items()})
+
+
 if __name__ == '__main__':
     assert os.path.isdir(REF), 'reference mount not present: goldens can only be generated in the build container'
     sys.path.insert(0, os.path.join(REF, 'AbDock'))
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['so3', 'ga_block', 'eps_net', 'schedule_tables', 'trajectory', 'structonly', 'abdesign_sample',
-                             'training', 'encode', 'rank', 'reconstruct', 'posterior']
+                             'training', 'training_abdesign', 'encode', 'rank', 'reconstruct', 'posterior', 'dockq']
     for w in which:
         print('==', w)
         globals()['case_' + w]()

@@ -62,3 +62,42 @@ def test_shard_helpers():
     g = torch.tensor([[0, 1, 1, 0, 0, 0], [0, 0, 0, 1, 1, 0]], dtype=torch.bool)
     c = sampler.candidates_from_positions(p, g)
     assert c.shape == (2, 2, 3) and torch.equal(c[1, 0], p[1, 3])
+
+
+def test_by_complex_partition():
+    """BASELINE config 4 layout: 64 complexes over 8 ranks = 8 per rank, every complex on exactly one rank, round-robin."""
+    owners = {}
+    for r in range(8):
+        mine = sampler.complexes_of_rank(64, 8, r)
+        assert len(mine) == 8
+        for c in mine:
+            assert c not in owners
+            owners[c] = r
+    assert sorted(owners) == list(range(64)) and owners[9] == 1
+    assert sampler.complexes_of_rank(3, 2, 1) == [1] and sampler.complexes_of_rank(1, 4, 2) == []
+
+
+def _object_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        # the exchange design_testset_sharded performs: per-complex summaries gathered as objects, merged in complex order
+        mine = [dict(complex=c, rank=rank, top=torch.tensor([c, c + 1])) for c in sampler.complexes_of_rank(5, world, rank)]
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        merged = sorted([e for part in everyone for e in part], key=lambda e: e['complex'])
+        out[rank] = [(e['complex'], e['rank'], e['top'].tolist()) for e in merged]
+        # an empty shard still joins the candidate gather (more ranks than samples)
+        cand = torch.zeros(1 if rank == 0 else 0, 4, 3)
+        allc = sampler.all_gather_candidates(cand, [1, 0])
+        assert allc.shape == (1, 4, 3)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_testset_summary_exchange_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_object_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0] == out[1] == [(0, 0, [0, 1]), (1, 1, [1, 2]), (2, 0, [2, 3]), (3, 1, [3, 4]), (4, 0, [4, 5])]

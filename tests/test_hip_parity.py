@@ -953,3 +953,127 @@ def test_non_contiguous_inputs_keep_their_copies_alive():
     args2 = [pad(a) if a.dtype == torch.float32 and a.dim() >= 2 and a.dim() < 4 else a for a in args]
     got = m.diffusion.eps_net(*args2)
     assert all(torch.equal(a, b) for a, b in zip(ref, got))
+
+
+# ------------------------------------------------------------------------------------------ DockQ of docked candidates
+def test_dockq_lite_vs_reference():
+    """abopt_dockq_lite against the golden built from the reference's `fnat` program and DockQ.py's formulas (tolerance 1e-4 on
+    Fnat / iRMS / LRMS / DockQ), per-candidate masks and the shared-mask form, plus properties at the BASELINE size (L=256, S=64):
+    a rigid motion of the whole complex changes nothing, the native itself scores 1."""
+    from ab_opt_amd import sampler
+    from oracle import geometry as G
+    g = load_golden('dockq_small')
+    pos, mask, group, models = [dev(a) for a in cases.dockq_case()]
+    S = models.shape[0]
+    for mm in (mask, mask[None].expand(S, -1, -1).contiguous()):
+        out = sampler.dockq_scores(models, mm, pos, mask, group=group)
+        for k in ('fnat', 'irms', 'Lrms', 'DockQ'):
+            assert max_abs(out[k].cpu(), g[k]) < 1e-4, (k, out[k].cpu(), g[k])
+    # full size: 64 candidates of a 256-residue complex (chains from fragment_type), invariance under a global rigid motion
+    b = synth.make_batch(1, synth.LAYOUT_256, seed=3)
+    npos, nmask, ft = dev(b['pos_heavyatom'][0]), dev(b['mask_heavyatom'][0]), dev(b['fragment_type'][0])
+    ab = (ft == 1) | (ft == 2)
+    S = 64
+    mods = npos[None].repeat(S, 1, 1, 1)
+    mods[:, ab] += dev(synth.hash_tensor((S, 1, 1, 3), 5, scale=6.0)) + dev(synth.hash_tensor((S, int(ab.sum()), 15, 3), 6, scale=0.5))
+    mods[0] = npos
+    base = sampler.dockq_scores(mods, nmask, npos, nmask, fragment_type=ft)
+    assert abs(base['DockQ'][0].item() - 1) < 1e-5 and base['irms'][0].item() < 1e-4 and base['fnat'][0].item() == 1
+    assert (base['DockQ'][1:] < 1).all() and torch.isfinite(base['DockQ']).all()
+    Q = dev(G.so3_exp(torch.tensor([[0.7, -0.4, 1.1]])))[0]
+    moved = sampler.dockq_scores(mods @ Q.T + 3.0, nmask, npos, nmask, fragment_type=ft)
+    for k in base:
+        assert max_abs(moved[k], base[k]) < 2e-4, k
+
+
+# ------------------------------------------------------------------------------------------ two ranks on one GPU
+def _spawn2(fn, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    mp.spawn(fn, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
+def test_two_rank_sharded_sampling_is_bit_identical_to_one_rank(tmp_path):
+    """sampler.sample_sharded on 2 ranks (both on cuda:0, gloo group, gather through host memory) against the same call in one
+    process: gathered candidates and top-k are bit-equal -- Philox counters depend on the GLOBAL sample index, never on the rank.
+    Also the by-complex partition of BASELINE config 4 (design_testset_sharded): every rank ends with the same per-complex
+    rankings as a single process."""
+    import mp_workers
+    from ab_opt_amd import sampler
+    m = build_model(10, 3, device=DEV)
+    b = {k: dev(v) for k, v in synth.make_batch(5, synth.LAYOUT_128, seed=11, replicate=True).items()}
+    traj, (a, e), top, cand = sampler.sample_sharded(m, b, dict(sample_structure=True, sample_sequence=True, contig=''), k=2, seed=42)
+    cx = [{k: dev(v) for k, v in synth.make_batch(1, synth.LAYOUT_128, seed=100 + c).items()} for c in range(3)]
+    ref = sampler.design_testset_sharded(m, cx, 4, k=2, seed=7)
+    assert [r['complex'] for r in ref] == [0, 1, 2] and ref[0]['ca'].shape[0] == 4
+    _spawn2(mp_workers.sharded_worker, tmp_path)
+    parts = [torch.load(tmp_path / f'sharded_{r}.pt') for r in range(2)]
+    assert (parts[0]['a'], parts[0]['e'], parts[1]['a'], parts[1]['e']) == (0, 3, 3, 5)
+    for p_ in parts:
+        assert torch.equal(p_['cand'], cand.cpu()) and torch.equal(p_['top'], top.cpu())
+    assert torch.equal(torch.cat([parts[0]['p0'], parts[1]['p0']]), traj[0][1].cpu())
+    assert torch.equal(torch.cat([parts[0]['s0'], parts[1]['s0']]), traj[0][2].cpu())
+    for r in range(2):
+        got = torch.load(tmp_path / f'testset_{r}.pt', weights_only=False)
+        assert [g_['complex'] for g_ in got] == [0, 1, 2] and [g_['rank'] for g_ in got] == [0, 1, 0]
+        for g_, r_ in zip(got, ref):
+            assert torch.equal(g_['ca'], r_['ca']) and torch.equal(g_['top'], r_['top']) and torch.equal(g_['score'], r_['score'])
+
+
+def test_two_rank_ddp_gradients_equal_the_mean(tmp_path):
+    """model(batch).backward() under DistributedDataParallel (2 ranks, one sample each): the all-reduced gradients equal the mean of
+    the two single-sample gradients computed in one process (the custom autograd functions survive DDP's bucketed all-reduce)."""
+    import mp_workers
+    m = build_model(10, 3, device=DEV).train()
+    full = synth.make_batch(2, synth.LAYOUT_128, seed=5, lengths=[64, 57])
+    grads = []
+    for r in range(2):
+        m.zero_grad()
+        torch.manual_seed(123)
+        sum(m({k: dev(v[r:r + 1]) for k, v in full.items()}).values()).backward()
+        grads.append({n: p.grad.detach().cpu().clone() for n, p in m.named_parameters() if p.grad is not None})
+    m.zero_grad(); m.eval()
+    _spawn2(mp_workers.ddp_worker, tmp_path)
+    got = [torch.load(tmp_path / f'ddp_{r}.pt') for r in range(2)]
+    assert len(got[0]['grads']) > 150
+    for n, g0 in got[0]['grads'].items():
+        assert torch.equal(g0, got[1]['grads'][n]), n                                   # both ranks hold the same averaged gradient
+        a_, b_ = grads[0].get(n), grads[1].get(n)
+        if a_ is None or b_ is None:
+            continue
+        mean = (a_ + b_) / 2
+        assert max_abs(g0, mean) <= 1e-5 * max(1.0, mean.abs().max().item()), n
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 5 flavour
+def test_training_abdesign_loss_and_grads_vs_reference():
+    """AbDesign FullDPM.forward on the device (rot, pos on the noise, seq) with the reference's recorded noise and fixed t:
+    losses (2e-5 rel) and gradients (3e-4 of max) against golden training_abdesign."""
+    from test_oracle_golden import _sub
+    g = load_golden('training_abdesign')
+    d = standalone_abdesign_dpm(100, 2).to(DEV).train()
+    d.zero_grad()
+    N, L = 2, 48
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(N, L, [48, 41], [(6, 17), (30, 37)], salt=300)
+    s = s.clamp(max=19)
+    res_feat = dev(res_feat).clone().requires_grad_(True)
+    pair_feat = dev(pair_feat).clone().requires_grad_(True)
+    noise = dict(axis=dev(g['rot_axis']), bin=dev(g['rot_bin']), ubin=dev(g['rot_ubin']), gauss=dev(g['rot_gauss']), pos=dev(g['pos']), s_noisy=dev(g['s_noisy']))
+    loss = d(dev(v), dev(p) * 10, dev(s), res_feat, pair_feat, dev(gen), dev(mres), True, True, t=torch.tensor([37, 80], device=DEV), noise=noise)
+    assert set(loss) == {'rot', 'pos', 'seq'}
+    for k, val in loss.items():
+        ref = g['loss_' + k].item()
+        assert abs(val.item() - ref) <= 2e-5 * max(1.0, abs(ref)), (k, val.item(), ref)
+    sum(loss.values()).backward()
+    params = dict(d.named_parameters())
+    n = 0
+    for k in g:
+        if k.startswith('grad_eps_net'):
+            got = _sub(params[k[len('grad_'):]].grad.cpu(), g[k])
+            assert max_abs(got, g[k]) <= 3e-4 * g[k].abs().max().item() + 1e-7, k
+            n += 1
+    assert n == 10
+    assert max_abs(res_feat.grad.cpu(), g['grad_res_feat']) <= 3e-4 * g['grad_res_feat'].abs().max().item()
+    assert max_abs(pair_feat.grad.cpu()[:, ::5, ::3], g['grad_pair_feat_sub']) <= 3e-4 * g['grad_pair_feat_sub'].abs().max().item()
+    d.zero_grad()

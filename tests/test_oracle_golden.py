@@ -258,6 +258,43 @@ def test_training_loss_and_grads():
     assert max_abs(pair_feat.grad[:, ::5, ::3], g['grad_pair_feat_sub']) <= 2e-4 * g['grad_pair_feat_sub'].abs().max().item()
 
 
+def _sub(got, ref):
+    """Fixtures store big gradient matrices as a [::3, ::5] sample."""
+    return got[::3, ::5] if got.shape != ref.shape else got
+
+
+def test_training_abdesign_loss_and_grads():
+    """BASELINE config 5 flavour: AbDesign FullDPM.forward (rot, pos on the noise, seq; A/modules/diffusion/dpm_full.py:138-191)."""
+    g = load_golden('training_abdesign')
+    m = standalone_abdesign_dpm(100, 2)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and 'eps_net' in k) for k, v in m.state_dict().items()}
+    N, L = 2, 48
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(N, L, [48, 41], [(6, 17), (30, 37)], salt=300)
+    s = s.clamp(max=19)
+    res_feat = res_feat.clone().requires_grad_(True)
+    pair_feat = pair_feat.clone().requires_grad_(True)
+    den = dpm.Denoiser(sd, num_steps=100, variant='abdesign', pre='', tables=(None, None))
+    f = m.trans_rot.angular_distrib_fwd
+    den.tab_fwd = dict(stddevs=f.stddevs, approx_flag=f.approx_flag, X=f.X, Y=f.Y)
+    noise = dict(rot=dict(axis=g['rot_axis'], bin=g['rot_bin'], ubin=g['rot_ubin'], gauss=g['rot_gauss']), pos=g['pos'], s_noisy=g['s_noisy'])
+    with torch.enable_grad():
+        loss = den.loss(v, p * 10, s, res_feat, pair_feat, gen, mres, torch.tensor([37, 80]), noise)
+        sum(loss.values()).backward()
+    assert set(loss) == {'rot', 'pos', 'seq'}
+    for k in loss:
+        ref = g['loss_' + k].item()
+        assert abs(loss[k].item() - ref) <= 1e-5 * max(1.0, abs(ref)), (k, loss[k].item(), ref)
+    n = 0
+    for k in g:
+        if k.startswith('grad_eps_net'):
+            got = _sub(sd[k[len('grad_'):]].grad, g[k])
+            assert max_abs(got, g[k]) <= 2e-4 * g[k].abs().max().item() + 1e-7, k
+            n += 1
+    assert n == 10
+    assert max_abs(res_feat.grad, g['grad_res_feat']) <= 2e-4 * g['grad_res_feat'].abs().max().item()
+    assert max_abs(pair_feat.grad[:, ::5, ::3], g['grad_pair_feat_sub']) <= 2e-4 * g['grad_pair_feat_sub'].abs().max().item()
+
+
 def test_encode_small():
     g = load_golden('encode_small')
     m = build_model(10, 3)
@@ -317,3 +354,27 @@ def test_rank_commoness():
     structs = synth.hash_tensor((16, 36, 3), 55, scale=8.0)
     structs[3] = structs[5] + 0.01
     assert torch.equal(dpm.rank_commoness(structs, 5), g['rank'])
+
+
+def test_dockq_vs_reference_scorer():
+    """DockQ of docked candidates: Fnat / contact counts / interface residues from the reference's own `fnat` program (golden
+    dockq_small, built from /root/reference/AbDock/DockQ/src), iRMS / LRMS / DockQ per DockQ.py:296-378."""
+    from oracle import dockq as DQ
+    g = load_golden('dockq_small')
+    pos, mask, group, models = cases.dockq_case()
+    for k in range(models.shape[0]):
+        o = DQ.dockq(models[k].numpy(), mask.numpy(), pos.numpy(), mask.numpy(), group.numpy())
+        assert (o['nat_correct'], o['nat_total']) == (int(g['nat_correct'][k]), int(g['nat_total'][k]))
+        assert abs(o['fnat'] - g['fnat'][k].item()) < 1e-6
+        assert abs(o['irms'] - g['irms'][k].item()) < 1e-9 and abs(o['Lrms'] - g['Lrms'][k].item()) < 1e-9
+        assert abs(o['DockQ'] - g['DockQ'][k].item()) < 1e-6
+    assert torch.equal(torch.from_numpy(o['interface']), g['interface'].bool())
+    # when oracle/_ref/fnat is present (build container, or shipped prebuilt), re-run the reference program itself
+    import os, subprocess, tempfile
+    fnat_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'fnat')
+    if os.path.exists(fnat_bin):
+        with tempfile.TemporaryDirectory() as d:
+            DQ.write_pdb(d + '/native.pdb', pos.numpy(), mask.numpy(), group.numpy())
+            DQ.write_pdb(d + '/model.pdb', models[3].numpy(), mask.numpy(), group.numpy())
+            r5 = DQ.parse_reference_fnat(subprocess.run([fnat_bin, d + '/model.pdb', d + '/native.pdb', '5', '-all'], capture_output=True, text=True).stdout)
+        assert (r5['nat_correct'], r5['nat_total']) == (int(g['nat_correct'][3]), int(g['nat_total'][3]))
