@@ -46,9 +46,13 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
                     float* x_out, int N, int L, const abopt_ga_debug* dbg, const GaScratch& s, hipStream_t st, const float* pbc = nullptr, int z_shared = 0) {
     const int64_t M = (int64_t)N * L;
     int rc;
-    // node projections: q|k|v|qp|kp|vp in one GEMM, then points to the global frame
-    if ((rc = launch_linear(x, F, w->w_node, F, nullptr, s.proj, NP, (int)M, ABOPT_NODE_PROJ, F, false, st))) return rc;
-    if ((rc = launch_ipa_frags(s.proj, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st))) return rc;
+    // node projections q|k|v|qp|kp|vp, points to the global frame, MFMA fragment layout: one fused kernel when the packed weights are given
+    if (w->w_node_frag) {
+        if ((rc = launch_node_frags(x, w->w_node_frag, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st))) return rc;
+    } else {
+        if ((rc = launch_linear(x, F, w->w_node, F, nullptr, s.proj, NP, (int)M, ABOPT_NODE_PROJ, F, false, st))) return rc;
+        if ((rc = launch_ipa_frags(s.proj, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st))) return rc;
+    }
     float* feat = (dbg && dbg->feat) ? dbg->feat : s.feat;
     if ((rc = launch_ipa_core(s.qf, s.kvf, z, mask, R, t, w->w_pair_bias, feat,
                               dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, N, L, st, z_shared))) return rc;
@@ -72,6 +76,16 @@ static int check_ga_weights(const abopt_ga_weights* w) {
 using namespace abopt;
 
 extern "C" int abopt_abi_version(void) { return ABOPT_ABI_VERSION; }
+
+extern "C" size_t abopt_node_frag_floats(void) { return node_wfrag_floats(); }
+extern "C" int abopt_node_frag_source_row(int h, int T, int m) {
+    if (h < 0 || h >= H || T < 0 || T >= 12 || m < 0 || m >= 16) return -1;
+    const int set = T / 2, half = T % 2;                      // set: 0 q, 1 k, 2 v, 3 q_pts, 4 k_pts, 5 v_pts
+    if (set < 3) return set * (H * D) + h * D + half * 16 + m;
+    const int p = half * 4 + m / 4, c = m % 4;
+    if (c == 3) return -1;
+    return 3 * H * D + (set - 3) * NPT + h * (P * 3) + p * 3 + c;
+}
 extern "C" const char* abopt_last_error(void) { return g_err; }
 
 extern "C" int abopt_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len) {

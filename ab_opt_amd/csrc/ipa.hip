@@ -16,11 +16,14 @@ namespace abopt {
 // (kvfrag) and one QUERY block (qfrag).  float4 units, lane = (fm = lane & 15, kq = lane >> 4):
 //
 //   kvfrag[((n * nchunk + ch) * H + h) * 8 + slot][lane]
-//     slot 0,1: k[j = 16 ch + fm][h][8 kq + 0..3], [.. + 4..7]         slot 2: k_pts coords (2 kq + {0,1}, 8 + 2 kq + {0,1}) of head h
-//     slot 3:   k_pts coords 16 + 2 kq + {0,1}, norm-step value, 0      slot 4 + s: (v[j = 16 ch + 4 kq + s][h][2 fm + {0,1}], v_pts coords 2 fm + {0,1} or 0 for fm >= 12)
+//     slot 0,1: k[j = 16 ch + fm][h][4 kq + 0..3], [16 + 4 kq + 0..3]      slot 2: k_pts point kq (x, y, z), norm-step value
+//     slot 3:   k_pts point 4 + kq (x, y, z), 0
+//     slot 4 + s: (v[j = 16 ch + 4 kq + s][h][fm], v[..][16 + fm], v_pts coordinate (fm & 3) of point (fm >> 2), of point 4 + (fm >> 2); 0 for fm & 3 == 3)
 //   qfrag[((n * nib + ib) * H + h) * 4 + slot][lane]   -- the same K order as slots 0..3 above, rows = queries i = 16 ib + fm, PRE-SCALED:
 //     q / sqrt(D)   |   -2 c_h q_pts   |   norm-step value            c_h = -softplus(spatial_coef_h) sqrt(2/(9 P)) / 2   (ga.py:108-111)
-//   norm step (one MFMA K-slice):  kq = 0: (k: 1, q: c_h |q_pts|^2)   kq = 1: (k: |k_pts|^2, q: c_h)   kq = 2,3: 0
+//   norm step (one MFMA K-slice, the .w of slot 2):  kq = 0: (k: 1, q: c_h |q_pts|^2)   kq = 1: (k: |k_pts|^2, q: c_h)   kq = 2,3: 0
+// (This is exactly the accumulator layout of the fused projection kernel node_frags.hip, whose weight rows are permuted so that a
+//  16-column MFMA tile holds 4 points as (x, y, z, pad) quadruples; this kernel produces the same layout from a plain proj buffer.)
 // so that  sum_K k'_j q'_i = q_i.k_j / sqrt(D) + c_h |q_pts_i - k_pts_j|^2  is ONE 15-step MFMA chain per head in the core
 // (ga.py:84-85,108-111; the cancellation error of the expanded square is <= 2e-6 on the logit in the global frame, |p| <~ 10).
 __global__ __launch_bounds__(256) void ipa_frags_kernel(const float* __restrict__ proj, const float* __restrict__ R, const float* __restrict__ t,
@@ -65,19 +68,20 @@ __global__ __launch_bounds__(256) void ipa_frags_kernel(const float* __restrict_
         float4 o;
         if (slot < 2) {
             const int64_t row = rowbase + min(ch * JC + fm, L - 1);
-            o = *reinterpret_cast<const float4*>(proj + row * NP + OFF_K + h * D + kq * 8 + slot * 4);
+            o = *reinterpret_cast<const float4*>(proj + row * NP + OFF_K + h * D + slot * 16 + kq * 4);
         } else if (slot == 2) {
-            const float* kp = &pts[fm][NPT + h * (P * 3)];
-            o = make_float4(kp[2 * kq], kp[2 * kq + 1], kp[8 + 2 * kq], kp[8 + 2 * kq + 1]);
+            const float* kp = &pts[fm][NPT + h * (P * 3) + kq * 3];
+            o = make_float4(kp[0], kp[1], kp[2], kq == 0 ? 1.f : (kq == 1 ? pts[fm][3 * NPT + H + h] : 0.f));
         } else if (slot == 3) {
-            const float* kp = &pts[fm][NPT + h * (P * 3)];
-            o = make_float4(kp[16 + 2 * kq], kp[16 + 2 * kq + 1], kq == 0 ? 1.f : (kq == 1 ? pts[fm][3 * NPT + H + h] : 0.f), 0.f);
+            const float* kp = &pts[fm][NPT + h * (P * 3) + (4 + kq) * 3];
+            o = make_float4(kp[0], kp[1], kp[2], 0.f);
         } else {
             const int r = kq * 4 + (slot - 4);
             const int64_t row = rowbase + min(ch * JC + r, L - 1);
-            const float2 vv = *reinterpret_cast<const float2*>(proj + row * NP + OFF_V + h * D + 2 * fm);
+            const float* vrow = proj + row * NP + OFF_V + h * D;
             const float* vp = &pts[r][2 * NPT + h * (P * 3)];
-            o = make_float4(vv.x, vv.y, fm < 12 ? vp[2 * fm] : 0.f, fm < 12 ? vp[2 * fm + 1] : 0.f);
+            const int pt = fm >> 2, c = fm & 3;
+            o = make_float4(vrow[fm], vrow[16 + fm], c < 3 ? vp[pt * 3 + c] : 0.f, c < 3 ? vp[(4 + pt) * 3 + c] : 0.f);
         }
         outk[e] = o;
     }
@@ -88,15 +92,15 @@ __global__ __launch_bounds__(256) void ipa_frags_kernel(const float* __restrict_
         float4 o;
         if (slot < 2) {
             const int64_t row = rowbase + min(ch * JC + fm, L - 1);
-            const float4 qv = *reinterpret_cast<const float4*>(proj + row * NP + OFF_Q + h * D + kq * 8 + slot * 4);
+            const float4 qv = *reinterpret_cast<const float4*>(proj + row * NP + OFF_Q + h * D + slot * 16 + kq * 4);
             const float s = 0.17677669529663687f;                                      // 1 / sqrt(D), ga.py:84
             o = make_float4(qv.x * s, qv.y * s, qv.z * s, qv.w * s);
         } else if (slot == 2) {
-            const float* qp = &pts[fm][h * (P * 3)];
-            o = make_float4(m2c * qp[2 * kq], m2c * qp[2 * kq + 1], m2c * qp[8 + 2 * kq], m2c * qp[8 + 2 * kq + 1]);
+            const float* qp = &pts[fm][h * (P * 3) + kq * 3];
+            o = make_float4(m2c * qp[0], m2c * qp[1], m2c * qp[2], kq == 0 ? c * pts[fm][3 * NPT + h] : (kq == 1 ? c : 0.f));
         } else {
-            const float* qp = &pts[fm][h * (P * 3)];
-            o = make_float4(m2c * qp[16 + 2 * kq], m2c * qp[16 + 2 * kq + 1], kq == 0 ? c * pts[fm][3 * NPT + h] : (kq == 1 ? c : 0.f), 0.f);
+            const float* qp = &pts[fm][h * (P * 3) + (4 + kq) * 3];
+            o = make_float4(m2c * qp[0], m2c * qp[1], m2c * qp[2], 0.f);
         }
         outq[e] = o;
     }

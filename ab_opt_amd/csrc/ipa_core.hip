@@ -363,17 +363,15 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         for (int hh = 0; hh < 3; ++hh) {
             const int h = h0 + hh;
             const float inv = mi_c ? 1.f / sm.lsum[fm * SCLD + h] : 0.f;
-            // accumulator row 4 kq + r of tile k <-> channel 2 (4 kq + r) + k: a lane owns 8 consecutive channels of query fm
+            // accumulator row 4 kq + r of tile k <-> value channel 16 k + 4 kq + r   /   coordinate r of point 4 k + kq (r = 3: padding)
             if (i < L) {
-                float* fo = feat + (rowbase + i) * FEAT + H * C + h * D + kq * 8;
-                reinterpret_cast<f32x4*>(fo)[0] = (f32x4){accV[hh][0][0] * inv, accV[hh][1][0] * inv, accV[hh][0][1] * inv, accV[hh][1][1] * inv};
-                reinterpret_cast<f32x4*>(fo)[1] = (f32x4){accV[hh][0][2] * inv, accV[hh][1][2] * inv, accV[hh][0][3] * inv, accV[hh][1][3] * inv};
+                float* fo = feat + (rowbase + i) * FEAT + H * C + h * D + kq * 4;
+                *reinterpret_cast<f32x4*>(fo) = accV[hh][0] * inv;
+                *reinterpret_cast<f32x4*>(fo + 16) = accV[hh][1] * inv;
             }
-            if (kq < 3) {
-                float* po = pts + (fm * H + h) * (P * 3) + kq * 8;
-                reinterpret_cast<f32x4*>(po)[0] = (f32x4){accT[hh][0][0] * inv, accT[hh][1][0] * inv, accT[hh][0][1] * inv, accT[hh][1][1] * inv};
-                reinterpret_cast<f32x4*>(po)[1] = (f32x4){accT[hh][0][2] * inv, accT[hh][1][2] * inv, accT[hh][0][3] * inv, accT[hh][1][3] * inv};
-            }
+            float* po = pts + (fm * H + h) * (P * 3) + kq * 3;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { po[r] = accT[hh][0][r] * inv; po[12 + r] = accT[hh][1][r] * inv; }
         }
         TSYNC(3, 4)                                                         // F2
     }

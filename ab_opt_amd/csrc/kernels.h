@@ -23,6 +23,11 @@ int launch_ipa_core(const float* qfrag, const float* kvfrag, const float* z, con
                     const float* w_pair_bias, float* feat, float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache,
                     int N, int L, hipStream_t st, int z_shared = 0 /* 1: z and the pair-bias cache hold ONE sample that every batch entry shares */);
 
+// node_frags.hip: x [N*L,128] -> qfrag / kvfrag directly (projection GEMM + frame transform + fragment layout in one kernel)
+size_t node_wfrag_floats();
+int launch_node_frags(const float* x, const float* wfrag, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag,
+                      int N, int L, hipStream_t st);
+
 // rows.hip ------------------------------------------------------------------------------------
 int launch_so3_exp(const float* w, float* R, int64_t n, hipStream_t st);
 int launch_so3_log(const float* R, float* w, int64_t n, int grad_mode, hipStream_t st);

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -21,7 +21,7 @@ c_u8 = C.c_void_p       # device uint8*
 class GaWeights(C.Structure):
     _fields_ = [(n, c_f) for n in (
         'w_node', 'w_pair_bias', 'spatial_coef', 'w_out', 'b_out', 'ln1_gamma', 'ln1_beta',
-        'w_mlp0', 'b_mlp0', 'w_mlp1', 'b_mlp1', 'w_mlp2', 'b_mlp2', 'ln2_gamma', 'ln2_beta')]
+        'w_mlp0', 'b_mlp0', 'w_mlp1', 'b_mlp1', 'w_mlp2', 'b_mlp2', 'ln2_gamma', 'ln2_beta', 'w_node_frag')]
 
 
 class GaDebug(C.Structure):
@@ -75,7 +75,7 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
-           'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite']
+           'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats']
 
 _lib = None
 _lock = threading.Lock()
@@ -140,6 +140,8 @@ def lib():
         L.abopt_pair_embed_backward_workspace_bytes.restype = C.c_size_t
         L.abopt_pair_embed_backward_workspace_bytes.argtypes = [C.c_int] * 3
         L.abopt_pair_embed_backward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, c_f, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_node_frag_source_row.argtypes = [C.c_int] * 3
+        L.abopt_node_frag_floats.restype = C.c_size_t
         L.abopt_dockq_workspace_bytes.restype = C.c_size_t
         L.abopt_dockq_workspace_bytes.argtypes = [C.c_int]
         L.abopt_dockq_lite.argtypes = [c_f, c_u8, C.c_int, c_f, c_u8, C.c_void_p, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -226,11 +228,29 @@ def so3_log(R, grad_mode=False):
 
 
 def ga_weights_struct(t):
-    """t: dict name -> contiguous device tensor with the field names of GaWeights."""
+    """t: dict name -> contiguous device tensor with the field names of GaWeights (w_node_frag optional)."""
     s = GaWeights()
     for name, _ in GaWeights._fields_:
-        setattr(s, name, ptr(t[name], torch.float32))
+        setattr(s, name, ptr(t.get(name), torch.float32, optional=(name == 'w_node_frag')))
     return s
+
+
+_NODE_FRAG_INDEX = None
+
+
+def pack_node_weights(w_node):
+    """w_node [2016, 128] -> w_node_frag [12, 12, 8, 64, 4] (include/abopt.h: abopt_node_frag_source_row): the per-head, tile-ordered,
+    fragment-order copy the fused projection kernel keeps in LDS.  Index tables come from the library so the layout has one owner."""
+    global _NODE_FRAG_INDEX
+    if _NODE_FRAG_INDEX is None:
+        L_ = lib()
+        rows = torch.tensor([[[L_.abopt_node_frag_source_row(h, T, m) for m in range(16)] for T in range(12)] for h in range(12)], dtype=torch.long)
+        _NODE_FRAG_INDEX = rows
+    rows = _NODE_FRAG_INDEX.to(w_node.device)
+    wz = torch.cat([w_node, torch.zeros(1, w_node.shape[1], dtype=w_node.dtype, device=w_node.device)], 0)
+    g = wz[torch.where(rows >= 0, rows, torch.full_like(rows, w_node.shape[0]))]          # [12, 12, 16 (m), 128]
+    g = g.reshape(12, 12, 16, 4, 8, 4)                                                     # [h, T, m, kq, j, i]
+    return g.permute(0, 1, 4, 3, 2, 5).contiguous()                                        # [h, T, j, kq, m, i] == [h][T][j][lane = 16 kq + m][i]
 
 
 def ga_block_forward(ws, R, t, x, z, mask, debug=False):

@@ -91,6 +91,8 @@ class GABlock(nn.Module):
             w_mlp1=f(self.mlp_transition[2].weight), b_mlp1=f(self.mlp_transition[2].bias),
             w_mlp2=f(self.mlp_transition[4].weight), b_mlp2=f(self.mlp_transition[4].bias),
             ln2_gamma=f(self.layer_norm_2.gamma), ln2_beta=f(self.layer_norm_2.beta))
+        if t['w_node'].is_cuda:
+            t['w_node_frag'] = hip.pack_node_weights(t['w_node'])
         s = hip.ga_weights_struct(t)
         self._pack = (snap, t, s)
         return t, s

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 14
+#define ABOPT_ABI_VERSION 15
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -56,7 +56,15 @@ typedef struct {
     const float* w_mlp1; const float* b_mlp1;
     const float* w_mlp2; const float* b_mlp2;
     const float* ln2_gamma; const float* ln2_beta;
+    const float* w_node_frag;   /* optional [12, 12, 8, 64, 4]: w_node re-laid out per head in MFMA fragment order (abopt_pack_node_weights);
+                                   when given, the fused projection kernel replaces the GEMM + fragment pass (same results up to fp32 summation order) */
 } abopt_ga_weights;
+
+/* Host-side description of the w_node_frag layout (used by the binding to pack weights once): for head h, tile T (0,1 q | 2,3 k | 4,5 v |
+ * 6,7 q_pts | 8,9 k_pts | 10,11 v_pts), tile row m (0..15) -> source row of w_node, or -1 for a zero row.  Point tiles hold 4 points as
+ * (x, y, z, pad): m = 4 p + c.  Element [h][T][j][lane = 16 kq + m][i] = w_node[row][32 kq + 4 j + i]. */
+int abopt_node_frag_source_row(int h, int T, int m);
+size_t abopt_node_frag_floats(void);
 
 /* Optional intermediates of one block for parity tests (any pointer may be NULL):
  * logits = (node+pair+spatial)*sqrt(1/3) before masking, alpha after softmax/masking: [N,L,L,12]; feat [N,L,1824]. */
