@@ -16,7 +16,7 @@
 
 namespace abopt {
 
-constexpr int NF_TILES = 12, NF_WAVES = 8;
+constexpr int NF_TILES = 12, NF_WAVES = 16;                   // 4 waves per SIMD: enough independent MFMA chains to keep the matrix pipe fed
 constexpr int NF_TILE_FLOATS = 8 * 64 * 4;                     // one weight tile in fragment order: [j = 0..7][lane][4]
 
 __device__ __forceinline__ float quad_bcast0(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x00, 0xf, 0xf, false)); }
@@ -42,36 +42,15 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
     const float m2c = -2.f * ch_;
     __syncthreads();
 
-    // tiles are dealt to the (workgroup, wave) slots round-robin; the operands of the NEXT tile are requested before this tile's
-    // MFMAs (x tile, frames), so their latency hides behind 384 MFMAs
-    struct TileIn { f32x4 xf[8]; float Rm[9], tv[3], Rv[4][4]; };
-    auto load_tile = [&](TileIn& ti, int tile) {
-        const int tl = min(tile, total_tiles - 1);                               // past the end: harmless reload of the last tile
-        const int n = tl / nchunk, cb = tl % nchunk;
+    // tiles are dealt to the (workgroup, wave) slots round-robin; with 4 waves per SIMD the other waves' MFMAs cover a wave's operand loads
+    const int stride = gridDim.x * NF_WAVES;
+    for (int tile = blockIdx.x * NF_WAVES + wave; tile < total_tiles; tile += stride) {
+        const int n = tile / nchunk, cb = tile % nchunk;
         const int64_t rowbase = (int64_t)n * L;
         const int64_t row = rowbase + min(cb * JC + fm, L - 1);                  // rows past the end: clamped copies (finite; the core never stores them)
+        f32x4 xf[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ti.xf[j] = *reinterpret_cast<const f32x4*>(x + row * 128 + kq * 32 + 4 * j);   // lane (row fm, kq) holds k = 32 kq + 4 j + i
-#pragma unroll
-        for (int k = 0; k < 9; ++k) ti.Rm[k] = R[row * 9 + k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ti.tv[k] = t[row * 3 + k];
-        const int c = min(fm & 3, 2);                                            // value-point epilogue: row c of R and t[c] of residues 4 kq + r
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t rr = rowbase + min(cb * JC + kq * 4 + r, L - 1);
-            ti.Rv[r][0] = R[rr * 9 + c * 3]; ti.Rv[r][1] = R[rr * 9 + c * 3 + 1]; ti.Rv[r][2] = R[rr * 9 + c * 3 + 2]; ti.Rv[r][3] = t[rr * 3 + c];
-        }
-    };
-    const int stride = gridDim.x * NF_WAVES;
-    int tile = blockIdx.x * NF_WAVES + wave;
-    TileIn cur, nxt;
-    if (tile < total_tiles) load_tile(cur, tile);
-    for (; tile < total_tiles; tile += stride) {
-        load_tile(nxt, tile + stride);
-        const f32x4* xf = cur.xf;
-        const float* Rm = cur.Rm;
-        const float* tv = cur.tv;
+        for (int j = 0; j < 8; ++j) xf[j] = *reinterpret_cast<const f32x4*>(x + row * 128 + kq * 32 + 4 * j);   // lane (row fm, kq) holds k = 32 kq + 4 j + i
         f32x4 acc[NF_TILES];
 #pragma unroll
         for (int T = 0; T < NF_TILES; ++T) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -95,6 +74,12 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // frames are fetched only now: x fragments and weight registers are dead, so the 128-VGPR budget (4 waves / SIMD) holds
+        float Rm[9], tv[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rm[k] = R[row * 9 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tv[k] = t[row * 3 + k];
         f32x4* outq = reinterpret_cast<f32x4*>(qfrag) + ((int64_t)tile * H + h) * (4 * 64) + lane;
         f32x4* outk = reinterpret_cast<f32x4*>(kvfrag) + ((int64_t)tile * H + h) * (8 * 64) + lane;
         // ---- q, k: accumulator row 4 kq + r = channel, column fm = residue
@@ -123,18 +108,19 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
         }
         // ---- v, v_pts: accumulator row 4 kq + r = residue, column fm = channel / (point fm >> 2, coordinate fm & 3)
         {
-            const int c = fm & 3;
+            const int c = fm & 3, cr = min(c, 2);                                 // row cr of R and t[cr] of residue 4 kq + r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                const int64_t rr = rowbase + min(cb * JC + kq * 4 + r, L - 1);
+                const float r0 = R[rr * 9 + cr * 3], r1 = R[rr * 9 + cr * 3 + 1], r2 = R[rr * 9 + cr * 3 + 2], r3 = t[rr * 3 + cr];
                 const float xa = quad_bcast0(acc[10][r]), ya = quad_bcast1(acc[10][r]), za = quad_bcast2(acc[10][r]);
                 const float xb = quad_bcast0(acc[11][r]), yb = quad_bcast1(acc[11][r]), zb = quad_bcast2(acc[11][r]);
-                float g0 = cur.Rv[r][0] * xa + cur.Rv[r][1] * ya + cur.Rv[r][2] * za + cur.Rv[r][3];
-                float g1 = cur.Rv[r][0] * xb + cur.Rv[r][1] * yb + cur.Rv[r][2] * zb + cur.Rv[r][3];
+                float g0 = r0 * xa + r1 * ya + r2 * za + r3;
+                float g1 = r0 * xb + r1 * yb + r2 * zb + r3;
                 if (c == 3) { g0 = 0.f; g1 = 0.f; }
                 outk[(4 + r) * 64] = (f32x4){acc[4][r], acc[5][r], g0, g1};
             }
         }
-        cur = nxt;
     }
 }
 

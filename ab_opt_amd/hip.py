@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -21,7 +21,7 @@ c_u8 = C.c_void_p       # device uint8*
 class GaWeights(C.Structure):
     _fields_ = [(n, c_f) for n in (
         'w_node', 'w_pair_bias', 'spatial_coef', 'w_out', 'b_out', 'ln1_gamma', 'ln1_beta',
-        'w_mlp0', 'b_mlp0', 'w_mlp1', 'b_mlp1', 'w_mlp2', 'b_mlp2', 'ln2_gamma', 'ln2_beta', 'w_node_frag')]
+        'w_mlp0', 'b_mlp0', 'w_mlp1', 'b_mlp1', 'w_mlp2', 'b_mlp2', 'ln2_gamma', 'ln2_beta', 'w_node_frag', 'w_out_frag')]
 
 
 class GaDebug(C.Structure):
@@ -231,8 +231,14 @@ def ga_weights_struct(t):
     """t: dict name -> contiguous device tensor with the field names of GaWeights (w_node_frag optional)."""
     s = GaWeights()
     for name, _ in GaWeights._fields_:
-        setattr(s, name, ptr(t.get(name), torch.float32, optional=(name == 'w_node_frag')))
+        setattr(s, name, ptr(t.get(name), torch.float32, optional=name in ('w_node_frag', 'w_out_frag')))
     return s
+
+
+def pack_out_weights(w_out):
+    """w_out [128, 1824] -> [8, 114, 64, 4] fragment order (include/abopt.h: abopt_ga_weights.w_out_frag)."""
+    g = w_out.reshape(8, 16, 114, 4, 4)                       # [w, m, g, kq, i]
+    return g.permute(0, 2, 3, 1, 4).contiguous()              # [w, g, kq, m, i] == [w][g][lane = 16 kq + m][i]
 
 
 _NODE_FRAG_INDEX = None

@@ -93,6 +93,7 @@ class GABlock(nn.Module):
             ln2_gamma=f(self.layer_norm_2.gamma), ln2_beta=f(self.layer_norm_2.beta))
         if t['w_node'].is_cuda:
             t['w_node_frag'] = hip.pack_node_weights(t['w_node'])
+            t['w_out_frag'] = hip.pack_out_weights(t['w_out'])
         s = hip.ga_weights_struct(t)
         self._pack = (snap, t, s)
         return t, s

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 15
+#define ABOPT_ABI_VERSION 16
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -58,6 +58,8 @@ typedef struct {
     const float* ln2_gamma; const float* ln2_beta;
     const float* w_node_frag;   /* optional [12, 12, 8, 64, 4]: w_node re-laid out per head in MFMA fragment order (abopt_pack_node_weights);
                                    when given, the fused projection kernel replaces the GEMM + fragment pass (same results up to fp32 summation order) */
+    const float* w_out_frag;    /* optional [8, 114, 64, 4]: w_out in MFMA fragment order, element [w][g][lane = 16 kq + m][i] = w_out[16 w + m][16 g + 4 kq + i];
+                                   when given, out_transform runs inside the LayerNorm/MLP kernel (no split-K partial slabs) */
 } abopt_ga_weights;
 
 /* Host-side description of the w_node_frag layout (used by the binding to pack weights once): for head h, tile T (0,1 q | 2,3 k | 4,5 v |

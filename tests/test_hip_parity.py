@@ -1080,13 +1080,16 @@ def test_training_abdesign_loss_and_grads_vs_reference():
 
 
 def test_fused_node_projection_matches_gemm_path():
-    """node_frags.hip (projection GEMM + frame transform + fragment layout in one kernel, weights packed per head) against the
-    plain path (gemm_xwT + ipa_frags) through the C ABI: same block output up to fp32 summation order, ragged lengths included."""
+    """node_frags.hip (projection GEMM + frame transform + fragment layout in one kernel, weights packed per head) and the fused
+    out_transform + LayerNorm/MLP tail (mlp.hip::out_ln_mlp_kernel) against the plain path (gemm_xwT + ipa_frags + split-K GEMM +
+    fused_ln_mlp) through the C ABI: same block output up to fp32 summation order, ragged lengths and row counts that are not a
+    multiple of the 32-row tile included."""
     from ab_opt_amd import hip
     blk = _block_on_device(seed=11)
     t_, s_full = blk.packed()
     assert 'w_node_frag' in t_ and t_['w_node_frag'].numel() == 12 * 12 * 8 * 64 * 4
-    plain = hip.ga_weights_struct({k: v for k, v in t_.items() if k != 'w_node_frag'})
+    assert t_['w_out_frag'].numel() == 128 * 1824
+    plain = hip.ga_weights_struct({k: v for k, v in t_.items() if k not in ('w_node_frag', 'w_out_frag')})
     for N, L, lengths in ((2, 40, [40, 33]), (3, 70, [70, 33, 1]), (8, 256, [256, 250, 256, 231, 256, 256, 17, 256])):
         R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(N, L, lengths, salt=1200 + L)]
         a = hip.ga_block_forward(s_full, R, t, x, z, mask)
