@@ -83,7 +83,8 @@ extern "C" int abopt_abi_version(void) { return ABOPT_ABI_VERSION; }
 extern "C" size_t abopt_node_frag_floats(void) { return node_wfrag_floats(); }
 extern "C" int abopt_node_frag_source_row(int h, int T, int m) {
     if (h < 0 || h >= H || T < 0 || T >= 12 || m < 0 || m >= 16) return -1;
-    const int set = T / 2, half = T % 2;                      // set: 0 q, 1 k, 2 v, 3 q_pts, 4 k_pts, 5 v_pts
+    static const int kSet[12] = {0, 0, 1, 1, 3, 3, 4, 4, 2, 2, 5, 5};   // tile -> projection: 0 q, 1 k, 2 v, 3 q_pts, 4 k_pts, 5 v_pts
+    const int set = kSet[T], half = T % 2;
     if (set < 3) return set * (H * D) + h * D + half * 16 + m;
     const int p = half * 4 + m / 4, c = m % 4;
     if (c == 3) return -1;

@@ -4,127 +4,227 @@
 // in ONE kernel.  The 67 MB projection buffer is never written or re-read.
 //
 // Weight-stationary: a workgroup owns ONE head.  Its 168 weight rows, permuted and zero-padded at pack time to 12 tiles of 16 rows
-//   tile 0,1: q channels 0..15, 16..31   2,3: k   4,5: v   6,7: q_pts points 0..3, 4..7 as (x, y, z, 0) quadruples   8,9: k_pts   10,11: v_pts
-// sit in LDS in A-operand fragment order (96 KB, loaded once); residues stream through in 16-row tiles, one tile per wave at a time,
-// the x tile in registers as the B operand.  Per (head, 16 residues): 12 x 32 fp32 MFMAs (v_mfma_f32_16x16x4_f32, exact fp32), then a
-// register-only epilogue: with this row order an accumulator tile IS a fragment slot -- lane (residue, kq) holds 4 consecutive
-// channels, or (x, y, z, pad) of one point, so the frame transform needs no cross-lane traffic.  The value tiles run with the operands
-// swapped (accumulator = [residue 4 kq + r][channel fm]), which is the key-major layout of the aggregation operand.
-// Traffic per launch at M = 8192: x re-read once per head from L2 (12 x 4 MB), weights 12 x 96 KB, fragments written once (75 MB).
+//   tile 0,1: q channels 0..15, 16..31   2,3: k   4,5: q_pts points 0..3, 4..7 as (x, y, z, 0) quadruples  |  6,7: k_pts   8,9: v   10,11: v_pts
+// sit in LDS in MFMA operand order (144 KB, loaded once); residues stream through in pairs of 16-row tiles.
+//
+// Arithmetic: fp32 x fp32 products on the bf16 matrix pipe.  An fp32 number is EXACTLY the sum of three bf16 numbers (8 + 8 + 8
+// significand bits: h = top 16 bits of x, m = top 16 bits of x - h, l = x - h - m), so
+//     x w = hH + (hM + mH) + (hL + lH + mM) + [mL + lM + lL, relative size <= 2^-23, dropped]
+// needs six v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32) where the exact-fp32 path needs eight v_mfma_f32_16x16x4_f32 (32
+// cycles each): 2.7x fewer matrix-pipe cycles.  Every bf16 x bf16 product is exact in fp32 and the accumulation is fp32, so the
+// result differs from an fp32 FMA chain by the dropped terms only -- the same order as one fp32 rounding per product.  The weights are
+// split once at pack time (hip.pack_node_weights); x is split in registers (11 VALU ops per pair of values).  Measured: 58 us (fp32
+// MFMA, same structure) -> see DESIGN.md; parity tests unchanged.
+//
+// A task is (32 residues, half of the head's tiles): 6 tiles x 4 k-steps x 2 row tiles x 6 products = 288 MFMAs on 48 accumulator
+// registers, with each weight fragment read from LDS once per TWO row tiles (at one row tile per read the kernel would sit exactly on
+// the 128 B/clk LDS limit).  Register-only epilogue: with this row order an accumulator tile IS a fragment slot -- lane (residue, kq)
+// holds 4 consecutive channels, or (x, y, z, pad) of one point, so the frame transform needs no cross-lane traffic.  The value tiles
+// run with the operands swapped (accumulator = [residue 4 kq + r][channel fm]), which is the key-major layout of the aggregation
+// operand.
+// Traffic per launch at M = 8192: x re-read from L2 (24 x 4 MB), weights 12 x 144 KB, fragments written once (75 MB).
 #include "ipa_common.h"
 #include "kernels.h"
 
+#ifdef NF_TIMING   // developer build: clocks of one workgroup
+#include <cstdio>
+__device__ long long g_nf_timing[16][8];
+#endif
+
 namespace abopt {
 
-constexpr int NF_TILES = 12, NF_WAVES = 16;                   // 4 waves per SIMD: enough independent MFMA chains to keep the matrix pipe fed
-constexpr int NF_TILE_FLOATS = 8 * 64 * 4;                     // one weight tile in fragment order: [j = 0..7][lane][4]
+constexpr int NF_F = 128;                                       // node feature width (ga.py:54-66 with node_feat_dim = 128)
+constexpr int NF_TILES = 12, NF_HT = NF_TILES / 2, NF_WAVES = 8;
+constexpr int NF_KS = NF_F / 32, NF_SPL = 3;                // k-steps of 32, bf16 terms per fp32 value
+constexpr int NF_HEAD_VEC = NF_TILES * NF_KS * NF_SPL * 64;    // 16-byte vectors (8 bf16) per head: [tile][k-step][term][lane]
+
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float quad_bcast0(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x00, 0xf, 0xf, false)); }
 __device__ __forceinline__ float quad_bcast1(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x55, 0xf, 0xf, false)); }
 __device__ __forceinline__ float quad_bcast2(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xAA, 0xf, 0xf, false)); }
+
+__device__ __forceinline__ f32x4 mfma_bf(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// 8 consecutive fp32 values -> their three bf16 terms, two values per register (element 2p in the low half)
+struct Split3 { u32x4 h, m, l; };
+__device__ __forceinline__ Split3 split3(const f32x4& lo, const f32x4& hi) {
+    Split3 o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float e0 = p < 2 ? lo[2 * p] : hi[2 * p - 4], e1 = p < 2 ? lo[2 * p + 1] : hi[2 * p - 3];
+        const unsigned b0 = __float_as_uint(e0), b1 = __float_as_uint(e1);
+        o.h[p] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);                       // top halves of (e1, e0)
+        const float r0 = e0 - __uint_as_float(b0 & 0xffff0000u), r1 = e1 - __uint_as_float(b1 & 0xffff0000u);    // exact
+        const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+        o.m[p] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+        const float q0 = r0 - __uint_as_float(c0 & 0xffff0000u), q1 = r1 - __uint_as_float(c1 & 0xffff0000u);    // exact, <= 8 significant bits left
+        o.l[p] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+    }
+    return o;
+}
+
+// One task: tiles [HALF * 6, HALF * 6 + 6) of head h for the row tiles tile0, tile0 + 1.
+template <int HALF>
+__device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4* wl, const float* __restrict__ R, const float* __restrict__ t,
+                                        float* __restrict__ qfrag, float* __restrict__ kvfrag, int L, int nchunk, int total_tiles, int tile0, int h,
+                                        float ch_, float m2c, int lane, int fm, int kq) {
+    int64_t rowbase[2], row[2];
+    int cbs[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int tile = min(tile0 + rt, total_tiles - 1);                       // odd tile count: the last task computes its last tile twice, stores once
+        const int n = tile / nchunk;
+        cbs[rt] = tile % nchunk;
+        rowbase[rt] = (int64_t)n * L;
+        row[rt] = rowbase[rt] + min(cbs[rt] * JC + fm, L - 1);                   // rows past the end: clamped copies (finite; the core never stores them)
+    }
+    // lane (row fm, kq) holds k = 32 s + 8 kq + i of its row for k-step s
+    f32x4 xa[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        xa[rt][0] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + kq * 8);
+        xa[rt][1] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + kq * 8 + 4);
+    }
+    f32x4 acc[2][NF_HT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int T = 0; T < NF_HT; ++T) acc[rt][T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u32x4* wh = wl + (HALF * NF_HT) * (NF_KS * NF_SPL * 64) + lane;
+    // weight fragments of step g + 1 are read from LDS before the 12 MFMAs of step g are issued (hipcc left to itself hoists every read)
+    u32x4 wa[2][NF_SPL];
+#pragma unroll
+    for (int sp = 0; sp < NF_SPL; ++sp) wa[0][sp] = wh[sp * 64];
+    Split3 xs[2];
+#pragma unroll
+    for (int g = 0; g < NF_KS * NF_HT; ++g) {
+        const int s = g / NF_HT, T = g % NF_HT;
+        if (T == 0) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) xs[rt] = split3(xa[rt][0], xa[rt][1]);
+            if (s + 1 < NF_KS) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    xa[rt][0] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + (s + 1) * 32 + kq * 8);
+                    xa[rt][1] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + (s + 1) * 32 + kq * 8 + 4);
+                }
+            }
+        }
+        if (g + 1 < NF_KS * NF_HT) {
+            const int sn = (g + 1) / NF_HT, Tn = (g + 1) % NF_HT;
+#pragma unroll
+            for (int sp = 0; sp < NF_SPL; ++sp) wa[(g + 1) & 1][sp] = wh[((Tn * NF_KS + sn) * NF_SPL + sp) * 64];
+        }
+        const u32x4 wH = wa[g & 1][0], wM = wa[g & 1][1], wL = wa[g & 1][2];
+        const bool swap = (HALF == 1) && (T >= 2);                               // value tiles: x is the A operand -> accumulator [residue 4 kq + r][channel fm]
+        // smallest terms first; the two row tiles alternate so consecutive MFMAs never depend on each other
+#define NF_PROD(XT, WT)                                                                                                         \
+        if (swap) { acc[0][T] = mfma_bf(xs[0].XT, WT, acc[0][T]); acc[1][T] = mfma_bf(xs[1].XT, WT, acc[1][T]); }               \
+        else      { acc[0][T] = mfma_bf(WT, xs[0].XT, acc[0][T]); acc[1][T] = mfma_bf(WT, xs[1].XT, acc[1][T]); }
+        NF_PROD(l, wH) NF_PROD(h, wL) NF_PROD(m, wM) NF_PROD(m, wH) NF_PROD(h, wM) NF_PROD(h, wH)
+#undef NF_PROD
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    auto sq = [](const f32x4& g) { return fmaf(g[2], g[2], fmaf(g[1], g[1], g[0] * g[0])); };
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        if (tile0 + rt >= total_tiles) break;
+        const int tile = tile0 + rt;
+        // frames are fetched only now: x fragments and weight registers are dead
+        float Rm[9], tv[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rm[k] = R[row[rt] * 9 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tv[k] = t[row[rt] * 3 + k];
+        // p <- R p + t (geometry.py:72-91) on (x, y, z, pad) of one point of residue fm
+        auto to_global = [&](const f32x4& p) {
+            return (f32x4){Rm[0] * p[0] + Rm[1] * p[1] + Rm[2] * p[2] + tv[0], Rm[3] * p[0] + Rm[4] * p[1] + Rm[5] * p[2] + tv[1],
+                           Rm[6] * p[0] + Rm[7] * p[1] + Rm[8] * p[2] + tv[2], 0.f};
+        };
+        f32x4* outq = reinterpret_cast<f32x4*>(qfrag) + ((int64_t)tile * H + h) * (4 * 64) + lane;
+        f32x4* outk = reinterpret_cast<f32x4*>(kvfrag) + ((int64_t)tile * H + h) * (8 * 64) + lane;
+        if (HALF == 0) {
+            // ---- q, k: accumulator row 4 kq + r = channel, column fm = residue
+            const float s = 0.17677669529663687f;                                // 1 / sqrt(D), ga.py:84
+            outq[0] = acc[rt][0] * s; outq[64] = acc[rt][1] * s;
+            outk[0] = acc[rt][2]; outk[64] = acc[rt][3];
+            // ---- q_pts: point kq (tile A) and 4 + kq (tile B) of residue fm
+            f32x4 ga = to_global(acc[rt][4]), gb = to_global(acc[rt][5]);
+            const float nq = rows_sum(sq(ga) + sq(gb));                          // |q_pts|^2 over the head's 8 points
+            ga *= m2c; gb *= m2c;
+            ga[3] = kq == 0 ? ch_ * nq : (kq == 1 ? ch_ : 0.f);                  // norm step, q side
+            gb[3] = 0.f;
+            outq[128] = ga; outq[192] = gb;
+        } else {
+            // ---- k_pts
+            f32x4 ga = to_global(acc[rt][0]), gb = to_global(acc[rt][1]);
+            const float nk = rows_sum(sq(ga) + sq(gb));
+            ga[3] = kq == 0 ? 1.f : (kq == 1 ? nk : 0.f);                        // norm step, k side
+            outk[128] = ga; outk[192] = gb;
+            // ---- v, v_pts: accumulator row 4 kq + r = residue, column fm = channel / (point fm >> 2, coordinate fm & 3)
+            const int c = fm & 3, cr = min(c, 2);                                // row cr of R and t[cr] of residue 4 kq + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t rr = rowbase[rt] + min(cbs[rt] * JC + kq * 4 + r, L - 1);
+                const float r0 = R[rr * 9 + cr * 3], r1 = R[rr * 9 + cr * 3 + 1], r2 = R[rr * 9 + cr * 3 + 2], r3 = t[rr * 3 + cr];
+                const float xa_ = quad_bcast0(acc[rt][4][r]), ya = quad_bcast1(acc[rt][4][r]), za = quad_bcast2(acc[rt][4][r]);
+                const float xb = quad_bcast0(acc[rt][5][r]), yb = quad_bcast1(acc[rt][5][r]), zb = quad_bcast2(acc[rt][5][r]);
+                float g0 = r0 * xa_ + r1 * ya + r2 * za + r3;
+                float g1 = r0 * xb + r1 * yb + r2 * zb + r3;
+                if (c == 3) { g0 = 0.f; g1 = 0.f; }
+                outk[(4 + r) * 64] = (f32x4){acc[rt][2][r], acc[rt][3][r], g0, g1};
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* __restrict__ x, const float* __restrict__ wfrag, const float* __restrict__ R,
                                                                    const float* __restrict__ t, const float* __restrict__ spatial_coef,
                                                                    float* __restrict__ qfrag, float* __restrict__ kvfrag, int L, int nchunk,
                                                                    int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char nf_smem[];
-    f32x4* wl = reinterpret_cast<f32x4*>(nf_smem);                             // [12 tiles][8][64]
+    u32x4* wl = reinterpret_cast<u32x4*>(nf_smem);                             // [12 tiles][4 k-steps][3 terms][64]
     const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef NF_TIMING
+    const long long c0 = clock64(), w0 = wall_clock64();
+#endif
     {
-        const f32x4* wg = reinterpret_cast<const f32x4*>(wfrag) + (int64_t)h * NF_TILES * 8 * 64;
+        const u32x4* wg = reinterpret_cast<const u32x4*>(wfrag) + (int64_t)h * NF_HEAD_VEC;
 #pragma unroll
-        for (int e = 0; e < NF_TILES * 8 * 64 / (NF_WAVES * 64); ++e) wl[e * (NF_WAVES * 64) + tid] = wg[e * (NF_WAVES * 64) + tid];
+        for (int e = 0; e < NF_HEAD_VEC / (NF_WAVES * 64); ++e) wl[e * (NF_WAVES * 64) + tid] = wg[e * (NF_WAVES * 64) + tid];
     }
     const float sc = spatial_coef[h];
     const float gamma = (sc > 20.f) ? sc : log1pf(expf(sc));                     // softplus, ga.py:108
     const float ch_ = (-1.f * gamma * 0.16666666666666666f) / 2.f;               // -gamma sqrt(2/(9*8)) / 2, ga.py:109-110
     const float m2c = -2.f * ch_;
     __syncthreads();
-
-    // tiles are dealt to the (workgroup, wave) slots round-robin; with 4 waves per SIMD the other waves' MFMAs cover a wave's operand loads
-    const int stride = gridDim.x * NF_WAVES;
-    for (int tile = blockIdx.x * NF_WAVES + wave; tile < total_tiles; tile += stride) {
-        const int n = tile / nchunk, cb = tile % nchunk;
-        const int64_t rowbase = (int64_t)n * L;
-        const int64_t row = rowbase + min(cb * JC + fm, L - 1);                  // rows past the end: clamped copies (finite; the core never stores them)
-        f32x4 xf[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xf[j] = *reinterpret_cast<const f32x4*>(x + row * 128 + kq * 32 + 4 * j);   // lane (row fm, kq) holds k = 32 kq + 4 j + i
-        f32x4 acc[NF_TILES];
-#pragma unroll
-        for (int T = 0; T < NF_TILES; ++T) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // two tiles at a time (two independent accumulator chains hide the 40-cycle dependent-MFMA latency); the weight fragments of
-        // step g + 1 are read from LDS before the 8 MFMAs of step g are issued (hipcc left to itself hoists all 96 reads = 384 VGPRs)
-        f32x4 wa[2][2];
-        wa[0][0] = wl[lane]; wa[0][1] = wl[8 * 64 + lane];
-#pragma unroll
-        for (int g = 0; g < (NF_TILES / 2) * 8; ++g) {
-            const int T = (g >> 3) * 2, j = g & 7;
-            const bool swap = (T == 4) || (T == 10);                             // value tiles: x is the A operand -> accumulator [residue 4 kq + r][channel fm]
-            if (g + 1 < (NF_TILES / 2) * 8) {
-                const int Tn = ((g + 1) >> 3) * 2, jn = (g + 1) & 7;
-                wa[(g + 1) & 1][0] = wl[(Tn * 8 + jn) * 64 + lane]; wa[(g + 1) & 1][1] = wl[((Tn + 1) * 8 + jn) * 64 + lane];
-            }
-            const f32x4 a0 = wa[g & 1][0], a1 = wa[g & 1][1];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (swap) { acc[T] = mfma4(xf[j][i], a0[i], acc[T]); acc[T + 1] = mfma4(xf[j][i], a1[i], acc[T + 1]); }
-                else      { acc[T] = mfma4(a0[i], xf[j][i], acc[T]); acc[T + 1] = mfma4(a1[i], xf[j][i], acc[T + 1]); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // frames are fetched only now: x fragments and weight registers are dead, so the 128-VGPR budget (4 waves / SIMD) holds
-        float Rm[9], tv[3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Rm[k] = R[row * 9 + k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) tv[k] = t[row * 3 + k];
-        f32x4* outq = reinterpret_cast<f32x4*>(qfrag) + ((int64_t)tile * H + h) * (4 * 64) + lane;
-        f32x4* outk = reinterpret_cast<f32x4*>(kvfrag) + ((int64_t)tile * H + h) * (8 * 64) + lane;
-        // ---- q, k: accumulator row 4 kq + r = channel, column fm = residue
-        const float s = 0.17677669529663687f;                                    // 1 / sqrt(D), ga.py:84
-        outq[0] = acc[0] * s; outq[64] = acc[1] * s;
-        outk[0] = acc[2]; outk[64] = acc[3];
-        // ---- q_pts, k_pts: (x, y, z, pad) of point kq (tile A) and 4 + kq (tile B) of residue fm; p <- R p + t (geometry.py:72-91)
-        auto to_global = [&](const f32x4& p) {
-            return (f32x4){Rm[0] * p[0] + Rm[1] * p[1] + Rm[2] * p[2] + tv[0], Rm[3] * p[0] + Rm[4] * p[1] + Rm[5] * p[2] + tv[1],
-                           Rm[6] * p[0] + Rm[7] * p[1] + Rm[8] * p[2] + tv[2], 0.f};
-        };
-        auto sq = [](const f32x4& g) { return fmaf(g[2], g[2], fmaf(g[1], g[1], g[0] * g[0])); };
-        {
-            f32x4 ga = to_global(acc[6]), gb = to_global(acc[7]);
-            const float nq = rows_sum(sq(ga) + sq(gb));                          // |q_pts|^2 over the head's 8 points
-            ga *= m2c; gb *= m2c;
-            ga[3] = kq == 0 ? ch_ * nq : (kq == 1 ? ch_ : 0.f);                  // norm step, q side
-            gb[3] = 0.f;
-            outq[128] = ga; outq[192] = gb;
-        }
-        {
-            f32x4 ga = to_global(acc[8]), gb = to_global(acc[9]);
-            const float nk = rows_sum(sq(ga) + sq(gb));
-            ga[3] = kq == 0 ? 1.f : (kq == 1 ? nk : 0.f);                        // norm step, k side
-            outk[128] = ga; outk[192] = gb;
-        }
-        // ---- v, v_pts: accumulator row 4 kq + r = residue, column fm = channel / (point fm >> 2, coordinate fm & 3)
-        {
-            const int c = fm & 3, cr = min(c, 2);                                 // row cr of R and t[cr] of residue 4 kq + r
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t rr = rowbase + min(cb * JC + kq * 4 + r, L - 1);
-                const float r0 = R[rr * 9 + cr * 3], r1 = R[rr * 9 + cr * 3 + 1], r2 = R[rr * 9 + cr * 3 + 2], r3 = t[rr * 3 + cr];
-                const float xa = quad_bcast0(acc[10][r]), ya = quad_bcast1(acc[10][r]), za = quad_bcast2(acc[10][r]);
-                const float xb = quad_bcast0(acc[11][r]), yb = quad_bcast1(acc[11][r]), zb = quad_bcast2(acc[11][r]);
-                float g0 = r0 * xa + r1 * ya + r2 * za + r3;
-                float g1 = r0 * xb + r1 * yb + r2 * zb + r3;
-                if (c == 3) { g0 = 0.f; g1 = 0.f; }
-                outk[(4 + r) * 64] = (f32x4){acc[4][r], acc[5][r], g0, g1};
-            }
-        }
+#ifdef NF_TIMING
+    const long long c1 = clock64();
+#endif
+    // every workgroup owns a contiguous, equal (+-1) share of the head's tasks (pair of row tiles, half of the tiles); its waves take
+    // them round-robin, so both halves of a row-tile pair run on neighbouring waves and share the x rows in L1
+    const int ntask = 2 * ((total_tiles + 1) / 2);
+    const int t_lo = (int)((int64_t)ntask * blockIdx.x / gridDim.x), t_hi = (int)((int64_t)ntask * (blockIdx.x + 1) / gridDim.x);
+    for (int task = t_lo + wave; task < t_hi; task += NF_WAVES) {
+        const int tile0 = (task >> 1) * 2;
+        if (task & 1) nf_task<1>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, lane, fm, kq);
+        else          nf_task<0>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, lane, fm, kq);
     }
+#ifdef NF_TIMING
+    if (blockIdx.x == 5 && blockIdx.y == 3 && lane == 0) {
+        long long* o = g_nf_timing[wave];
+        o[0] = c1 - c0; o[1] = clock64() - c0; o[2] = wall_clock64() - w0; o[3] = 0; o[4] = 0; o[5] = (t_hi - t_lo);
+    }
+#endif
 }
 
-size_t node_wfrag_floats() { return (size_t)H * NF_TILES * NF_TILE_FLOATS; }
+size_t node_wfrag_floats() { return (size_t)H * NF_HEAD_VEC * 4; }
 
 int launch_node_frags(const float* x, const float* wfrag, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag,
                       int N, int L, hipStream_t st) {
@@ -137,12 +237,25 @@ int launch_node_frags(const float* x, const float* wfrag, const float* R, const 
         hipDeviceProp_t prop;
         ABOPT_HIP(hipGetDeviceProperties(&prop, dev));
         cus = prop.multiProcessorCount;
-        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(node_frags_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NF_TILES * NF_TILE_FLOATS * 4));
+        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(node_frags_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NF_HEAD_VEC * 16));
     }
-    const int groups = max(1, min(cus / H, (total + NF_WAVES - 1) / NF_WAVES));          // one workgroup per CU: 96 KB of LDS each
-    hipLaunchKernelGGL(node_frags_kernel, dim3(groups, H), dim3(NF_WAVES * 64), NF_TILES * NF_TILE_FLOATS * 4, st, x, wfrag, R, t, spatial_coef,
+    const int ntask = 2 * ((total + 1) / 2);
+    const int groups = max(1, min(cus / H, (ntask + NF_WAVES - 1) / NF_WAVES));          // one workgroup per CU: 144 KB of LDS each
+    hipLaunchKernelGGL(node_frags_kernel, dim3(groups, H), dim3(NF_WAVES * 64), NF_HEAD_VEC * 16, st, x, wfrag, R, t, spatial_coef,
                        qfrag, kvfrag, L, nchunk, total);
     ABOPT_LAUNCH_CHECK();
+#ifdef NF_TIMING
+    {
+        long long hh[16][8];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_nf_timing), sizeof(hh));
+        static int calls = 0;
+        if (++calls == 8)
+            for (int w = 0; w < NF_WAVES; ++w)
+                fprintf(stderr, "[nf timing WG(5,3) wave %d] W load %lld | total %lld shader clk = %lld x 10 ns wall | mfma loops %lld | epilogues %lld | tiles of WG %lld\n",
+                        w, hh[w][0], hh[w][1], hh[w][2], hh[w][3], hh[w][4], hh[w][5]);
+    }
+#endif
     return ABOPT_OK;
 }
 

@@ -244,9 +244,21 @@ def pack_out_weights(w_out):
 _NODE_FRAG_INDEX = None
 
 
+def split_bf16x3(w):
+    """fp32 tensor -> (h, m, l) int16 bf16 bit patterns with h + m + l == w exactly (csrc/node_frags.hip: split3)."""
+    def top(v):
+        return (v.contiguous().view(torch.int32) & -65536).view(torch.float32)
+    h = top(w)
+    r1 = w - h
+    m = top(r1)
+    l = top(r1 - m)
+    return [(v.view(torch.int32) >> 16).to(torch.int16) for v in (h, m, l)]
+
+
 def pack_node_weights(w_node):
-    """w_node [2016, 128] -> w_node_frag [12, 12, 8, 64, 4] (include/abopt.h: abopt_node_frag_source_row): the per-head, tile-ordered,
-    fragment-order copy the fused projection kernel keeps in LDS.  Index tables come from the library so the layout has one owner."""
+    """w_node [2016, 128] -> w_node_frag [12 heads, 12 tiles, 4 k-steps, 3 bf16 terms, 64 lanes, 4] (fp32 container of 8 bf16 per
+    lane; include/abopt.h: abopt_node_frag_source_row): the per-head, tile-ordered, operand-order copy the fused projection kernel
+    keeps in LDS.  Index tables come from the library so the layout has one owner."""
     global _NODE_FRAG_INDEX
     if _NODE_FRAG_INDEX is None:
         L_ = lib()
@@ -255,8 +267,10 @@ def pack_node_weights(w_node):
     rows = _NODE_FRAG_INDEX.to(w_node.device)
     wz = torch.cat([w_node, torch.zeros(1, w_node.shape[1], dtype=w_node.dtype, device=w_node.device)], 0)
     g = wz[torch.where(rows >= 0, rows, torch.full_like(rows, w_node.shape[0]))]          # [12, 12, 16 (m), 128]
-    g = g.reshape(12, 12, 16, 4, 8, 4)                                                     # [h, T, m, kq, j, i]
-    return g.permute(0, 1, 4, 3, 2, 5).contiguous()                                        # [h, T, j, kq, m, i] == [h][T][j][lane = 16 kq + m][i]
+    terms = torch.stack(split_bf16x3(g.float()), 0)                                        # [3, h, T, m, 128] int16
+    terms = terms.reshape(3, 12, 12, 16, 4, 4, 8)                                          # [term, h, T, m, s, kq, i]: k = 32 s + 8 kq + i
+    out = terms.permute(1, 2, 4, 0, 5, 3, 6).contiguous()                                  # [h, T, s, term, kq, m, i] == [h][T][s][term][lane = 16 kq + m][i]
+    return out.view(12, 12, 4, 3, 64, 8).view(torch.float32)                               # 8 bf16 = 4 fp32 containers per lane
 
 
 def ga_block_forward(ws, R, t, x, z, mask, debug=False):

@@ -56,15 +56,18 @@ typedef struct {
     const float* w_mlp1; const float* b_mlp1;
     const float* w_mlp2; const float* b_mlp2;
     const float* ln2_gamma; const float* ln2_beta;
-    const float* w_node_frag;   /* optional [12, 12, 8, 64, 4]: w_node re-laid out per head in MFMA fragment order (abopt_pack_node_weights);
-                                   when given, the fused projection kernel replaces the GEMM + fragment pass (same results up to fp32 summation order) */
+    const float* w_node_frag;   /* optional [12, 12, 4, 3, 64, 4]: w_node re-laid out per head in MFMA operand order, every weight as its three
+                                   bf16 terms (layout below); when given, the fused projection kernel replaces the GEMM + fragment pass
+                                   (same results up to fp32 summation order) */
     const float* w_out_frag;    /* optional [8, 114, 64, 4]: w_out in MFMA fragment order, element [w][g][lane = 16 kq + m][i] = w_out[16 w + m][16 g + 4 kq + i];
                                    when given, out_transform runs inside the LayerNorm/MLP kernel (no split-K partial slabs) */
 } abopt_ga_weights;
 
-/* Host-side description of the w_node_frag layout (used by the binding to pack weights once): for head h, tile T (0,1 q | 2,3 k | 4,5 v |
- * 6,7 q_pts | 8,9 k_pts | 10,11 v_pts), tile row m (0..15) -> source row of w_node, or -1 for a zero row.  Point tiles hold 4 points as
- * (x, y, z, pad): m = 4 p + c.  Element [h][T][j][lane = 16 kq + m][i] = w_node[row][32 kq + 4 j + i]. */
+/* Host-side description of the w_node_frag layout (used by the binding to pack weights once): for head h, tile T (0,1 q | 2,3 k |
+ * 4,5 q_pts | 6,7 k_pts | 8,9 v | 10,11 v_pts), tile row m (0..15) -> source row of w_node, or -1 for a zero row.  Point tiles hold 4
+ * points as (x, y, z, pad): m = 4 p + c.  A weight w is stored as three bf16 numbers with h + m + l == w exactly (h = w with the low
+ * 16 bits cleared, m = (w - h) likewise, l = w - h - m).  Element [h][T][s][term][lane = 16 kq + m] is a 16-byte vector of 8 bf16:
+ * entry i = term(w_node[row][32 s + 8 kq + i]), term 0 = h, 1 = m, 2 = l.  abopt_node_frag_floats() = size in 4-byte units. */
 int abopt_node_frag_source_row(int h, int T, int m);
 size_t abopt_node_frag_floats(void);
 

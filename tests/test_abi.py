@@ -64,3 +64,24 @@ def test_contig_mask_and_registry():
     assert {'diffab_abdock', 'diffab_abdesign'} <= set(_MODEL_DICT)
     assert type(build_model(10, 3)).__name__ == 'DiffusionAntibodyDesign'
     assert type(build_model(10, 3, flavour='abdesign')).__name__ == 'DiffusionAntibodyDesignAbDesign'
+
+
+def test_bf16_three_term_split_is_exact():
+    """hip.split_bf16x3 (the pack-time half of csrc/node_frags.hip's arithmetic): h + m + l == w bit for bit, every term is a bf16
+    number, and the six products the kernel keeps reproduce x * w to ~2^-23 (the dropped m*l, l*m, l*l terms).  (Exactness needs the
+    residuals to stay normal numbers, i.e. |w| > ~1e-31; below that the error is < 1e-38 absolute.)"""
+    g = torch.Generator().manual_seed(5)
+    w = torch.cat([torch.randn(4096, generator=g) * s for s in (1e-6, 1e-2, 1.0, 37.0, 1e6)] +
+                  [torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e-30, 1.0 + 2.0 ** -23, -(2.0 - 2.0 ** -23), 65280.0, 1.9999999])])
+    terms = [(t.to(torch.int32) << 16).view(torch.float32) for t in hip.split_bf16x3(w)]
+    for t in terms:
+        assert torch.equal(t.to(torch.bfloat16).float(), t)                      # representable in bf16
+    assert torch.equal((terms[0].double() + terms[1].double() + terms[2].double()).float(), w)
+    assert torch.equal(terms[0] + (terms[1] + terms[2]), w)
+    x = torch.randn(w.numel(), generator=g)
+    xt = [(t.to(torch.int32) << 16).view(torch.float32).double() for t in hip.split_bf16x3(x)]
+    wt = [t.double() for t in terms]
+    kept = xt[2] * wt[0] + xt[0] * wt[2] + xt[1] * wt[1] + xt[1] * wt[0] + xt[0] * wt[1] + xt[0] * wt[0]
+    exact = x.double() * w.double()
+    rel = ((kept - exact).abs() / exact.abs().clamp_min(1e-300))[exact != 0]
+    assert rel.max().item() < 2.0 ** -22

@@ -1087,7 +1087,7 @@ def test_fused_node_projection_matches_gemm_path():
     from ab_opt_amd import hip
     blk = _block_on_device(seed=11)
     t_, s_full = blk.packed()
-    assert 'w_node_frag' in t_ and t_['w_node_frag'].numel() == 12 * 12 * 8 * 64 * 4
+    assert 'w_node_frag' in t_ and t_['w_node_frag'].numel() == hip.lib().abopt_node_frag_floats()
     assert t_['w_out_frag'].numel() == 128 * 1824
     plain = hip.ga_weights_struct({k: v for k, v in t_.items() if k not in ('w_node_frag', 'w_out_frag')})
     for N, L, lengths in ((2, 40, [40, 33]), (3, 70, [70, 33, 1]), (8, 256, [256, 250, 256, 231, 256, 256, 17, 256])):
