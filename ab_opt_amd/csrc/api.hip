@@ -57,9 +57,9 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     if ((rc = launch_ipa_core(s.qf, s.kvf, z, mask, R, t, w->w_pair_bias, feat,
                               dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, N, L, st, z_shared))) return rc;
     // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
-    if (w->w_out_frag)
-        return launch_out_ln_mlp(feat, w->w_out_frag, x, w->b_out, mask, w->ln1_gamma, w->ln1_beta, w->w_mlp0, w->b_mlp0, w->w_mlp1, w->b_mlp1,
-                                 w->w_mlp2, w->b_mlp2, w->ln2_gamma, w->ln2_beta, x_out, M, st);
+    if (w->w_out_frag && w->w_mlp_frag)
+        return launch_out_ln_mlp(feat, w->w_out_frag, w->w_mlp_frag, x, w->b_out, mask, w->ln1_gamma, w->ln1_beta, w->b_mlp0, w->b_mlp1, w->b_mlp2,
+                                 w->ln2_gamma, w->ln2_beta, x_out, M, st);
     if ((rc = launch_linear(feat, ABOPT_IPA_FEAT, w->w_out, ABOPT_IPA_FEAT, nullptr, s.u, F, (int)M, F, ABOPT_IPA_FEAT, false, st,
                             OUT_KSPLIT, M * F))) return rc;
     if ((rc = launch_fused_ln_mlp(x, s.u, OUT_KSPLIT, M * F, w->b_out, mask, w->ln1_gamma, w->ln1_beta, w->w_mlp0, w->b_mlp0, w->w_mlp1, w->b_mlp1,

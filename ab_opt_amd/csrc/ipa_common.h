@@ -35,6 +35,37 @@ __device__ __forceinline__ float rows_sum(float v) {
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// ---- fp32 x fp32 on the bf16 matrix pipe: an fp32 value is exactly h + m + l with three bf16 terms (see node_frags.hip header)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// (lo, hi) -> one register of two bf16, round to nearest even
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// 8 consecutive fp32 values -> their three bf16 terms, two values per register (element 2p in the low half)
+struct Split3 { u32x4 h, m, l; };
+__device__ __forceinline__ Split3 split3(const f32x4& lo, const f32x4& hi) {
+    Split3 o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float e0 = p < 2 ? lo[2 * p] : hi[2 * p - 4], e1 = p < 2 ? lo[2 * p + 1] : hi[2 * p - 3];
+        o.h[p] = pk_bf16(e0, e1);
+        const float r0 = e0 - __uint_as_float(o.h[p] << 16), r1 = e1 - __uint_as_float(o.h[p] & 0xffff0000u);    // exact, |r| <= 2^-9 |e|
+        o.m[p] = pk_bf16(r0, r1);
+        const float q0 = r0 - __uint_as_float(o.m[p] << 16), q1 = r1 - __uint_as_float(o.m[p] & 0xffff0000u);    // exact, <= 8 significant bits left
+        o.l[p] = pk_bf16(q0, q1);                                                  // exact
+    }
+    return o;
+}
+__device__ __forceinline__ f32x4 mfma_bf(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_bf32(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 
 namespace prof { void begin(hipStream_t st); void end(hipStream_t st); }

@@ -35,10 +35,10 @@ int launch_so3_log(const float* R, float* w, int64_t n, int grad_mode, hipStream
 int launch_fused_ln_mlp(const float* x, const float* u, int nslab, int64_t slab_stride, const float* ubias, const uint8_t* mask,
                         const float* g1, const float* be1, const float* W0, const float* b0, const float* W1, const float* b1,
                         const float* W2, const float* b2, const float* g2, const float* be2, float* out, int64_t rows, hipStream_t st);
-// mlp.hip: the same tail with out_transform fused in (feat [rows,1824] x W_out in fragment order)
-int launch_out_ln_mlp(const float* feat, const float* wof, const float* x, const float* ubias, const uint8_t* mask,
-                      const float* g1, const float* be1, const float* W0, const float* b0, const float* W1, const float* b1,
-                      const float* W2, const float* b2, const float* g2, const float* be2, float* out, int64_t rows, hipStream_t st);
+// mlp.hip: the same tail with out_transform fused in; W_out and W_mlp0..2 as bf16 terms in MFMA operand order (abopt.h: w_out_frag, w_mlp_frag)
+int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, const float* x, const float* ubias, const uint8_t* mask,
+                      const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2, const float* be2,
+                      float* out, int64_t rows, hipStream_t st);
 // cat[row] = [res_feat[row] | embed[s_t[row]]], F == 128
 int launch_embed_concat(const float* res_feat, const int64_t* s_t, const float* embed, float* cat, int64_t rows, hipStream_t st);
 // infeat[row, 0:128] = x, [128:131] = beta, sin beta, cos beta, [131] = 0 ; optional LN'd copy for the prmsd head

@@ -6,12 +6,11 @@
 // work per row block is latency/launch bound, so a 256-thread workgroup keeps its 32 rows on chip (LDS) through all three
 // layers and stages each 64 KB weight matrix into LDS once (register-prefetched behind the previous phase).
 // fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32.
-#include "abopt_common.h"
+#include "ipa_common.h"
 #include "kernels.h"
 
 namespace abopt {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int F = 128, XLD = F + 4;
 
 __device__ __forceinline__ f32x4 mfma4m(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -195,114 +194,184 @@ int launch_fused_ln_mlp(const float* x, const float* u, int nslab, int64_t slab_
 
 // =====================================================================================================================
 // out_transform + tail in ONE launch:  out = LN2(y + MLP(y)),  y = LN1(x + mask * (feat W_out^T + b_out))      (ga.py:174-177)
-// Replaces the split-K out_transform GEMM (two 4 MB partial slabs written and re-read) + fused_ln_mlp.  One 1024-thread
-// workgroup (16 waves, 4 per SIMD) owns 32 residues.  Phase 1: u[32,128] = feat[32,1824] . W_out^T on the matrix cores -- wave
-// (ct, kh) owns output columns 16 ct .. 16 ct + 15 of both 16-row tiles for one half of every K chunk; its W_out fragments stream
-// from L2 in fragment order (packed once, 1 KB per wave load, one chunk ahead in registers), the feat tile goes through LDS in
-// 96-column chunks (double buffered, one barrier per chunk) shared by all waves; the two K halves are summed through LDS.
-// Phase 2: the 32 rows stay in LDS through LayerNorm1, the three 128x128 layers and LayerNorm2.
+// Replaces the split-K out_transform GEMM (two 4 MB partial slabs written and re-read) + fused_ln_mlp.  One 1024-thread workgroup
+// (16 waves, 4 per SIMD) owns 32 residues.  Every contraction runs on the bf16 matrix pipe with exact three-term splits of both fp32
+// operands (six v_mfma_f32_32x32x16_bf16 per 16 k; node_frags.hip explains the arithmetic); all weights arrive already split, in
+// MFMA operand order (packed once by the host), straight from L2 into registers -- no weight staging through LDS.
+// Phase 1: u[32,128] = feat[32,1824] . W_out^T.  Wave (cb, kg) owns output columns 32 cb .. 32 cb + 31 of all 32 rows for k-steps
+// 3 kg .. 3 kg + 2 of every 192-column chunk (operands one chunk ahead in registers); the feat chunk is split ONCE by the loader
+// threads and staged in LDS as three bf16 planes (double buffered, one barrier per chunk) shared by all waves.
+// Phase 2: LayerNorm1, three 128x128 layers, LayerNorm2 with the 32 rows in LDS: layer inputs as bf16 planes, wave (cb, kg) takes
+// two of the eight k-steps; the four K groups of a phase meet in LDS and one pass adds bias, applies relu and re-splits.
+// [Measured on the way here, per layer of the sampler at M = 8192: split-K GEMM + fused_ln_mlp 66 us; this kernel with fp32 MFMA
+//  45 us; as it stands 41 us = 4k + 47k + 22k cycles (prologue, phase 1, phase 2).  Phase 1 without its weight stream runs at the
+//  matrix-pipe bound (22k cycles); with it, it is bound by L2 -> CU bandwidth: every CU has to pull all of W_out (1.4 MB as bf16
+//  terms) for its 32 rows and sustains ~35 B/clk while all 256 CUs do the same.  Streaming fp32 weights and splitting them in
+//  registers moves 1/3 fewer bytes but pays it back in VALU work: 40k cycles, same wall time.]
+#ifndef OT_ABL     // developer ablation mask (results are wrong when non-zero): 1 no W stream, 2 no feat staging, 8 no LDS operand reads
+#define OT_ABL 0
+#endif
+#ifdef OT_TIMING   // developer build: section clocks of one workgroup, printed by the launcher
+}  // namespace abopt
+#include <cstdio>
+__device__ long long g_ot_timing[16][4];
+namespace abopt {
+#endif
 namespace {
 constexpr int OT_K = ABOPT_IPA_FEAT;          // 1824
-constexpr int OT_KC = 96, OT_NCH = OT_K / OT_KC, OT_LD = OT_KC + 4;      // 19 chunks of 96 columns; +4: rows 4 banks apart
-constexpr int OT_G = OT_K / 16;               // 114 groups of 16 k: lane group kq holds k = 16 g + 4 kq + i
-constexpr int OT_GPW = OT_KC / 16 / 2;        // 3 groups per wave per chunk
-constexpr int OT_TH = 1024;
-static_assert(OT_K % OT_KC == 0 && OT_KC % 32 == 0, "out_transform K tiling");
+constexpr int OT_KC = 192, OT_NCH = (OT_K + OT_KC - 1) / OT_KC;           // 10 chunks of 192 columns = 12 k-steps of 16 (the last one half full)
+constexpr int OT_ST = OT_K / 16;              // 114 k-steps
+constexpr int OT_SPC = OT_KC / 16, OT_SPW = OT_SPC / 4;                   // 12 k-steps per chunk, 3 per wave
+constexpr int OT_TH = 1024, OT_NW = OT_TH / 64;
+constexpr int OT_SROW = OT_KC * 2 + 16;       // bytes per row of one bf16 plane of a chunk: 400, rows 36 banks apart (conflict-free b128 reads)
+constexpr int OT_PLANE = MR * OT_SROW, OT_STAGE = 3 * OT_PLANE;           // 12800, 38400 bytes
+constexpr int AP_ROW = F * 2 + 16, AP_PLANE = MR * AP_ROW;                // activation planes: 272 bytes per row (rows 4 banks apart)
+constexpr int OT_MS = F / 16;                 // 8 k-steps per MLP layer
+static_assert(OT_K % 16 == 0 && OT_KC % 64 == 0 && MR == 32 && F == 128, "out_transform tiling");
 
 struct OtSmem {
-    float fs[2][MR][OT_LD];                   // feat chunks
-    float ys[MR][XLD], ha[MR][XLD], hb[MR][XLD];
-    float wl[F][XLD];
+    float ys[MR][XLD];                        // y = LayerNorm1(...) in fp32 (residual of the MLP)
+    char ap[3 * AP_PLANE];                    // input of the current layer as [term][row][128 bf16 + pad]
+    union {
+        char stage[2][OT_STAGE];              // phase 1: feat chunks as [term][row][192 bf16 + pad]
+        float part[4][MR][XLD];               // partial sums of the four K groups
+    };
 };
 
-// one dense layer of the tail for 16 waves: wave = (row group rg, column tile c8): 16 rows x 16 output columns
-__device__ __forceinline__ f32x4 wave_linear16(const float (*xs)[XLD], const float (*wl)[XLD], int c8, int fm, int kq) {
-    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;                   // two chains (dependent-MFMA latency)
+__device__ __forceinline__ void acc_zero(f32x16& a) {
 #pragma unroll
-    for (int kb = 0; kb < F / 16; kb += 2) {
-        const float4 a0 = *reinterpret_cast<const float4*>(&xs[fm][kb * 16 + kq * 4]);
-        const float4 b0 = *reinterpret_cast<const float4*>(&wl[c8 * 16 + fm][kb * 16 + kq * 4]);
-        const float4 a1 = *reinterpret_cast<const float4*>(&xs[fm][kb * 16 + 16 + kq * 4]);
-        const float4 b1 = *reinterpret_cast<const float4*>(&wl[c8 * 16 + fm][kb * 16 + 16 + kq * 4]);
-        acc0 = mfma4m(b0.x, a0.x, acc0); acc1 = mfma4m(b1.x, a1.x, acc1);
-        acc0 = mfma4m(b0.y, a0.y, acc0); acc1 = mfma4m(b1.y, a1.y, acc1);
-        acc0 = mfma4m(b0.z, a0.z, acc0); acc1 = mfma4m(b1.z, a1.z, acc1);
-        acc0 = mfma4m(b0.w, a0.w, acc0); acc1 = mfma4m(b1.w, a1.w, acc1);
-    }
-    return acc0 + acc1;
+    for (int i = 0; i < 16; ++i) a[i] = 0.f;
 }
-constexpr int OT_WPT = F * F / 4 / OT_TH;      // float4 weight loads per thread per layer (4)
-struct WRegs16 { f32x4 v[OT_WPT]; };
-__device__ __forceinline__ WRegs16 mlp_load_w16(const float* __restrict__ W) {
-    WRegs16 r;
+// accumulator register 4 g + i = output column 32 cb + 8 g + 4 (lane >> 5) + i, lane & 31 = residue
+__device__ __forceinline__ void store_partial(float (*dst)[XLD], const f32x16& a0, const f32x16& a1, int cb, int lane) {
 #pragma unroll
-    for (int i = 0; i < OT_WPT; ++i) r.v[i] = reinterpret_cast<const f32x4*>(W)[i * OT_TH + threadIdx.x];
-    return r;
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(&dst[lane & 31][cb * 32 + g * 8 + (lane >> 5) * 4]) =
+            (f32x4){a0[4 * g] + a1[4 * g], a0[4 * g + 1] + a1[4 * g + 1], a0[4 * g + 2] + a1[4 * g + 2], a0[4 * g + 3] + a1[4 * g + 3]};
 }
-__device__ __forceinline__ void mlp_store_w16(float (*wl)[XLD], const WRegs16& r) {
+// two adjacent values -> one 4-byte entry in each of the three planes
+__device__ __forceinline__ void store_terms2(char* ap, int byte_off, float e0, float e1) {
+    const unsigned h = pk_bf16(e0, e1);
+    const float r0 = e0 - __uint_as_float(h << 16), r1 = e1 - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = pk_bf16(r0, r1);
+    const unsigned l = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+    *reinterpret_cast<unsigned*>(ap + byte_off) = h;
+    *reinterpret_cast<unsigned*>(ap + AP_PLANE + byte_off) = m;
+    *reinterpret_cast<unsigned*>(ap + 2 * AP_PLANE + byte_off) = l;
+}
+struct MlpW { u32x4 v[2][3]; };               // a wave's two k-steps of one layer: [step][term]
+__device__ __forceinline__ MlpW load_mlp_w(const float* __restrict__ wm, int layer, int cb, int kg, int lane) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(wm) + ((int64_t)(layer * 4 + cb) * OT_MS + kg * 2) * 192 + lane;
+    MlpW w;
 #pragma unroll
-    for (int i = 0; i < OT_WPT; ++i) {
-        const int e = (i * OT_TH + threadIdx.x) * 4;
-        *reinterpret_cast<f32x4*>(&wl[e >> 7][e & 127]) = r.v[i];
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) w.v[j][sp] = p[j * 192 + sp * 64];
+    return w;
+}
+// partial [32 rows x 32 columns] of one layer for the wave's two k-steps
+__device__ __forceinline__ void mlp_partial(const char* ap, const MlpW& w, float (*dst)[XLD], int cb, int kg, int lane) {
+    f32x16 a0, a1;
+    acc_zero(a0); acc_zero(a1);
+    const char* xp = ap + (lane & 31) * AP_ROW + kg * 64 + (lane >> 5) * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const u32x4 xh = *reinterpret_cast<const u32x4*>(xp + j * 32), xm = *reinterpret_cast<const u32x4*>(xp + j * 32 + AP_PLANE),
+                    xl = *reinterpret_cast<const u32x4*>(xp + j * 32 + 2 * AP_PLANE);
+        a0 = mfma_bf32(w.v[j][0], xl, a0); a1 = mfma_bf32(w.v[j][2], xh, a1);
+        a0 = mfma_bf32(w.v[j][1], xm, a0); a1 = mfma_bf32(w.v[j][0], xm, a1);
+        a0 = mfma_bf32(w.v[j][1], xh, a0); a1 = mfma_bf32(w.v[j][0], xh, a1);
     }
+    store_partial(dst, a0, a1, cb, lane);
 }
 }  // namespace
 
-__global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restrict__ feat, const float* __restrict__ wof /* W_out in fragment order */,
+__global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restrict__ feat, const float* __restrict__ wof /* W_out terms, operand order */,
+                                                           const float* __restrict__ wmf /* W_mlp0..2 terms, operand order */,
                                                            const float* __restrict__ x, const float* __restrict__ ubias, const uint8_t* __restrict__ mask,
                                                            const float* __restrict__ g1, const float* __restrict__ be1,
-                                                           const float* __restrict__ W0, const float* __restrict__ b0,
-                                                           const float* __restrict__ W1, const float* __restrict__ b1,
-                                                           const float* __restrict__ W2, const float* __restrict__ b2,
+                                                           const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2,
                                                            const float* __restrict__ g2, const float* __restrict__ be2,
                                                            float* __restrict__ out, int64_t rows) {
     extern __shared__ __attribute__((aligned(16))) char ot_raw[];
     OtSmem& sm = *reinterpret_cast<OtSmem*>(ot_raw);
-    const int tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * MR;
+#ifdef OT_TIMING
+    const long long tc0 = clock64();
+#endif
     // ---------------------------------------------------------------- phase 1: u = feat . W_out^T
-    // feat chunk loader: 32 rows x 96 floats = 768 float4: thread e < 768 -> (row e / 24, float4 e % 24)
-    const bool ldr = tid < MR * (OT_KC / 4);
-    const float* fsrc = feat + min(row0 + tid / (OT_KC / 4), rows - 1) * OT_K + (tid % (OT_KC / 4)) * 4;
-    float* fdst0 = &sm.fs[0][min(tid / (OT_KC / 4), MR - 1)][(tid % (OT_KC / 4)) * 4];
-    const int ct = wave & 7, kh = wave >> 3;
-    const f32x4* wfr = reinterpret_cast<const f32x4*>(wof) + (int64_t)ct * OT_G * 64 + lane;         // this wave's column tile: [g][lane]
-    f32x4 wq[OT_GPW];
+    // feat chunk loader: 32 rows x 24 octets of 8 floats: thread e < 768 -> (row e / 24, octet e % 24); split, then three 16-byte stores
+    const int lr = min(tid / (OT_KC / 8), MR - 1), lo = tid % (OT_KC / 8);
+    const bool ldr = tid < MR * (OT_KC / 8);
+    const float* fsrc = feat + min(row0 + lr, rows - 1) * OT_K + lo * 8;
+    char* fdst0 = &sm.stage[0][0] + lr * OT_SROW + lo * 16;
+    auto chunk_ok = [&](int c) { return ldr && c < OT_NCH && c * OT_KC + lo * 8 < OT_K; };          // the last chunk is half full
+    auto stage_store = [&](int b, const f32x4& v0, const f32x4& v1) {
+        const Split3 sp = split3(v0, v1);
+        char* d = fdst0 + b * OT_STAGE;
+        *reinterpret_cast<u32x4*>(d) = sp.h; *reinterpret_cast<u32x4*>(d + OT_PLANE) = sp.m; *reinterpret_cast<u32x4*>(d + 2 * OT_PLANE) = sp.l;
+    };
+    const int cb = wave & 3, kg = wave >> 2;
+    // this wave's operand stream: [cb][k-step][term][lane] vectors of 8 bf16, lane (column lane & 31, k half lane >> 5)
+    const u32x4* wfr = reinterpret_cast<const u32x4*>(wof) + (int64_t)cb * OT_ST * 192 + lane;
+    u32x4 wq[OT_SPW][3];
 #pragma unroll
-    for (int gl = 0; gl < OT_GPW; ++gl) wq[gl] = wfr[(kh * OT_GPW + gl) * 64];
-    f32x4 fv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (ldr) { fv = *reinterpret_cast<const f32x4*>(fsrc); *reinterpret_cast<f32x4*>(fdst0) = fv; fv = *reinterpret_cast<const f32x4*>(fsrc + OT_KC); }
-    WRegs16 wreg = mlp_load_w16(W0);
+    for (int j = 0; j < OT_SPW; ++j)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) wq[j][sp] = wfr[(kg * OT_SPW + j) * 192 + sp * 64];
+    f32x4 fv0 = (f32x4){0.f, 0.f, 0.f, 0.f}, fv1 = fv0;
+    if (chunk_ok(0)) {
+        fv0 = *reinterpret_cast<const f32x4*>(fsrc); fv1 = *reinterpret_cast<const f32x4*>(fsrc + 4);
+        stage_store(0, fv0, fv1);
+    }
+    if (chunk_ok(1)) { fv0 = *reinterpret_cast<const f32x4*>(fsrc + OT_KC); fv1 = *reinterpret_cast<const f32x4*>(fsrc + OT_KC + 4); }
     __syncthreads();
-    f32x4 accu[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#ifdef OT_TIMING
+    const long long tc1 = clock64();
+#endif
+    f32x16 acc0, acc1;
+    acc_zero(acc0); acc_zero(acc1);
+    const char* xrd = &sm.stage[0][0] + (lane & 31) * OT_SROW + (kg * OT_SPW) * 32 + (lane >> 5) * 16;
     for (int c = 0; c < OT_NCH; ++c) {
         const int b = c & 1;
+        if (c * OT_SPC + kg * OT_SPW < OT_ST) {                                                         // the last chunk has work for K groups 0 and 1 only
 #pragma unroll
-        for (int gl = 0; gl < OT_GPW; ++gl) {
-            const f32x4 a = wq[gl];
-            const int gloc = kh * OT_GPW + gl;                                                        // group within the chunk
-            wq[gl] = wfr[(int64_t)min((c + 1) * (OT_KC / 16) + gloc, OT_G - 1) * 64];                  // next chunk's fragment of this slot (clamped past the end)
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(&sm.fs[b][fm][gloc * 16 + kq * 4]);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(&sm.fs[b][16 + fm][gloc * 16 + kq * 4]);
+            for (int j = 0; j < OT_SPW; ++j) {
+                const int64_t nst = min((c + 1) * OT_SPC + kg * OT_SPW + j, OT_ST - 1);               // next chunk's k-step of this slot (past the end: a reload)
+                const u32x4 wH = wq[j][0], wM = wq[j][1], wL = wq[j][2];
+#if !(OT_ABL & 1)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { accu[0] = mfma4m(a[i], x0[i], accu[0]); accu[1] = mfma4m(a[i], x1[i], accu[1]); }
+                for (int sp = 0; sp < 3; ++sp) wq[j][sp] = wfr[nst * 192 + sp * 64];
+#endif
+                const char* xp = xrd + b * OT_STAGE + j * 32;
+#if OT_ABL & 8
+                const u32x4 xh = wM, xm = wL, xl = wH; (void)xp;
+#else
+                const u32x4 xh = *reinterpret_cast<const u32x4*>(xp), xm = *reinterpret_cast<const u32x4*>(xp + OT_PLANE),
+                            xl = *reinterpret_cast<const u32x4*>(xp + 2 * OT_PLANE);
+#endif
+                // smallest terms first; two accumulators so consecutive MFMAs never depend on each other
+                acc0 = mfma_bf32(wH, xl, acc0); acc1 = mfma_bf32(wL, xh, acc1);
+                acc0 = mfma_bf32(wM, xm, acc0); acc1 = mfma_bf32(wH, xm, acc1);
+                acc0 = mfma_bf32(wM, xh, acc0); acc1 = mfma_bf32(wH, xh, acc1);
+            }
         }
-        if (ldr) {
-            if (c + 1 < OT_NCH) *reinterpret_cast<f32x4*>(fdst0 + (b ^ 1) * (MR * OT_LD)) = fv;       // chunk c + 1 -> the other buffer
-            if (c + 2 < OT_NCH) fv = *reinterpret_cast<const f32x4*>(fsrc + (c + 2) * OT_KC);
+        if (!(OT_ABL & 2)) {
+            if (chunk_ok(c + 1)) stage_store(b ^ 1, fv0, fv1);                                          // chunk c + 1 -> the other buffer
+            if (chunk_ok(c + 2)) { fv0 = *reinterpret_cast<const f32x4*>(fsrc + (c + 2) * OT_KC); fv1 = *reinterpret_cast<const f32x4*>(fsrc + (c + 2) * OT_KC + 4); }
         }
         __syncthreads();
     }
-    // accumulator row 4 kq + r = output column 16 ct + 4 kq + r, column fm = residue; the two K halves land in ha / hb
-    {
-        float (*dst)[XLD] = kh ? sm.hb : sm.ha;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) *reinterpret_cast<f32x4*>(&dst[rt * 16 + fm][ct * 16 + kq * 4]) = accu[rt];
-    }
+#ifdef OT_TIMING
+    const long long tc2 = clock64();
+#endif
+    MlpW mw = load_mlp_w(wmf, 0, cb, kg, lane);
+    store_partial(sm.part[kg], acc0, acc1, cb, lane);                                                   // the staging planes are dead: the loop ended on a barrier
     __syncthreads();
     // ---------------------------------------------------------------- phase 2: LayerNorm1 (each wave 2 rows), MLP, LayerNorm2
-    constexpr int RW = MR / 16;
+    constexpr int RW = MR / OT_NW;
     {
         const float2 bb = ubias ? reinterpret_cast<const float2*>(ubias)[lane] : make_float2(0.f, 0.f);
         const float2 g = reinterpret_cast<const float2*>(g1)[lane], bt = reinterpret_cast<const float2*>(be1)[lane];
@@ -313,8 +382,9 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
             const int64_t row = min(row0 + rl, rows - 1);
             const bool keep = mask ? (mask[row] != 0) : true;
             const float2 xv = reinterpret_cast<const float2*>(x + row * F)[lane];
-            const float2 u0 = *reinterpret_cast<const float2*>(&sm.ha[rl][2 * lane]), u1 = *reinterpret_cast<const float2*>(&sm.hb[rl][2 * lane]);
-            float2 us = make_float2((u0.x + u1.x) + bb.x, (u0.y + u1.y) + bb.y);
+            const float2 u0 = *reinterpret_cast<const float2*>(&sm.part[0][rl][2 * lane]), u1 = *reinterpret_cast<const float2*>(&sm.part[1][rl][2 * lane]);
+            const float2 u2 = *reinterpret_cast<const float2*>(&sm.part[2][rl][2 * lane]), u3 = *reinterpret_cast<const float2*>(&sm.part[3][rl][2 * lane]);
+            float2 us = make_float2(((u0.x + u1.x) + (u2.x + u3.x)) + bb.x, ((u0.y + u1.y) + (u2.y + u3.y)) + bb.y);
             if (!keep) us = make_float2(0.f, 0.f);
             a_[rr] = xv.x + us.x; b_[rr] = xv.y + us.y;
         }
@@ -324,40 +394,49 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
         for (int rr = 0; rr < RW; ++rr) { a_[rr] -= mean[rr]; b_[rr] -= mean[rr]; var[rr] = wave_sum(a_[rr] * a_[rr] + b_[rr] * b_[rr]) * (1.f / F); }
 #pragma unroll
         for (int rr = 0; rr < RW; ++rr) {
+            const int rl = wave * RW + rr;
             const float sd = sqrtf(var[rr] + 1e-10f);
-            *reinterpret_cast<float2*>(&sm.ys[wave * RW + rr][2 * lane]) = make_float2(a_[rr] / sd * g.x + bt.x, b_[rr] / sd * g.y + bt.y);
+            const float y0 = a_[rr] / sd * g.x + bt.x, y1 = b_[rr] / sd * g.y + bt.y;
+            *reinterpret_cast<float2*>(&sm.ys[rl][2 * lane]) = make_float2(y0, y1);
+            store_terms2(sm.ap, rl * AP_ROW + lane * 4, y0, y1);
         }
     }
-    mlp_store_w16(sm.wl, wreg);
-    wreg = mlp_load_w16(W1);
     __syncthreads();
-    const int rg = wave >> 3, c8 = wave & 7;
-    const int col = c8 * 16 + kq * 4;
-    // ---- layer 0: relu(W0 y + b0) -> ha   (u in ha / hb was consumed by LayerNorm1 before the barrier above)
+    // one pass after each layer: thread -> (row tid >> 5, columns 4 (tid & 31) ..): sum of the four K groups + bias
+    const int er = tid >> 5, ec = (tid & 31) * 4;
+    auto gather = [&](const float* __restrict__ bias) {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&sm.part[0][er][ec]), p1 = *reinterpret_cast<const f32x4*>(&sm.part[1][er][ec]);
+        const f32x4 p2 = *reinterpret_cast<const f32x4*>(&sm.part[2][er][ec]), p3 = *reinterpret_cast<const f32x4*>(&sm.part[3][er][ec]);
+        return ((p0 + p1) + (p2 + p3)) + *reinterpret_cast<const f32x4*>(bias + ec);
+    };
+    // ---- layer 0: relu(W0 y + b0)
+    mlp_partial(sm.ap, mw, sm.part[kg], cb, kg, lane);
+    mw = load_mlp_w(wmf, 1, cb, kg, lane);
+    __syncthreads();
     {
-        const f32x4 acc = wave_linear16(sm.ys + rg * 16, sm.wl, c8, fm, kq);
-        const float4 bv = *reinterpret_cast<const float4*>(b0 + col);
-        *reinterpret_cast<float4*>(&sm.ha[rg * 16 + fm][col]) = make_float4(fmaxf(acc[0] + bv.x, 0.f), fmaxf(acc[1] + bv.y, 0.f), fmaxf(acc[2] + bv.z, 0.f), fmaxf(acc[3] + bv.w, 0.f));
+        const f32x4 v = gather(b0);
+        store_terms2(sm.ap, er * AP_ROW + ec * 2, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+        store_terms2(sm.ap, er * AP_ROW + ec * 2 + 4, fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
     }
     __syncthreads();
-    mlp_store_w16(sm.wl, wreg);
-    wreg = mlp_load_w16(W2);
+    // ---- layer 1: relu(W1 h + b1)
+    mlp_partial(sm.ap, mw, sm.part[kg], cb, kg, lane);
+    mw = load_mlp_w(wmf, 2, cb, kg, lane);
     __syncthreads();
-    // ---- layer 1: relu(W1 h + b1) -> hb
     {
-        const f32x4 acc = wave_linear16(sm.ha + rg * 16, sm.wl, c8, fm, kq);
-        const float4 bv = *reinterpret_cast<const float4*>(b1 + col);
-        *reinterpret_cast<float4*>(&sm.hb[rg * 16 + fm][col]) = make_float4(fmaxf(acc[0] + bv.x, 0.f), fmaxf(acc[1] + bv.y, 0.f), fmaxf(acc[2] + bv.z, 0.f), fmaxf(acc[3] + bv.w, 0.f));
+        const f32x4 v = gather(b1);
+        store_terms2(sm.ap, er * AP_ROW + ec * 2, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+        store_terms2(sm.ap, er * AP_ROW + ec * 2 + 4, fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
     }
     __syncthreads();
-    mlp_store_w16(sm.wl, wreg);
+    // ---- layer 2 + residual (in place in ys), then LayerNorm2
+    mlp_partial(sm.ap, mw, sm.part[kg], cb, kg, lane);
     __syncthreads();
-    // ---- layer 2 + residual -> ha, then LayerNorm2
     {
-        const f32x4 acc = wave_linear16(sm.hb + rg * 16, sm.wl, c8, fm, kq);
-        const float4 bv = *reinterpret_cast<const float4*>(b2 + col);
-        const float4 yv = *reinterpret_cast<const float4*>(&sm.ys[rg * 16 + fm][col]);
-        *reinterpret_cast<float4*>(&sm.ha[rg * 16 + fm][col]) = make_float4(yv.x + (acc[0] + bv.x), yv.y + (acc[1] + bv.y), yv.z + (acc[2] + bv.z), yv.w + (acc[3] + bv.w));
+        const f32x4 v = gather(b2);
+        f32x4 yv = *reinterpret_cast<const f32x4*>(&sm.ys[er][ec]);
+        yv += v;
+        *reinterpret_cast<f32x4*>(&sm.ys[er][ec]) = yv;
     }
     __syncthreads();
     {
@@ -365,7 +444,7 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
         float2 v[RW];
         float mean[RW], var[RW];
 #pragma unroll
-        for (int rr = 0; rr < RW; ++rr) { v[rr] = *reinterpret_cast<const float2*>(&sm.ha[wave * RW + rr][2 * lane]); mean[rr] = wave_sum(v[rr].x + v[rr].y) * (1.f / F); }
+        for (int rr = 0; rr < RW; ++rr) { v[rr] = *reinterpret_cast<const float2*>(&sm.ys[wave * RW + rr][2 * lane]); mean[rr] = wave_sum(v[rr].x + v[rr].y) * (1.f / F); }
 #pragma unroll
         for (int rr = 0; rr < RW; ++rr) { v[rr].x -= mean[rr]; v[rr].y -= mean[rr]; var[rr] = wave_sum(v[rr].x * v[rr].x + v[rr].y * v[rr].y) * (1.f / F); }
 #pragma unroll
@@ -375,22 +454,36 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
             if (row < rows) reinterpret_cast<float2*>(out + row * F)[lane] = make_float2(v[rr].x / sd * g.x + bt.x, v[rr].y / sd * g.y + bt.y);
         }
     }
+#ifdef OT_TIMING
+    if (blockIdx.x == 17 && lane == 0) { long long* o = g_ot_timing[wave]; o[0] = tc1 - tc0; o[1] = tc2 - tc1; o[2] = clock64() - tc2; }
+#endif
 }
 
-size_t out_wfrag_floats() { return (size_t)F * OT_K; }
+size_t out_wfrag_floats() { return (size_t)F * OT_K * 3 / 2; }      // three bf16 per weight
+size_t mlp_wfrag_floats() { return (size_t)3 * F * F * 3 / 2; }
 
-int launch_out_ln_mlp(const float* feat, const float* wof, const float* x, const float* ubias, const uint8_t* mask,
-                      const float* g1, const float* be1, const float* W0, const float* b0, const float* W1, const float* b1,
-                      const float* W2, const float* b2, const float* g2, const float* be2, float* out, int64_t rows, hipStream_t st) {
+int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, const float* x, const float* ubias, const uint8_t* mask,
+                      const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2, const float* be2,
+                      float* out, int64_t rows, hipStream_t st) {
     if (rows == 0) return ABOPT_OK;
     static bool configured = false;
     if (!configured) {
         ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(out_ln_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OtSmem)));
         configured = true;
     }
-    hipLaunchKernelGGL(out_ln_mlp_kernel, dim3((unsigned)((rows + MR - 1) / MR)), dim3(OT_TH), sizeof(OtSmem), st, feat, wof, x, ubias, mask,
-                       g1, be1, W0, b0, W1, b1, W2, b2, g2, be2, out, rows);
+    hipLaunchKernelGGL(out_ln_mlp_kernel, dim3((unsigned)((rows + MR - 1) / MR)), dim3(OT_TH), sizeof(OtSmem), st, feat, wof, wmf, x, ubias, mask,
+                       g1, be1, b0, b1, b2, g2, be2, out, rows);
     ABOPT_LAUNCH_CHECK();
+#ifdef OT_TIMING
+    {
+        long long hh[16][4];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_ot_timing), sizeof(hh));
+        static int calls = 0;
+        if (++calls == 8)
+            for (int w = 0; w < 16; w += 5) fprintf(stderr, "[ot timing WG 17 wave %d] prologue %lld | phase 1 loop %lld | phase 2 %lld\n", w, hh[w][0], hh[w][1], hh[w][2]);
+    }
+#endif
     return ABOPT_OK;
 }
 

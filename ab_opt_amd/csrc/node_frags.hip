@@ -8,12 +8,12 @@
 // sit in LDS in MFMA operand order (144 KB, loaded once); residues stream through in pairs of 16-row tiles.
 //
 // Arithmetic: fp32 x fp32 products on the bf16 matrix pipe.  An fp32 number is EXACTLY the sum of three bf16 numbers (8 + 8 + 8
-// significand bits: h = top 16 bits of x, m = top 16 bits of x - h, l = x - h - m), so
-//     x w = hH + (hM + mH) + (hL + lH + mM) + [mL + lM + lL, relative size <= 2^-23, dropped]
+// significand bits: h = bf16(x), m = bf16(x - h), l = x - h - m, round-to-nearest so |m| <= 2^-9 |x|, |l| <= 2^-17 |x|), so
+//     x w = hH + (hM + mH) + (hL + lH + mM) + [mL + lM + lL, relative size <= 2^-25, dropped]
 // needs six v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32) where the exact-fp32 path needs eight v_mfma_f32_16x16x4_f32 (32
 // cycles each): 2.7x fewer matrix-pipe cycles.  Every bf16 x bf16 product is exact in fp32 and the accumulation is fp32, so the
 // result differs from an fp32 FMA chain by the dropped terms only -- the same order as one fp32 rounding per product.  The weights are
-// split once at pack time (hip.pack_node_weights); x is split in registers (11 VALU ops per pair of values).  Measured: 58 us (fp32
+// split once at pack time (hip.pack_node_weights); x is split in registers (v_cvt_pk_bf16_f32, 11 VALU ops per pair of values).  Measured: 58 us (fp32
 // MFMA, same structure) -> see DESIGN.md; parity tests unchanged.
 //
 // A task is (32 residues, half of the head's tiles): 6 tiles x 4 k-steps x 2 row tiles x 6 products = 288 MFMAs on 48 accumulator
@@ -39,34 +39,9 @@ constexpr int NF_KS = NF_F / 32, NF_SPL = 3;                // k-steps of 32, bf
 constexpr int NF_HEAD_VEC = NF_TILES * NF_KS * NF_SPL * 64;    // 16-byte vectors (8 bf16) per head: [tile][k-step][term][lane]
 
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ float quad_bcast0(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x00, 0xf, 0xf, false)); }
 __device__ __forceinline__ float quad_bcast1(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x55, 0xf, 0xf, false)); }
 __device__ __forceinline__ float quad_bcast2(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xAA, 0xf, 0xf, false)); }
-
-__device__ __forceinline__ f32x4 mfma_bf(const u32x4& a, const u32x4& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// 8 consecutive fp32 values -> their three bf16 terms, two values per register (element 2p in the low half)
-struct Split3 { u32x4 h, m, l; };
-__device__ __forceinline__ Split3 split3(const f32x4& lo, const f32x4& hi) {
-    Split3 o;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const float e0 = p < 2 ? lo[2 * p] : hi[2 * p - 4], e1 = p < 2 ? lo[2 * p + 1] : hi[2 * p - 3];
-        const unsigned b0 = __float_as_uint(e0), b1 = __float_as_uint(e1);
-        o.h[p] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);                       // top halves of (e1, e0)
-        const float r0 = e0 - __uint_as_float(b0 & 0xffff0000u), r1 = e1 - __uint_as_float(b1 & 0xffff0000u);    // exact
-        const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
-        o.m[p] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
-        const float q0 = r0 - __uint_as_float(c0 & 0xffff0000u), q1 = r1 - __uint_as_float(c1 & 0xffff0000u);    // exact, <= 8 significant bits left
-        o.l[p] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
-    }
-    return o;
-}
 
 // One task: tiles [HALF * 6, HALF * 6 + 6) of head h for the row tiles tile0, tile0 + 1.
 template <int HALF>

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -21,7 +21,7 @@ c_u8 = C.c_void_p       # device uint8*
 class GaWeights(C.Structure):
     _fields_ = [(n, c_f) for n in (
         'w_node', 'w_pair_bias', 'spatial_coef', 'w_out', 'b_out', 'ln1_gamma', 'ln1_beta',
-        'w_mlp0', 'b_mlp0', 'w_mlp1', 'b_mlp1', 'w_mlp2', 'b_mlp2', 'ln2_gamma', 'ln2_beta', 'w_node_frag', 'w_out_frag')]
+        'w_mlp0', 'b_mlp0', 'w_mlp1', 'b_mlp1', 'w_mlp2', 'b_mlp2', 'ln2_gamma', 'ln2_beta', 'w_node_frag', 'w_out_frag', 'w_mlp_frag')]
 
 
 class GaDebug(C.Structure):
@@ -231,28 +231,42 @@ def ga_weights_struct(t):
     """t: dict name -> contiguous device tensor with the field names of GaWeights (w_node_frag optional)."""
     s = GaWeights()
     for name, _ in GaWeights._fields_:
-        setattr(s, name, ptr(t.get(name), torch.float32, optional=name in ('w_node_frag', 'w_out_frag')))
+        setattr(s, name, ptr(t.get(name), torch.float32, optional=name in ('w_node_frag', 'w_out_frag', 'w_mlp_frag')))
     return s
 
 
+def pack_mfma_operand(w):
+    """w [128, K] (K a multiple of 16) -> [4, K/16, 3, 64, 4]: 32x32x16 MFMA operand order, every weight as its three bf16 terms
+    (fp32 container of 8 bf16 per lane): [cb][step][term][lane = 32 khalf + c][i] = term(w[32 cb + c][16 step + 8 khalf + i])."""
+    K = w.shape[1]
+    terms = torch.stack(split_bf16x3(w.float()), 0)           # [term, 128, K] int16
+    g = terms.reshape(3, 4, 32, K // 16, 2, 8)                # [term, cb, col, step, k half, i]
+    out = g.permute(1, 3, 0, 4, 2, 5).contiguous()            # [cb, step, term, k half, col, i]
+    return out.view(4, K // 16, 3, 64, 8).view(torch.float32)
+
+
 def pack_out_weights(w_out):
-    """w_out [128, 1824] -> [8, 114, 64, 4] fragment order (include/abopt.h: abopt_ga_weights.w_out_frag)."""
-    g = w_out.reshape(8, 16, 114, 4, 4)                       # [w, m, g, kq, i]
-    return g.permute(0, 2, 3, 1, 4).contiguous()              # [w, g, kq, m, i] == [w][g][lane = 16 kq + m][i]
+    """w_out [128, 1824] -> w_out_frag [4, 114, 3, 64, 4] (include/abopt.h: abopt_ga_weights.w_out_frag)."""
+    return pack_mfma_operand(w_out)
+
+
+def pack_mlp_weights(w0, w1, w2):
+    """three [128, 128] layers -> w_mlp_frag [3, 4, 8, 3, 64, 4] (include/abopt.h: abopt_ga_weights.w_mlp_frag)."""
+    return torch.stack([pack_mfma_operand(w) for w in (w0, w1, w2)], 0).contiguous()
 
 
 _NODE_FRAG_INDEX = None
 
-
 def split_bf16x3(w):
-    """fp32 tensor -> (h, m, l) int16 bf16 bit patterns with h + m + l == w exactly (csrc/node_frags.hip: split3)."""
-    def top(v):
-        return (v.contiguous().view(torch.int32) & -65536).view(torch.float32)
-    h = top(w)
+    """fp32 tensor -> (h, m, l) int16 bf16 bit patterns with h + m + l == w exactly (csrc/node_frags.hip: split3): each term is the
+    round-to-nearest bf16 of what the previous terms left."""
+    def rne(v):
+        return v.to(torch.bfloat16).to(torch.float32)
+    h = rne(w)
     r1 = w - h
-    m = top(r1)
-    l = top(r1 - m)
-    return [(v.view(torch.int32) >> 16).to(torch.int16) for v in (h, m, l)]
+    m = rne(r1)
+    l = rne(r1 - m)
+    return [(v.contiguous().view(torch.int32) >> 16).to(torch.int16) for v in (h, m, l)]
 
 
 def pack_node_weights(w_node):

@@ -68,7 +68,7 @@ def test_contig_mask_and_registry():
 
 def test_bf16_three_term_split_is_exact():
     """hip.split_bf16x3 (the pack-time half of csrc/node_frags.hip's arithmetic): h + m + l == w bit for bit, every term is a bf16
-    number, and the six products the kernel keeps reproduce x * w to ~2^-23 (the dropped m*l, l*m, l*l terms).  (Exactness needs the
+    number, and the six products the kernel keeps reproduce x * w to 2^-24 (the dropped m*l, l*m, l*l terms).  (Exactness needs the
     residuals to stay normal numbers, i.e. |w| > ~1e-31; below that the error is < 1e-38 absolute.)"""
     g = torch.Generator().manual_seed(5)
     w = torch.cat([torch.randn(4096, generator=g) * s for s in (1e-6, 1e-2, 1.0, 37.0, 1e6)] +
@@ -84,4 +84,4 @@ def test_bf16_three_term_split_is_exact():
     kept = xt[2] * wt[0] + xt[0] * wt[2] + xt[1] * wt[1] + xt[1] * wt[0] + xt[0] * wt[1] + xt[0] * wt[0]
     exact = x.double() * w.double()
     rel = ((kept - exact).abs() / exact.abs().clamp_min(1e-300))[exact != 0]
-    assert rel.max().item() < 2.0 ** -22
+    assert rel.max().item() < 2.0 ** -24

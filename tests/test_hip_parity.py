@@ -1088,8 +1088,8 @@ def test_fused_node_projection_matches_gemm_path():
     blk = _block_on_device(seed=11)
     t_, s_full = blk.packed()
     assert 'w_node_frag' in t_ and t_['w_node_frag'].numel() == hip.lib().abopt_node_frag_floats()
-    assert t_['w_out_frag'].numel() == 128 * 1824
-    plain = hip.ga_weights_struct({k: v for k, v in t_.items() if k not in ('w_node_frag', 'w_out_frag')})
+    assert t_['w_out_frag'].numel() == 128 * 1824 * 3 // 2
+    plain = hip.ga_weights_struct({k: v for k, v in t_.items() if k not in ('w_node_frag', 'w_out_frag', 'w_mlp_frag')})
     for N, L, lengths in ((2, 40, [40, 33]), (3, 70, [70, 33, 1]), (8, 256, [256, 250, 256, 231, 256, 256, 17, 256])):
         R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(N, L, lengths, salt=1200 + L)]
         a = hip.ga_block_forward(s_full, R, t, x, z, mask)
