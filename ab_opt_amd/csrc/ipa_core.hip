@@ -9,13 +9,13 @@
 // The 16 waves (4 per SIMD, <= 128 VGPRs each) have three roles, pipelined one key chunk apart through a triple-buffered
 // S/P tile in LDS, one barrier per chunk:
 //
-//   8 "pair" waves  (2 query rows each)   chunk t  : stream z[i, chunk] through a 3-deep register ring, logits = (S + pair bias)
+//   8 "pair" waves  (2 query rows each)   chunk t  : stream z[i, chunk] (+ the cached pair bias row) through a 3-deep register ring, logits = (S + pair bias)
 //                                                    sqrt(1/3), mask, online softmax, pair aggregation  fp[c,h] += z[j,c] P[j,h]
 //                                                    (M = channel, N = head, K = key); P back to LDS in place of S
 //   4 "A" waves     (3 heads each)        chunk t+1: S^T[j,i] = k'_j . q'_i  -- ONE 15-step MFMA chain per head: the operands are
 //                                                    augmented so that q.k/sqrt(D), the point cross term and both squared norms
 //                                                    of  -gamma sqrt(2/(9P))/2 |q_pts - k_pts|^2  are K-slices of the same product
-//                                                    (no epilogue arithmetic); adds the cached pair bias; writes S as 16-byte rows
+//                                                    (no epilogue arithmetic); writes S as 16-byte rows
 //   4 "C" waves     (3 heads each)        chunk t-1: fn[d,i] += v[j,d] P[i,j], pts[e,i] += v_pts[j,e] P[i,j]  (M = channel, N = query)
 //
 // Each SIMD hosts 2 pair waves + 1 A + 1 C wave: four independent instruction streams share its matrix pipe (157 MFMAs per
