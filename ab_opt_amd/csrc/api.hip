@@ -59,7 +59,7 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
     if (w->w_out_frag && w->w_mlp_frag)
         return launch_out_ln_mlp(feat, w->w_out_frag, w->w_mlp_frag, x, w->b_out, mask, w->ln1_gamma, w->ln1_beta, w->b_mlp0, w->b_mlp1, w->b_mlp2,
-                                 w->ln2_gamma, w->ln2_beta, x_out, M, st);
+                                 w->ln2_gamma, w->ln2_beta, x_out, nullptr, M, st);
     if ((rc = launch_linear(feat, ABOPT_IPA_FEAT, w->w_out, ABOPT_IPA_FEAT, nullptr, s.u, F, (int)M, F, ABOPT_IPA_FEAT, false, st,
                             OUT_KSPLIT, M * F))) return rc;
     if ((rc = launch_fused_ln_mlp(x, s.u, OUT_KSPLIT, M * F, w->b_out, mask, w->ln1_gamma, w->ln1_beta, w->w_mlp0, w->b_mlp0, w->w_mlp1, w->b_mlp1,
@@ -91,6 +91,32 @@ extern "C" int abopt_node_frag_source_row(int h, int T, int m) {
     return 3 * H * D + (set - 3) * NPT + h * (P * 3) + p * 3 + c;
 }
 extern "C" const char* abopt_last_error(void) { return g_err; }
+
+extern "C" size_t abopt_out_frag_floats(void) { return out_wfrag_floats(); }
+extern "C" size_t abopt_mlp_frag_floats(void) { return mlp_wfrag_floats(); }
+extern "C" int abopt_pack_tail_weights(const float* w_out, const float* w_mlp0, const float* w_mlp1, const float* w_mlp2, float* w_out_frag,
+                                       float* w_mlp_frag, float* w_mlpT_frag, abopt_stream stream) {
+    ABOPT_CHECK_ARG(w_out && w_mlp0 && w_mlp1 && w_mlp2 && w_out_frag && w_mlp_frag, "pack_tail_weights: NULL argument");
+    return launch_pack_tail_weights(w_out, w_mlp0, w_mlp1, w_mlp2, w_out_frag, w_mlp_frag, w_mlpT_frag, (hipStream_t)stream);
+}
+extern "C" int abopt_block_tail_forward(const float* feat, const float* w_out_frag, const float* w_mlp_frag, const float* x, const float* b_out,
+                                        const uint8_t* mask, const float* ln1_gamma, const float* ln1_beta, const float* b_mlp0, const float* b_mlp1,
+                                        const float* b_mlp2, const float* ln2_gamma, const float* ln2_beta, float* out, float* saved, int64_t rows,
+                                        abopt_stream stream) {
+    ABOPT_CHECK_ARG(rows >= 0, "block_tail_forward: negative row count");
+    if (rows == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(feat && w_out_frag && w_mlp_frag && x && ln1_gamma && ln1_beta && b_mlp0 && b_mlp1 && b_mlp2 && ln2_gamma && ln2_beta && out,
+                    "block_tail_forward: NULL argument");
+    return launch_out_ln_mlp(feat, w_out_frag, w_mlp_frag, x, b_out, mask, ln1_gamma, ln1_beta, b_mlp0, b_mlp1, b_mlp2, ln2_gamma, ln2_beta, out, saved,
+                             rows, (hipStream_t)stream);
+}
+extern "C" int abopt_block_tail_backward(const float* dout, const float* saved, const float* w_mlpT_frag, const uint8_t* mask, const float* ln1_gamma,
+                                         const float* ln2_gamma, float* dpre, float* da1, float* du, float* colpart, int64_t rows, abopt_stream stream) {
+    ABOPT_CHECK_ARG(rows >= 0, "block_tail_backward: negative row count");
+    if (rows == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(dout && saved && w_mlpT_frag && ln1_gamma && ln2_gamma && dpre && da1 && du && colpart, "block_tail_backward: NULL argument");
+    return launch_tail_backward(dout, saved, w_mlpT_frag, mask, ln1_gamma, ln2_gamma, dpre, da1, du, colpart, rows, (hipStream_t)stream);
+}
 
 extern "C" int abopt_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len) {
     int dev = 0;
@@ -188,14 +214,15 @@ static int check_dims(int N, int L, int Fd, int Cd) {
 extern "C" size_t abopt_ipa_train_workspace_bytes(int N, int L) { return ipa_train_ws_floats(N, L) * sizeof(float); }
 
 extern "C" int abopt_ipa_core_train_forward(const float* proj_local, const float* R, const float* t, const float* pair_feat, const uint8_t* mask,
-                                            const float* w_pair_bias, const float* spatial_coef, float* feat, float* alpha,
-                                            int N, int L, int Cd, void* ws, size_t ws_bytes, abopt_stream stream) {
+                                            const float* w_pair_bias, const float* spatial_coef, const float* pair_bias_cache, float* feat,
+                                            float* alpha, int N, int L, int Cd, void* ws, size_t ws_bytes, abopt_stream stream) {
     int rc;
     if ((rc = check_dims(N, L, F, Cd))) return rc;
     if ((int64_t)N * L == 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(proj_local && R && t && pair_feat && mask && w_pair_bias && spatial_coef && feat && alpha && ws, "ipa_core_train_forward: NULL argument");
     if (ws_bytes < ipa_train_ws_floats(N, L) * sizeof(float)) { set_error("ipa_core_train_forward: workspace too small (%zu bytes given)", ws_bytes); return ABOPT_EWORKSPACE; }
-    return launch_ipa_train_forward(proj_local, R, t, pair_feat, mask, w_pair_bias, spatial_coef, feat, alpha, N, L, (float*)ws, (hipStream_t)stream);
+    return launch_ipa_train_forward(proj_local, R, t, pair_feat, mask, w_pair_bias, spatial_coef, pair_bias_cache, feat, alpha, N, L, (float*)ws,
+                                    (hipStream_t)stream);
 }
 
 extern "C" int abopt_ipa_points_backward(const float* dfeat, int ld_dfeat, const float* feat, const float* R, const float* t,

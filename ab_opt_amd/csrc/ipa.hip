@@ -118,31 +118,22 @@ int launch_ipa_frags(const float* proj, const float* R, const float* t, const fl
     return ABOPT_OK;
 }
 
-// debug only: alpha from the unmasked logits the core dumped (ga.py:11-26), one wave per (n, i, h)
-__global__ __launch_bounds__(64) void alpha_from_logits_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ mask,
-                                                               float* __restrict__ alpha, int L) {
-    const int64_t row = blockIdx.x;                              // n * L + i
-    const int h = blockIdx.y, lane = threadIdx.x;
-    const int64_t nbase = (row / L) * L;
-    const bool mi = mask[row] != 0;
-    float mx = -INFINITY;
-    for (int j = lane; j < L; j += 64) {
-        float v = logits[(row * L + j) * H + h];
-        if (!(mi && mask[nbase + j] != 0)) v -= 1e5f;
-        mx = fmaxf(mx, v);
-    }
-    mx = wave_max(mx);
-    float sm = 0.f;
-    for (int j = lane; j < L; j += 64) {
-        float v = logits[(row * L + j) * H + h];
-        if (!(mi && mask[nbase + j] != 0)) v -= 1e5f;
-        sm += expf(v - mx);
-    }
-    sm = wave_sum(sm);
-    for (int j = lane; j < L; j += 64) {
-        float v = logits[(row * L + j) * H + h];
-        if (!(mi && mask[nbase + j] != 0)) v -= 1e5f;
-        alpha[(row * L + j) * H + h] = mi ? expf(v - mx) / sm : 0.f;
+// debug only: the reference-layout intermediates [N,L,L,12] from the core's head-major dump (x = logit * sqrt(1/3) * log2 e, unmasked,
+// and the final (max, sum) of every row): logits = x / log2 e, alpha = mask ? exp2(x - m) / l : 0  (ga.py:11-26,165-166)
+__global__ __launch_bounds__(256) void debug_from_dump_kernel(const float* __restrict__ dump, const float* __restrict__ stats, const uint8_t* __restrict__ mask,
+                                                              float* __restrict__ logits, float* __restrict__ alpha, int L, int64_t total) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;      // ((n * L + i) * L + j) * H + h
+    if (e >= total) return;
+    const int h = (int)(e % H);
+    const int64_t rj = e / H, row = rj / L;
+    const int j = (int)(rj % L);
+    const int64_t n = row / L;
+    const int i = (int)(row % L);
+    const float x = dump[((n * H + h) * L + i) * L + j];
+    if (logits) logits[e] = x * 0.6931471805599453f;
+    if (alpha) {
+        const bool live = mask[row] != 0 && mask[n * L + j] != 0;
+        alpha[e] = live ? __builtin_amdgcn_exp2f(x - stats[(row * H + h) * 2]) / stats[(row * H + h) * 2 + 1] : 0.f;
     }
 }
 
@@ -174,13 +165,20 @@ int launch_ipa_core(const float* qfrag, const float* kvfrag, const float* z, con
     const int nib = (L + BI - 1) / BI;
     ABOPT_CHECK_ARG((int64_t)N * nib < (1ll << 31), "ipa_core: grid too large");
     ABOPT_CHECK_ARG(!z_shared || pair_bias_cache, "ipa_core: a shared pair_feat comes with its shared pair-bias cache");
-    int rc = launch_ipa_core_kernel(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dbg_logits, pair_bias_cache, N, L, st, z_shared);
-    if (rc) return rc;
-    if (dbg_alpha) {
-        ABOPT_CHECK_ARG(dbg_logits != nullptr, "ipa_core: alpha dump needs the logits dump");
-        hipLaunchKernelGGL(alpha_from_logits_kernel, dim3((unsigned)(N * L), H), dim3(64), 0, st, dbg_logits, mask, dbg_alpha, L);
-        ABOPT_LAUNCH_CHECK();
+    if (!dbg_logits && !dbg_alpha)
+        return launch_ipa_core_kernel(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, nullptr, nullptr, pair_bias_cache, N, L, st, z_shared);
+    // parity-test path only: a stream-ordered temporary for the head-major dump (the product path never allocates)
+    const size_t nd = (size_t)N * H * L * L, ns = (size_t)N * L * H * 2;
+    float* tmp = nullptr;
+    ABOPT_HIP(hipMallocAsync(reinterpret_cast<void**>(&tmp), (nd + ns) * sizeof(float), st));
+    int rc = launch_ipa_core_kernel(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, tmp, tmp + nd, pair_bias_cache, N, L, st, z_shared);
+    if (!rc) {
+        const int64_t total = (int64_t)N * L * L * H;
+        hipLaunchKernelGGL(debug_from_dump_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, tmp + nd, mask, dbg_logits, dbg_alpha, L, total);
+        if (hipGetLastError() != hipSuccess) rc = ABOPT_EHIP;
     }
+    (void)hipFreeAsync(tmp, st);
+    if (rc) return rc;
     return ABOPT_OK;
 }
 

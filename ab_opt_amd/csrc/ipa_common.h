@@ -71,7 +71,8 @@ __device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ?
 namespace prof { void begin(hipStream_t st); void end(hipStream_t st); }
 
 int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
-                           const float* w_pair_bias, float* feat, float* dbg_logits, const float* pair_bias_cache, int N, int L, hipStream_t st, int z_shared);
+                           const float* w_pair_bias, float* feat, float* dump, float* dump_stats, const float* pair_bias_cache, int N, int L,
+                           hipStream_t st, int z_shared);
 int launch_pair_bias_cache(const float* z, const float* const* wb, int num_layers, float* cache, int N, int L, hipStream_t st);
 
 }  // namespace abopt

@@ -71,10 +71,14 @@ __host__ __device__ constexpr size_t core_lds_fixed_bytes() {
     return sizeof(float) * (3 * BI * SROW + H * 4 * 64 * 4 + 2 * BI * SCLD + BI * SCLD + (CACHED ? 0 : NPW * JC * ZSLD + 16 * (C + 4)));
 }
 
-template <bool DBG, bool CACHED>
+// DUMP (training / parity tests): the pair waves also write the scaled, UNMASKED logits x = logit * sqrt(1/3) * log2(e) head-major
+// (dump [N,12,L,L], one 16-byte store per lane and row chunk) and the final running maximum / sum of every (row, head)
+// (dump_stats [N*L,12,2]); alpha = mask ? exp2(x - m) / l : 0 is one elementwise pass later (ipa_train.hip: alpha_finalize).
+template <bool DUMP, bool CACHED>
 __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__ qfrag, const float* __restrict__ kvfrag, const float* __restrict__ z,
                                                        const uint8_t* __restrict__ mask, const float* __restrict__ R, const float* __restrict__ t,
-                                                       const float* __restrict__ Wb, float* __restrict__ feat, float* __restrict__ dbg_logits,
+                                                       const float* __restrict__ Wb, float* __restrict__ feat, float* __restrict__ dump,
+                                                       float* __restrict__ dump_stats,
                                                        const float* __restrict__ pbc, int N, int L, int nib, int xcd_remap, int z_shared) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     CoreLds sm;
@@ -143,6 +147,11 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         for (int ii = 0; ii < RPW; ++ii)
             pbrow[ii] = CACHED ? reinterpret_cast<const char*>(pbc + ((zbase + min(i0 + il0 + ii, L - 1)) * (int64_t)nchunk) * (H * JC)) : nullptr;
         const unsigned pb_lane = (unsigned)(min(fm, H - 1) * JC + kq * 4) * 4u;
+        // the dump goes out through a buffer descriptor: base = this sample's [12,L,L] slab (SGPRs), one lane-constant byte offset
+        // (head, key group) and a wave-uniform row/chunk offset -- no 64-bit per-lane addresses in the hot loop
+        const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(DUMP ? dump + (int64_t)n * H * L * L : nullptr, 0, 0x7fffffff, 0x00020000);
+        const unsigned dvoff = (unsigned)((min(fm, H - 1) * L) * L + kq * 4) * 4u;
+        const bool dvec = (L & 3) == 0;                                  // rows of the dump are 16-byte aligned
 #define PW_ISSUE(SLOT, II, CH)                                                                                          \
     {                                                                                                                    \
         const int ch_ = chunk_of(min((CH), nchunk - 1));                       /* past the end: harmless re-read */      \
@@ -197,12 +206,15 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
             sv_ += (a4_[0] + a4_[1]) + (a4_[2] + a4_[3]);                                                                \
         }                                                                                                                \
         float l2_[4];                                                                                                    \
+        sv_ *= kScale2;                                                                                                  \
+        if (DUMP && fm < H && (i0 + il_) < L) {                                                                          \
+            const int j0_ = chunk_of(CH) * JC + kq * 4;                                                                  \
+            const int so_ = ((i0 + il_) * L + chunk_of(CH) * JC) * 4;                                                    \
+            if (dvec) { if (j0_ < L) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv_), drsrc, dvoff, so_, 0); } \
+            else { _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) if (j0_ + r_ < L) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv_[r_]), drsrc, dvoff + 4 * r_, so_, 0); } \
+        }                                                                                                                \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                               \
-            if (DBG) {                                                                                                   \
-                const int j_ = chunk_of(CH) * JC + kq * 4 + r_;                                                          \
-                if (j_ < L && fm < H && (i0 + il_) < L) dbg_logits[((rowbase + i0 + il_) * L + j_) * H + fm] = sv_[r_] * kSqrt13; \
-            }                                                                                                            \
-            const float x_ = sv_[r_] * kScale2;                                                                               \
+            const float x_ = sv_[r_];                                                                                    \
             l2_[r_] = ((mk4_ >> (8 * r_)) & 0xffu) ? x_ : x_ - kMask2;      /* ga.py:20-23 (masked QUERY rows are zeroed at the end instead) */ \
         }                                                                                                                \
         f32x4 pv_; float sc_;                                                                                            \
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         for (int ii = 0; ii < RPW; ++ii) {
             const int il = il0 + ii, i = i0 + il;
             if (kq == 0) sm.lsum[il * SCLD + fm] = l_run[ii];
+            if (DUMP && kq == 0 && i < L && fm < H) *reinterpret_cast<float2*>(dump_stats + ((rowbase + i) * H + fm) * 2) = make_float2(m_run[ii], l_run[ii]);
             if (i < L && fm < H) {
                 const float inv = mi_b[ii] ? 1.f / l_run[ii] : 0.f;
                 float* fo = feat + (rowbase + i) * FEAT + fm * C + kq * 16;        // accumulator row 4 kq + r of tile mt <-> channel 16 kq + 4 r + mt
@@ -469,19 +482,19 @@ int launch_pair_bias_cache(const float* z, const float* const* wb, int num_layer
     return ABOPT_OK;
 }
 
-template <bool DBG, bool CACHED>
+template <bool DUMP, bool CACHED>
 static int launch_core_variant(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
-                               const float* Wb, float* feat, float* dbg_logits, const float* pbc, int N, int L, hipStream_t st, int z_shared) {
+                               const float* Wb, float* feat, float* dump, float* dump_stats, const float* pbc, int N, int L, hipStream_t st, int z_shared) {
     const int nib = (L + BI - 1) / BI, nchunk = (L + JC - 1) / JC;
     const size_t lds = core_lds_fixed_bytes<CACHED>() + (size_t)nchunk * JC;
     ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core: L=%d needs %zu bytes of LDS for the key mask (max 163840)", L, lds);
     static size_t configured = 0;                                           // per instantiation
     if (lds > configured) {
-        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_core_kernel<DBG, CACHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_core_kernel<DUMP, CACHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
     prof::begin(st);
-    hipLaunchKernelGGL((ipa_core_kernel<DBG, CACHED>), dim3((unsigned)(N * nib)), dim3(NTH), lds, st, qfrag, kvfrag, z, mask, R, t, Wb, feat, dbg_logits, pbc,
+    hipLaunchKernelGGL((ipa_core_kernel<DUMP, CACHED>), dim3((unsigned)(N * nib)), dim3(NTH), lds, st, qfrag, kvfrag, z, mask, R, t, Wb, feat, dump, dump_stats, pbc,
                        N, L, nib, (N % 8 == 0) ? 1 : 0, z_shared);
     prof::end(st);
     ABOPT_LAUNCH_CHECK();
@@ -501,13 +514,16 @@ static int launch_core_variant(const float* qfrag, const float* kvfrag, const fl
 }
 
 int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
-                           const float* w_pair_bias, float* feat, float* dbg_logits, const float* pair_bias_cache, int N, int L, hipStream_t st, int z_shared) {
+                           const float* w_pair_bias, float* feat, float* dump, float* dump_stats, const float* pair_bias_cache, int N, int L, hipStream_t st,
+                           int z_shared) {
+    ABOPT_CHECK_ARG(!dump == !dump_stats, "ipa_core: the logits dump and its row statistics come together");
+    ABOPT_CHECK_ARG(!dump || (int64_t)H * L * L * 4 < (1ll << 31), "ipa_core: L=%d too long for the logits dump", L);
     if (pair_bias_cache) {
-        if (dbg_logits) return launch_core_variant<true, true>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dbg_logits, pair_bias_cache, N, L, st, z_shared);
-        return launch_core_variant<false, true>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dbg_logits, pair_bias_cache, N, L, st, z_shared);
+        if (dump) return launch_core_variant<true, true>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dump, dump_stats, pair_bias_cache, N, L, st, z_shared);
+        return launch_core_variant<false, true>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, nullptr, nullptr, pair_bias_cache, N, L, st, z_shared);
     }
-    if (dbg_logits) return launch_core_variant<true, false>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dbg_logits, nullptr, N, L, st, z_shared);
-    return launch_core_variant<false, false>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dbg_logits, nullptr, N, L, st, z_shared);
+    if (dump) return launch_core_variant<true, false>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dump, dump_stats, nullptr, N, L, st, z_shared);
+    return launch_core_variant<false, false>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, nullptr, nullptr, nullptr, N, L, st, z_shared);
 }
 
 }  // namespace abopt

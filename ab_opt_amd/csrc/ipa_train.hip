@@ -139,32 +139,41 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
     }
 }
 
-// masked softmax of the logits dump, written head-major (ga.py:11-26): one workgroup per (n, i); the row's L x 12 logits are
-// staged in LDS with coalesced loads, wave w reduces heads 3w..3w+2, rows of alpha[n, h, i, :] are written coalesced
-__global__ __launch_bounds__(256) void alpha_head_major_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ mask,
-                                                               float* __restrict__ alpha, int L) {
-    extern __shared__ float lg[];                                // [L][12] then overwritten with the probabilities
-    const int64_t row = blockIdx.x;                              // n * L + i
-    const int64_t n = row / L, nbase = n * L;
-    const int i = (int)(row % L), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+// alpha (ga.py:11-26,166) in place over the core's head-major dump x [N,12,L,L]: alpha = mask_i mask_j ? exp2(x - m_ih) / l_ih : 0
+// with the row statistics the core kept; one thread per 4 keys (scalar tail when L is not a multiple of 4)
+__global__ __launch_bounds__(256) void alpha_finalize_kernel(float* __restrict__ xa, const float* __restrict__ stats, const uint8_t* __restrict__ mask,
+                                                             int L, int64_t quads) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;       // ((n * H + h) * L + i) * (L / 4) + j / 4
+    if (q >= quads) return;
+    const int l4 = L >> 2;
+    const int jq = (int)(q % l4);
+    const int64_t nhi = q / l4;
+    const int i = (int)(nhi % L);
+    const int64_t nh = nhi / L, n = nh / H;
+    const int h = (int)(nh % H);
+    const int64_t row = n * L + i;
+    const float2 st = *reinterpret_cast<const float2*>(stats + (row * H + h) * 2);
     const bool mi = mask[row] != 0;
-    const float* src = logits + row * (int64_t)L * H;
-    for (int e = tid; e < L * H; e += 256) {
-        float v = src[e];
-        if (!(mi && mask[nbase + e / H] != 0)) v -= 1e5f;
-        lg[e] = v;
-    }
-    __syncthreads();
-    for (int h = wave * 3; h < wave * 3 + 3; ++h) {
-        float mx = -INFINITY;
-        for (int j = lane; j < L; j += 64) mx = fmaxf(mx, lg[j * H + h]);
-        mx = wave_max(mx);
-        float sm = 0.f;
-        for (int j = lane; j < L; j += 64) sm += expf(lg[j * H + h] - mx);
-        sm = wave_sum(sm);
-        float* out = alpha + ((n * H + h) * (int64_t)L + i) * L;
-        for (int j = lane; j < L; j += 64) out[j] = mi ? expf(lg[j * H + h] - mx) / sm : 0.f;
-    }
+    const float inv = 1.f / st.y;
+    f32x4* p = reinterpret_cast<f32x4*>(xa) + q;
+    f32x4 v = *p;
+    const uint32_t mk = *reinterpret_cast<const uint32_t*>(mask + n * L + jq * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (mi && ((mk >> (8 * r)) & 0xffu)) ? __builtin_amdgcn_exp2f(v[r] - st.x) * inv : 0.f;
+    *p = v;
+}
+__global__ __launch_bounds__(256) void alpha_finalize_scalar_kernel(float* __restrict__ xa, const float* __restrict__ stats, const uint8_t* __restrict__ mask,
+                                                                    int L, int64_t total) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;       // ((n * H + h) * L + i) * L + j
+    if (e >= total) return;
+    const int j = (int)(e % L);
+    const int64_t nhi = e / L;
+    const int i = (int)(nhi % L);
+    const int64_t nh = nhi / L, n = nh / H;
+    const int h = (int)(nh % H);
+    const int64_t row = n * L + i;
+    const bool live = mask[row] != 0 && mask[n * L + j] != 0;
+    xa[e] = live ? __builtin_amdgcn_exp2f(xa[e] - stats[(row * H + h) * 2]) / stats[(row * H + h) * 2 + 1] : 0.f;
 }
 
 // Backward of the points epilogue (ga.py:133-139: loc = R^T (agg - t), dist = |loc|, dir = loc / (dist + 1e-4)) and the
@@ -320,11 +329,13 @@ int launch_ipa_pair_backward(const float* z, const float* alpha, const float* da
     return ABOPT_OK;
 }
 
-size_t ipa_train_ws_floats(int N, int L) { return (size_t)N * L * NP + ipa_kvfrag_floats(N, L) + ipa_qfrag_floats(N, L) + (size_t)N * L * L * H + 64; }
+size_t ipa_train_ws_floats(int N, int L) { return (size_t)N * L * NP + ipa_kvfrag_floats(N, L) + ipa_qfrag_floats(N, L) + (size_t)N * L * H * 2 + 64; }
 
-// proj_local [N*L, 2016] (points in the residue frames, as the six projections produce them) -> feat [N*L, 1824], alpha [N, 12, L, L]
+// proj_local [N*L, 2016] (points in the residue frames, as the six projections produce them) -> feat [N*L, 1824], alpha [N, 12, L, L];
+// pbc (optional): this layer's slice of a pair-bias cache built from the same z and weights (launch_pair_bias_cache)
 int launch_ipa_train_forward(const float* proj_local, const float* R, const float* t, const float* z, const uint8_t* mask,
-                             const float* Wb, const float* spatial_coef, float* feat, float* alpha, int N, int L, float* ws, hipStream_t st) {
+                             const float* Wb, const float* spatial_coef, const float* pbc, float* feat, float* alpha, int N, int L, float* ws,
+                             hipStream_t st) {
     const int64_t M = (int64_t)N * L;
     if (M == 0) return ABOPT_OK;
     float* proj = ws;
@@ -334,12 +345,16 @@ int launch_ipa_train_forward(const float* proj_local, const float* R, const floa
     int rc;
     float* qf = kvf + ipa_kvfrag_floats(N, L);
     if ((rc = launch_ipa_frags(proj, R, t, spatial_coef, qf, kvf, N, L, st))) return rc;
-    float* logits = qf + ipa_qfrag_floats(N, L);
-    if ((rc = launch_ipa_core(qf, kvf, z, mask, R, t, Wb, feat, logits, nullptr, nullptr, N, L, st))) return rc;
-    const size_t lds = (size_t)L * H * sizeof(float);
-    ABOPT_CHECK_ARG(lds <= 96 * 1024, "ipa_core_train_forward: L=%d too long (max 2048)", L);
-    ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alpha_head_major_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(alpha_head_major_kernel, dim3((unsigned)M), dim3(256), lds, st, logits, mask, alpha, L);
+    float* stats = qf + ipa_qfrag_floats(N, L);
+    // the core writes its scaled logits head-major into the alpha buffer; one elementwise pass turns them into alpha in place
+    if ((rc = launch_ipa_core_kernel(qf, kvf, z, mask, R, t, Wb, feat, alpha, stats, pbc, N, L, st, 0))) return rc;
+    if ((L & 3) == 0) {
+        const int64_t quads = (int64_t)N * H * L * (L / 4);
+        hipLaunchKernelGGL(alpha_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, alpha, stats, mask, L, quads);
+    } else {
+        const int64_t total = (int64_t)N * H * L * L;
+        hipLaunchKernelGGL(alpha_finalize_scalar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, alpha, stats, mask, L, total);
+    }
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

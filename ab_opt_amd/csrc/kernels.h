@@ -36,9 +36,15 @@ int launch_fused_ln_mlp(const float* x, const float* u, int nslab, int64_t slab_
                         const float* g1, const float* be1, const float* W0, const float* b0, const float* W1, const float* b1,
                         const float* W2, const float* b2, const float* g2, const float* be2, float* out, int64_t rows, hipStream_t st);
 // mlp.hip: the same tail with out_transform fused in; W_out and W_mlp0..2 as bf16 terms in MFMA operand order (abopt.h: w_out_frag, w_mlp_frag)
+// dump (optional, training): five [rows,128] slabs for launch_tail_backward
 int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, const float* x, const float* ubias, const uint8_t* mask,
                       const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2, const float* be2,
-                      float* out, int64_t rows, hipStream_t st);
+                      float* out, float* dump, int64_t rows, hipStream_t st);
+size_t out_wfrag_floats();
+size_t mlp_wfrag_floats();
+int launch_pack_tail_weights(const float* w_out, const float* w0, const float* w1, const float* w2, float* wof, float* wmf, float* wmt, hipStream_t st);
+int launch_tail_backward(const float* dout, const float* saved, const float* wmt, const uint8_t* mask, const float* g1, const float* g2,
+                         float* dpre, float* da1, float* du, float* colpart, int64_t rows, hipStream_t st);
 // cat[row] = [res_feat[row] | embed[s_t[row]]], F == 128
 int launch_embed_concat(const float* res_feat, const int64_t* s_t, const float* embed, float* cat, int64_t rows, hipStream_t st);
 // infeat[row, 0:128] = x, [128:131] = beta, sin beta, cos beta, [131] = 0 ; optional LN'd copy for the prmsd head
@@ -54,7 +60,8 @@ int launch_mean_over_L(const float* in, float* out, int N, int L, int B, hipStre
 // ipa_train.hip: training side of the IPA core -----------------------------------------------------
 size_t ipa_train_ws_floats(int N, int L);
 int launch_ipa_train_forward(const float* proj_local, const float* R, const float* t, const float* z, const uint8_t* mask,
-                             const float* Wb, const float* spatial_coef, float* feat, float* alpha, int N, int L, float* ws, hipStream_t st);
+                             const float* Wb, const float* spatial_coef, const float* pbc, float* feat, float* alpha, int N, int L, float* ws,
+                             hipStream_t st);
 int launch_ipa_points_backward(const float* dfeat, int ld_dfeat, const float* feat, const float* R, const float* t, float* dout_cat, float* delta,
                                int N, int L, hipStream_t st);
 int launch_ipa_backward_operands(const float* proj, const float* R, const float* t, float* Aq, float* Ak, float* Av, int N, int L, hipStream_t st);

@@ -286,16 +286,19 @@ __device__ __forceinline__ void mlp_partial(const char* ap, const MlpW& w, float
 }
 }  // namespace
 
+// DUMP (training): also writes what the backward needs, five [rows,128] slabs: pre-LayerNorm1 sum | y | h0 | h1 | pre-LayerNorm2 sum
+template <bool DUMP>
 __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restrict__ feat, const float* __restrict__ wof /* W_out terms, operand order */,
                                                            const float* __restrict__ wmf /* W_mlp0..2 terms, operand order */,
                                                            const float* __restrict__ x, const float* __restrict__ ubias, const uint8_t* __restrict__ mask,
                                                            const float* __restrict__ g1, const float* __restrict__ be1,
                                                            const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2,
                                                            const float* __restrict__ g2, const float* __restrict__ be2,
-                                                           float* __restrict__ out, int64_t rows) {
+                                                           float* __restrict__ out, float* __restrict__ dump, int64_t rows) {
     extern __shared__ __attribute__((aligned(16))) char ot_raw[];
     OtSmem& sm = *reinterpret_cast<OtSmem*>(ot_raw);
     const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t slab = rows * F;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * MR;
 #ifdef OT_TIMING
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
             float2 us = make_float2(((u0.x + u1.x) + (u2.x + u3.x)) + bb.x, ((u0.y + u1.y) + (u2.y + u3.y)) + bb.y);
             if (!keep) us = make_float2(0.f, 0.f);
             a_[rr] = xv.x + us.x; b_[rr] = xv.y + us.y;
+            if (DUMP && row0 + rl < rows) reinterpret_cast<float2*>(dump + (row0 + rl) * F)[lane] = make_float2(a_[rr], b_[rr]);
         }
 #pragma unroll
         for (int rr = 0; rr < RW; ++rr) mean[rr] = wave_sum(a_[rr] + b_[rr]) * (1.f / F);
@@ -399,6 +403,7 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
             const float y0 = a_[rr] / sd * g.x + bt.x, y1 = b_[rr] / sd * g.y + bt.y;
             *reinterpret_cast<float2*>(&sm.ys[rl][2 * lane]) = make_float2(y0, y1);
             store_terms2(sm.ap, rl * AP_ROW + lane * 4, y0, y1);
+            if (DUMP && row0 + rl < rows) reinterpret_cast<float2*>(dump + slab + (row0 + rl) * F)[lane] = make_float2(y0, y1);
         }
     }
     __syncthreads();
@@ -415,8 +420,10 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
     __syncthreads();
     {
         const f32x4 v = gather(b0);
-        store_terms2(sm.ap, er * AP_ROW + ec * 2, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
-        store_terms2(sm.ap, er * AP_ROW + ec * 2 + 4, fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+        const f32x4 hv = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        store_terms2(sm.ap, er * AP_ROW + ec * 2, hv[0], hv[1]);
+        store_terms2(sm.ap, er * AP_ROW + ec * 2 + 4, hv[2], hv[3]);
+        if (DUMP && row0 + er < rows) *reinterpret_cast<f32x4*>(dump + 2 * slab + (row0 + er) * F + ec) = hv;
     }
     __syncthreads();
     // ---- layer 1: relu(W1 h + b1)
@@ -425,8 +432,10 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
     __syncthreads();
     {
         const f32x4 v = gather(b1);
-        store_terms2(sm.ap, er * AP_ROW + ec * 2, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
-        store_terms2(sm.ap, er * AP_ROW + ec * 2 + 4, fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+        const f32x4 hv = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        store_terms2(sm.ap, er * AP_ROW + ec * 2, hv[0], hv[1]);
+        store_terms2(sm.ap, er * AP_ROW + ec * 2 + 4, hv[2], hv[3]);
+        if (DUMP && row0 + er < rows) *reinterpret_cast<f32x4*>(dump + 3 * slab + (row0 + er) * F + ec) = hv;
     }
     __syncthreads();
     // ---- layer 2 + residual (in place in ys), then LayerNorm2
@@ -437,6 +446,7 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
         f32x4 yv = *reinterpret_cast<const f32x4*>(&sm.ys[er][ec]);
         yv += v;
         *reinterpret_cast<f32x4*>(&sm.ys[er][ec]) = yv;
+        if (DUMP && row0 + er < rows) *reinterpret_cast<f32x4*>(dump + 4 * slab + (row0 + er) * F + ec) = yv;
     }
     __syncthreads();
     {
@@ -462,18 +472,27 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
 size_t out_wfrag_floats() { return (size_t)F * OT_K * 3 / 2; }      // three bf16 per weight
 size_t mlp_wfrag_floats() { return (size_t)3 * F * F * 3 / 2; }
 
-int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, const float* x, const float* ubias, const uint8_t* mask,
-                      const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2, const float* be2,
-                      float* out, int64_t rows, hipStream_t st) {
-    if (rows == 0) return ABOPT_OK;
+template <bool DUMP>
+static int launch_out_ln_mlp_t(const float* feat, const float* wof, const float* wmf, const float* x, const float* ubias, const uint8_t* mask,
+                               const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2, const float* be2,
+                               float* out, float* dump, int64_t rows, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
-        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(out_ln_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OtSmem)));
+        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(out_ln_mlp_kernel<DUMP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OtSmem)));
         configured = true;
     }
-    hipLaunchKernelGGL(out_ln_mlp_kernel, dim3((unsigned)((rows + MR - 1) / MR)), dim3(OT_TH), sizeof(OtSmem), st, feat, wof, wmf, x, ubias, mask,
-                       g1, be1, b0, b1, b2, g2, be2, out, rows);
+    hipLaunchKernelGGL(out_ln_mlp_kernel<DUMP>, dim3((unsigned)((rows + MR - 1) / MR)), dim3(OT_TH), sizeof(OtSmem), st, feat, wof, wmf, x, ubias, mask,
+                       g1, be1, b0, b1, b2, g2, be2, out, dump, rows);
     ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, const float* x, const float* ubias, const uint8_t* mask,
+                      const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2, const float* be2,
+                      float* out, float* dump, int64_t rows, hipStream_t st) {
+    if (rows == 0) return ABOPT_OK;
+    const int rc = dump ? launch_out_ln_mlp_t<true>(feat, wof, wmf, x, ubias, mask, g1, be1, b0, b1, b2, g2, be2, out, dump, rows, st)
+                        : launch_out_ln_mlp_t<false>(feat, wof, wmf, x, ubias, mask, g1, be1, b0, b1, b2, g2, be2, out, dump, rows, st);
 #ifdef OT_TIMING
     {
         long long hh[16][4];
@@ -484,6 +503,201 @@ int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, con
             for (int w = 0; w < 16; w += 5) fprintf(stderr, "[ot timing WG 17 wave %d] prologue %lld | phase 1 loop %lld | phase 2 %lld\n", w, hh[w][0], hh[w][1], hh[w][2]);
     }
 #endif
+    return rc;
+}
+
+// =====================================================================================================================
+// Weights of the tail as bf16 terms in MFMA operand order, packed on the device (one launch per block): W_out -> wof
+// [4][114][3][64], W_mlp0..2 -> wmf [3][4][8][3][64], and their transposes -> wmt (operands of the backward chain).  One thread
+// per (matrix, cb, step, lane): 8 values -> three 16-byte vectors.  Layout: include/abopt.h (w_out_frag, w_mlp_frag).
+__global__ __launch_bounds__(256) void pack_tail_weights_kernel(const float* __restrict__ w_out, const float* __restrict__ w0, const float* __restrict__ w1,
+                                                                const float* __restrict__ w2, float* __restrict__ wof, float* __restrict__ wmf,
+                                                                float* __restrict__ wmt) {
+    constexpr int NOUT = 4 * OT_ST * 64, NMLP = 4 * OT_MS * 64;
+    int id = blockIdx.x * 256 + threadIdx.x;
+    const float* src; u32x4* dst; int K, rs, cs, steps;
+    if (id < NOUT) { src = w_out; dst = reinterpret_cast<u32x4*>(wof); K = OT_K; rs = OT_K; cs = 1; steps = OT_ST; }
+    else {
+        id -= NOUT;
+        if (id >= 6 * NMLP) return;
+        const int m = id / NMLP; id %= NMLP;
+        const int layer = m % 3; const bool tr = m >= 3;
+        if (tr && !wmt) return;
+        src = layer == 0 ? w0 : (layer == 1 ? w1 : w2);
+        dst = reinterpret_cast<u32x4*>(tr ? wmt : wmf) + layer * (NMLP * 3);
+        K = F; steps = OT_MS;
+        rs = tr ? 1 : F; cs = tr ? F : 1;                                        // transposed: element (row, k) = w[k][row]
+    }
+    (void)K;
+    const int lane = id & 63, st = (id >> 6) % steps, cb = (id >> 6) / steps;
+    const float* p = src + (int64_t)(cb * 32 + (lane & 31)) * rs + (int64_t)(st * 16 + (lane >> 5) * 8) * cs;
+    f32x4 lo, hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { lo[i] = p[(int64_t)i * cs]; hi[i] = p[(int64_t)(i + 4) * cs]; }
+    const Split3 sp = split3(lo, hi);
+    u32x4* d = dst + ((int64_t)(cb * steps + st) * 3) * 64 + lane;
+    d[0] = sp.h; d[64] = sp.m; d[128] = sp.l;
+}
+
+int launch_pack_tail_weights(const float* w_out, const float* w0, const float* w1, const float* w2, float* wof, float* wmf, float* wmt, hipStream_t st) {
+    const int total = 4 * OT_ST * 64 + 6 * 4 * OT_MS * 64;
+    hipLaunchKernelGGL(pack_tail_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w_out, w0, w1, w2, wof, wmf, wmt);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+// =====================================================================================================================
+// Backward of the tail for 32 rows per workgroup (training): everything that is row-local in
+//     out = LN2(r),  r = y + W2 h1 + b2,  h1 = relu(W1 h0 + b1),  h0 = relu(W0 y + b0),  y = LN1(a1),  a1 = x + mask * u
+// from d out and the five slabs the forward dumped (a1 | y | h0 | h1 | r).  Writes d pre-activations of the three layers (the weight
+// gradients are tall GEMMs on them, left to the caller), d a1 (= d x through the residual), d u = mask * d a1 (operand of the two
+// out_transform GEMMs) and the column sums of this tile for the eight vector gradients
+//     0 d beta2 | 1 d gamma2 | 2 d b2 | 3 d b1 | 4 d b0 | 5 d beta1 | 6 d gamma1 | 7 d b_out
+// as per-workgroup partials [tiles][8][128] (summed by the caller: deterministic, no atomics).  The three chain products
+// d h = d pre . W run on the bf16 matrix pipe like the forward, with the transposed weights packed by pack_tail_weights.
+namespace {
+struct TbSmem {
+    char ap[3 * AP_PLANE];
+    float part[4][MR][XLD];                   // K-group partials; also scratch for the column sums of the row-wise phases
+    float drs[MR][XLD];                       // d r, later d y
+    float scr[MR][XLD];
+};
+// column sums of up to three [32][XLD] arrays: thread t < 128 nq -> (array t >> 7, column t & 127); quantity ids q0, q0 + 1, ...
+__device__ __forceinline__ void column_sums(const float (*a0)[XLD], const float (*a1)[XLD], const float (*a2)[XLD], int q0, int nq,
+                                            float* __restrict__ colpart, int tid) {
+    if (tid < 128 * nq) {
+        const int q = tid >> 7, col = tid & 127;
+        const float (*a)[XLD] = q == 0 ? a0 : (q == 1 ? a1 : a2);
+        float sacc = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < MR; ++r) sacc += a[r][col];
+        colpart[(q0 + q) * F + col] = sacc;
+    }
+}
+}  // namespace
+
+__global__ __launch_bounds__(OT_TH) void tail_backward_kernel(const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ wmt,
+                                                              const uint8_t* __restrict__ mask, const float* __restrict__ g1, const float* __restrict__ g2,
+                                                              float* __restrict__ dpre, float* __restrict__ da1, float* __restrict__ du,
+                                                              float* __restrict__ colpart, int64_t rows) {
+    extern __shared__ __attribute__((aligned(16))) char tb_raw[];
+    TbSmem& sm = *reinterpret_cast<TbSmem*>(tb_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * MR, slab = rows * F;
+    const int cb = wave & 3, kg = wave >> 2;
+    float* cp = colpart + (int64_t)blockIdx.x * 8 * F;
+    constexpr int RW = MR / OT_NW;
+    MlpW mw = load_mlp_w(wmt, 2, cb, kg, lane);
+    // ---- LayerNorm2 backward (each wave 2 rows): d r = (g2 d out - mean(.) - xhat mean(. xhat)) / sigma
+    {
+        const float2 g = reinterpret_cast<const float2*>(g2)[lane];
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int rl = wave * RW + rr;
+            const bool live = row0 + rl < rows;
+            const int64_t row = min(row0 + rl, rows - 1);
+            float2 rv = reinterpret_cast<const float2*>(saved + 4 * slab + row * F)[lane];
+            float2 dv = reinterpret_cast<const float2*>(dout + row * F)[lane];
+            if (!live) dv = make_float2(0.f, 0.f);
+            const float mean = wave_sum(rv.x + rv.y) * (1.f / F);
+            rv.x -= mean; rv.y -= mean;
+            const float rsd = 1.f / sqrtf(wave_sum(rv.x * rv.x + rv.y * rv.y) * (1.f / F) + 1e-10f);
+            const float2 xh = make_float2(rv.x * rsd, rv.y * rsd);
+            const float2 dh = make_float2(dv.x * g.x, dv.y * g.y);
+            const float m1 = wave_sum(dh.x + dh.y) * (1.f / F), m2 = wave_sum(dh.x * xh.x + dh.y * xh.y) * (1.f / F);
+            const float2 dr = make_float2((dh.x - m1 - xh.x * m2) * rsd, (dh.y - m1 - xh.y * m2) * rsd);
+            *reinterpret_cast<float2*>(&sm.drs[rl][2 * lane]) = dr;
+            *reinterpret_cast<float2*>(&sm.part[0][rl][2 * lane]) = dv;
+            *reinterpret_cast<float2*>(&sm.part[1][rl][2 * lane]) = make_float2(dv.x * xh.x, dv.y * xh.y);
+            store_terms2(sm.ap, rl * AP_ROW + lane * 4, dr.x, dr.y);
+            if (live) reinterpret_cast<float2*>(dpre + 2 * slab + row * F)[lane] = dr;          // d pre-activation of layer 2 (no relu)
+        }
+    }
+    __syncthreads();
+    column_sums(sm.part[0], sm.part[1], sm.drs, 0, 3, cp, tid);
+    __syncthreads();
+    const int er = tid >> 5, ec = (tid & 31) * 4;
+    const bool elive = row0 + er < rows;
+    const int64_t erow = min(row0 + er, rows - 1);
+    auto gather = [&]() {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&sm.part[0][er][ec]), p1 = *reinterpret_cast<const f32x4*>(&sm.part[1][er][ec]);
+        const f32x4 p2 = *reinterpret_cast<const f32x4*>(&sm.part[2][er][ec]), p3 = *reinterpret_cast<const f32x4*>(&sm.part[3][er][ec]);
+        return (p0 + p1) + (p2 + p3);
+    };
+    // ---- d h1 = d pre2 . W2, relu mask -> d pre1 ; d h0 = d pre1 . W1, relu mask -> d pre0
+#pragma unroll
+    for (int layer = 1; layer >= 0; --layer) {
+        mlp_partial(sm.ap, mw, sm.part[kg], cb, kg, lane);
+        mw = load_mlp_w(wmt, layer, cb, kg, lane);
+        __syncthreads();
+        {
+            f32x4 v = gather();
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(saved + (2 + layer) * slab + erow * F + ec);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = hv[i] > 0.f ? v[i] : 0.f;
+            if (!elive) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            store_terms2(sm.ap, er * AP_ROW + ec * 2, v[0], v[1]);
+            store_terms2(sm.ap, er * AP_ROW + ec * 2 + 4, v[2], v[3]);
+            *reinterpret_cast<f32x4*>(&sm.scr[er][ec]) = v;
+            if (elive) *reinterpret_cast<f32x4*>(dpre + layer * slab + erow * F + ec) = v;
+        }
+        __syncthreads();
+        column_sums(sm.scr, sm.scr, sm.scr, layer == 1 ? 3 : 4, 1, cp, tid);
+    }
+    // ---- d y = d r + d pre0 . W0
+    mlp_partial(sm.ap, mw, sm.part[kg], cb, kg, lane);
+    __syncthreads();
+    {
+        const f32x4 v = gather();
+        f32x4 d = *reinterpret_cast<const f32x4*>(&sm.drs[er][ec]);
+        d += v;
+        *reinterpret_cast<f32x4*>(&sm.drs[er][ec]) = d;
+    }
+    __syncthreads();
+    // ---- LayerNorm1 backward (each wave 2 rows) -> d a1, d u
+    {
+        const float2 g = reinterpret_cast<const float2*>(g1)[lane];
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int rl = wave * RW + rr;
+            const bool live = row0 + rl < rows;
+            const int64_t row = min(row0 + rl, rows - 1);
+            float2 av = reinterpret_cast<const float2*>(saved + row * F)[lane];
+            const float2 dv = *reinterpret_cast<const float2*>(&sm.drs[rl][2 * lane]);
+            const float mean = wave_sum(av.x + av.y) * (1.f / F);
+            av.x -= mean; av.y -= mean;
+            const float rsd = 1.f / sqrtf(wave_sum(av.x * av.x + av.y * av.y) * (1.f / F) + 1e-10f);
+            const float2 xh = make_float2(av.x * rsd, av.y * rsd);
+            const float2 dh = make_float2(dv.x * g.x, dv.y * g.y);
+            const float m1 = wave_sum(dh.x + dh.y) * (1.f / F), m2 = wave_sum(dh.x * xh.x + dh.y * xh.y) * (1.f / F);
+            const float2 da = make_float2((dh.x - m1 - xh.x * m2) * rsd, (dh.y - m1 - xh.y * m2) * rsd);
+            const bool keep = mask ? (mask[row] != 0) : true;
+            const float2 duv = keep ? da : make_float2(0.f, 0.f);
+            *reinterpret_cast<float2*>(&sm.part[0][rl][2 * lane]) = dv;                           // d beta1 (rows past the end hold zeros: d r and d pre0 were zeroed)
+            *reinterpret_cast<float2*>(&sm.part[1][rl][2 * lane]) = make_float2(dv.x * xh.x, dv.y * xh.y);
+            *reinterpret_cast<float2*>(&sm.part[2][rl][2 * lane]) = live ? duv : make_float2(0.f, 0.f);
+            if (live) {
+                reinterpret_cast<float2*>(da1 + row * F)[lane] = da;
+                reinterpret_cast<float2*>(du + row * F)[lane] = duv;
+            }
+        }
+    }
+    __syncthreads();
+    column_sums(sm.part[0], sm.part[1], sm.part[2], 5, 3, cp, tid);
+}
+
+int launch_tail_backward(const float* dout, const float* saved, const float* wmt, const uint8_t* mask, const float* g1, const float* g2,
+                         float* dpre, float* da1, float* du, float* colpart, int64_t rows, hipStream_t st) {
+    if (rows == 0) return ABOPT_OK;
+    static bool configured = false;
+    if (!configured) {
+        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TbSmem)));
+        configured = true;
+    }
+    hipLaunchKernelGGL(tail_backward_kernel, dim3((unsigned)((rows + MR - 1) / MR)), dim3(OT_TH), sizeof(TbSmem), st, dout, saved, wmt, mask, g1, g2,
+                       dpre, da1, du, colpart, rows);
+    ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }
 

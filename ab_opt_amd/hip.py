@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 17
+ABI_VERSION = 19
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -75,7 +75,8 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
-           'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats']
+           'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
+           'abopt_out_frag_floats', 'abopt_mlp_frag_floats', 'abopt_pack_tail_weights', 'abopt_block_tail_forward', 'abopt_block_tail_backward']
 
 _lib = None
 _lock = threading.Lock()
@@ -126,7 +127,7 @@ def lib():
         L.abopt_reconstruct_backbone_partially.argtypes = [c_f, c_f, c_f, c_i64, c_i64, c_i64, c_u8, c_u8, c_f, c_f, c_f, c_u8] + [C.c_int] * 3 + [C.c_void_p]
         L.abopt_ipa_train_workspace_bytes.restype = C.c_size_t
         L.abopt_ipa_train_workspace_bytes.argtypes = [C.c_int] * 2
-        L.abopt_ipa_core_train_forward.argtypes = [c_f, c_f, c_f, c_f, c_u8, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_ipa_core_train_forward.argtypes = [c_f, c_f, c_f, c_f, c_u8, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_ipa_points_backward.argtypes = [c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_ipa_backward_operands.argtypes = [c_f] * 6 + [C.c_int, C.c_int, C.c_void_p]
         L.abopt_ipa_backward_assemble.argtypes = [c_f] * 9 + [C.c_int, C.c_int, C.c_void_p]
@@ -145,6 +146,11 @@ def lib():
         L.abopt_dockq_workspace_bytes.restype = C.c_size_t
         L.abopt_dockq_workspace_bytes.argtypes = [C.c_int]
         L.abopt_dockq_lite.argtypes = [c_f, c_u8, C.c_int, c_f, c_u8, C.c_void_p, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_out_frag_floats.restype = C.c_size_t
+        L.abopt_mlp_frag_floats.restype = C.c_size_t
+        L.abopt_pack_tail_weights.argtypes = [c_f] * 7 + [C.c_void_p]
+        L.abopt_block_tail_forward.argtypes = [c_f] * 5 + [c_u8] + [c_f] * 9 + [C.c_int64, C.c_void_p]
+        L.abopt_block_tail_backward.argtypes = [c_f] * 3 + [c_u8] + [c_f] * 6 + [C.c_int64, C.c_void_p]
         for name in EXPORTS:
             getattr(L, name)          # AttributeError here = a symbol of include/abopt.h is missing
         if L.abopt_abi_version() != ABI_VERSION:
@@ -417,7 +423,18 @@ def commonness_score(structs):
     return score
 
 
-def ipa_core_train_forward(proj_local, R, t, z, mask, w_pair_bias, spatial_coef):
+def pair_bias_cache_layers(w_pair_bias_list, pair_feat):
+    """The cache from bare proj_pair_bias weights (training: built once per step for all blocks) -> list of per-layer views."""
+    n = len(w_pair_bias_list)
+    ws = _contig(*[w.detach().float() for w in w_pair_bias_list])
+    arr = (GaWeights * n)()
+    for i, w in enumerate(ws):
+        arr[i].w_pair_bias = ptr(w, torch.float32)
+    cache = pair_bias_cache(arr, n, pair_feat)
+    return list(cache.view(n, -1).unbind(0))
+
+
+def ipa_core_train_forward(proj_local, R, t, z, mask, w_pair_bias, spatial_coef, pbc=None):
     """Training-mode IPA core: -> feat (N,L,1824), alpha head-major (N,12,L,L)  (include/abopt.h: abopt_ipa_core_train_forward)."""
     N, L = mask.shape
     dev = z.device
@@ -428,7 +445,7 @@ def ipa_core_train_forward(proj_local, R, t, z, mask, w_pair_bias, spatial_coef)
     proj_local, R, t, z, mask, w_pair_bias, spatial_coef = _contig(proj_local, R, t, z, mask, w_pair_bias, spatial_coef)
     _check(lib().abopt_ipa_core_train_forward(ptr(proj_local, torch.float32), ptr(R, torch.float32), ptr(t, torch.float32),
                                               ptr(z, torch.float32), ptr(mask, torch.bool),
-                                              ptr(w_pair_bias, torch.float32), ptr(spatial_coef, torch.float32),
+                                              ptr(w_pair_bias, torch.float32), ptr(spatial_coef, torch.float32), ptr(pbc, torch.float32, optional=True),
                                               ptr(feat), ptr(alpha), N, L, z.shape[-1], ptr(buf), buf.numel(), stream()))
     return feat, alpha
 
@@ -575,6 +592,46 @@ def dockq_lite(model_pos, model_mask, native_pos, native_mask, group):
     _check(lib().abopt_dockq_lite(ptr(model_pos, torch.float32), ptr(model_mask, torch.bool), int(shared), ptr(native_pos, torch.float32),
                                   ptr(native_mask, torch.bool), ptr(group, torch.int32), S, L, A, ptr(out), ptr(buf), buf.numel(), stream()))
     return out
+
+
+def pack_tail_weights(w_out, w0, w1, w2, transposed=False):
+    """(w_out_frag, w_mlp_frag[, w_mlpT_frag]) packed on the device in one launch (include/abopt.h: abopt_pack_tail_weights)."""
+    dev = w_out.device
+    w_out, w0, w1, w2 = _contig(w_out.detach().float(), w0.detach().float(), w1.detach().float(), w2.detach().float())
+    wof = torch.empty(lib().abopt_out_frag_floats(), dtype=torch.float32, device=dev)
+    wmf = torch.empty(lib().abopt_mlp_frag_floats(), dtype=torch.float32, device=dev)
+    wmt = torch.empty(lib().abopt_mlp_frag_floats(), dtype=torch.float32, device=dev) if transposed else None
+    _check(lib().abopt_pack_tail_weights(ptr(w_out, torch.float32), ptr(w0, torch.float32), ptr(w1, torch.float32), ptr(w2, torch.float32),
+                                         ptr(wof), ptr(wmf), ptr(wmt, torch.float32, optional=True), stream()))
+    return (wof, wmf, wmt) if transposed else (wof, wmf)
+
+
+def block_tail_forward(feat, wof, wmf, x, b_out, mask, g1, be1, b0, b1, b2, g2, be2, save=False):
+    """out = LN2(y + MLP(y)), y = LN1(x + mask * (feat W_out^T + b_out)) for [rows, .] inputs (abopt_block_tail_forward).
+    save=True also returns the [5, rows, 128] activation dump the backward consumes."""
+    rows = x.numel() // 128
+    feat, x, mask, b_out, g1, be1, b0, b1, b2, g2, be2 = _contig(feat, x, mask, b_out, g1, be1, b0, b1, b2, g2, be2)
+    out = torch.empty_like(x)
+    saved = torch.empty(5, rows, 128, dtype=torch.float32, device=x.device) if save else None
+    f = lambda t: ptr(t, torch.float32)
+    _check(lib().abopt_block_tail_forward(f(feat), f(wof), f(wmf), f(x), f(b_out), ptr(mask, torch.bool), f(g1), f(be1), f(b0), f(b1), f(b2), f(g2), f(be2),
+                                          ptr(out), ptr(saved, torch.float32, optional=True), rows, stream()))
+    return (out, saved) if save else out
+
+
+def block_tail_backward(dout, saved, wmt, mask, g1, g2):
+    """Row-local backward of the tail (abopt_block_tail_backward) -> dpre [3, rows, 128], da1, du [rows, 128], colsum [8, 128]."""
+    rows = saved.shape[1]
+    dout, mask, g1, g2 = _contig(dout, mask, g1, g2)
+    dev = dout.device
+    dpre = torch.empty(3, rows, 128, dtype=torch.float32, device=dev)
+    da1 = torch.empty(rows, 128, dtype=torch.float32, device=dev)
+    du = torch.empty(rows, 128, dtype=torch.float32, device=dev)
+    colpart = torch.empty((rows + 31) // 32, 8, 128, dtype=torch.float32, device=dev)
+    f = lambda t: ptr(t, torch.float32)
+    _check(lib().abopt_block_tail_backward(f(dout), f(saved), f(wmt), ptr(mask, torch.bool), f(g1), f(g2), ptr(dpre), ptr(da1), ptr(du), ptr(colpart),
+                                           rows, stream()))
+    return dpre, da1, du, colpart.sum(0)
 
 
 def prof_enable(on=True):

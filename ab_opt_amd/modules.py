@@ -93,8 +93,7 @@ class GABlock(nn.Module):
             ln2_gamma=f(self.layer_norm_2.gamma), ln2_beta=f(self.layer_norm_2.beta))
         if t['w_node'].is_cuda:
             t['w_node_frag'] = hip.pack_node_weights(t['w_node'])
-            t['w_out_frag'] = hip.pack_out_weights(t['w_out'])
-            t['w_mlp_frag'] = hip.pack_mlp_weights(t['w_mlp0'], t['w_mlp1'], t['w_mlp2'])
+            t['w_out_frag'], t['w_mlp_frag'] = hip.pack_tail_weights(t['w_out'], t['w_mlp0'], t['w_mlp1'], t['w_mlp2'])
         s = hip.ga_weights_struct(t)
         self._pack = (snap, t, s)
         return t, s

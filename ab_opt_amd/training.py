@@ -83,9 +83,9 @@ class IpaCore(torch.autograd.Function):
     (they come from the noised state)."""
 
     @staticmethod
-    def forward(ctx, proj, z, R, t, mask, w_pair_bias, spatial_coef):
+    def forward(ctx, proj, z, R, t, mask, w_pair_bias, spatial_coef, pbc=None):
         from . import hip
-        feat, alpha = hip.ipa_core_train_forward(proj, R, t, z, mask, w_pair_bias, spatial_coef.reshape(-1))
+        feat, alpha = hip.ipa_core_train_forward(proj, R, t, z, mask, w_pair_bias, spatial_coef.reshape(-1), pbc)
         ctx.save_for_backward(proj, z, R, t, w_pair_bias, spatial_coef, feat, alpha)
         return feat
 
@@ -112,13 +112,45 @@ class IpaCore(torch.autograd.Function):
         dproj, e = hip.ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, gamma_raw.reshape(-1))
         gam = gamma_raw.reshape(-1)
         dgamma = (e.sum((0, 1)) * (-torch.sigmoid(gam) * (math.sqrt(2 / (9 * P)) / 2))).reshape(gamma_raw.shape)
-        return dproj, dz, None, None, None, dWb, dgamma
+        return dproj, dz, None, None, None, dWb, dgamma, None
 
 
 NATIVE_IPA = True      # tests flip this to compare the native path with the plain torch statement
 
 
-def _block_tail(blk, x, feat, mask):
+class BlockTail(torch.autograd.Function):
+    """out_transform -> mask -> +x -> LayerNorm -> mlp_transition -> +y -> LayerNorm (ga.py:174-177) as ONE forward launch
+    (csrc/mlp.hip: out_ln_mlp_kernel with its activation dump) and, backward, one launch for everything row-local
+    (tail_backward_kernel) plus five library GEMMs for d feat and the four weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, feat, mask, w_out, b_out, g1, be1, w0, b0, w1, b1, w2, b2, g2, be2):
+        from . import hip
+        shape = x.shape
+        wof, wmf, wmt = hip.pack_tail_weights(w_out, w0, w1, w2, transposed=True)
+        feat2 = feat.reshape(-1, feat.shape[-1]).contiguous()
+        out, saved = hip.block_tail_forward(feat2, wof, wmf, x.reshape(-1, 128), b_out, mask.reshape(-1), g1, be1, b0, b1, b2, g2, be2, save=True)
+        ctx.save_for_backward(feat2, mask, saved, wmt, w_out, g1, g2)
+        return out.view(shape)
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, dout):
+        from . import hip
+        feat2, mask, saved, wmt, w_out, g1, g2 = ctx.saved_tensors
+        dpre, da1, du, cs = hip.block_tail_backward(dout.reshape(-1, 128), saved, wmt, mask.reshape(-1), g1, g2)
+        dfeat = (du @ w_out).view(dout.shape[:-1] + (w_out.shape[1],))
+        dw_out = du.t() @ feat2
+        dw0, dw1, dw2 = torch.bmm(dpre.transpose(1, 2), saved[1:4]).unbind(0)      # d W_l = d pre_l^T . input_l, one batched launch
+        #      x               feat   mask  w_out   b_out  g1     be1    w0   b0     w1   b1     w2   b2     g2     be2
+        return da1.view(dout.shape), dfeat, None, dw_out, cs[7], cs[6], cs[5], dw0, cs[4], dw1, cs[3], dw2, cs[2], cs[1], cs[0]
+
+
+def _block_tail(blk, x, feat, mask, native=True):
+    if native and x.is_cuda:
+        m = blk.mlp_transition
+        return BlockTail.apply(x, feat, mask, blk.out_transform.weight, blk.out_transform.bias, blk.layer_norm_1.gamma, blk.layer_norm_1.beta,
+                               m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias, blk.layer_norm_2.gamma, blk.layer_norm_2.beta)
     u = blk.out_transform(feat)
     u = torch.where(mask.unsqueeze(-1), u, torch.zeros_like(u))
     y = _ln(x + u, blk.layer_norm_1)
@@ -126,12 +158,14 @@ def _block_tail(blk, x, feat, mask):
 
 
 # ------------------------------------------------------------------ network
-def ga_block(blk, R, t, x, z, mask, native=None):
+def ga_block(blk, R, t, x, z, mask, native=None, pbc=None):
+    """pbc: this block's slice of hip.pair_bias_cache_layers (forward-only shortcut: the core reads proj_pair_bias(z) instead of
+    recomputing it; gradients of z and the weight still come from the backward kernel)."""
     N, L, _ = x.shape
     if NATIVE_IPA if native is None else native:
         w_node = torch.cat([blk.proj_query.weight, blk.proj_key.weight, blk.proj_value.weight,
                             blk.proj_query_point.weight, blk.proj_key_point.weight, blk.proj_value_point.weight], dim=0)
-        feat = IpaCore.apply(x @ w_node.t(), z, R.detach(), t.detach(), mask, blk.proj_pair_bias.weight, blk.spatial_coef)
+        feat = IpaCore.apply(x @ w_node.t(), z, R.detach(), t.detach(), mask, blk.proj_pair_bias.weight, blk.spatial_coef, pbc)
         return _block_tail(blk, x, feat, mask)
     q = blk.proj_query(x).view(N, L, H, D)
     k = blk.proj_key(x).view(N, L, H, D)
@@ -156,15 +190,20 @@ def ga_block(blk, R, t, x, z, mask, native=None):
     dist = loc.norm(dim=-1)
     direc = loc / (dist.unsqueeze(-1) + 1e-4)
     feat = torch.cat([f_pair, f_node, loc.reshape(N, L, -1), dist, direc.reshape(N, L, -1)], dim=-1)
-    return _block_tail(blk, x, feat, mask)
+    return _block_tail(blk, x, feat, mask, native=False)
 
 
 def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res):
     N, L = mask_res.shape
     R = so3_exp(v_t)
     x = net.res_feat_mixer(torch.cat([res_feat, net.current_sequence_embedding(s_t)], dim=-1))
-    for blk in net.encoder.blocks:
-        x = ga_block(blk, R, p_t, x, pair_feat, mask_res)
+    caches = [None] * len(net.encoder.blocks)
+    if NATIVE_IPA and pair_feat.is_cuda:
+        # proj_pair_bias(pair_feat) of all blocks in one pass over pair_feat (the sampler's per-call cache, rebuilt every training step)
+        from . import hip
+        caches = hip.pair_bias_cache_layers([blk.proj_pair_bias.weight for blk in net.encoder.blocks], pair_feat.detach())
+    for blk, pbc in zip(net.encoder.blocks, caches):
+        x = ga_block(blk, R, p_t, x, pair_feat, mask_res, pbc=pbc)
     temb = torch.stack([beta, torch.sin(beta), torch.cos(beta)], dim=-1)[:, None, :].expand(N, L, 3)
     feat = torch.cat([x, temb], dim=-1)
     gen3 = mask_generate[:, :, None].expand(N, L, 3)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 17
+#define ABOPT_ABI_VERSION 19
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -73,6 +73,29 @@ typedef struct {
  * entry i = term(w_node[row][32 s + 8 kq + i]), term 0 = h, 1 = m, 2 = l.  abopt_node_frag_floats() = size in 4-byte units. */
 int abopt_node_frag_source_row(int h, int T, int m);
 size_t abopt_node_frag_floats(void);
+
+/* The tail of a GABlock on its own -- out_transform, mask, residual, LayerNorm, mlp_transition, LayerNorm
+ * (AbDock/src/modules/encoders/ga.py:174-177; LayerNorm: AbDock/src/modules/common/layers.py:146-155) -- for hosts that drive the
+ * block piecewise (the training path: forward with an activation dump, then the row-local part of its backward).
+ *   abopt_pack_tail_weights  : w_out [128,1824], w_mlp0..2 [128,128] -> w_out_frag (abopt_out_frag_floats() floats), w_mlp_frag and
+ *                              (optional) w_mlpT_frag = the three transposed layers (abopt_mlp_frag_floats() floats each), on the device.
+ *   abopt_block_tail_forward : out [rows,128] = LN2(y + MLP(y)), y = LN1(x + mask * (feat W_out^T + b_out)).  saved (optional) receives
+ *                              five [rows,128] slabs: x + mask*u | y | h0 = relu(W0 y + b0) | h1 = relu(W1 h0 + b1) | y + W2 h1 + b2.
+ *   abopt_block_tail_backward: from d out and `saved`: dpre [3,rows,128] = d loss / d (pre-activation) of the three MLP layers (so
+ *                              d W_l = dpre[l]^T . input_l), da1 [rows,128] = gradient reaching x through the residual,
+ *                              du = mask * da1 (so d feat = du . W_out, d W_out = du^T . feat), and colpart [ceil(rows/32), 8, 128] =
+ *                              per-tile column sums: 0 d ln2.beta | 1 d ln2.gamma | 2 d b_mlp2 | 3 d b_mlp1 | 4 d b_mlp0 | 5 d ln1.beta |
+ *                              6 d ln1.gamma | 7 d b_out; the caller sums over tiles (deterministic). */
+size_t abopt_out_frag_floats(void);
+size_t abopt_mlp_frag_floats(void);
+int abopt_pack_tail_weights(const float* w_out, const float* w_mlp0, const float* w_mlp1, const float* w_mlp2, float* w_out_frag,
+                            float* w_mlp_frag, float* w_mlpT_frag, abopt_stream stream);
+int abopt_block_tail_forward(const float* feat, const float* w_out_frag, const float* w_mlp_frag, const float* x, const float* b_out,
+                             const uint8_t* mask, const float* ln1_gamma, const float* ln1_beta, const float* b_mlp0, const float* b_mlp1,
+                             const float* b_mlp2, const float* ln2_gamma, const float* ln2_beta, float* out, float* saved, int64_t rows,
+                             abopt_stream stream);
+int abopt_block_tail_backward(const float* dout, const float* saved, const float* w_mlpT_frag, const uint8_t* mask, const float* ln1_gamma,
+                              const float* ln2_gamma, float* dpre, float* da1, float* du, float* colpart, int64_t rows, abopt_stream stream);
 
 /* Optional intermediates of one block for parity tests (any pointer may be NULL):
  * logits = (node+pair+spatial)*sqrt(1/3) before masking, alpha after softmax/masking: [N,L,L,12]; feat [N,L,1824]. */
@@ -229,8 +252,9 @@ int abopt_dockq_lite(const float* model_pos, const uint8_t* model_mask, int mode
  *             dfeat (its first 12*C columns are d feat_p2n, row stride ld_dfeat) and proj_pair_bias.weight. */
 size_t abopt_ipa_train_workspace_bytes(int N, int L);
 int abopt_ipa_core_train_forward(const float* proj_local, const float* R, const float* t, const float* pair_feat, const uint8_t* mask,
-                                 const float* w_pair_bias, const float* spatial_coef, float* feat, float* alpha,
-                                 int N, int L, int C, void* ws, size_t ws_bytes, abopt_stream stream);
+                                 const float* w_pair_bias, const float* spatial_coef,
+                                 const float* pair_bias_cache /* optional: this block's slice of abopt_pair_bias_cache built from the same pair_feat and weights */,
+                                 float* feat, float* alpha, int N, int L, int C, void* ws, size_t ws_bytes, abopt_stream stream);
 /* prologue of the backward: the points epilogue (ga.py:133-139) differentiated, d feat_node re-laid out head-major next to
  * it (dout_cat [N,12,L,32+24]) and delta [N,L,12] = sum_j alpha dalpha (see above). */
 int abopt_ipa_points_backward(const float* dfeat, int ld_dfeat, const float* feat, const float* R, const float* t,

@@ -1095,3 +1095,33 @@ def test_fused_node_projection_matches_gemm_path():
         a = hip.ga_block_forward(s_full, R, t, x, z, mask)
         b = hip.ga_block_forward(plain, R, t, x, z, mask)
         assert max_abs(a, b) < 1e-5, (N, L, max_abs(a, b))
+
+
+@pytest.mark.parametrize('N,L,lengths', [(1, 7, [5]), (3, 70, [70, 33, 1]), (4, 256, [256, 250, 17, 256])])
+def test_block_tail_autograd_function_vs_torch_statement(N, L, lengths):
+    """training.BlockTail (fused forward with activation dump + tail_backward_kernel + five GEMMs, csrc/mlp.hip) against the plain
+    torch statement of ga.py:174-177: output, d x, d feat and the gradient of every parameter of the tail; row counts that are not a
+    multiple of the 32-row tile and masked rows included."""
+    from ab_opt_amd import training
+    blk = _block_on_device(seed=13)
+    with torch.no_grad():
+        for ln in (blk.layer_norm_1, blk.layer_norm_2):          # non-trivial LayerNorm parameters
+            ln.gamma.copy_(1.0 + 0.3 * dev(synth.hash_tensor((128,), 91, scale=1.0)))
+            ln.beta.copy_(0.2 * dev(synth.hash_tensor((128,), 92, scale=1.0)))
+    _, _, x, _, mask = [dev(a) for a in cases.ipa_inputs(N, L, lengths, salt=1300 + L)]
+    feat = dev(synth.hash_tensor((N, L, 1824), 93, scale=1.0))
+    wout = dev(synth.hash_tensor((N, L, 128), 94, scale=1.0))
+    names = ['out_transform', 'layer_norm_1', 'mlp_transition', 'layer_norm_2']
+    res = {}
+    for native in (False, True):
+        blk.zero_grad()
+        xx, ff = x.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+        out = training._block_tail(blk, xx, ff, mask, native=native)
+        (out * wout).sum().backward()
+        res[native] = dict(out=out.detach(), dx=xx.grad, dfeat=ff.grad,
+                           **{'d_' + n: p.grad.clone() for n, p in blk.named_parameters() if n.split('.')[0] in names})
+    assert len(res[True]) == 3 + 12
+    for k, ref in res[False].items():
+        tol = 2e-5 if k == 'out' else 1e-4
+        assert max_abs(res[True][k], ref) <= tol * max(1.0, ref.abs().max().item()), (k, max_abs(res[True][k], ref), ref.abs().max().item())
+    blk.zero_grad()
