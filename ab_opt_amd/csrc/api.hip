@@ -92,6 +92,7 @@ extern "C" int abopt_node_frag_source_row(int h, int T, int m) {
 }
 extern "C" const char* abopt_last_error(void) { return g_err; }
 
+extern "C" size_t abopt_heads_frag_floats(void) { return heads_wfrag_floats(); }
 extern "C" size_t abopt_out_frag_floats(void) { return out_wfrag_floats(); }
 extern "C" size_t abopt_mlp_frag_floats(void) { return mlp_wfrag_floats(); }
 extern "C" int abopt_pack_tail_weights(const float* w_out, const float* w_mlp0, const float* w_mlp1, const float* w_mlp2, float* w_out_frag,
@@ -385,6 +386,12 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
     if ((rc = launch_linear(e.x0, F, w->w_mix1, F, w->b_mix1, e.cat, F, (int)M, F, F, false, st))) return rc;   // reuse cat[:, :F] as x (ld = F)
     // dpm_full.py:90  encoder
     if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st, pair_bias_cache, pair_feat_shared ? 1 : 0))) return rc;
+    if (w->w_heads_frag) {
+        // dpm_full.py:92-101: time features + the three heads in one launch (heads.hip)
+        if (has_prmsd && (rc = launch_build_infeat(e.xe, beta, e.infeat, w->prmsd_ln_gamma, w->prmsd_ln_beta, e.infeat_ln, N, L, st))) return rc;
+        if ((rc = launch_heads_mlp(e.xe, beta, w->w_heads_frag, w->w_head1, FI, w->b_head1, w->b_crd2, w->b_rot2, w->b_seq2, w->b_crd3, w->b_rot3,
+                                   w->b_seq3, e.out3, M, L, st))) return rc;
+    } else {
     // dpm_full.py:92-93 time features
     if ((rc = launch_build_infeat(e.xe, beta, e.infeat, w->prmsd_ln_gamma, w->prmsd_ln_beta, has_prmsd ? e.infeat_ln : nullptr, N, L, st))) return rc;
     // three heads, first layers fused (shared input): [M,132] x [384,132]^T
@@ -396,6 +403,7 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
     if ((rc = launch_linear(e.hh2 + 0 * F, 3 * F, w->w_crd3, F, w->b_crd3, e.out3 + 0, 32, (int)M, 3, F, false, st))) return rc;
     if ((rc = launch_linear(e.hh2 + 1 * F, 3 * F, w->w_rot3, F, w->b_rot3, e.out3 + 4, 32, (int)M, 3, F, false, st))) return rc;
     if ((rc = launch_linear(e.hh2 + 2 * F, 3 * F, w->w_seq3, F, w->b_seq3, e.out3 + 8, 32, (int)M, ABOPT_AA, F, false, st))) return rc;
+    }
     if ((rc = launch_heads_epilogue(e.R, v_t, e.out3 + 0, e.out3 + 4, e.out3 + 8, 32, 32, mask_generate, v_next, R_next, eps_pos, c_denoised,
                                     M, grad_mode, st))) return rc;
     if (has_prmsd) {

@@ -1,0 +1,156 @@
+// The three denoiser heads of EpsilonNet after the encoder (AbDock/src/modules/diffusion/dpm_full.py:92-101: eps_crd_net, eps_rot_net,
+// eps_seq_net, each Linear(F+3,F) ReLU Linear(F,F) ReLU Linear(F,out)) in ONE launch; round 1 ran them as nine small GEMMs plus a
+// feature-building pass (81 + 5 us of a 1.5 ms step, each GEMM a 10 us launch with M = 8192, N <= 384, K = 128).
+//
+// One 1024-thread workgroup owns 32 residues.  Everything is K = 128 on the bf16 matrix pipe with exact three-term splits (node_frags.hip
+// explains the arithmetic): the three time features [beta, sin beta, cos beta] of in_feat are constant per sample, so their part of the
+// first layer is an affine term added in the epilogue (3 FMAs per output) instead of a ragged K = 131 product.  Weights arrive pre-split in
+// MFMA operand order from L2 (27 blocks of [32 outputs x 128]: 12 for the fused first layers, 4 per head for the second, one zero-padded
+// block per head for the third), activations live in LDS as bf16 planes.  Wave w < 12 owns one 32-column block of layers 1 and 2; waves
+// 0..2 the three output blocks.  Output: out3 [rows, 32] = eps_crd (0..2) | eps_rot (4..6) | sequence logits (8..27), consumed by the
+// geometric epilogue (rows.hip: heads_epilogue_kernel).
+#include "ipa_common.h"
+#include "kernels.h"
+
+namespace abopt {
+namespace {
+constexpr int HF = 128, HR = 32, HTH = 1024;
+constexpr int HP_ROW = HF * 2 + 16, HP_PLANE = HR * HP_ROW;      // one bf16 plane of [32 rows x 128]: rows 4 banks apart (conflict-free b128 reads)
+constexpr int HBLK = 8 * 3 * 64;                                 // 16-byte vectors per weight block: [k-step][term][lane]
+
+struct HeadsSmem {
+    char xp[3 * HP_PLANE];                    // input x as three planes
+    char hp[3][3 * HP_PLANE];                 // per head: hidden activations (layer 1 output, then layer 2 output in place)
+};
+
+// two adjacent values -> one 4-byte entry in each of the three planes
+__device__ __forceinline__ void put_terms2(char* planes, int byte_off, float e0, float e1) {
+    const unsigned h = pk_bf16(e0, e1);
+    const float r0 = e0 - __uint_as_float(h << 16), r1 = e1 - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = pk_bf16(r0, r1);
+    const unsigned l = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+    *reinterpret_cast<unsigned*>(planes + byte_off) = h;
+    *reinterpret_cast<unsigned*>(planes + HP_PLANE + byte_off) = m;
+    *reinterpret_cast<unsigned*>(planes + 2 * HP_PLANE + byte_off) = l;
+}
+
+// acc[32 rows x 32 outputs] = planes[32 x 128] . block^T ; operands of k-step s + 3 are requested while step s computes
+__device__ __forceinline__ void block_gemm(const char* planes, const u32x4* __restrict__ wb, int lane, f32x16& a0, f32x16& a1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+    const u32x4* wl = wb + lane;
+    u32x4 w[3][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) w[s][sp] = wl[(s * 3 + sp) * 64];
+    const char* xp = planes + (lane & 31) * HP_ROW + (lane >> 5) * 16;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const u32x4 wH = w[s % 3][0], wM = w[s % 3][1], wL = w[s % 3][2];
+        if (s + 3 < 8) {
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) w[s % 3][sp] = wl[((s + 3) * 3 + sp) * 64];
+        }
+        const u32x4 xh = *reinterpret_cast<const u32x4*>(xp + s * 32), xm = *reinterpret_cast<const u32x4*>(xp + s * 32 + HP_PLANE),
+                    xl = *reinterpret_cast<const u32x4*>(xp + s * 32 + 2 * HP_PLANE);
+        a0 = mfma_bf32(wH, xl, a0); a1 = mfma_bf32(wL, xh, a1);
+        a0 = mfma_bf32(wM, xm, a0); a1 = mfma_bf32(wH, xm, a1);
+        a0 = mfma_bf32(wM, xh, a0); a1 = mfma_bf32(wH, xh, a1);
+    }
+}
+}  // namespace
+
+__global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict__ xe, const float* __restrict__ beta, const float* __restrict__ wfrag,
+                                                        const float* __restrict__ w1 /* [384, ld1]: columns 128..130 = the time features */, int ld1,
+                                                        const float* __restrict__ b1, const float* __restrict__ b2c, const float* __restrict__ b2r,
+                                                        const float* __restrict__ b2s, const float* __restrict__ b3c, const float* __restrict__ b3r,
+                                                        const float* __restrict__ b3s, float* __restrict__ out3, int64_t rows, int L) {
+    extern __shared__ __attribute__((aligned(16))) char hd_raw[];
+    HeadsSmem& sm = *reinterpret_cast<HeadsSmem*>(hd_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * HR;
+    const u32x4* wf = reinterpret_cast<const u32x4*>(wfrag);
+    {   // x rows -> planes: thread -> (row tid >> 5, 4 columns)
+        const int r = tid >> 5, c = (tid & 31) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xe + min(row0 + r, rows - 1) * HF + c);
+        put_terms2(sm.xp, r * HP_ROW + c * 2, v[0], v[1]);
+        put_terms2(sm.xp, r * HP_ROW + c * 2 + 4, v[2], v[3]);
+    }
+    __syncthreads();
+    const int mrow = lane & 31, csub = (lane >> 5) * 4;           // accumulator register 4 g + i = output column 8 g + csub + i of the block, row mrow
+    f32x16 a0, a1;
+    if (wave < 12) {
+        // ---- layer 1 (three heads side by side): block `wave` = outputs 32 wave .. 32 wave + 31 of the 384
+        block_gemm(sm.xp, wf + (int64_t)wave * HBLK, lane, a0, a1);
+        const float bt = beta[min(row0 + mrow, rows - 1) / L];
+        const float sb = sinf(bt), cb = cosf(bt);
+        char* dst = sm.hp[wave >> 2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = wave * 32 + g * 8 + csub + i;
+                const float* wt = w1 + (int64_t)o * ld1 + HF;
+                v[i] = fmaxf((a0[4 * g + i] + a1[4 * g + i]) + (b1[o] + (wt[0] * bt + (wt[1] * sb + wt[2] * cb))), 0.f);
+            }
+            const int col = (wave & 3) * 32 + g * 8 + csub;
+            put_terms2(dst, mrow * HP_ROW + col * 2, v[0], v[1]);
+            put_terms2(dst, mrow * HP_ROW + col * 2 + 4, v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    if (wave < 12) block_gemm(sm.hp[wave >> 2], wf + (int64_t)(12 + wave) * HBLK, lane, a0, a1);      // ---- layer 2: head wave / 4, block wave % 4
+    __syncthreads();                                                                                  // every read of the layer-1 planes is done: overwrite in place
+    if (wave < 12) {
+        const float* b2 = (wave >> 2) == 0 ? b2c : ((wave >> 2) == 1 ? b2r : b2s);
+        char* dst = sm.hp[wave >> 2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = (wave & 3) * 32 + g * 8 + csub;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf((a0[4 * g + i] + a1[4 * g + i]) + b2[col + i], 0.f);
+            put_terms2(dst, mrow * HP_ROW + col * 2, v[0], v[1]);
+            put_terms2(dst, mrow * HP_ROW + col * 2 + 4, v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    if (wave < 3) {
+        // ---- layer 3: head `wave`, outputs zero-padded to 32
+        block_gemm(sm.hp[wave], wf + (int64_t)(24 + wave) * HBLK, lane, a0, a1);
+        const int nout = wave == 2 ? ABOPT_AA : 3, base = wave == 0 ? 0 : (wave == 1 ? 4 : 8);
+        const float* b3 = wave == 0 ? b3c : (wave == 1 ? b3r : b3s);
+        if (row0 + mrow < rows) {
+            float* o = out3 + (row0 + mrow) * 32 + base;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = g * 8 + csub + i;
+                    if (c < nout) o[c] = (a0[4 * g + i] + a1[4 * g + i]) + b3[c];
+                }
+        }
+    }
+}
+
+size_t heads_wfrag_floats() { return (size_t)27 * HBLK * 4; }
+
+int launch_heads_mlp(const float* xe, const float* beta, const float* wfrag, const float* w1, int ld1, const float* b1, const float* b2c,
+                     const float* b2r, const float* b2s, const float* b3c, const float* b3r, const float* b3s, float* out3, int64_t rows, int L,
+                     hipStream_t st) {
+    if (rows == 0) return ABOPT_OK;
+    static bool configured = false;
+    if (!configured) {
+        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HeadsSmem)));
+        configured = true;
+    }
+    hipLaunchKernelGGL(heads_mlp_kernel, dim3((unsigned)((rows + HR - 1) / HR)), dim3(HTH), sizeof(HeadsSmem), st, xe, beta, wfrag, w1, ld1, b1,
+                       b2c, b2r, b2s, b3c, b3r, b3s, out3, rows, L);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+}  // namespace abopt

@@ -40,6 +40,11 @@ int launch_fused_ln_mlp(const float* x, const float* u, int nslab, int64_t slab_
 int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, const float* x, const float* ubias, const uint8_t* mask,
                       const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2, const float* be2,
                       float* out, float* dump, int64_t rows, hipStream_t st);
+// heads.hip: the three denoiser heads (first layers fused, time features as an affine term) -> out3 [rows,32]
+size_t heads_wfrag_floats();
+int launch_heads_mlp(const float* xe, const float* beta, const float* wfrag, const float* w1, int ld1, const float* b1, const float* b2c,
+                     const float* b2r, const float* b2s, const float* b3c, const float* b3r, const float* b3s, float* out3, int64_t rows, int L,
+                     hipStream_t st);
 size_t out_wfrag_floats();
 size_t mlp_wfrag_floats();
 int launch_pack_tail_weights(const float* w_out, const float* w0, const float* w1, const float* w2, float* wof, float* wmf, float* wmt, hipStream_t st);

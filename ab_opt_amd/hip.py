@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -35,7 +35,7 @@ class EpsWeights(C.Structure):
                                     'w_rot2', 'b_rot2', 'w_rot3', 'b_rot3', 'w_seq2', 'b_seq2', 'w_seq3', 'b_seq3',
                                     'prmsd_ln_gamma', 'prmsd_ln_beta', 'w_prmsd1', 'b_prmsd1', 'w_prmsd2', 'b_prmsd2',
                                     'w_prmsd3', 'b_prmsd3')] +
-                [('num_bins', C.c_int)])
+                [('num_bins', C.c_int), ('w_heads_frag', c_f)])
 
 
 class EncodeInputs(C.Structure):
@@ -76,7 +76,7 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
-           'abopt_out_frag_floats', 'abopt_mlp_frag_floats', 'abopt_pack_tail_weights', 'abopt_block_tail_forward', 'abopt_block_tail_backward']
+           'abopt_out_frag_floats', 'abopt_heads_frag_floats', 'abopt_mlp_frag_floats', 'abopt_pack_tail_weights', 'abopt_block_tail_forward', 'abopt_block_tail_backward']
 
 _lib = None
 _lock = threading.Lock()
@@ -147,6 +147,7 @@ def lib():
         L.abopt_dockq_workspace_bytes.argtypes = [C.c_int]
         L.abopt_dockq_lite.argtypes = [c_f, c_u8, C.c_int, c_f, c_u8, C.c_void_p, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_out_frag_floats.restype = C.c_size_t
+        L.abopt_heads_frag_floats.restype = C.c_size_t
         L.abopt_mlp_frag_floats.restype = C.c_size_t
         L.abopt_pack_tail_weights.argtypes = [c_f] * 7 + [C.c_void_p]
         L.abopt_block_tail_forward.argtypes = [c_f] * 5 + [c_u8] + [c_f] * 9 + [C.c_int64, C.c_void_p]
@@ -242,13 +243,20 @@ def ga_weights_struct(t):
 
 
 def pack_mfma_operand(w):
-    """w [128, K] (K a multiple of 16) -> [4, K/16, 3, 64, 4]: 32x32x16 MFMA operand order, every weight as its three bf16 terms
+    """w [32 B, K] (K a multiple of 16) -> [B, K/16, 3, 64, 4]: 32x32x16 MFMA operand order, every weight as its three bf16 terms
     (fp32 container of 8 bf16 per lane): [cb][step][term][lane = 32 khalf + c][i] = term(w[32 cb + c][16 step + 8 khalf + i])."""
-    K = w.shape[1]
-    terms = torch.stack(split_bf16x3(w.float()), 0)           # [term, 128, K] int16
-    g = terms.reshape(3, 4, 32, K // 16, 2, 8)                # [term, cb, col, step, k half, i]
+    R, K = w.shape
+    terms = torch.stack(split_bf16x3(w.float()), 0)           # [term, R, K] int16
+    g = terms.reshape(3, R // 32, 32, K // 16, 2, 8)          # [term, cb, col, step, k half, i]
     out = g.permute(1, 3, 0, 4, 2, 5).contiguous()            # [cb, step, term, k half, col, i]
-    return out.view(4, K // 16, 3, 64, 8).view(torch.float32)
+    return out.view(R // 32, K // 16, 3, 64, 8).view(torch.float32)
+
+
+def pack_heads_weights(w_head1, w_crd2, w_rot2, w_seq2, w_crd3, w_rot3, w_seq3):
+    """-> w_heads_frag [27, 8, 3, 64, 4] (include/abopt.h: abopt_eps_weights.w_heads_frag)."""
+    pad32 = lambda w: torch.cat([w, torch.zeros(32 - w.shape[0], w.shape[1], dtype=w.dtype, device=w.device)], 0)
+    rows = torch.cat([w_head1[:, :128], w_crd2, w_rot2, w_seq2, pad32(w_crd3), pad32(w_rot3), pad32(w_seq3)], 0)      # [27 * 32, 128]
+    return pack_mfma_operand(rows.contiguous())
 
 
 def pack_out_weights(w_out):

@@ -229,6 +229,8 @@ class EpsilonNet(nn.Module):
                      w_prmsd1=_pad_k(f(pp.linear_1.weight), F + 4), b_prmsd1=f(pp.linear_1.bias),
                      w_prmsd2=f(pp.linear_2.weight), b_prmsd2=f(pp.linear_2.bias),
                      w_prmsd3=f(pp.linear_3.weight), b_prmsd3=f(pp.linear_3.bias))
+        if t['w_head1'].is_cuda:
+            t['w_heads_frag'] = hip.pack_heads_weights(t['w_head1'], t['w_crd2'], t['w_rot2'], t['w_seq2'], t['w_crd3'], t['w_rot3'], t['w_seq3'])
         ew = hip.EpsWeights()
         for name, typ in hip.EpsWeights._fields_:
             if name == 'blocks':

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 19
+#define ABOPT_ABI_VERSION 20
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -87,6 +87,7 @@ size_t abopt_node_frag_floats(void);
  *                              per-tile column sums: 0 d ln2.beta | 1 d ln2.gamma | 2 d b_mlp2 | 3 d b_mlp1 | 4 d b_mlp0 | 5 d ln1.beta |
  *                              6 d ln1.gamma | 7 d b_out; the caller sums over tiles (deterministic). */
 size_t abopt_out_frag_floats(void);
+size_t abopt_heads_frag_floats(void);
 size_t abopt_mlp_frag_floats(void);
 int abopt_pack_tail_weights(const float* w_out, const float* w_mlp0, const float* w_mlp1, const float* w_mlp2, float* w_out_frag,
                             float* w_mlp_frag, float* w_mlpT_frag, abopt_stream stream);
@@ -131,6 +132,11 @@ typedef struct {
     const float* w_prmsd1; const float* b_prmsd1;                 /* [F, F+4] (K padded), [F] */
     const float* w_prmsd2; const float* b_prmsd2;                 /* [F, F], [F] */
     const float* w_prmsd3; const float* b_prmsd3; int num_bins;   /* [num_bins, F], [num_bins] */
+    const float* w_heads_frag;  /* optional [27, 8, 3, 64, 4] (abopt_heads_frag_floats() floats): the heads' weights as bf16 terms in MFMA operand order
+                                   (block layout of w_out_frag with one column block per entry: [block][s][term][lane = 32 kh + c] -> 8 bf16,
+                                   entry i = term(W[32 blk + c][16 s + 8 kh + i])): blocks 0..11 = w_head1[:, :F] (crd | rot | seq first layers),
+                                   12..15 w_crd2, 16..19 w_rot2, 20..23 w_seq2, 24 w_crd3, 25 w_rot3, 26 w_seq3 (rows zero-padded to 32).
+                                   When given, the three heads run as one kernel (time features enter as an affine term from w_head1[:, F:F+3]). */
 } abopt_eps_weights;
 
 size_t abopt_eps_workspace_bytes(int N, int L, int F, int C);

@@ -1125,3 +1125,25 @@ def test_block_tail_autograd_function_vs_torch_statement(N, L, lengths):
         tol = 2e-5 if k == 'out' else 1e-4
         assert max_abs(res[True][k], ref) <= tol * max(1.0, ref.abs().max().item()), (k, max_abs(res[True][k], ref), ref.abs().max().item())
     blk.zero_grad()
+
+
+@pytest.mark.parametrize('flavour', ['abdesign', 'abdock'])
+def test_fused_heads_match_gemm_path(flavour):
+    """heads.hip (the three denoiser heads as one kernel, time features as an affine term) against the nine-GEMM path through the C ABI:
+    same R_next / eps_pos / c up to fp32 summation order; per-sample beta, row count not a multiple of the 32-row tile."""
+    from ab_opt_amd import hip
+    T, t, N, L = 100, 41, 3, 70
+    d = (standalone_abdesign_dpm(T, 2) if flavour == 'abdesign' else build_model(T, 2).diffusion).to(DEV)
+    v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, [70, 33, 1], 3100, [(5, 14), (22, 30)])
+    beta = d.trans_pos.var_sched.betas[torch.tensor([t, 7, 93], device=DEV)].contiguous()
+    ew = d.eps_net.packed()
+    assert ew.w_heads_frag
+    plain = hip.EpsWeights()
+    for name, _ in hip.EpsWeights._fields_:
+        setattr(plain, name, getattr(ew, name))
+    plain.w_heads_frag = None
+    a = hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False)
+    b = hip.eps_net_forward(plain, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False)
+    for k in ('R_next', 'eps_pos', 'c'):          # v_next = log(R_next) amplifies near theta = pi (DESIGN 4.1); R_next pins it
+        assert max_abs(a[k], b[k]) < 2e-5, (k, max_abs(a[k], b[k]))
+    assert max_abs(a['v_next'], b['v_next']) < 1e-3

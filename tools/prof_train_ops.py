@@ -1,0 +1,29 @@
+"""Operator-level view of one training step (torch.profiler, device time by aten op / autograd function): N=16, L=256."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from conftest import build_model
+from ab_opt_amd.utils.synth import make_batch, LAYOUT_256
+N = 16
+dev = torch.device('cuda:0')
+model = build_model(100, 7, flavour='abdesign', device=dev).train()
+batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(N, LAYOUT_256).items()}
+opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    sum(model(dict(batch)).values()).backward()
+    opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by='self_cuda_time_total', row_limit=45, max_name_column_width=60))
