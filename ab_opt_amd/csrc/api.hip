@@ -93,6 +93,7 @@ extern "C" int abopt_node_frag_source_row(int h, int T, int m) {
 extern "C" const char* abopt_last_error(void) { return g_err; }
 
 extern "C" size_t abopt_heads_frag_floats(void) { return heads_wfrag_floats(); }
+extern "C" size_t abopt_mixer_frag_floats(void) { return mixer_wfrag_floats(); }
 extern "C" size_t abopt_out_frag_floats(void) { return out_wfrag_floats(); }
 extern "C" size_t abopt_mlp_frag_floats(void) { return mlp_wfrag_floats(); }
 extern "C" int abopt_pack_tail_weights(const float* w_out, const float* w_mlp0, const float* w_mlp1, const float* w_mlp2, float* w_out_frag,
@@ -381,9 +382,13 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
     // dpm_full.py:86  R = exp(v_t)
     if ((rc = launch_so3_exp(v_t, e.R, M, st))) return rc;
     // dpm_full.py:89  res_feat_mixer([res_feat | Embedding(s_t)])
-    if ((rc = launch_embed_concat(res_feat, s_t, w->seq_embed, e.cat, M, st))) return rc;
-    if ((rc = launch_linear(e.cat, 2 * F, w->w_mix0, 2 * F, w->b_mix0, e.x0, F, (int)M, F, 2 * F, true, st))) return rc;
-    if ((rc = launch_linear(e.x0, F, w->w_mix1, F, w->b_mix1, e.cat, F, (int)M, F, F, false, st))) return rc;   // reuse cat[:, :F] as x (ld = F)
+    if (w->w_mix_frag && w->mix_table) {
+        if ((rc = launch_mixer(res_feat, s_t, w->w_mix_frag, w->mix_table, w->b_mix1, e.cat, M, st))) return rc;
+    } else {
+        if ((rc = launch_embed_concat(res_feat, s_t, w->seq_embed, e.cat, M, st))) return rc;
+        if ((rc = launch_linear(e.cat, 2 * F, w->w_mix0, 2 * F, w->b_mix0, e.x0, F, (int)M, F, 2 * F, true, st))) return rc;
+        if ((rc = launch_linear(e.x0, F, w->w_mix1, F, w->b_mix1, e.cat, F, (int)M, F, F, false, st))) return rc;   // reuse cat[:, :F] as x (ld = F)
+    }
     // dpm_full.py:90  encoder
     if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st, pair_bias_cache, pair_feat_shared ? 1 : 0))) return rc;
     if (w->w_heads_frag) {

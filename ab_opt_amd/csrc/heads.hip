@@ -136,7 +136,72 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
     }
 }
 
+// res_feat_mixer of EpsilonNet (dpm_full.py:56-59,89: Linear(2F,F) ReLU Linear(F,F) on [res_feat | Embedding(s_t)]) in one launch: the
+// embedding half of the first layer is a 25-row table T[s] = W0[:, F:] embed[s] + b0 (built once at pack time), so both layers are K = 128
+// products on the same path as the heads.  Waves 0..3 own the four 32-column blocks of each layer.
+__global__ __launch_bounds__(HTH) void mixer_kernel(const float* __restrict__ res_feat, const int64_t* __restrict__ s_t, const float* __restrict__ wfrag,
+                                                    const float* __restrict__ table, const float* __restrict__ b1, float* __restrict__ x_out,
+                                                    int64_t rows) {
+    extern __shared__ __attribute__((aligned(16))) char hd_raw[];
+    HeadsSmem& sm = *reinterpret_cast<HeadsSmem*>(hd_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * HR;
+    const u32x4* wf = reinterpret_cast<const u32x4*>(wfrag);
+    {
+        const int r = tid >> 5, c = (tid & 31) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(res_feat + min(row0 + r, rows - 1) * HF + c);
+        put_terms2(sm.xp, r * HP_ROW + c * 2, v[0], v[1]);
+        put_terms2(sm.xp, r * HP_ROW + c * 2 + 4, v[2], v[3]);
+    }
+    __syncthreads();
+    const int mrow = lane & 31, csub = (lane >> 5) * 4;
+    f32x16 a0, a1;
+    if (wave < 4) {
+        block_gemm(sm.xp, wf + (int64_t)wave * HBLK, lane, a0, a1);
+        const int64_t s = s_t[min(row0 + mrow, rows - 1)];
+        const bool ok = s >= 0 && s < 25;                                        // nn.Embedding(25) raises on anything else: poison instead of reading out of bounds
+        const float* tr = table + (ok ? s : 0) * HF;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = wave * 32 + g * 8 + csub;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ok ? fmaxf((a0[4 * g + i] + a1[4 * g + i]) + tr[col + i], 0.f) : __builtin_nanf("");
+            put_terms2(sm.hp[0], mrow * HP_ROW + col * 2, v[0], v[1]);
+            put_terms2(sm.hp[0], mrow * HP_ROW + col * 2 + 4, v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    if (wave < 4) {
+        block_gemm(sm.hp[0], wf + (int64_t)(4 + wave) * HBLK, lane, a0, a1);
+        if (row0 + mrow < rows) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wave * 32 + g * 8 + csub;
+                *reinterpret_cast<f32x4*>(x_out + (row0 + mrow) * HF + col) =
+                    (f32x4){(a0[4 * g] + a1[4 * g]) + b1[col], (a0[4 * g + 1] + a1[4 * g + 1]) + b1[col + 1], (a0[4 * g + 2] + a1[4 * g + 2]) + b1[col + 2],
+                            (a0[4 * g + 3] + a1[4 * g + 3]) + b1[col + 3]};
+            }
+        }
+    }
+}
+
+int launch_mixer(const float* res_feat, const int64_t* s_t, const float* wfrag, const float* table, const float* b1, float* x_out, int64_t rows,
+                 hipStream_t st) {
+    if (rows == 0) return ABOPT_OK;
+    static bool configured = false;
+    if (!configured) {
+        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mixer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HeadsSmem)));
+        configured = true;
+    }
+    hipLaunchKernelGGL(mixer_kernel, dim3((unsigned)((rows + HR - 1) / HR)), dim3(HTH), sizeof(HeadsSmem), st, res_feat, s_t, wfrag, table, b1, x_out, rows);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
 size_t heads_wfrag_floats() { return (size_t)27 * HBLK * 4; }
+size_t mixer_wfrag_floats() { return (size_t)8 * HBLK * 4; }
 
 int launch_heads_mlp(const float* xe, const float* beta, const float* wfrag, const float* w1, int ld1, const float* b1, const float* b2c,
                      const float* b2r, const float* b2s, const float* b3c, const float* b3r, const float* b3s, float* out3, int64_t rows, int L,

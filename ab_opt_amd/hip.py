@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -35,7 +35,7 @@ class EpsWeights(C.Structure):
                                     'w_rot2', 'b_rot2', 'w_rot3', 'b_rot3', 'w_seq2', 'b_seq2', 'w_seq3', 'b_seq3',
                                     'prmsd_ln_gamma', 'prmsd_ln_beta', 'w_prmsd1', 'b_prmsd1', 'w_prmsd2', 'b_prmsd2',
                                     'w_prmsd3', 'b_prmsd3')] +
-                [('num_bins', C.c_int), ('w_heads_frag', c_f)])
+                [('num_bins', C.c_int), ('w_heads_frag', c_f), ('w_mix_frag', c_f), ('mix_table', c_f)])
 
 
 class EncodeInputs(C.Structure):
@@ -76,7 +76,7 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
-           'abopt_out_frag_floats', 'abopt_heads_frag_floats', 'abopt_mlp_frag_floats', 'abopt_pack_tail_weights', 'abopt_block_tail_forward', 'abopt_block_tail_backward']
+           'abopt_out_frag_floats', 'abopt_heads_frag_floats', 'abopt_mixer_frag_floats', 'abopt_mlp_frag_floats', 'abopt_pack_tail_weights', 'abopt_block_tail_forward', 'abopt_block_tail_backward']
 
 _lib = None
 _lock = threading.Lock()
@@ -148,6 +148,7 @@ def lib():
         L.abopt_dockq_lite.argtypes = [c_f, c_u8, C.c_int, c_f, c_u8, C.c_void_p, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_out_frag_floats.restype = C.c_size_t
         L.abopt_heads_frag_floats.restype = C.c_size_t
+        L.abopt_mixer_frag_floats.restype = C.c_size_t
         L.abopt_mlp_frag_floats.restype = C.c_size_t
         L.abopt_pack_tail_weights.argtypes = [c_f] * 7 + [C.c_void_p]
         L.abopt_block_tail_forward.argtypes = [c_f] * 5 + [c_u8] + [c_f] * 9 + [C.c_int64, C.c_void_p]

@@ -231,6 +231,8 @@ class EpsilonNet(nn.Module):
                      w_prmsd3=f(pp.linear_3.weight), b_prmsd3=f(pp.linear_3.bias))
         if t['w_head1'].is_cuda:
             t['w_heads_frag'] = hip.pack_heads_weights(t['w_head1'], t['w_crd2'], t['w_rot2'], t['w_seq2'], t['w_crd3'], t['w_rot3'], t['w_seq3'])
+            t['w_mix_frag'] = hip.pack_mfma_operand(torch.cat([t['w_mix0'][:, :F], t['w_mix1']], 0).contiguous())
+            t['mix_table'] = (t['seq_embed'] @ t['w_mix0'][:, F:].t() + t['b_mix0']).contiguous()
         ew = hip.EpsWeights()
         for name, typ in hip.EpsWeights._fields_:
             if name == 'blocks':

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 20
+#define ABOPT_ABI_VERSION 21
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -88,6 +88,7 @@ size_t abopt_node_frag_floats(void);
  *                              6 d ln1.gamma | 7 d b_out; the caller sums over tiles (deterministic). */
 size_t abopt_out_frag_floats(void);
 size_t abopt_heads_frag_floats(void);
+size_t abopt_mixer_frag_floats(void);
 size_t abopt_mlp_frag_floats(void);
 int abopt_pack_tail_weights(const float* w_out, const float* w_mlp0, const float* w_mlp1, const float* w_mlp2, float* w_out_frag,
                             float* w_mlp_frag, float* w_mlpT_frag, abopt_stream stream);
@@ -137,6 +138,8 @@ typedef struct {
                                    entry i = term(W[32 blk + c][16 s + 8 kh + i])): blocks 0..11 = w_head1[:, :F] (crd | rot | seq first layers),
                                    12..15 w_crd2, 16..19 w_rot2, 20..23 w_seq2, 24 w_crd3, 25 w_rot3, 26 w_seq3 (rows zero-padded to 32).
                                    When given, the three heads run as one kernel (time features enter as an affine term from w_head1[:, F:F+3]). */
+    const float* w_mix_frag;    /* optional [8, 8, 3, 64, 4]: blocks 0..3 = w_mix0[:, :F], 4..7 = w_mix1, same layout; with mix_table the mixer is one kernel */
+    const float* mix_table;     /* optional [25, F]: row s = w_mix0[:, F:] . seq_embed[s] + b_mix0 (the embedding half of the mixer's first layer) */
 } abopt_eps_weights;
 
 size_t abopt_eps_workspace_bytes(int N, int L, int F, int C);

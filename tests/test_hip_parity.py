@@ -1129,7 +1129,8 @@ def test_block_tail_autograd_function_vs_torch_statement(N, L, lengths):
 
 @pytest.mark.parametrize('flavour', ['abdesign', 'abdock'])
 def test_fused_heads_match_gemm_path(flavour):
-    """heads.hip (the three denoiser heads as one kernel, time features as an affine term) against the nine-GEMM path through the C ABI:
+    """heads.hip (the three denoiser heads as one kernel, time features as an affine term; the mixer as one kernel with the sequence
+    embedding folded into a table) against the GEMM path through the C ABI:
     same R_next / eps_pos / c up to fp32 summation order; per-sample beta, row count not a multiple of the 32-row tile."""
     from ab_opt_amd import hip
     T, t, N, L = 100, 41, 3, 70
@@ -1142,6 +1143,7 @@ def test_fused_heads_match_gemm_path(flavour):
     for name, _ in hip.EpsWeights._fields_:
         setattr(plain, name, getattr(ew, name))
     plain.w_heads_frag = None
+    plain.w_mix_frag = None
     a = hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False)
     b = hip.eps_net_forward(plain, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False)
     for k in ('R_next', 'eps_pos', 'c'):          # v_next = log(R_next) amplifies near theta = pi; R_next pins it
