@@ -111,7 +111,7 @@ class FullDPM(nn.Module):
             # the cache costs num_layers * N * L^2 * 48 B next to pair_feat's N * L^2 * 256 B: take it when it fits comfortably,
             # otherwise the kernels compute the pair bias in place (bit-identical, test_pair_bias_cache_is_bit_identical)
             need = hip.pair_bias_cache_bytes(pair_feat.shape[0], L, len(self.eps_net.encoder.blocks))
-            use_bias_cache = shared or (L <= 2048 and need <= torch.cuda.mem_get_info(dev)[0] // 2)
+            use_bias_cache = shared or need <= torch.cuda.mem_get_info(dev)[0] // 2
         if shared and not use_bias_cache:
             raise ValueError('a shared pair_feat requires the pair-bias cache')
         if res_feat.shape[0] == 1 and N > 1:

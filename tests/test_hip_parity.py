@@ -1149,3 +1149,28 @@ def test_fused_heads_match_gemm_path(flavour):
     for k in ('R_next', 'eps_pos', 'c'):          # v_next = log(R_next) amplifies near theta = pi; R_next pins it
         assert max_abs(a[k], b[k]) < 2e-5, (k, max_abs(a[k], b[k]))
     assert max_abs(a['v_next'], b['v_next']) < 1e-3
+
+
+def test_ga_block_and_cache_above_2048_residues():
+    """L = 2085 (> 2048, not a multiple of the 16-key chunk; round 1 fell back to a superseded kernel there): the sampler's block (fused
+    projections, core with and without the pair-bias cache, fused tail) against the plain torch statement of the block evaluated on the
+    same GPU -- which the reference's recorded gradients pin (test_ipa_core_autograd_function_vs_torch_statement)."""
+    from ab_opt_amd import hip, training
+    N, L = 1, 2085
+    blk = _block_on_device(seed=17)
+    R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(N, L, [2003], salt=4100)]
+    with torch.no_grad():
+        ref = training.ga_block(blk, R, t, x, z, mask, native=False)
+    _, s_full = blk.packed()
+    out = hip.ga_block_forward(s_full, R, t, x, z, mask)
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    assert max_abs(out, ref) <= tol, max_abs(out, ref)
+    # the cached variant at the same length: EpsilonNet with and without the per-call cache, bit for bit
+    d = standalone_abdesign_dpm(100, 2).to(DEV)
+    v, p, s_, rf, pf, gen, mres = _rand_eps_inputs(N, L, [2003], 4200, [(25, 33), (1500, 1530)])
+    beta = d.trans_pos.var_sched.betas[50].expand([N]).contiguous()
+    pbc = hip.pair_bias_cache(d.eps_net.encoder.packed_array(), 6, pf)
+    a = hip.eps_net_forward(d.eps_net.packed(), v, p, s_, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc)
+    b = hip.eps_net_forward(d.eps_net.packed(), v, p, s_, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False)
+    for k in ('R_next', 'eps_pos', 'c'):
+        assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), k
