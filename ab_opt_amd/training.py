@@ -196,7 +196,8 @@ def ga_block(blk, R, t, x, z, mask, native=None, pbc=None):
 def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res):
     N, L = mask_res.shape
     R = so3_exp(v_t)
-    x = net.res_feat_mixer(torch.cat([res_feat, net.current_sequence_embedding(s_t)], dim=-1))
+    from .embed import embed_rows
+    x = net.res_feat_mixer(torch.cat([res_feat, embed_rows(net.current_sequence_embedding, s_t)], dim=-1))
     caches = [None] * len(net.encoder.blocks)
     if NATIVE_IPA and pair_feat.is_cuda:
         # proj_pair_bias(pair_feat) of all blocks in one pass over pair_feat (the sampler's per-call cache, rebuilt every training step)
