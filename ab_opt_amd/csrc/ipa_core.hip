@@ -431,6 +431,375 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
 #endif
 }
 
+// =====================================================================================================================
+// Persistent form of the cached core (the sampler's variant: no dump, pair bias from the per-call cache).  At the bench shape a CU
+// runs two workgroups back to back, and each pays a prologue of three dependent memory round trips (q' -> LDS, first key fragments,
+// first z rows: ~15k of its ~185k cycles) and an epilogue in which most waves idle (~13k).  Here ONE workgroup per CU walks its
+// query blocks b, b + G, b + 2G, ... as a single stream of (block, chunk) positions g: the roles keep their one-position offsets
+// ACROSS block boundaries, so while the pair waves finish a block the A waves already fetch the next block's q' (each A wave only
+// ever reads its own three heads' q' slots: a wave-private swap, no extra barrier) and produce its S(0), the z ring and the C
+// waves' value fragments roll on into the next block, and a block's epilogue is spread over the next block's first two intervals
+// (C waves: node features and aggregated points after their last chunk; A waves: the per-point epilogue one interval later, out of
+// line -- the same call from the pair waves costs their hot loop 90 spilled registers, 173 -> 200 us).
+// Same arithmetic in the same order as ipa_core_kernel<false, true>: results are bit-identical (test_persistent_core_is_bit_identical).
+struct PBlk { int n, i0; int64_t rowbase, zbase; };
+__device__ __forceinline__ PBlk pblk_of(int b, int nib, int L, int xcd_remap, int z_shared) {
+    int n, ib;
+    if (xcd_remap) { const int xcd = b & 7, k = b >> 3; n = xcd + 8 * (k / nib); ib = k % nib; }
+    else { n = b / nib; ib = b % nib; }
+    PBlk r;
+    r.n = n; r.i0 = ib * BI; r.rowbase = (int64_t)n * L; r.zbase = z_shared ? 0 : r.rowbase;
+    return r;
+}
+
+// per-point epilogue of a finished block (ga.py:136-139): local frame, norm, direction of the aggregated points; one thread per 4
+// consecutive points of a residue.  Out of line on purpose: it runs once per block on waves whose hot loop must keep its registers.
+__device__ __attribute__((noinline)) void persist_point_epilogue(const float* __restrict__ ptsb, const float* __restrict__ R, const float* __restrict__ t,
+                                                                 float* __restrict__ feat, int64_t rowbase, int i0, int L, int th, int nth) {
+    for (int e = th; e < BI * (H * P / 4); e += nth) {
+        const int il = e / (H * P / 4), g4 = e % (H * P / 4), i = i0 + il;
+        if (i >= L) continue;
+        const float* Rr = R + (rowbase + i) * 9;
+        const float* tr = t + (rowbase + i) * 3;
+        const float r0 = Rr[0], r1 = Rr[1], r2 = Rr[2], r3 = Rr[3], r4 = Rr[4], r5 = Rr[5], r6 = Rr[6], r7 = Rr[7], r8 = Rr[8];
+        const float t0 = tr[0], t1 = tr[1], t2 = tr[2];
+        f32x4 a[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const f32x4*>(ptsb + (il * H * P + 4 * g4) * 3 + 4 * q);
+        float loc[12], dir[12];
+        f32x4 dist;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dx = a[(3 * k) >> 2][(3 * k) & 3] - t0, dy = a[(3 * k + 1) >> 2][(3 * k + 1) & 3] - t1, dz = a[(3 * k + 2) >> 2][(3 * k + 2) & 3] - t2;
+            const float lx = r0 * dx + r3 * dy + r6 * dz;                // R^T (a - t), geometry.py:94-117
+            const float ly = r1 * dx + r4 * dy + r7 * dz;
+            const float lz = r2 * dx + r5 * dy + r8 * dz;
+            const float d = sqrtf(lx * lx + ly * ly + lz * lz);
+            const float inv = 1.f / (d + 1e-4f);                         // ga.py:138-139
+            loc[3 * k] = lx; loc[3 * k + 1] = ly; loc[3 * k + 2] = lz;
+            dir[3 * k] = lx * inv; dir[3 * k + 1] = ly * inv; dir[3 * k + 2] = lz * inv;
+            dist[k] = d;
+        }
+        float* fpnt = feat + (rowbase + i) * FEAT + H * C + H * D;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            reinterpret_cast<f32x4*>(fpnt + 12 * g4)[q] = (f32x4){loc[4 * q], loc[4 * q + 1], loc[4 * q + 2], loc[4 * q + 3]};
+            reinterpret_cast<f32x4*>(fpnt + H * P * 3 + H * P + 12 * g4)[q] = (f32x4){dir[4 * q], dir[4 * q + 1], dir[4 * q + 2], dir[4 * q + 3]};
+        }
+        *reinterpret_cast<f32x4*>(fpnt + H * P * 3 + 4 * g4) = dist;
+    }
+}
+
+__global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __restrict__ qfrag, const float* __restrict__ kvfrag, const float* __restrict__ z,
+                                                               const uint8_t* __restrict__ mask, const float* __restrict__ R, const float* __restrict__ t,
+                                                               float* __restrict__ feat, const float* __restrict__ pbc, int L, int nib, int total_blocks,
+                                                               int xcd_remap, int z_shared) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int nchunk = (L + JC - 1) / JC;
+    float* sp = reinterpret_cast<float*>(smem_raw);                     // [3][BI][SROW]
+    f32x4* qf = reinterpret_cast<f32x4*>(sp + 3 * BI * SROW);           // [H][4][64]
+    float* scl = reinterpret_cast<float*>(qf + H * 4 * 64);             // [2][BI][SCLD]  by position parity
+    float* lsum = scl + 2 * BI * SCLD;                                  // [BI][SCLD]
+    float* ptsb = lsum + BI * SCLD;                                     // [BI][H][24]   aggregated global-frame points of the block being finished
+    uint8_t* mk = reinterpret_cast<uint8_t*>(ptsb + BI * H * P * 3);     // [2][nchunk * JC]  key masks of the current / next sample
+    const int mkld = nchunk * JC;
+    const int tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x;
+    const int nb = (total_blocks - (int)blockIdx.x + G - 1) / G;        // blocks of this workgroup (>= 1)
+    const int gtot = nb * nchunk;                                       // positions
+    auto blk = [&](int j) { return pblk_of((int)blockIdx.x + min(j, nb - 1) * G, nib, L, xcd_remap, z_shared); };
+
+    // first block: q' of all heads and the key mask by all threads (later blocks: by the A waves)
+    auto fill_first = [&]() {
+        const PBlk b0 = blk(0);
+        const f32x4* qg = reinterpret_cast<const f32x4*>(qfrag) + ((int64_t)b0.n * nib + b0.i0 / BI) * (H * 4 * 64);
+#pragma unroll
+        for (int e = 0; e < H * 4 * 64 / NTH; ++e) qf[e * NTH + tid] = qg[e * NTH + tid];
+        for (int e = tid; e < mkld; e += NTH) mk[e] = (e < L) ? mask[b0.rowbase + e] : 0;
+    };
+    if (wave < NPW) {
+        // =========================================================================================== pair waves: position g in interval g
+        const int il0 = wave * RPW;
+        const unsigned lane_b = (unsigned)fm * 16u;
+        const unsigned pb_lane = (unsigned)(min(fm, H - 1) * JC + kq * 4) * 4u;
+        const char *zrow[RPW], *pbrow[RPW], *zrow_n[RPW], *pbrow_n[RPW];     // wave-uniform row bases of the current and the next block
+        auto rows_of = [&](const PBlk& b, const char** zr, const char** pr) {
+#pragma unroll
+            for (int ii = 0; ii < RPW; ++ii) {
+                const int64_t row = b.zbase + min(b.i0 + il0 + ii, L - 1);
+                zr[ii] = reinterpret_cast<const char*>(z + (row * (int64_t)L) * C);
+                pr[ii] = reinterpret_cast<const char*>(pbc + (row * (int64_t)nchunk) * (H * JC));
+            }
+        };
+        f32x4 ring[3][4], ringb[3];
+        bool has_next = nb > 1;
+        // CH may be nchunk (= chunk 0 of the next block); past the very last position: a harmless re-read
+#define PP_ISSUE(SLOT, II, CH)                                                                                           \
+    {                                                                                                                    \
+        const bool nx_ = (CH) >= nchunk;                                                                                 \
+        const int ch_ = nx_ ? (has_next ? 0 : nchunk - 1) : (CH);                                                        \
+        const char* zr_ = (nx_ && has_next) ? zrow_n[II] : zrow[II];                                                     \
+        const char* pr_ = (nx_ && has_next) ? pbrow_n[II] : pbrow[II];                                                   \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                \
+            ring[SLOT][r_] = ZLOAD(reinterpret_cast<const f32x4*>(zr_ + ((unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b))); \
+        ringb[SLOT] = ZLOAD(reinterpret_cast<const f32x4*>(pr_ + ((unsigned)ch_ * (unsigned)(H * JC * 4) + pb_lane)));   \
+    }
+        PBlk bk = blk(0);
+        rows_of(bk, zrow, pbrow);
+        { const PBlk bn = blk(1); rows_of(bn, zrow_n, pbrow_n); }
+        PP_ISSUE(0, 0, 0) PP_ISSUE(1, 1, 0)
+        fill_first();
+        float m_run[RPW], l_run[RPW];
+        f32x4 accP[RPW][4];
+        const int spo = sp_off(fm, kq);
+        __syncthreads();                                                    // LDS tile visible
+        __syncthreads();                                                    // S(0) ready
+        // one (query row, position): ring slot SLOT holds its z; BUF = position % 3; PAR = position parity
+#define PP_POS(SLOT, II, CH, BUF, PAR)                                                                                   \
+    {                                                                                                                    \
+        PP_ISSUE(((SLOT) + 2) % 3, II, (CH) + 1)                            /* two ring positions ahead = same row, next chunk */ \
+        const int il_ = il0 + (II);                                                                                      \
+        float* spp_ = sp + ((BUF) * BI + il_) * SROW + spo;                                                              \
+        f32x4 sv_ = *reinterpret_cast<const f32x4*>(spp_);                                                               \
+        sv_ += ringb[SLOT];                                                                                              \
+        sv_ *= kScale2;                                                                                                  \
+        float l2_[4];                                                                                                    \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                               \
+            const float x_ = sv_[r_];                                                                                    \
+            l2_[r_] = ((mk4_ >> (8 * r_)) & 0xffu) ? x_ : x_ - kMask2;                                                   \
+        }                                                                                                                \
+        const float mx_ = rows_max(fmaxf(fmaxf(l2_[0], l2_[1]), fmaxf(l2_[2], l2_[3])));                                 \
+        const float mn_ = fmaxf(m_run[II], mx_);                                                                         \
+        const float sc_ = __builtin_amdgcn_exp2f(m_run[II] - mn_);                                                       \
+        f32x4 pv_;                                                                                                       \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) pv_[r_] = __builtin_amdgcn_exp2f(l2_[r_] - mn_);                \
+        const float ps_ = rows_sum((pv_[0] + pv_[1]) + (pv_[2] + pv_[3]));                                               \
+        l_run[II] = l_run[II] * sc_ + ps_;                                                                               \
+        m_run[II] = mn_;                                                                                                 \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[II][mt_] *= sc_;                                        \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                 \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[II][mt_] = mfma4(ring[SLOT][r_][mt_], pv_[r_], accP[II][mt_]); \
+        *reinterpret_cast<f32x4*>(spp_) = pv_;                                                                           \
+        if (kq == 0) scl[((PAR) * BI + il_) * SCLD + fm] = sc_;                                                          \
+    }
+#define PP_CHUNK(K, CH, PAR)                                                                                             \
+    {                                                                                                                    \
+        const uint32_t mk4_ = *reinterpret_cast<const uint32_t*>(&mkc[(CH) * JC + kq * 4]);                              \
+        PP_POS((2 * (K)) % 3, 0, CH, K, PAR)                                                                             \
+        PP_POS((2 * (K) + 1) % 3, 1, CH, K, PAR)                                                                         \
+    }
+        // The position stream is unrolled by 3 so that every ring slot is a compile-time register (hipcc turns a run-time choice between
+        // slot patterns into hundreds of spills); block boundaries are run-time events inside each copy.
+        int c = 0, j = 0;                                                   // chunk within the block, block of the current position
+        const uint8_t* mkc = mk;
+        bool mi_b[RPW];
+        auto block_begin = [&]() {
+            if (j > 0) {
+                bk = blk(j);
+#pragma unroll
+                for (int ii = 0; ii < RPW; ++ii) { zrow[ii] = zrow_n[ii]; pbrow[ii] = pbrow_n[ii]; }
+            }
+            has_next = j + 1 < nb;
+            { const PBlk bn = blk(j + 1); rows_of(bn, zrow_n, pbrow_n); }
+            mkc = mk + (j & 1) * mkld;
+#pragma unroll
+            for (int ii = 0; ii < RPW; ++ii) {
+                mi_b[ii] = (bk.i0 + il0 + ii < L) && mkc[min(bk.i0 + il0 + ii, L - 1)] != 0;
+                m_run[ii] = -INFINITY; l_run[ii] = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) accP[ii][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        // alpha = P / l, zero for masked queries (ga.py:24-25): pair features out, denominators for the C waves
+        auto block_end = [&]() {
+#pragma unroll
+            for (int ii = 0; ii < RPW; ++ii) {
+                const int il = il0 + ii, i = bk.i0 + il;
+                if (kq == 0) lsum[il * SCLD + fm] = l_run[ii];
+                if (i < L && fm < H) {
+                    const float inv = mi_b[ii] ? 1.f / l_run[ii] : 0.f;
+                    float* fo = feat + (bk.rowbase + i) * FEAT + fm * C + kq * 16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        reinterpret_cast<f32x4*>(fo)[r] = (f32x4){accP[ii][0][r] * inv, accP[ii][1][r] * inv, accP[ii][2][r] * inv, accP[ii][3][r] * inv};
+                }
+            }
+        };
+#define PP_STEP(K, G)                                                                                                    \
+    {                                                                                                                    \
+        if (c == 0) block_begin();                                                                                       \
+        PP_CHUNK(K, c, (G) & 1)                                                                                          \
+        if (c == nchunk - 1) { block_end(); c = 0; ++j; } else ++c;                                                      \
+        __syncthreads();                                                    /* B_g */                                     \
+    }
+        int g = 0;
+        for (; g + 3 <= gtot; g += 3) { PP_STEP(0, g) PP_STEP(1, g + 1) PP_STEP(2, g + 2) }
+        if (g < gtot) {
+            PP_STEP(0, g)
+            if (g + 1 < gtot) PP_STEP(1, g + 1)
+        }
+#undef PP_STEP
+        __syncthreads();                                                    // T1: the C waves finished the last block
+    } else if (wave < NPW + 4) {
+        // =========================================================================================== A waves: S(g + 1) in interval g
+        const int h0 = (wave - NPW) * 3;
+        const int atid = tid - NPW * 64;
+        f32x4 kf[3][4];
+        auto kv_of = [&](const PBlk& b) { return reinterpret_cast<const f32x4*>(kvfrag) + (int64_t)b.n * nchunk * H * 512; };
+#define PA_ISSUE(HH, KV, CH) { const f32x4* fr_ = (KV) + ((int64_t)(CH) * H + h0 + (HH)) * 512 + lane;                   \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) kf[HH][s_] = fr_[s_ * 64]; }
+        // S(position) -> sp[buf]; after each head's MFMAs its registers are refilled with the NEXT position's key fragments
+        auto produce = [&](int buf, const f32x4* kv_next, int ch_next) {
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) {
+                const int h = h0 + hh;
+                const f32x4* qh = qf + (h * 4) * 64 + lane;
+                const f32x4 q0 = qh[0], q1 = qh[64], q2 = qh[128], q3 = qh[192];
+                f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { acc0 = mfma4(kf[hh][0][s], q0[s], acc0); acc1 = mfma4(kf[hh][2][s], q2[s], acc1); }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { acc0 = mfma4(kf[hh][1][s], q1[s], acc0); if (s < 3) acc1 = mfma4(kf[hh][3][s], q3[s], acc1); }
+                const f32x4 sres = acc0 + acc1;
+                if (hh == 0) PA_ISSUE(0, kv_next, ch_next) else if (hh == 1) PA_ISSUE(1, kv_next, ch_next) else PA_ISSUE(2, kv_next, ch_next)
+                *reinterpret_cast<f32x4*>(sp + (buf * BI + fm) * SROW + sp_off(h, kq)) = sres;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // position p -> (key/value base of its block, chunk); past the last position: re-read the last chunk
+        auto kv_pos = [&](int p, const f32x4*& kv, int& ch) {
+            const int pc = min(p, gtot - 1);
+            const PBlk b = blk(pc / nchunk);
+            kv = kv_of(b); ch = pc % nchunk;
+        };
+        {
+            const f32x4* kv0; int ch0;
+            kv_pos(0, kv0, ch0);
+            PA_ISSUE(0, kv0, ch0) PA_ISSUE(1, kv0, ch0) PA_ISSUE(2, kv0, ch0)
+        }
+        fill_first();
+        __syncthreads();
+        { const f32x4* kv1; int ch1; kv_pos(1, kv1, ch1); produce(0, kv1, ch1); }
+        __syncthreads();                                                    // S(0) ready
+        int bufn = 1;                                                       // buffer of position g + 1
+        for (int g = 0; g < gtot; ++g) {
+            const int gn = g + 1;
+            if (gn < gtot) {
+                if (gn % nchunk == 0) {
+                    // block switch: this wave's three heads of q' (nobody else reads these LDS slots) and, shared by the four A waves, the next key mask
+                    const int jn = gn / nchunk;
+                    const PBlk bnx = blk(jn);
+                    const f32x4* qg = reinterpret_cast<const f32x4*>(qfrag) + ((int64_t)bnx.n * nib + bnx.i0 / BI) * (H * 4 * 64);
+#pragma unroll
+                    for (int hh = 0; hh < 3; ++hh) {
+                        f32x4 tq[4];
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_) tq[s_] = qg[((h0 + hh) * 4 + s_) * 64 + lane];
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_) qf[((h0 + hh) * 4 + s_) * 64 + lane] = tq[s_];
+                    }
+                    uint8_t* mkn = mk + (jn & 1) * mkld;
+                    for (int e = atid; e < mkld; e += 4 * 64) mkn[e] = (e < L) ? mask[bnx.rowbase + e] : 0;
+                    wave_lds_sync();
+                }
+                const f32x4* kvx; int chx;
+                kv_pos(gn + 1, kvx, chx);
+                produce(bufn, kvx, chx);
+                bufn = (bufn == 2) ? 0 : bufn + 1;
+            }
+            if (g >= nchunk && g % nchunk == 1) {                          // second interval of a block: the C waves wrote the previous block's points last interval
+                const PBlk bp = blk(g / nchunk - 1);
+                persist_point_epilogue(ptsb, R, t, feat, bp.rowbase, bp.i0, L, atid, 4 * 64);
+            }
+            __syncthreads();                                                // B_g
+        }
+        __syncthreads();                                                    // T1: the C waves finished the last block
+        { const PBlk bl = blk(nb - 1); persist_point_epilogue(ptsb, R, t, feat, bl.rowbase, bl.i0, L, atid, 4 * 64); }
+    } else {
+        // =========================================================================================== C waves: position g - 1 in interval g
+        const int h0 = (wave - NPW - 4) * 3;
+        f32x4 vf[3][4];
+        f32x4 accV[3][2], accT[3][2];
+#pragma unroll
+        for (int hh = 0; hh < 3; ++hh)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { accV[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; accT[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        auto kv_of = [&](const PBlk& b) { return reinterpret_cast<const f32x4*>(kvfrag) + (int64_t)b.n * nchunk * H * 512; };
+#define PC_ISSUE(HH, KV, CH) { const f32x4* fr_ = (KV) + ((int64_t)(CH) * H + h0 + (HH)) * 512 + 4 * 64 + lane;         \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) vf[HH][s_] = fr_[s_ * 64]; }
+        auto kv_pos = [&](int p, const f32x4*& kv, int& ch) {
+            const int pc = min(p, gtot - 1);
+            const PBlk b = blk(pc / nchunk);
+            kv = kv_of(b); ch = pc % nchunk;
+        };
+        auto consume = [&](int buf, int par, const f32x4* kv_next, int ch_next) {
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) {
+                const int h = h0 + hh;
+                const float sc = scl[(par * BI + fm) * SCLD + h];
+                const f32x4 pa = *reinterpret_cast<const f32x4*>(sp + (buf * BI + fm) * SROW + sp_off(h, kq));
+                accV[hh][0] *= sc; accV[hh][1] *= sc; accT[hh][0] *= sc; accT[hh][1] *= sc;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    accV[hh][0] = mfma4(vf[hh][s][0], pa[s], accV[hh][0]);
+                    accV[hh][1] = mfma4(vf[hh][s][1], pa[s], accV[hh][1]);
+                    accT[hh][0] = mfma4(vf[hh][s][2], pa[s], accT[hh][0]);
+                    accT[hh][1] = mfma4(vf[hh][s][3], pa[s], accT[hh][1]);
+                }
+                if (hh == 0) PC_ISSUE(0, kv_next, ch_next) else if (hh == 1) PC_ISSUE(1, kv_next, ch_next) else PC_ISSUE(2, kv_next, ch_next)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // after a block's last chunk: node features to HBM, aggregated points to LDS, accumulators back to zero
+        auto block_epilogue = [&](int j) {
+            const PBlk b = blk(j);
+            const uint8_t* mkc = mk + (j & 1) * mkld;
+            const bool mi_c = (b.i0 + fm < L) && mkc[min(b.i0 + fm, L - 1)] != 0;
+            const int i = b.i0 + fm;
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) {
+                const int h = h0 + hh;
+                const float inv = mi_c ? 1.f / lsum[fm * SCLD + h] : 0.f;
+                if (i < L) {
+                    float* fo = feat + (b.rowbase + i) * FEAT + H * C + h * D + kq * 4;
+                    *reinterpret_cast<f32x4*>(fo) = accV[hh][0] * inv;
+                    *reinterpret_cast<f32x4*>(fo + 16) = accV[hh][1] * inv;
+                }
+                float* po = ptsb + (fm * H + h) * (P * 3) + kq * 3;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { po[r] = accT[hh][0][r] * inv; po[12 + r] = accT[hh][1][r] * inv; }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { accV[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; accT[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            }
+        };
+        {
+            const f32x4* kv0; int ch0;
+            kv_pos(0, kv0, ch0);
+            PC_ISSUE(0, kv0, ch0) PC_ISSUE(1, kv0, ch0) PC_ISSUE(2, kv0, ch0)
+        }
+        fill_first();
+        __syncthreads();
+        __syncthreads();                                                    // S(0) ready
+        __syncthreads();                                                    // B_0: P(0) ready
+        int buf = 0;                                                        // buffer of position g - 1
+        for (int g = 1; g <= gtot; ++g) {
+            const int p = g - 1;
+            const f32x4* kvx; int chx;
+            kv_pos(g, kvx, chx);
+            consume(buf, p & 1, kvx, chx);
+            buf = (buf == 2) ? 0 : buf + 1;
+            if (p % nchunk == nchunk - 1) block_epilogue(p / nchunk);
+            __syncthreads();                                                // B_g (g < gtot), T1 (g == gtot)
+        }
+    }
+#undef PP_ISSUE
+#undef PP_POS
+#undef PP_CHUNK
+#undef PA_ISSUE
+#undef PC_ISSUE
+}
+
 // Pair-bias cache: lp[l][n,i,j,h] = z[n,i,j,:] . Wb_l[h,:] for every layer l in ONE pass over z (ga.py:88-90).  z and the weights do
 // not change during the 100 steps of FullDPM.sample, so the sampler builds this once per call and the per-step kernel reads 48
 // bytes per (i,j) instead of spending 64 more MFMAs per (row, chunk) and an LDS transpose on it.
@@ -518,6 +887,35 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
                            int z_shared) {
     ABOPT_CHECK_ARG(!dump == !dump_stats, "ipa_core: the logits dump and its row statistics come together");
     ABOPT_CHECK_ARG(!dump || (int64_t)H * L * L * 4 < (1ll << 31), "ipa_core: L=%d too long for the logits dump", L);
+    if (pair_bias_cache && !dump) {
+        const int nib = (L + BI - 1) / BI, nchunk = (L + JC - 1) / JC;
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            ABOPT_HIP(hipGetDevice(&dev));
+            hipDeviceProp_t prop;
+            ABOPT_HIP(hipGetDeviceProperties(&prop, dev));
+            cus = prop.multiProcessorCount & ~7;                              // a multiple of 8 keeps blockIdx & 7 = XCD for every block of a workgroup
+        }
+        const int total = N * nib;
+#ifndef CORE_NO_PERSIST      // developer A/B switch
+        if (nchunk >= 2 && cus >= 8 && total > cus && !CORE_ABL) {
+            const size_t lds = sizeof(float) * (3 * BI * SROW + H * 4 * 64 * 4 + 2 * BI * SCLD + BI * SCLD + BI * H * P * 3) + 2 * (size_t)nchunk * JC;
+            ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core: L=%d needs %zu bytes of LDS for the key masks (max 163840)", L, lds);
+            static size_t configured = 0;
+            if (lds > configured) {
+                ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_core_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                configured = lds;
+            }
+            prof::begin(st);
+            hipLaunchKernelGGL(ipa_core_persist_kernel, dim3((unsigned)cus), dim3(NTH), lds, st, qfrag, kvfrag, z, mask, R, t, feat, pair_bias_cache, L, nib, total,
+                               (N % 8 == 0) ? 1 : 0, z_shared);
+            prof::end(st);
+            ABOPT_LAUNCH_CHECK();
+            return ABOPT_OK;
+        }
+#endif
+    }
     if (pair_bias_cache) {
         if (dump) return launch_core_variant<true, true>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dump, dump_stats, pair_bias_cache, N, L, st, z_shared);
         return launch_core_variant<false, true>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, nullptr, nullptr, pair_bias_cache, N, L, st, z_shared);

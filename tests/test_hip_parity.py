@@ -1174,3 +1174,25 @@ def test_ga_block_and_cache_above_2048_residues():
     b = hip.eps_net_forward(d.eps_net.packed(), v, p, s_, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False)
     for k in ('R_next', 'eps_pos', 'c'):
         assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize('N,L,lengths', [(32, 256, None), (40, 100, None), (24, 250, 'ragged')])
+def test_persistent_core_is_bit_identical(N, L, lengths):
+    """With the pair-bias cache and more query blocks than CUs the sampler's core runs as ONE persistent workgroup per CU that walks
+    several query blocks with the roles' pipeline kept across block boundaries (csrc/ipa_core.hip: ipa_core_persist_kernel).  Same
+    arithmetic in the same order: every sample must come out bit-identical to the same sample run in a small batch (one block per
+    workgroup, the plain kernel) -- odd block counts per workgroup, chunk counts not divisible by 3 and ragged lengths included."""
+    from ab_opt_amd import hip
+    d = standalone_abdesign_dpm(100, 2).to(DEV)
+    lens = [L] * N if lengths is None else [L - (7 * i) % 60 for i in range(N)]
+    v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lens, 5200 + N, [(5, 14), (22, 30)])
+    beta = d.trans_pos.var_sched.betas[37].expand([N]).contiguous()
+    arr, ew = d.eps_net.encoder.packed_array(), d.eps_net.packed()
+    big = hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=hip.pair_bias_cache(arr, 6, pf))
+    for lo in (0, N - 3):
+        sl = slice(lo, lo + 3)
+        c = lambda a: a[sl].contiguous()
+        small = hip.eps_net_forward(ew, c(v), c(p), c(s), c(rf), c(pf), c(beta), c(gen), c(mres), d.abdock, d.num_bins, False,
+                                    pair_bias_cache=hip.pair_bias_cache(arr, 6, c(pf)))
+        for k in ('R_next', 'eps_pos', 'c'):
+            assert torch.isfinite(big[k]).all() and torch.equal(big[k][sl], small[k]), (k, lo)
