@@ -506,6 +506,12 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x;
+#ifdef PERSIST_TIMING
+    long long pt_wait = 0, pt_start = clock64();
+#define PSYNC() { const long long a_ = clock64(); __syncthreads(); pt_wait += clock64() - a_; }
+#else
+#define PSYNC() __syncthreads();
+#endif
     const int nb = (total_blocks - (int)blockIdx.x + G - 1) / G;        // blocks of this workgroup (>= 1)
     const int gtot = nb * nchunk;                                       // positions
     auto blk = [&](int j) { return pblk_of((int)blockIdx.x + min(j, nb - 1) * G, nib, L, xcd_remap, z_shared); };
@@ -553,8 +559,8 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
         float m_run[RPW], l_run[RPW];
         f32x4 accP[RPW][4];
         const int spo = sp_off(fm, kq);
-        __syncthreads();                                                    // LDS tile visible
-        __syncthreads();                                                    // S(0) ready
+        PSYNC()                                                    // LDS tile visible
+        PSYNC()                                                    // S(0) ready
         // one (query row, position): ring slot SLOT holds its z; BUF = position % 3; PAR = position parity
 #define PP_POS(SLOT, II, CH, BUF, PAR)                                                                                   \
     {                                                                                                                    \
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
         if (c == 0) block_begin();                                                                                       \
         PP_CHUNK(K, c, (G) & 1)                                                                                          \
         if (c == nchunk - 1) { block_end(); c = 0; ++j; } else ++c;                                                      \
-        __syncthreads();                                                    /* B_g */                                     \
+        PSYNC()                                                    /* B_g */                                     \
     }
         int g = 0;
         for (; g + 3 <= gtot; g += 3) { PP_STEP(0, g) PP_STEP(1, g + 1) PP_STEP(2, g + 2) }
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
             if (g + 1 < gtot) PP_STEP(1, g + 1)
         }
 #undef PP_STEP
-        __syncthreads();                                                    // T1: the C waves finished the last block
+        PSYNC()                                                    // T1: the C waves finished the last block
     } else if (wave < NPW + 4) {
         // =========================================================================================== A waves: S(g + 1) in interval g
         const int h0 = (wave - NPW) * 3;
@@ -679,9 +685,9 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
             PA_ISSUE(0, kv0, ch0) PA_ISSUE(1, kv0, ch0) PA_ISSUE(2, kv0, ch0)
         }
         fill_first();
-        __syncthreads();
+        PSYNC()
         { const f32x4* kv1; int ch1; kv_pos(1, kv1, ch1); produce(0, kv1, ch1); }
-        __syncthreads();                                                    // S(0) ready
+        PSYNC()                                                    // S(0) ready
         int bufn = 1;                                                       // buffer of position g + 1
         for (int g = 0; g < gtot; ++g) {
             const int gn = g + 1;
@@ -712,9 +718,9 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
                 const PBlk bp = blk(g / nchunk - 1);
                 persist_point_epilogue(ptsb, R, t, feat, bp.rowbase, bp.i0, L, atid, 4 * 64);
             }
-            __syncthreads();                                                // B_g
+            PSYNC()                                                // B_g
         }
-        __syncthreads();                                                    // T1: the C waves finished the last block
+        PSYNC()                                                    // T1: the C waves finished the last block
         { const PBlk bl = blk(nb - 1); persist_point_epilogue(ptsb, R, t, feat, bl.rowbase, bl.i0, L, atid, 4 * 64); }
     } else {
         // =========================================================================================== C waves: position g - 1 in interval g
@@ -779,9 +785,9 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
             PC_ISSUE(0, kv0, ch0) PC_ISSUE(1, kv0, ch0) PC_ISSUE(2, kv0, ch0)
         }
         fill_first();
-        __syncthreads();
-        __syncthreads();                                                    // S(0) ready
-        __syncthreads();                                                    // B_0: P(0) ready
+        PSYNC()
+        PSYNC()                                                    // S(0) ready
+        PSYNC()                                                    // B_0: P(0) ready
         int buf = 0;                                                        // buffer of position g - 1
         for (int g = 1; g <= gtot; ++g) {
             const int p = g - 1;
@@ -790,13 +796,20 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
             consume(buf, p & 1, kvx, chx);
             buf = (buf == 2) ? 0 : buf + 1;
             if (p % nchunk == nchunk - 1) block_epilogue(p / nchunk);
-            __syncthreads();                                                // B_g (g < gtot), T1 (g == gtot)
+            PSYNC()                                                // B_g (g < gtot), T1 (g == gtot)
         }
     }
 #undef PP_ISSUE
 #undef PP_POS
 #undef PP_CHUNK
 #undef PA_ISSUE
+#ifdef PERSIST_TIMING
+    if (blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == NPW || wave == NPW + 4)) {
+        long long* o = g_core_timing[wave == 0 ? 0 : (wave == NPW ? 1 : 2)];
+        o[0] = clock64() - pt_start; o[1] = pt_wait;
+    }
+#endif
+#undef PSYNC
 #undef PC_ISSUE
 }
 
@@ -912,6 +925,17 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
                                (N % 8 == 0) ? 1 : 0, z_shared);
             prof::end(st);
             ABOPT_LAUNCH_CHECK();
+#ifdef PERSIST_TIMING
+            {
+                long long h[3][8];
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_core_timing), sizeof(h));
+                static int calls = 0;
+                if (++calls == 8)
+                    for (int r = 0; r < 3; ++r)
+                        fprintf(stderr, "[persist timing, cycles of WG 17] %s: total %lld | barrier wait %lld\n", r == 0 ? "pair" : (r == 1 ? "A   " : "C   "), h[r][0], h[r][1]);
+            }
+#endif
             return ABOPT_OK;
         }
 #endif

@@ -26,7 +26,7 @@ TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum T
 TA_TA_BUSY_sum TD_TD_BUSY_sum TD_TC_STALL_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
 GRPS
 cd $ROOT
-for k in ipa_core_kernel node_frags_kernel out_ln_mlp_kernel; do
+for k in ipa_core node_frags_kernel out_ln_mlp_kernel; do
   python tools/pmc_summary.py $OUT/pmc --kernel $k > $OUT/pmc_$k.txt
 done
 rm -rf $OUT/stats $OUT/pmc
