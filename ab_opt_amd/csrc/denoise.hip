@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void denoise_step_kernel(abopt_step_params sp,
                                                            const float* __restrict__ igX, const float* __restrict__ igCdf, int bins, int num_bins,
                                                            float* __restrict__ v_next, float* __restrict__ p_next, int64_t* __restrict__ s_next,
                                                            float* __restrict__ prmsd, float* __restrict__ ppl, float* __restrict__ post_out,
-                                                           int L, int ppl_masked) {
+                                                           float* __restrict__ p_next_norm, int L, int ppl_masked) {
     const int n = blockIdx.x, tid = threadIdx.x;
     const bool injected = nz.axis != nullptr;
     const Philox rng(seed);
@@ -101,7 +101,12 @@ __global__ __launch_bounds__(256) void denoise_step_kernel(abopt_step_params sp,
         if (!sp.sample_structure) { nvx = vx; nvy = vy; nvz = vz; pn[0] = pt[0]; pn[1] = pt[1]; pn[2] = pt[2]; }
         v_next[i * 3] = nvx; v_next[i * 3 + 1] = nvy; v_next[i * 3 + 2] = nvz;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p_next[i * 3 + k] = pn[k] * sp.position_scale + sp.position_mean[k];
+        for (int k = 0; k < 3; ++k) {
+            const float pa_next = pn[k] * sp.position_scale + sp.position_mean[k];
+            p_next[i * 3 + k] = pa_next;
+            // what the next step feeds the network (dpm_full.py:276 normalises the STORED Angstrom value again): saves the host two launches per step
+            if (p_next_norm) p_next_norm[i * 3 + k] = (pa_next - sp.position_mean[k]) / sp.position_scale;
+        }
 
         // ---- sequence (transition.py:202-245): NOTE alpha_bar_t multiplies both factors (reference quirk)
         const int64_t st = s_t[i];
@@ -317,7 +322,7 @@ extern "C" int abopt_denoise_step(const abopt_step_params* sp, const abopt_step_
                                   const float* v_net, const float* p_net, const float* c_net, const float* prmsd_logits,
                                   const uint8_t* mask_generate, const float* igso3_X, const float* igso3_cdf, int igso3_bins, int num_bins,
                                   float* v_next, float* p_next, int64_t* s_next, float* prmsd, float* perplexity,
-                                  float* post_out, int N, int L, abopt_stream stream) {
+                                  float* post_out, float* p_next_norm, int N, int L, abopt_stream stream) {
     ABOPT_CHECK_ARG(sp && v_t && p_t && s_t && v_net && p_net && c_net && mask_generate && v_next && p_next && s_next, "denoise_step: NULL argument");
     ABOPT_CHECK_ARG(igso3_X && igso3_bins >= 2, "denoise_step: IGSO(3) histogram row missing");
     abopt_step_noise nz = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -330,7 +335,7 @@ extern "C" int abopt_denoise_step(const abopt_step_params* sp, const abopt_step_
     if (N == 0 || L == 0) return ABOPT_OK;
     hipLaunchKernelGGL(denoise_step_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, *sp, nz, seed, offset, v_t, p_t, s_t, v_net, p_net, c_net,
                        prmsd_logits, mask_generate, igso3_X, igso3_cdf, igso3_bins, num_bins, v_next, p_next, s_next, prmsd, perplexity, post_out,
-                       L, sp->ppl_masked);
+                       p_next_norm, L, sp->ppl_masked);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

@@ -134,16 +134,16 @@ class FullDPM(nn.Module):
         if pbar:
             from tqdm.auto import tqdm
             it = tqdm(it, total=T0, desc='Sampling')
+        # dpm_full.py:276: p_t = normalize(traj[t].p) -- here for the first step, afterwards written by the step kernel itself
+        torch.sub(tp[T0], mean, out=p_norm).div_(scale)
         for t in it:
             if stop_after is not None and T0 - t >= stop_after:
                 break
-            # dpm_full.py:276: p_t = normalize(traj[t].p)
-            torch.sub(tp[t], mean, out=p_norm).div_(scale)
             beta = beta_rows[t]
             hip.eps_net_forward(ew, tv[t], p_norm, ts[t], res_feat, pair_feat, beta, mask_generate, mask_res,
                                 self.abdock, self.num_bins, False, out=net, pair_bias_cache=pbc, pair_feat_shared=shared)
             sp = self._step_params(t, sample_structure, sample_sequence, ppl_masked, optimize_mode)
-            out = dict(v=tv[t - 1], p=tp[t - 1], s=ts[t - 1])
+            out = dict(v=tv[t - 1], p=tp[t - 1], s=ts[t - 1], p_norm=p_norm)
             if self.abdock:
                 out.update(prmsd=tpr[t - 1], ppl=tpp[t - 1])
             hip.denoise_step(sp, noise[t] if noise is not None else None, seed, rng_offset,

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -115,7 +115,7 @@ def lib():
         L.abopt_pair_bias_cache.argtypes = [C.POINTER(GaWeights), C.c_int, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.abopt_denoise_step.argtypes = [C.POINTER(StepParams), C.POINTER(StepNoise), C.c_uint64, C.c_uint64,
                                          c_f, c_f, c_i64, c_f, c_f, c_f, c_f, c_u8, c_f, c_f, C.c_int, C.c_int,
-                                         c_f, c_f, c_i64, c_f, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
+                                         c_f, c_f, c_i64, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_sample_init.argtypes = [c_f, c_f, c_i64, c_u8, c_f, c_f, c_i64, C.c_uint64, C.c_uint64,
                                         C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, c_f, c_f, c_i64, C.c_int, C.c_int, C.c_void_p]
         L.abopt_commonness_score.argtypes = [c_f, c_f, C.c_int, C.c_int, C.c_void_p]
@@ -381,7 +381,7 @@ def denoise_step(sp, noise, seed, offset, v_t, p_t, s_t, v_net, p_net, c_net, pr
                                     ptr(prmsd_logits, optional=True), ptr(mask_generate, torch.bool),
                                     ptr(ig_X_row, torch.float32), ptr(ig_cdf_row, optional=True), ig_X_row.numel(), num_bins,
                                     ptr(out['v']), ptr(out['p']), ptr(out['s']), ptr(out.get('prmsd'), optional=True),
-                                    ptr(out.get('ppl'), optional=True), ptr(post, optional=True), N, L, stream()))
+                                    ptr(out.get('ppl'), optional=True), ptr(post, optional=True), ptr(out.get('p_norm'), optional=True), N, L, stream()))
     return post
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 21
+#define ABOPT_ABI_VERSION 22
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -201,7 +201,8 @@ typedef struct {
 /* One loop iteration after eps_net: state (v_t, p_t in Angstrom, s_t) -> (v_next, p_next in Angstrom, s_next),
  * plus per-sample prmsd [N] and perplexity [N] (either may be NULL).
  * igso3_X / igso3_cdf: row t of the inverse-process histogram, [bins] bin starts and [bins-1] normalised CDF
- * (cdf only used without injected noise). post_out [N,L,20] optional (posterior, for tests). */
+ * (cdf only used without injected noise). post_out [N,L,20] optional (posterior, for tests).  p_next_norm [N,L,3] optional:
+ * (p_next - position_mean) / position_scale, the normalised positions the next step's network call takes (dpm_full.py:276). */
 int abopt_denoise_step(const abopt_step_params* sp, const abopt_step_noise* noise,
                        uint64_t seed, uint64_t offset,
                        const float* v_t, const float* p_t, const int64_t* s_t,
@@ -209,7 +210,7 @@ int abopt_denoise_step(const abopt_step_params* sp, const abopt_step_noise* nois
                        const uint8_t* mask_generate,
                        const float* igso3_X, const float* igso3_cdf, int igso3_bins, int num_bins,
                        float* v_next, float* p_next, int64_t* s_next, float* prmsd, float* perplexity,
-                       float* post_out, int N, int L, abopt_stream stream);
+                       float* post_out, float* p_next_norm, int N, int L, abopt_stream stream);
 
 /* Initial state of FullDPM.sample (dpm_full.py:255-269): q4 [N,L,4], pn [N,L,3], sr [N,L] are the
  * reference's three draws (NULL => Philox).  p in/out in Angstrom.  position_mean is a HOST pointer to 3 floats. */
