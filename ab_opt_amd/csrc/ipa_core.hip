@@ -149,9 +149,11 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         const unsigned pb_lane = (unsigned)(min(fm, H - 1) * JC + kq * 4) * 4u;
         // the dump goes out through a buffer descriptor: base = this sample's [12,L,L] slab (SGPRs), one lane-constant byte offset
         // (head, key group) and a wave-uniform row/chunk offset -- no 64-bit per-lane addresses in the hot loop
-        const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(DUMP ? dump + (int64_t)n * H * L * L : nullptr, 0, 0x7fffffff, 0x00020000);
-        const unsigned dvoff = (unsigned)((min(fm, H - 1) * L) * L + kq * 4) * 4u;
+        // (the descriptor covers exactly this sample's slab, so an offset past it is discarded by the hardware)
+        const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(DUMP ? dump + (int64_t)n * H * L * L : nullptr, 0, H * L * L * 4, 0x00020000);
+        const unsigned dvoff = fm < H ? (unsigned)((fm * L) * L + kq * 4) * 4u : 0x7ffffff0u;
         const bool dvec = (L & 3) == 0;                                  // rows of the dump are 16-byte aligned
+        const bool dfull = (L & 15) == 0;                                // no partial key chunk: every lane of heads 0..11 stores
 #define PW_ISSUE(SLOT, II, CH)                                                                                          \
     {                                                                                                                    \
         const int ch_ = chunk_of(min((CH), nchunk - 1));                       /* past the end: harmless re-read */      \
@@ -207,11 +209,14 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         }                                                                                                                \
         float l2_[4];                                                                                                    \
         sv_ *= kScale2;                                                                                                  \
-        if (DUMP && fm < H && (i0 + il_) < L) {                                                                          \
-            const int j0_ = chunk_of(CH) * JC + kq * 4;                                                                  \
+        if (DUMP && (i0 + il_) < L) {                                           /* wave-uniform */                        \
             const int so_ = ((i0 + il_) * L + chunk_of(CH) * JC) * 4;                                                    \
-            if (dvec) { if (j0_ < L) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv_), drsrc, dvoff, so_, 0); } \
-            else { _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) if (j0_ + r_ < L) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv_[r_]), drsrc, dvoff + 4 * r_, so_, 0); } \
+            if (dfull) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv_), drsrc, dvoff, so_, 0);     /* lanes of heads 12..15 carry an out-of-range offset: dropped by the buffer bounds check */ \
+            else if (fm < H) {                                                                                           \
+                const int j0_ = chunk_of(CH) * JC + kq * 4;                                                              \
+                if (dvec) { if (j0_ < L) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv_), drsrc, dvoff, so_, 0); } \
+                else { _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) if (j0_ + r_ < L) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv_[r_]), drsrc, dvoff + 4 * r_, so_, 0); } \
+            }                                                                                                            \
         }                                                                                                                \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                               \
             const float x_ = sv_[r_];                                                                                    \
