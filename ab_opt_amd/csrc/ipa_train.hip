@@ -1,8 +1,8 @@
 // Training side of the IPA core (FullDPM.forward, AbDock/src/modules/diffusion/dpm_full.py:156-234, config 5).
 //
-// Forward: the inference kernel (ipa_ws.hip) run with its logits dump, followed by the masked softmax, so autograd can keep
-// alpha (N, L, L, 12) instead of the (N, L, L, 12, 64) products the reference's broadcast formulation materialises
-// (ga.py:114-118: 805 MB per sample and layer).
+// Forward: the inference kernel (ipa_core.hip) with its head-major dump of the scaled logits and the row statistics, then one
+// elementwise pass that turns the dump into alpha in place (alpha_finalize), so autograd keeps alpha (N, 12, L, L) instead of the
+// (N, L, L, 12, 64) products the reference's broadcast formulation materialises (ga.py:114-118: 805 MB per sample and layer).
 //
 // Backward, pair side: everything that touches z[n,i,j,:] in one streaming pass (read z once, write dz once):
 //     dalpha_ijh = dalpha_node_ijh + sum_c dfp_ihc z_ijc                       (d/d alpha of ga.py:116-118; the node/point terms are (N,L,L,12) GEMMs done by the host)
@@ -18,7 +18,7 @@ namespace abopt {
 // alpha, dalpha_node and g use the head-major layout (N, 12, L, L): every (n, h) slice is then a plain row-major L x L
 // matrix for the batched library GEMMs the host runs on them.
 // One workgroup per query row (n, i), four waves; wave w takes the 16-key chunks w, w+4, ...  Same tiling as the pair waves of
-// the forward kernel (ipa_ws.hip), all three contractions on the matrix cores:
+// the forward kernel (ipa_core.hip), all three contractions on the matrix cores:
 //   dalpha_pair[j, h] = z[j, :] . dfp[h, :]          A = z chunk transposed through a wave-private LDS tile, B = dfp (LDS)
 //   dz[j, c]          = sum_h alpha[h,j] dfp[h,c] + g[h,j] Wb[h,c]     A = [dfp^T | Wb^T] (LDS), B = [alpha ; g] transposed through LDS
 // g is produced in lanes (h = lane & 15, keys 4 (lane >> 4) + r): the accumulator layout of the first product and the
