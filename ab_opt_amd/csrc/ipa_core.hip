@@ -512,7 +512,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x;
 #ifdef PERSIST_TIMING
-    long long pt_wait = 0, pt_start = clock64();
+    long long pt_wait = 0, pt_mem = 0, pt_lds = 0, pt_mf = 0, pt_start = clock64();
 #define PSYNC() { const long long a_ = clock64(); __syncthreads(); pt_wait += clock64() - a_; }
 #else
 #define PSYNC() __syncthreads();
@@ -662,6 +662,9 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
         _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) kf[HH][s_] = fr_[s_ * 64]; }
         // S(position) -> sp[buf]; after each head's MFMAs its registers are refilled with the NEXT position's key fragments
         auto produce = [&](int buf, const f32x4* kv_next, int ch_next) {
+#ifdef PERSIST_TIMING
+            { const long long a_ = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt_mem += clock64() - a_; }
+#endif
 #pragma unroll
             for (int hh = 0; hh < 3; ++hh) {
                 const int h = h0 + hh;
@@ -745,11 +748,21 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
             kv = kv_of(b); ch = pc % nchunk;
         };
         auto consume = [&](int buf, int par, const f32x4* kv_next, int ch_next) {
+#ifdef PERSIST_TIMING
+            { const long long a_ = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt_mem += clock64() - a_; }
+#endif
 #pragma unroll
             for (int hh = 0; hh < 3; ++hh) {
                 const int h = h0 + hh;
+#ifdef PERSIST_TIMING
+                const long long ta_ = clock64();
+#endif
                 const float sc = scl[(par * BI + fm) * SCLD + h];
                 const f32x4 pa = *reinterpret_cast<const f32x4*>(sp + (buf * BI + fm) * SROW + sp_off(h, kq));
+#ifdef PERSIST_TIMING
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const long long tb_ = clock64();
+#endif
                 accV[hh][0] *= sc; accV[hh][1] *= sc; accT[hh][0] *= sc; accT[hh][1] *= sc;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -758,6 +771,10 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
                     accT[hh][0] = mfma4(vf[hh][s][2], pa[s], accT[hh][0]);
                     accT[hh][1] = mfma4(vf[hh][s][3], pa[s], accT[hh][1]);
                 }
+#ifdef PERSIST_TIMING
+                __builtin_amdgcn_sched_barrier(0);
+                { const long long tc_ = clock64(); pt_lds += tb_ - ta_; pt_mf += tc_ - tb_; }
+#endif
                 if (hh == 0) PC_ISSUE(0, kv_next, ch_next) else if (hh == 1) PC_ISSUE(1, kv_next, ch_next) else PC_ISSUE(2, kv_next, ch_next)
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -811,7 +828,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
 #ifdef PERSIST_TIMING
     if (blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == NPW || wave == NPW + 4)) {
         long long* o = g_core_timing[wave == 0 ? 0 : (wave == NPW ? 1 : 2)];
-        o[0] = clock64() - pt_start; o[1] = pt_wait;
+        o[0] = clock64() - pt_start; o[1] = pt_wait; o[2] = pt_mem; o[3] = pt_lds; o[4] = pt_mf;
     }
 #endif
 #undef PSYNC
@@ -938,7 +955,7 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
                 static int calls = 0;
                 if (++calls == 8)
                     for (int r = 0; r < 3; ++r)
-                        fprintf(stderr, "[persist timing, cycles of WG 17] %s: total %lld | barrier wait %lld\n", r == 0 ? "pair" : (r == 1 ? "A   " : "C   "), h[r][0], h[r][1]);
+                        fprintf(stderr, "[persist timing, cycles of WG 17] %s: total %lld | barrier wait %lld | waiting for its fragment loads %lld | (C) LDS reads %lld, scale + MFMA issue %lld\n", r == 0 ? "pair" : (r == 1 ? "A   " : "C   "), h[r][0], h[r][1], h[r][2], h[r][3], h[r][4]);
             }
 #endif
             return ABOPT_OK;
