@@ -460,6 +460,18 @@ def test_c_abi_error_paths():
         inp, keep = hip.encode_inputs(b['aa'], b['res_nb'], b['chain_nb'], b['pos_heavyatom'], b['mask_heavyatom'], 2, fragment_type=b['fragment_type'])
         m = build_model(10, 3, device=DEV)
         hip.pair_embed_forward(inp, m.pair_embed._hip_weights())
+    # the piecewise tail entry points (training path): NULL tensors and a negative row count are rejected, zero rows are a no-op
+    f = hip.ptr
+    t_, _ = blk.packed()
+    o128 = torch.empty(16, 128, device=DEV)
+    tail = lambda feat, rows: L_.abopt_block_tail_forward(feat, f(t_['w_out_frag']), f(t_['w_mlp_frag']), f(x), f(t_['b_out']), f(mask), f(t_['ln1_gamma']),
+                                                          f(t_['ln1_beta']), f(t_['b_mlp0']), f(t_['b_mlp1']), f(t_['b_mlp2']), f(t_['ln2_gamma']), f(t_['ln2_beta']),
+                                                          f(o128), None, rows, hip.stream())
+    assert tail(None, 16) == 1 and b'NULL' in L_.abopt_last_error()                    # ABOPT_EINVAL
+    assert tail(None, -1) == 1
+    assert tail(None, 0) == 0
+    assert L_.abopt_pack_tail_weights(f(t_['w_out']), None, None, None, None, None, None, hip.stream()) == 1
+    assert L_.abopt_block_tail_backward(None, None, None, None, None, None, None, None, None, None, 16, hip.stream()) == 1
 
 
 def test_sample_init_vs_reference():
