@@ -196,8 +196,9 @@ int launch_fused_ln_mlp(const float* x, const float* u, int nslab, int64_t slab_
 // out_transform + tail in ONE launch:  out = LN2(y + MLP(y)),  y = LN1(x + mask * (feat W_out^T + b_out))      (ga.py:174-177)
 // Replaces the split-K out_transform GEMM (two 4 MB partial slabs written and re-read) + fused_ln_mlp.  One 1024-thread workgroup
 // (16 waves, 4 per SIMD) owns 32 residues.  Every contraction runs on the bf16 matrix pipe with exact three-term splits of both fp32
-// operands (six v_mfma_f32_32x32x16_bf16 per 16 k; node_frags.hip explains the arithmetic); all weights arrive already split, in
-// MFMA operand order (packed once by the host), straight from L2 into registers -- no weight staging through LDS.
+// operands (six v_mfma_f32_32x32x16_bf16 per 16 k; node_frags.hip explains the arithmetic); all weights arrive in MFMA operand
+// order (packed once), straight from L2 into registers -- no weight staging through LDS.  W_out streams as fp32 and is split in
+// registers (2/3 of the bytes of the pre-split form: 41.9 -> 39.6 us on the same box), the small MLP layers arrive pre-split.
 // Phase 1: u[32,128] = feat[32,1824] . W_out^T.  Wave (cb, kg) owns output columns 32 cb .. 32 cb + 31 of all 32 rows for k-steps
 // 3 kg .. 3 kg + 2 of every 192-column chunk (operands one chunk ahead in registers); the feat chunk is split ONCE by the loader
 // threads and staged in LDS as three bf16 planes (double buffered, one barrier per chunk) shared by all waves.
@@ -317,13 +318,11 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
         *reinterpret_cast<u32x4*>(d) = sp.h; *reinterpret_cast<u32x4*>(d + OT_PLANE) = sp.m; *reinterpret_cast<u32x4*>(d + 2 * OT_PLANE) = sp.l;
     };
     const int cb = wave & 3, kg = wave >> 2;
-    // this wave's operand stream: [cb][k-step][term][lane] vectors of 8 bf16, lane (column lane & 31, k half lane >> 5)
-    const u32x4* wfr = reinterpret_cast<const u32x4*>(wof) + (int64_t)cb * OT_ST * 192 + lane;
-    u32x4 wq[OT_SPW][3];
+    // this wave's W_out stream: fp32 in operand order, [cb][k-step][lane][8 floats], lane (column lane & 31, k half lane >> 5); split here
+    const f32x4* wfr = reinterpret_cast<const f32x4*>(wof) + ((int64_t)cb * OT_ST * 64 + lane) * 2;
+    f32x4 wq[OT_SPW][2];
 #pragma unroll
-    for (int j = 0; j < OT_SPW; ++j)
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) wq[j][sp] = wfr[(kg * OT_SPW + j) * 192 + sp * 64];
+    for (int j = 0; j < OT_SPW; ++j) { wq[j][0] = wfr[(kg * OT_SPW + j) * 128]; wq[j][1] = wfr[(kg * OT_SPW + j) * 128 + 1]; }
     f32x4 fv0 = (f32x4){0.f, 0.f, 0.f, 0.f}, fv1 = fv0;
     if (chunk_ok(0)) {
         fv0 = *reinterpret_cast<const f32x4*>(fsrc); fv1 = *reinterpret_cast<const f32x4*>(fsrc + 4);
@@ -343,10 +342,10 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
 #pragma unroll
             for (int j = 0; j < OT_SPW; ++j) {
                 const int64_t nst = min((c + 1) * OT_SPC + kg * OT_SPW + j, OT_ST - 1);               // next chunk's k-step of this slot (past the end: a reload)
-                const u32x4 wH = wq[j][0], wM = wq[j][1], wL = wq[j][2];
+                const Split3 w3 = split3(wq[j][0], wq[j][1]);
+                const u32x4 wH = w3.h, wM = w3.m, wL = w3.l;
 #if !(OT_ABL & 1)
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp) wq[j][sp] = wfr[nst * 192 + sp * 64];
+                wq[j][0] = wfr[nst * 128]; wq[j][1] = wfr[nst * 128 + 1];
 #endif
                 const char* xp = xrd + b * OT_STAGE + j * 32;
 #if OT_ABL & 8
@@ -469,7 +468,7 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
 #endif
 }
 
-size_t out_wfrag_floats() { return (size_t)F * OT_K * 3 / 2; }      // three bf16 per weight
+size_t out_wfrag_floats() { return (size_t)F * OT_K; }
 size_t mlp_wfrag_floats() { return (size_t)3 * F * F * 3 / 2; }
 
 template <bool DUMP>
@@ -534,6 +533,11 @@ __global__ __launch_bounds__(256) void pack_tail_weights_kernel(const float* __r
     f32x4 lo, hi;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { lo[i] = p[(int64_t)i * cs]; hi[i] = p[(int64_t)(i + 4) * cs]; }
+    if (src == w_out) {                                                          // W_out stays fp32 (the tail kernel splits it in registers)
+        f32x4* d32 = reinterpret_cast<f32x4*>(wof) + ((int64_t)(cb * steps + st) * 64 + lane) * 2;
+        d32[0] = lo; d32[1] = hi;
+        return;
+    }
     const Split3 sp = split3(lo, hi);
     u32x4* d = dst + ((int64_t)(cb * steps + st) * 3) * 64 + lane;
     d[0] = sp.h; d[64] = sp.m; d[128] = sp.l;

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -261,8 +261,8 @@ def pack_heads_weights(w_head1, w_crd2, w_rot2, w_seq2, w_crd3, w_rot3, w_seq3):
 
 
 def pack_out_weights(w_out):
-    """w_out [128, 1824] -> w_out_frag [4, 114, 3, 64, 4] (include/abopt.h: abopt_ga_weights.w_out_frag)."""
-    return pack_mfma_operand(w_out)
+    """w_out [128, 1824] -> w_out_frag [4, 114, 64, 8] fp32 in operand order (include/abopt.h: abopt_ga_weights.w_out_frag)."""
+    return w_out.float().reshape(4, 32, 114, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
 def pack_mlp_weights(w0, w1, w2):

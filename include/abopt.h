@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 22
+#define ABOPT_ABI_VERSION 23
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -59,11 +59,12 @@ typedef struct {
     const float* w_node_frag;   /* optional [12, 12, 4, 3, 64, 4]: w_node re-laid out per head in MFMA operand order, every weight as its three
                                    bf16 terms (layout below); when given, the fused projection kernel replaces the GEMM + fragment pass
                                    (same results up to fp32 summation order) */
-    const float* w_out_frag;    /* optional [4, 114, 3, 64, 4]: w_out in MFMA operand order as three bf16 terms per weight (h + m + l == w, as
-                                   w_node_frag): [cb][s][term][lane = 32 kh + c] is a 16-byte vector of 8 bf16, entry i = term(w_out[32 cb + c][16 s + 8 kh + i]);
+    const float* w_out_frag;    /* optional [4, 114, 64, 8]: w_out as fp32 in MFMA operand order: [cb][s][lane = 32 kh + c][i] = w_out[32 cb + c][16 s + 8 kh + i]
+                                   (the kernel splits it into bf16 terms in registers);
                                    when given together with w_mlp_frag, out_transform runs inside the LayerNorm/MLP kernel (no split-K partial slabs) */
-    const float* w_mlp_frag;    /* optional [3, 4, 8, 3, 64, 4]: w_mlp0, w_mlp1, w_mlp2 in the same operand order and term split as w_out_frag
-                                   ([layer][cb][s][term][lane]); the fused tail kernel reads its weights from here */
+    const float* w_mlp_frag;    /* optional [3, 4, 8, 3, 64, 4]: w_mlp0, w_mlp1, w_mlp2 in the same operand order, every weight as three bf16 terms
+                                   (h + m + l == w, as w_node_frag): [layer][cb][s][term][lane] is a 16-byte vector of 8 bf16, entry i =
+                                   term(w[32 cb + c][16 s + 8 kh + i]); the fused tail kernel reads its weights from here */
 } abopt_ga_weights;
 
 /* Host-side description of the w_node_frag layout (used by the binding to pack weights once): for head h, tile T (0,1 q | 2,3 k |
