@@ -16,6 +16,13 @@ void set_error(const char* fmt, ...);
     ::abopt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return ABOPT_EHIP; } } while (0)
 #define ABOPT_LAUNCH_CHECK() ABOPT_HIP(hipGetLastError())
 
+// Per-DEVICE launch state (api.hip).  One process may drive several GPUs (`with torch.cuda.device(...)`): the CU count and the
+// "this kernel may use > 64 KB of dynamic LDS" attribute belong to the device that is current at the launch, not to the first one seen.
+constexpr int kMaxDevices = 64;
+struct LdsConfig { size_t bytes[kMaxDevices] = {}; };       // one static instance per kernel: bytes already granted, by device ordinal
+int device_cu_count(int* cus);                               // CUs of the current device (cached per ordinal, thread-safe)
+int ensure_dynamic_lds(const void* kernel, size_t bytes, LdsConfig& cfg);
+
 // Lanes of ONE wave exchanging data through LDS (write, then read what other lanes wrote): the hardware executes a wave's
 // LDS instructions in order, but the compiler may reorder a ds_read above a ds_write it cannot prove aliased.  This pins the
 // order at wavefront scope (no s_barrier; at most an s_waitcnt).

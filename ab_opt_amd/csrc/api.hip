@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include "ipa_common.h"
 #include "kernels.h"
 
@@ -13,6 +14,33 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+static std::mutex g_dev_mu;
+int device_cu_count(int* cus) {
+    static int cached[kMaxDevices] = {};
+    int dev = 0;
+    ABOPT_HIP(hipGetDevice(&dev));
+    ABOPT_CHECK_ARG(dev >= 0 && dev < kMaxDevices, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (!cached[dev]) {
+        hipDeviceProp_t prop;
+        ABOPT_HIP(hipGetDeviceProperties(&prop, dev));
+        cached[dev] = prop.multiProcessorCount;
+    }
+    *cus = cached[dev];
+    return ABOPT_OK;
+}
+int ensure_dynamic_lds(const void* kernel, size_t bytes, LdsConfig& cfg) {
+    int dev = 0;
+    ABOPT_HIP(hipGetDevice(&dev));
+    ABOPT_CHECK_ARG(dev >= 0 && dev < kMaxDevices, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (bytes > cfg.bytes[dev]) {
+        ABOPT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        cfg.bytes[dev] = bytes;
+    }
+    return ABOPT_OK;
 }
 
 // bump allocator over the caller's workspace, 256-byte aligned carves

@@ -26,6 +26,7 @@ __device__ __forceinline__ float torch_linspace(float a, float b, int steps, int
 
 // one workgroup per sample n; threads stride over residues; block-reduce the two per-sample scalars.
 __global__ __launch_bounds__(256) void denoise_step_kernel(abopt_step_params sp, abopt_step_noise nz, uint64_t seed, uint64_t offset,
+                                                           const uint64_t* __restrict__ seed_dev,
                                                            const float* __restrict__ v_t, const float* __restrict__ p_t,
                                                            const int64_t* __restrict__ s_t, const float* __restrict__ v_net,
                                                            const float* __restrict__ p_net, const float* __restrict__ c_net,
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void denoise_step_kernel(abopt_step_params sp,
                                                            float* __restrict__ p_next_norm, int L, int ppl_masked) {
     const int n = blockIdx.x, tid = threadIdx.x;
     const bool injected = nz.axis != nullptr;
+    if (seed_dev) { seed = seed_dev[0]; offset = seed_dev[1]; }     // graph replays: the stream position comes from device memory
     const Philox rng(seed);
     float ppl_num = 0.f, ppl_den = 0.f;
 
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void sample_init_kernel(const float* __restric
 __global__ __launch_bounds__(256) void add_noise_kernel(const int64_t* __restrict__ t, const float* __restrict__ alpha_bars,
                                                         const float* __restrict__ fstd, const uint8_t* __restrict__ fapprox,
                                                         const float* __restrict__ fX, const float* __restrict__ fcdf, int bins,
-                                                        abopt_addnoise_noise nz, uint64_t seed, uint64_t offset,
+                                                        abopt_addnoise_noise nz, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ seed_dev,
                                                         const float* __restrict__ v_0, const float* __restrict__ p_0, const int64_t* __restrict__ s_0,
                                                         const uint8_t* __restrict__ mask_generate, float scale, float m0, float m1, float m2,
                                                         int noise_structure, int noise_sequence, int grad_mode,
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const int64_t* __restric
         ex = nz.pos[i * 3]; ey = nz.pos[i * 3 + 1]; ez = nz.pos[i * 3 + 2];
         useq = 0.f;
     } else {
+        if (seed_dev) { seed = seed_dev[0]; offset = seed_dev[1]; }
         const Philox rng(seed);
         const uint4 r0 = rng(offset + (uint64_t)i, 0xA00000ull), r1 = rng(offset + (uint64_t)i, 0xA00001ull), r2 = rng(offset + (uint64_t)i, 0xA00002ull);
         float d0;
@@ -293,6 +296,9 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const int64_t* __restric
             sn = KAA - 1;
             for (int k = 0; k < KAA; ++k) { cum += c[k]; if (cum > target) { sn = k; break; } }
         }
+    } else if (c_noisy) {
+#pragma unroll
+        for (int k = 0; k < KAA; ++k) c_noisy[i * KAA + k] = (s0 == k) ? 1.f : 0.f;      // c_0 = clampped_one_hot(s_0), transition.py:189
     }
     s_noisy[i] = sn;
 }
@@ -322,7 +328,7 @@ extern "C" int abopt_denoise_step(const abopt_step_params* sp, const abopt_step_
                                   const float* v_net, const float* p_net, const float* c_net, const float* prmsd_logits,
                                   const uint8_t* mask_generate, const float* igso3_X, const float* igso3_cdf, int igso3_bins, int num_bins,
                                   float* v_next, float* p_next, int64_t* s_next, float* prmsd, float* perplexity,
-                                  float* post_out, float* p_next_norm, int N, int L, abopt_stream stream) {
+                                  float* post_out, float* p_next_norm, const uint64_t* seed_offset_dev, int N, int L, abopt_stream stream) {
     ABOPT_CHECK_ARG(sp && v_t && p_t && s_t && v_net && p_net && c_net && mask_generate && v_next && p_next && s_next, "denoise_step: NULL argument");
     ABOPT_CHECK_ARG(igso3_X && igso3_bins >= 2, "denoise_step: IGSO(3) histogram row missing");
     abopt_step_noise nz = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -333,7 +339,7 @@ extern "C" int abopt_denoise_step(const abopt_step_params* sp, const abopt_step_
         ABOPT_CHECK_ARG(igso3_cdf, "denoise_step: device RNG path needs the CDF row");
     }
     if (N == 0 || L == 0) return ABOPT_OK;
-    hipLaunchKernelGGL(denoise_step_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, *sp, nz, seed, offset, v_t, p_t, s_t, v_net, p_net, c_net,
+    hipLaunchKernelGGL(denoise_step_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, *sp, nz, seed, offset, seed_offset_dev, v_t, p_t, s_t, v_net, p_net, c_net,
                        prmsd_logits, mask_generate, igso3_X, igso3_cdf, igso3_bins, num_bins, v_next, p_next, s_next, prmsd, perplexity, post_out,
                        p_next_norm, L, sp->ppl_masked);
     ABOPT_LAUNCH_CHECK();
@@ -360,7 +366,8 @@ extern "C" int abopt_add_noise(const int64_t* t, const float* alpha_bars, const 
                                const abopt_addnoise_noise* noise, uint64_t seed, uint64_t offset,
                                const float* v_0, const float* p_0, const int64_t* s_0, const uint8_t* mask_generate,
                                float position_scale, const float* position_mean, int noise_structure, int noise_sequence, int grad_mode,
-                               float* v_noisy, float* p_noisy, int64_t* s_noisy, float* eps_p, float* c_noisy, int N, int L, abopt_stream stream) {
+                               float* v_noisy, float* p_noisy, int64_t* s_noisy, float* eps_p, float* c_noisy, const uint64_t* seed_offset_dev,
+                               int N, int L, abopt_stream stream) {
     ABOPT_CHECK_ARG(t && alpha_bars && fwd_stddevs && fwd_approx && fwd_X && v_0 && p_0 && s_0 && mask_generate && position_mean &&
                     v_noisy && p_noisy && s_noisy && bins >= 2 && num_sched >= 1, "add_noise: bad arguments");
     abopt_addnoise_noise nz = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -373,7 +380,7 @@ extern "C" int abopt_add_noise(const int64_t* t, const float* alpha_bars, const 
     const int64_t rows = (int64_t)N * L;
     if (rows == 0) return ABOPT_OK;
     hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, alpha_bars, fwd_stddevs, fwd_approx,
-                       fwd_X, fwd_cdf, bins, nz, seed, offset, v_0, p_0, s_0, mask_generate, position_scale, position_mean[0], position_mean[1],
+                       fwd_X, fwd_cdf, bins, nz, seed, offset, seed_offset_dev, v_0, p_0, s_0, mask_generate, position_scale, position_mean[0], position_mean[1],
                        position_mean[2], noise_structure, noise_sequence, grad_mode, v_noisy, p_noisy, s_noisy, eps_p, c_noisy, L, rows);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;

@@ -87,6 +87,7 @@ __device__ double fit_and_rmsd(const float* __restrict__ mp, const float* __rest
             cnt += 1;
         }
     const double n = block_sum(cnt, red);
+    if (n < 0.5) return -1.0;                                                   // nothing to superimpose (block-uniform): undefined, see abopt.h
     double cx[3], cy[3];
     for (int k = 0; k < 3; ++k) { cx[k] = block_sum(sx[k], red) / n; cy[k] = block_sum(sy[k], red) / n; }
     double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                                 // S[a][b] = sum (y_a - cy_a)(x_b - cx_b)
@@ -119,7 +120,7 @@ __device__ double fit_and_rmsd(const float* __restrict__ mp, const float* __rest
             m += 1;
         }
     const double tot = block_sum(ss, red), mm = block_sum(m, red);
-    return sqrt(tot / mm);
+    return mm < 0.5 ? -1.0 : sqrt(tot / mm);
 }
 
 // one workgroup per candidate: Fnat (fnat.c:225-243), iRMS (DockQ.py:296-301), LRMS (DockQ.py:303-366), DockQ (:378)
@@ -157,7 +158,9 @@ __global__ __launch_bounds__(256) void dockq_model_kernel(const float* __restric
         out[s * 4 + 0] = (float)fnat;
         out[s * 4 + 1] = (float)irms;
         out[s * 4 + 2] = (float)lrms;
-        out[s * 4 + 3] = (float)((fnat + 1.0 / (1.0 + (irms / 1.5) * (irms / 1.5)) + 1.0 / (1.0 + (lrms / 8.5) * (lrms / 8.5))) / 3.0);
+        // an empty interface / receptor / ligand selection has no RMSD (calc_DockQ asserts there, DockQ.py:150-188,296-366): -1 marks it
+        out[s * 4 + 3] = (irms < 0 || lrms < 0) ? -1.f
+                                                : (float)((fnat + 1.0 / (1.0 + (irms / 1.5) * (irms / 1.5)) + 1.0 / (1.0 + (lrms / 8.5) * (lrms / 8.5))) / 3.0);
     }
 }
 

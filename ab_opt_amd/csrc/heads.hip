@@ -190,11 +190,8 @@ __global__ __launch_bounds__(HTH) void mixer_kernel(const float* __restrict__ re
 int launch_mixer(const float* res_feat, const int64_t* s_t, const float* wfrag, const float* table, const float* b1, float* x_out, int64_t rows,
                  hipStream_t st) {
     if (rows == 0) return ABOPT_OK;
-    static bool configured = false;
-    if (!configured) {
-        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mixer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HeadsSmem)));
-        configured = true;
-    }
+    static LdsConfig lds_cfg;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(mixer_kernel), sizeof(HeadsSmem), lds_cfg)) return rc;
     hipLaunchKernelGGL(mixer_kernel, dim3((unsigned)((rows + HR - 1) / HR)), dim3(HTH), sizeof(HeadsSmem), st, res_feat, s_t, wfrag, table, b1, x_out, rows);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
@@ -207,11 +204,8 @@ int launch_heads_mlp(const float* xe, const float* beta, const float* wfrag, con
                      const float* b2r, const float* b2s, const float* b3c, const float* b3r, const float* b3s, float* out3, int64_t rows, int L,
                      hipStream_t st) {
     if (rows == 0) return ABOPT_OK;
-    static bool configured = false;
-    if (!configured) {
-        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HeadsSmem)));
-        configured = true;
-    }
+    static LdsConfig lds_cfg;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(heads_mlp_kernel), sizeof(HeadsSmem), lds_cfg)) return rc;
     hipLaunchKernelGGL(heads_mlp_kernel, dim3((unsigned)((rows + HR - 1) / HR)), dim3(HTH), sizeof(HeadsSmem), st, xe, beta, wfrag, w1, ld1, b1,
                        b2c, b2r, b2s, b3c, b3r, b3s, out3, rows, L);
     ABOPT_LAUNCH_CHECK();

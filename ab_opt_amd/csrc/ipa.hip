@@ -185,12 +185,12 @@ int launch_ipa_core(const float* qfrag, const float* kvfrag, const float* z, con
 }  // namespace abopt
 
 extern "C" int abopt_prof_enable(int on) {
-    abopt::prof::g_on = on != 0;
-    abopt::prof::g_used = 0;
+    abopt::prof::g_on = on == 1;
+    if (on != 2) abopt::prof::g_used = 0;        // 2: stop bracketing new launches but keep the recorded pairs (see abopt_prof_peek)
     return ABOPT_OK;
 }
 
-extern "C" int abopt_prof_collect(int* launches, double* total_ms) {
+static int prof_sum(int* launches, double* total_ms, bool reset) {
     double tot = 0.0;
     for (size_t i = 0; i < abopt::prof::g_used; ++i) {
         float ms = 0.f;
@@ -200,6 +200,9 @@ extern "C" int abopt_prof_collect(int* launches, double* total_ms) {
     }
     if (launches) *launches = (int)abopt::prof::g_used;
     if (total_ms) *total_ms = tot;
-    abopt::prof::g_used = 0;
+    if (reset) abopt::prof::g_used = 0;
     return ABOPT_OK;
 }
+extern "C" int abopt_prof_collect(int* launches, double* total_ms) { return prof_sum(launches, total_ms, true); }
+// the same without forgetting the pairs: event records captured into a hipGraph are re-recorded by every replay
+extern "C" int abopt_prof_peek(int* launches, double* total_ms) { return prof_sum(launches, total_ms, false); }

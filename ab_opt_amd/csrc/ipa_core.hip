@@ -892,11 +892,8 @@ static int launch_core_variant(const float* qfrag, const float* kvfrag, const fl
     const int nib = (L + BI - 1) / BI, nchunk = (L + JC - 1) / JC;
     const size_t lds = core_lds_fixed_bytes<CACHED>() + (size_t)nchunk * JC;
     ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core: L=%d needs %zu bytes of LDS for the key mask (max 163840)", L, lds);
-    static size_t configured = 0;                                           // per instantiation
-    if (lds > configured) {
-        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_core_kernel<DUMP, CACHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    static LdsConfig lds_cfg;                                               // per instantiation
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core_kernel<DUMP, CACHED>), lds, lds_cfg)) return rc;
     prof::begin(st);
     hipLaunchKernelGGL((ipa_core_kernel<DUMP, CACHED>), dim3((unsigned)(N * nib)), dim3(NTH), lds, st, qfrag, kvfrag, z, mask, R, t, Wb, feat, dump, dump_stats, pbc,
                        N, L, nib, (N % 8 == 0) ? 1 : 0, z_shared);
@@ -924,24 +921,16 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
     ABOPT_CHECK_ARG(!dump || (int64_t)H * L * L * 4 < (1ll << 31), "ipa_core: L=%d too long for the logits dump", L);
     if (pair_bias_cache && !dump) {
         const int nib = (L + BI - 1) / BI, nchunk = (L + JC - 1) / JC;
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            ABOPT_HIP(hipGetDevice(&dev));
-            hipDeviceProp_t prop;
-            ABOPT_HIP(hipGetDeviceProperties(&prop, dev));
-            cus = prop.multiProcessorCount & ~7;                              // a multiple of 8 keeps blockIdx & 7 = XCD for every block of a workgroup
-        }
+        int cus = 0;
+        if (int rc = device_cu_count(&cus)) return rc;
+        cus &= ~7;                                                          // a multiple of 8 keeps blockIdx & 7 = XCD for every block of a workgroup
         const int total = N * nib;
 #ifndef CORE_NO_PERSIST      // developer A/B switch
         if (nchunk >= 2 && cus >= 8 && total > cus && !CORE_ABL) {
             const size_t lds = sizeof(float) * (3 * BI * SROW + H * 4 * 64 * 4 + 2 * BI * SCLD + BI * SCLD + BI * H * P * 3) + 2 * (size_t)nchunk * JC;
             ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core: L=%d needs %zu bytes of LDS for the key masks (max 163840)", L, lds);
-            static size_t configured = 0;
-            if (lds > configured) {
-                ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_core_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                configured = lds;
-            }
+            static LdsConfig lds_cfg;
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core_persist_kernel), lds, lds_cfg)) return rc;
             prof::begin(st);
             hipLaunchKernelGGL(ipa_core_persist_kernel, dim3((unsigned)cus), dim3(NTH), lds, st, qfrag, kvfrag, z, mask, R, t, feat, pair_bias_cache, L, nib, total,
                                (N % 8 == 0) ? 1 : 0, z_shared);

@@ -475,11 +475,8 @@ template <bool DUMP>
 static int launch_out_ln_mlp_t(const float* feat, const float* wof, const float* wmf, const float* x, const float* ubias, const uint8_t* mask,
                                const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2, const float* be2,
                                float* out, float* dump, int64_t rows, hipStream_t st) {
-    static bool configured = false;
-    if (!configured) {
-        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(out_ln_mlp_kernel<DUMP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OtSmem)));
-        configured = true;
-    }
+    static LdsConfig lds_cfg;                                               // per instantiation
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(out_ln_mlp_kernel<DUMP>), sizeof(OtSmem), lds_cfg)) return rc;
     hipLaunchKernelGGL(out_ln_mlp_kernel<DUMP>, dim3((unsigned)((rows + MR - 1) / MR)), dim3(OT_TH), sizeof(OtSmem), st, feat, wof, wmf, x, ubias, mask,
                        g1, be1, b0, b1, b2, g2, be2, out, dump, rows);
     ABOPT_LAUNCH_CHECK();
@@ -694,11 +691,8 @@ __global__ __launch_bounds__(OT_TH) void tail_backward_kernel(const float* __res
 int launch_tail_backward(const float* dout, const float* saved, const float* wmt, const uint8_t* mask, const float* g1, const float* g2,
                          float* dpre, float* da1, float* du, float* colpart, int64_t rows, hipStream_t st) {
     if (rows == 0) return ABOPT_OK;
-    static bool configured = false;
-    if (!configured) {
-        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TbSmem)));
-        configured = true;
-    }
+    static LdsConfig lds_cfg;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(tail_backward_kernel), sizeof(TbSmem), lds_cfg)) return rc;
     hipLaunchKernelGGL(tail_backward_kernel, dim3((unsigned)((rows + MR - 1) / MR)), dim3(OT_TH), sizeof(TbSmem), st, dout, saved, wmt, mask, g1, g2,
                        dpre, da1, du, colpart, rows);
     ABOPT_LAUNCH_CHECK();

@@ -205,15 +205,10 @@ int launch_node_frags(const float* x, const float* wfrag, const float* R, const 
                       int N, int L, hipStream_t st) {
     if ((int64_t)N * L == 0) return ABOPT_OK;
     const int nchunk = (L + JC - 1) / JC, total = N * nchunk;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        ABOPT_HIP(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        ABOPT_HIP(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount;
-        ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(node_frags_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NF_HEAD_VEC * 16));
-    }
+    int cus = 0, rc;
+    if ((rc = device_cu_count(&cus))) return rc;
+    static LdsConfig lds_cfg;
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(node_frags_kernel), NF_HEAD_VEC * 16, lds_cfg))) return rc;
     const int ntask = 2 * ((total + 1) / 2);
     const int groups = max(1, min(cus / H, (ntask + NF_WAVES - 1) / NF_WAVES));          // one workgroup per CU: 144 KB of LDS each
     hipLaunchKernelGGL(node_frags_kernel, dim3(groups, H), dim3(NF_WAVES * 64), NF_HEAD_VEC * 16, st, x, wfrag, R, t, spatial_coef,

@@ -7,7 +7,10 @@ deliberate and MI355X-first:
     copied to the host once, after the last step (the reference does a D2H of every state per step,
     dpm_full.py:300);
   * noise comes from a counter-based Philox stream inside the transition kernel, or is injected
-    (`noise=`) to replay a recorded reference run.
+    (`noise=`) to replay a recorded reference run;
+  * the loop can be captured ONCE into a hipGraph and replayed (`graph=True`, or automatically from the second call with the same
+    shapes and options): every per-step scalar is a kernel argument baked into its node, the Philox stream position is read from a
+    16-byte device buffer at execution time, inputs are copied into the graph's static buffers before a replay.
 """
 import functools
 import torch
@@ -38,6 +41,14 @@ class FullDPM(nn.Module):
         if self.abdock:
             self.prmsd = pRMSDCa(num_bins, dist_min=dist_min, dist_max=dist_max)
         self._host_sched = None
+        self._graphs, self._graph_seen = {}, set()
+        self.graph_mode = 'auto'          # 'auto': eager first, captured from the second call with the same signature; True / False
+
+    def __getstate__(self):
+        """Captured graphs and host-side caches are per-process objects: a pickled / deep-copied model starts without them."""
+        d = dict(self.__dict__)
+        d['_graphs'], d['_graph_seen'], d['_host_sched'] = {}, set(), None
+        return d
 
     # ------------------------------------------------------------------ helpers
     def _normalize_position(self, p):
@@ -90,8 +101,47 @@ class FullDPM(nn.Module):
 
     # ------------------------------------------------------------------ sampling
     def _run(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
-             ppl_masked, noise, seed, rng_offset, pbar, stop_after=None, optimize_mode=False, use_bias_cache=None):
-        """Denoise from step t_start down to 0.  state = (v, p_angstrom, s) on device."""
+             ppl_masked, noise, seed, rng_offset, pbar, stop_after=None, optimize_mode=False, use_bias_cache=None, graph=None):
+        """Denoise from step t_start down to 0.  state = (v, p_angstrom, s) on device.  graph: None = self.graph_mode."""
+        graph = self.graph_mode if graph is None else graph
+        if noise is not None or pbar or not graph or not res_feat.is_cuda:     # (a CPU tensor reaches hip.ptr()'s "no CPU path" error)
+            return self._run_eager(state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
+                                   ppl_masked, noise, seed, rng_offset, pbar, stop_after, optimize_mode, use_bias_cache)
+        N, L = mask_res.shape
+        shared = pair_feat.shape[0] == 1 and N > 1
+        if use_bias_cache is None:
+            use_bias_cache = shared or self._bias_cache_fits(pair_feat.shape[0], L, res_feat.device, graph=True)
+        self.eps_net.packed()
+        key = (res_feat.device.index, N, L, t_start, stop_after, bool(sample_structure), bool(sample_sequence), bool(ppl_masked),
+               bool(optimize_mode), tuple(res_feat.shape), tuple(pair_feat.shape), bool(use_bias_cache), id(self.eps_net._pack))
+        g = self._graphs.get(key)
+        if g is None:
+            if graph == 'auto' and key not in self._graph_seen:         # a one-off call should not pay for a capture
+                self._graph_seen.add(key)
+                return self._run_eager(state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
+                                       ppl_masked, noise, seed, rng_offset, pbar, stop_after, optimize_mode, use_bias_cache)
+            for k in [k for k, v in self._graphs.items() if v.pack is not self.eps_net._pack]:
+                del self._graphs[k]                                     # weights were repacked: those graphs point at dead copies
+            g = self._graphs[key] = _LoopGraph(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure,
+                                               sample_sequence, ppl_masked, stop_after, optimize_mode, use_bias_cache)
+        return g.replay(state, res_feat, pair_feat, mask_generate, mask_res, seed, rng_offset)
+
+    def _bias_cache_fits(self, n_pair, L, dev, graph=False):
+        """The cache costs num_layers * N * L^2 * 48 B next to pair_feat's N * L^2 * 256 B: take it when it fits comfortably
+        (a captured graph also keeps its own copy of pair_feat), otherwise the kernels compute the pair bias in place
+        (bit-identical, test_pair_bias_cache_is_bit_identical).  Free = what the driver reports + what torch's caching allocator
+        holds but is not using, so the choice does not depend on what ran before in this process."""
+        if dev.type != 'cuda':
+            return False
+        need = hip.pair_bias_cache_bytes(n_pair, L, len(self.eps_net.encoder.blocks))
+        if graph:
+            need += n_pair * L * L * 64 * 4
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        return need <= free // 2
+
+    def _run_eager(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
+                   ppl_masked, noise, seed, rng_offset, pbar, stop_after=None, optimize_mode=False, use_bias_cache=None, seed_dev=None):
+        """The loop itself, one C call per network evaluation and one per transition.  seed_dev: device {seed, offset} (graph capture)."""
         dev = res_feat.device
         N, L = mask_res.shape
         T0 = t_start
@@ -108,10 +158,7 @@ class FullDPM(nn.Module):
         # with batch stride 0, so the 100 x 6 passes over it are served from L2/MALL instead of HBM.
         shared = pair_feat.shape[0] == 1 and N > 1
         if use_bias_cache is None:
-            # the cache costs num_layers * N * L^2 * 48 B next to pair_feat's N * L^2 * 256 B: take it when it fits comfortably,
-            # otherwise the kernels compute the pair bias in place (bit-identical, test_pair_bias_cache_is_bit_identical)
-            need = hip.pair_bias_cache_bytes(pair_feat.shape[0], L, len(self.eps_net.encoder.blocks))
-            use_bias_cache = shared or need <= torch.cuda.mem_get_info(dev)[0] // 2
+            use_bias_cache = shared or self._bias_cache_fits(pair_feat.shape[0], L, dev)
         if shared and not use_bias_cache:
             raise ValueError('a shared pair_feat requires the pair-bias cache')
         if res_feat.shape[0] == 1 and N > 1:
@@ -148,7 +195,8 @@ class FullDPM(nn.Module):
                 out.update(prmsd=tpr[t - 1], ppl=tpp[t - 1])
             hip.denoise_step(sp, noise[t] if noise is not None else None, seed, rng_offset,
                              tv[t], tp[t], ts[t], net['v_next'], net['eps_pos'], net['c'], net['prmsd_logits'], mask_generate,
-                             X[t], cdf[t] if cdf is not None else None, self.num_bins, out)
+                             X[t], cdf[t] if cdf is not None else None, self.num_bins, out, seed_dev=seed_dev)
+        self.last_run_info = dict(bias_cache=bool(use_bias_cache), shared_context=bool(shared), graph=seed_dev is not None)
         return tv, tp, ts, tpr, tpp
 
     def _to_traj(self, T0, tv, tp, ts, tpr, tpp, first_extra):
@@ -162,7 +210,7 @@ class FullDPM(nn.Module):
             if self.abdock:
                 e += list(first_extra(hs[t - 1])) if t == T0 else [hpr[t], hpp[t]]
             traj[t] = e if self.abdock else tuple(e)
-        e0 = [tv[0], tp[0], ts[0]]
+        e0 = [tv[0].clone(), tp[0].clone(), ts[0].clone()]       # own storage: the buffers may be a captured graph's static ones
         if self.abdock:
             e0 += [hpr[0], hpp[0]]
         traj[0] = e0 if self.abdock else tuple(e0)
@@ -170,7 +218,7 @@ class FullDPM(nn.Module):
 
     @torch.no_grad()
     def sample(self, v, p, s, res_feat, pair_feat, mask_generate, mask_res, sample_structure=True, sample_sequence=True,
-               pbar=False, noise=None, seed=None, rng_offset=0, use_bias_cache=None, **kwargs):
+               pbar=False, noise=None, seed=None, rng_offset=0, use_bias_cache=None, graph=None, **kwargs):
         """dpm_full.py:236-302.  `noise` (optional) = {'init': {q4,p,s}, t: {axis,bin,ubin,gauss,z,s_next}} replays
         recorded draws; otherwise a Philox stream seeded from torch's CPU generator is used."""
         hip.lib()
@@ -180,13 +228,13 @@ class FullDPM(nn.Module):
                                 h['scale'], h['mean'], sample_structure, sample_sequence)
         T = self.num_steps
         out = self._run(state, T, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, True,
-                        noise, seed, rng_offset, pbar, use_bias_cache=use_bias_cache)
+                        noise, seed, rng_offset, pbar, use_bias_cache=use_bias_cache, graph=graph)
         # dpm_full.py:269: the first entry carries zeros_like(s) / ones_like(s) in the two extra slots
         return self._to_traj(T, *out, first_extra=lambda s_: (torch.zeros_like(s_), torch.ones_like(s_)))
 
     @torch.no_grad()
     def optimize(self, v, p, s, opt_step, res_feat, pair_feat, mask_generate, mask_res, sample_structure=True,
-                 sample_sequence=True, pbar=False, noise=None, seed=None, rng_offset=0, use_bias_cache=None):
+                 sample_sequence=True, pbar=False, noise=None, seed=None, rng_offset=0, use_bias_cache=None, graph=None):
         """dpm_full.py:304-367: noise the input to step `opt_step`, then denoise."""
         hip.lib()
         seed = self._new_seed() if seed is None else int(seed)
@@ -202,6 +250,53 @@ class FullDPM(nn.Module):
         # dpm_full.py:351-358: the loop feeds the net's third output to the position update as noise whatever `obj` is,
         # and averages the perplexity over all residues (calc_perplexity(logits) without a mask)
         out = self._run(state, opt_step, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, False,
-                        noise, seed, rng_offset + N * v.shape[1], pbar, optimize_mode=True, use_bias_cache=use_bias_cache)
+                        noise, seed, rng_offset + N * v.shape[1], pbar, optimize_mode=True, use_bias_cache=use_bias_cache, graph=graph)
         traj = self._to_traj(opt_step, *out, first_extra=lambda s_: (torch.zeros_like(s_), torch.ones_like(s_)))
         return {k: tuple(e) for k, e in traj.items()}
+
+
+class _LoopGraph:
+    """One captured denoising loop: static copies of the inputs, the hipGraph, and the trajectory buffers it writes.
+
+    Capture runs FullDPM._run_eager under torch.cuda.graph(): every launch of libabopt_hip.so goes to torch's current stream, which
+    is the capturing stream, and every tensor the loop allocates (trajectory, network outputs, pair-bias cache, workspace) comes from
+    the graph's private pool and keeps its address across replays.  Nothing in the loop reads device memory on the host."""
+
+    def __init__(self, dpm, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, ppl_masked,
+                 stop_after, optimize_mode, use_bias_cache):
+        dev = res_feat.device
+        self.pack = dpm.eps_net._pack                                   # keeps the packed weights this graph points at alive
+        self.state = tuple(a.clone() for a in state)
+        self.res_feat, self.pair_feat = res_feat.contiguous().float().clone(), pair_feat.contiguous().float().clone()
+        self.mask_generate, self.mask_res = mask_generate.contiguous().clone(), mask_res.contiguous().clone()
+        self.seed_dev = torch.zeros(2, dtype=torch.int64, device=dev)
+        args = (self.state, t_start, self.res_feat, self.pair_feat, self.mask_generate, self.mask_res, sample_structure, sample_sequence,
+                ppl_masked, None, 0, 0, False)
+        kw = dict(optimize_mode=optimize_mode, use_bias_cache=use_bias_cache, seed_dev=self.seed_dev)
+        hip.prof_enable(False)
+        dpm._run_eager(*args, stop_after=1, **kw)                       # warm: kernel attributes, host-side caches, cdf tables
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        before = set(hip.Workspace._bufs)
+        hip.prof_enable(hip.GRAPH_CAPTURE_EVENTS)                       # normally off: the measurement hook's event pairs stay out of the graph
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = dpm._run_eager(*args, stop_after=stop_after, **kw)
+        finally:
+            if hip.GRAPH_CAPTURE_EVENTS:
+                hip.lib().abopt_prof_enable(2)           # stop bracketing launches, keep the pairs the graph re-records
+        # the scratch slab the capture allocated on the capturing stream lives in this graph's pool: it must not serve another stream user
+        self.keep = [hip.Workspace._bufs.pop(k) for k in set(hip.Workspace._bufs) - before]
+        self.info = dict(dpm.last_run_info)
+
+    def replay(self, state, res_feat, pair_feat, mask_generate, mask_res, seed, rng_offset):
+        for dst, src in zip(self.state, state):
+            dst.copy_(src)
+        self.res_feat.copy_(res_feat.expand_as(self.res_feat))
+        if pair_feat.data_ptr() != self.pair_feat.data_ptr():
+            self.pair_feat.copy_(pair_feat)
+        self.mask_generate.copy_(mask_generate)
+        self.mask_res.copy_(mask_res)
+        self.seed_dev.copy_(torch.tensor([int(seed), int(rng_offset)], dtype=torch.int64))
+        self.graph.replay()
+        return self.out

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -72,7 +72,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect',
+           'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
@@ -115,15 +115,16 @@ def lib():
         L.abopt_pair_bias_cache.argtypes = [C.POINTER(GaWeights), C.c_int, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.abopt_denoise_step.argtypes = [C.POINTER(StepParams), C.POINTER(StepNoise), C.c_uint64, C.c_uint64,
                                          c_f, c_f, c_i64, c_f, c_f, c_f, c_f, c_u8, c_f, c_f, C.c_int, C.c_int,
-                                         c_f, c_f, c_i64, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
+                                         c_f, c_f, c_i64, c_f, c_f, c_f, c_f, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.abopt_sample_init.argtypes = [c_f, c_f, c_i64, c_u8, c_f, c_f, c_i64, C.c_uint64, C.c_uint64,
                                         C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, c_f, c_f, c_i64, C.c_int, C.c_int, C.c_void_p]
         L.abopt_commonness_score.argtypes = [c_f, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_add_noise.argtypes = [c_i64, c_f, c_f, c_u8, c_f, c_f, C.c_int, C.c_int, C.POINTER(AddNoiseNoise), C.c_uint64, C.c_uint64,
                                       c_f, c_f, c_i64, c_u8, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,
-                                      c_f, c_f, c_i64, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
+                                      c_f, c_f, c_i64, c_f, c_f, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.abopt_prof_enable.argtypes = [C.c_int]
         L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.abopt_prof_peek.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.abopt_reconstruct_backbone_partially.argtypes = [c_f, c_f, c_f, c_i64, c_i64, c_i64, c_u8, c_u8, c_f, c_f, c_f, c_u8] + [C.c_int] * 3 + [C.c_void_p]
         L.abopt_ipa_train_workspace_bytes.restype = C.c_size_t
         L.abopt_ipa_train_workspace_bytes.argtypes = [C.c_int] * 2
@@ -368,7 +369,8 @@ def pair_bias_cache(blocks_array, num_layers, pair_feat):
 
 
 def denoise_step(sp, noise, seed, offset, v_t, p_t, s_t, v_net, p_net, c_net, prmsd_logits, mask_generate,
-                 ig_X_row, ig_cdf_row, num_bins, out, want_post=False):
+                 ig_X_row, ig_cdf_row, num_bins, out, want_post=False, seed_dev=None):
+    """seed_dev (optional): int64 device tensor {seed, offset} read by the kernel in place of the two host values (graph replays)."""
     N, L = mask_generate.shape
     nz = None
     if noise is not None:
@@ -381,7 +383,8 @@ def denoise_step(sp, noise, seed, offset, v_t, p_t, s_t, v_net, p_net, c_net, pr
                                     ptr(prmsd_logits, optional=True), ptr(mask_generate, torch.bool),
                                     ptr(ig_X_row, torch.float32), ptr(ig_cdf_row, optional=True), ig_X_row.numel(), num_bins,
                                     ptr(out['v']), ptr(out['p']), ptr(out['s']), ptr(out.get('prmsd'), optional=True),
-                                    ptr(out.get('ppl'), optional=True), ptr(post, optional=True), ptr(out.get('p_norm'), optional=True), N, L, stream()))
+                                    ptr(out.get('ppl'), optional=True), ptr(post, optional=True), ptr(out.get('p_norm'), optional=True),
+                                    ptr(seed_dev, torch.int64, optional=True), N, L, stream()))
     return post
 
 
@@ -401,7 +404,7 @@ def sample_init(v, p, s, mask_generate, init_noise, seed, offset, scale, mean, s
 
 
 def add_noise(t, alpha_bars, fwd, noise, seed, offset, v_0, p_0, s_0, mask_generate, scale, mean,
-              noise_structure=True, noise_sequence=True, grad_mode=False, want_eps=False, want_probs=False):
+              noise_structure=True, noise_sequence=True, grad_mode=False, want_eps=False, want_probs=False, seed_dev=None):
     """fwd: ApproxAngularDistribution of the forward process (buffers stddevs, approx_flag, X + cdf())."""
     N, L = mask_generate.shape
     v_n, p_n, s_n = torch.empty_like(v_0), torch.empty_like(p_0), torch.empty_like(s_0)
@@ -419,7 +422,8 @@ def add_noise(t, alpha_bars, fwd, noise, seed, offset, v_0, p_0, s_0, mask_gener
                                  C.byref(nz) if nz is not None else None, seed, offset,
                                  ptr(v_0, torch.float32), ptr(p_0, torch.float32), ptr(s_0, torch.int64),
                                  ptr(mask_generate, torch.bool), float(scale), mean_arr, int(noise_structure), int(noise_sequence),
-                                 int(grad_mode), ptr(v_n), ptr(p_n), ptr(s_n), ptr(eps, optional=True), ptr(probs, optional=True), N, L, stream()))
+                                 int(grad_mode), ptr(v_n), ptr(p_n), ptr(s_n), ptr(eps, optional=True), ptr(probs, optional=True),
+                                 ptr(seed_dev, torch.int64, optional=True), N, L, stream()))
     out = (v_n, p_n, s_n) + ((eps,) if want_eps else ()) + ((probs,) if want_probs else ())
     return out
 
@@ -588,9 +592,11 @@ def reconstruct_backbone_partially(pos_ctx, R_new, t_new, aa, chain_nb, res_nb, 
     return pos_new, mask_new
 
 
-def dockq_lite(model_pos, model_mask, native_pos, native_mask, group):
+def dockq_lite(model_pos, model_mask, native_pos, native_mask, group, check=True):
     """DockQ of S candidates against one native (include/abopt.h: abopt_dockq_lite) -> (S, 4) = fnat, irms, Lrms, DockQ.
-    model_pos (S,L,A,3); model_mask (S,L,A) or (L,A) shared; native_pos (L,A,3); native_mask (L,A); group (L,) int {0,1,2}."""
+    model_pos (S,L,A,3); model_mask (S,L,A) or (L,A) shared; native_pos (L,A,3); native_mask (L,A); group (L,) int {0,1,2}.
+    check=True (one device read-back) raises, like the reference's asserts (DockQ.py:150-188), when a candidate has no CA atom
+    common to model and native in its interface, receptor or ligand; check=False leaves the kernel's -1 markers in place."""
     S, L, A, _ = model_pos.shape
     shared = model_mask.dim() == 2
     model_pos, model_mask, native_pos, native_mask = _contig(model_pos.float(), model_mask, native_pos.float(), native_mask)
@@ -600,6 +606,9 @@ def dockq_lite(model_pos, model_mask, native_pos, native_mask, group):
     buf = Workspace.get(nb, model_pos.device)
     _check(lib().abopt_dockq_lite(ptr(model_pos, torch.float32), ptr(model_mask, torch.bool), int(shared), ptr(native_pos, torch.float32),
                                   ptr(native_mask, torch.bool), ptr(group, torch.int32), S, L, A, ptr(out), ptr(buf), buf.numel(), stream()))
+    if check and S > 0 and bool((out[:, 1:3] < 0).any()):
+        bad = (out[:, 1:3] < 0).any(1).nonzero().flatten().tolist()
+        raise ValueError(f'dockq_lite: candidates {bad} have an empty interface / receptor / ligand CA selection (no atoms in both model and native)')
     return out
 
 
@@ -647,8 +656,12 @@ def prof_enable(on=True):
     _check(lib().abopt_prof_enable(int(on)))
 
 
-def prof_collect():
-    """(launches, total_ms) of the IPA-core kernel since prof_enable(True)."""
+GRAPH_CAPTURE_EVENTS = False      # bench.py experiment: keep the IPA-core event records inside a captured loop graph
+
+
+def prof_collect(keep=False):
+    """(launches, total_ms) of the IPA-core kernel since prof_enable(True).  keep=True: do not forget the event pairs (they were
+    captured into a hipGraph and every replay records them again)."""
     n, ms = C.c_int(), C.c_double()
-    _check(lib().abopt_prof_collect(C.byref(n), C.byref(ms)))
+    _check((lib().abopt_prof_peek if keep else lib().abopt_prof_collect)(C.byref(n), C.byref(ms)))
     return n.value, ms.value

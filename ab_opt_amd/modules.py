@@ -33,6 +33,11 @@ class LayerNorm(nn.Module):
         self.beta = nn.Parameter(torch.zeros(n))
 
 
+def _drop_packs(module, incompatible_keys):
+    """load_state_dict post-hook (a module-level function, so modules that carry it stay picklable)."""
+    module.invalidate_packed()
+
+
 def _snapshot(params):
     """Cheap fingerprint of a parameter list: rebuilt packs when a tensor is replaced, moved or updated in place."""
     return tuple((p.data_ptr(), p._version, p.device) for p in params)
@@ -100,6 +105,11 @@ class GABlock(nn.Module):
 
     def invalidate_packed(self):
         self._pack = None
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d['_pack'] = None
+        return d
 
     @torch.no_grad()
     def forward(self, R, t, x, z, mask, return_parts=False):
@@ -188,7 +198,7 @@ class EpsilonNet(nn.Module):
         self._pack = None
         # packed (kernel-layout) weight copies are keyed on (data_ptr, _version, device) of their sources; writes that bypass the
         # version counter (`p.data.copy_(ema)`) are invisible to that key, so the usual entry points drop the packs outright
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+        self.register_load_state_dict_post_hook(_drop_packs)
 
     def invalidate_packed(self):
         """Forget the kernel-layout weight copies (rebuilt at the next call).  Call after writing parameters through `.data`
@@ -198,8 +208,14 @@ class EpsilonNet(nn.Module):
             b.invalidate_packed()
 
     def train(self, mode=True):
-        self.invalidate_packed()
+        if bool(mode) != self.training:          # an actual train <-> eval switch (EMA swaps happen around these), not every .eval() call
+            self.invalidate_packed()
         return super().train(mode)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d['_pack'] = None                        # ctypes structs + device copies: rebuilt on first use
+        return d
 
     def _sources(self):
         ps = [p for n, p in self.named_parameters() if not n.startswith('encoder.')]

@@ -169,6 +169,8 @@ def wrap_ddp(model, device=None, **kw):
     the wrapper a multi-GPU launch adds around `get_model(cfg)`.  The custom autograd functions of the training path are ordinary
     torch.autograd.Function nodes, so DistributedDataParallel's hooks see their parameter gradients like any other."""
     from torch.nn.parallel import DistributedDataParallel as DDP
-    dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+    dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
     kw.setdefault('find_unused_parameters', True)      # the prmsd loss touches no parameter when mask_generate[:, 0] is all False
-    return DDP(model.to(dev), device_ids=[dev.index], **kw)
+    return DDP(model.to(dev), device_ids=[dev.index] if dev.type == 'cuda' else None, **kw)

@@ -152,3 +152,80 @@ def make_batch(n, layout=LAYOUT_256, seed=2022, lengths=None, replicate=False):
         return collate([one] * n)
     lengths = lengths or [None] * n
     return collate([make_complex(layout, seed + 7919 * i, lengths[i]) for i in range(n)])
+
+
+# ---------------------------------------------------------------------------- model + denoiser inputs (bench.py, smoke(), tests)
+MODEL_CFG_ABDOCK = dict(
+    type='diffab', res_feat_dim=128, pair_feat_dim=64,
+    diffusion=dict(num_steps=100, eps_net_opt=dict(num_layers=6), obj='pred_x0'),
+    train_structure=True, train_sequence=False, num_bins=40, dist_min=0.5, dist_max=19.5,
+)   # AbDock/configs/train/dock_single.yml:2-17
+
+
+def cfg_abdock(num_steps=100, **over):
+    c = {k: (dict(v) if isinstance(v, dict) else v) for k, v in MODEL_CFG_ABDOCK.items()}
+    c['diffusion'] = dict(c['diffusion'], num_steps=num_steps, eps_net_opt=dict(num_layers=6))
+    c.update(over)
+    return c
+
+
+class AttrDict(dict):
+    """dict with attribute access, nested: stands in for the reference's EasyDict configs."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = AttrDict(v) if isinstance(v, dict) else v
+    __setattr__ = dict.__setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None         # (pickle / copy probe for dunder attributes this way)
+
+
+_MODELS = {}
+
+
+def build_model(num_steps, seed, flavour='abdock', device='cpu'):
+    """get_model(cfg) of the dock_single / codesign_single model block with hash-filled weights (the same fill the reference got
+    when the golden vectors were made); cached per (num_steps, seed, flavour, device)."""
+    from .. import get_model
+    key = (num_steps, seed, flavour, str(device))
+    if key not in _MODELS:
+        cfg = cfg_abdock(num_steps)
+        if flavour == 'abdesign':
+            for k in ('num_bins', 'dist_min', 'dist_max'):
+                cfg.pop(k)
+            cfg['diffusion'].pop('obj')
+        m = get_model(AttrDict(cfg)).eval()
+        fill_module_(m, seed=seed)
+        _MODELS[key] = m.to(device)
+    return _MODELS[key]
+
+
+def mask_from_lengths(lengths, L):
+    return torch.stack([torch.arange(L) < n for n in lengths], 0)
+
+
+def gen_from_ranges(N, L, ranges):
+    g = torch.zeros(N, L, dtype=torch.bool)
+    for a, b in ranges:
+        g[:, a:b] = True
+    return g
+
+
+def eps_inputs(N, L, lengths, gen_ranges, salt=200, F=128, C=64, t=37, num_steps=100):
+    """Hash-filled inputs of one EpsilonNet call: v, p, s, res_feat, pair_feat, beta, mask_generate, mask_res (CPU tensors)."""
+    from ..modules import VarianceSchedule
+    v = hash_tensor((N, L, 3), salt + 0, scale=4.0)
+    p = hash_tensor((N, L, 3), salt + 1, scale=3.0)
+    s = (hash_tensor((N, L), salt + 2) + 0.5).mul(21).long().clamp(0, 20)
+    mres = mask_from_lengths(lengths, L)
+    s = torch.where(mres, s, torch.full_like(s, 21))
+    res_feat = hash_tensor((N, L, F), salt + 3, scale=2.0)
+    pair_feat = hash_tensor((N, L, L, C), salt + 4, scale=2.0)
+    beta = VarianceSchedule(num_steps).betas[t].expand([N]).clone()
+    gen = gen_from_ranges(N, L, gen_ranges) & mres
+    return v, p, s, res_feat, pair_feat, beta, gen, mres

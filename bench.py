@@ -16,7 +16,8 @@ timed region at N>1.
 
 Roofline accounting: the dominant kernel is the IPA core; its ALGORITHMIC bytes
 per launch are N*(256*L^2 + 1076*L) (pair features once + node features in/out + frames/mask), its duration is measured
-live with HIP events recorded on the launch stream around every launch inside the timed region.
+live with HIP events recorded on the launch stream around every launch (DESIGN.md section 5 says where they sit when the loop is
+replayed from a hipGraph).  The timed region is run `--repeats` times and the median is reported (min / max alongside).
 """
 import argparse
 import json
@@ -26,7 +27,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 import torch  # noqa: E402
 
@@ -69,7 +69,6 @@ def step_flops(N, L):
 
 
 def build_workload(dev, N, L, T, seed, abdesign=True):
-    import cases  # noqa: F401
     from ab_opt_amd.dpm import FullDPM
     from ab_opt_amd.utils import synth
     kw = dict(_abdesign=True) if abdesign else dict(obj='pred_x0', num_bins=40, dist_min=0.5, dist_max=19.5)
@@ -101,8 +100,8 @@ def cpu_baseline(L, T, budget_s=45.0, check=None):
     from oracle import dpm as odpm
     from ab_opt_amd.dpm import FullDPM
     from ab_opt_amd.utils import synth
-    import cases
-    threads = min(os.cpu_count() or 1, 32)
+    host_cores = os.cpu_count() or 1
+    threads = min(host_cores, 32)
     torch.set_num_threads(threads)
     out = {}
     if check is not None:
@@ -124,12 +123,12 @@ def cpu_baseline(L, T, budget_s=45.0, check=None):
     den = odpm.Denoiser(m.state_dict(), num_steps=10, variant='abdesign', pre='', mode='ref',
                         tables=(None, odpm.igso3_tables(sch['sigmas'].tolist())))
     best, detail, t_all = 0.0, {}, time.perf_counter()
-    for mode, N, reps in (('mm', 1, 4), ('ref', 1, 2), ('mm', 4, 2)):
+    for mode, N, reps in (('ref', 1, 2), ('mm', 1, 4), ('mm', 4, 2)):
         if time.perf_counter() - t_all > budget_s:
             detail[f'{mode}_N{N}'] = 'skipped (time budget)'
             continue
         den.mode = mode
-        v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(N, L, [L] * N, [(25, 33), (51, 57), (94, 106)], num_steps=10, t=7)
+        v, p, s, res_feat, pair_feat, _, gen, mres = synth.eps_inputs(N, L, [L] * N, [(25, 33), (51, 57), (94, 106)], num_steps=10, t=7)
         nz = dict(axis=torch.randn(N, L, 3), bin=torch.randint(0, 8191, (N, L)), ubin=torch.rand(N, L), gauss=torch.randn(N, L),
                   z=torch.randn(N, L, 3), s_next=torch.randint(0, 20, (N, L)))
         den.step(7, v, p, s, res_feat, pair_feat, gen, mres, nz)             # warm
@@ -143,10 +142,14 @@ def cpu_baseline(L, T, budget_s=45.0, check=None):
         rate = N * done / (time.perf_counter() - t0)
         detail[f'{mode}_N{N}'] = round(rate, 3)
         best = max(best, rate)
-    out.update(value=round(best, 3), unit='sample-steps/s', cores=threads, kind='port',
-               sample=f'oracle Denoiser.step (EpsilonNet + transitions) at L={L}, {threads} threads: N=1 with matmul contractions, '
-                      f'N=1 in the reference op order, N=4 with matmul contractions (a few steps each, {budget_s:.0f}s budget); '
-                      f'best rate reported; per-variant: {detail}')
+    ref_rate = detail.get('ref_N1') if isinstance(detail.get('ref_N1'), float) else None
+    # `value` is the reference's OWN op order (what the reference's CPU path executes; oracle mode 'ref' is bit-equal to it,
+    # tests/test_oracle_golden.py); the matmul-contracted restatement of the same arithmetic is the fastest CPU port we have.
+    out.update(value=ref_rate if ref_rate is not None else round(best, 3), unit='sample-steps/s', cores=threads, threads=threads,
+               host_cores=host_cores, kind='port', ref_order_value=ref_rate, matmul_contracted_value=round(best, 3),
+               sample=f'oracle Denoiser.step (EpsilonNet + transitions) at L={L} on {threads} threads of a {host_cores}-core host '
+                      f'(the op mix is bandwidth bound and slows down beyond 32 threads): N=1 in the reference op order (= value), N=1 and N=4 with '
+                      f'matmul contractions (a few steps each, {budget_s:.0f}s budget); per-variant: {detail}')
     return out
 
 
@@ -156,8 +159,7 @@ def secondary_measurements(dev, L):
       train_step_ms               config 5: AbDesign flavour model(batch) -> losses -> backward -> Adam, N=16, L=256
       sample_e2e_ms               config 2 end to end: model.sample(batch) incl. encode(), the pair-bias cache and the trajectory hand-over, N=32
       config3_sample_steps_per_s  config 3: AbDock pose sampling (prmsd head, pred_x0, sample_sequence=False), N=64, the sampling loop alone"""
-    from conftest import build_model
-    from ab_opt_amd.utils.synth import make_batch, LAYOUT_256, LAYOUT_128
+    from ab_opt_amd.utils.synth import build_model, make_batch, LAYOUT_256, LAYOUT_128
     layout = LAYOUT_256 if L == 256 else LAYOUT_128
     res = {}
     # ---- config 2 end to end
@@ -218,10 +220,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--repeats', type=int, default=7, help='the K-step timed region is run this many times; the median is reported')
     ap.add_argument('--batch', type=int, default=32, help='samples per GPU')
     ap.add_argument('--length', type=int, default=256)
+    ap.add_argument('--graph', choices=('on', 'off'), default='on', help='replay the K-step loop from a hipGraph captured before the timed region')
+    ap.add_argument('--graph-events', action='store_true', help='(experiment) record the per-launch HIP events inside the captured graph')
+    ap.add_argument('--no-prof', action='store_true', help='no HIP events around the IPA-core launches (A/B of their cost)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-secondary', action='store_true', help='skip train_step_ms / sample_e2e_ms / config3 (N=1 only)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip train_step_ms / sample_e2e_ms / config3 / poses1000 (N=1 only)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -229,21 +235,31 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    dist = None
+    ndev = torch.cuda.device_count()
+    local_dev = local % ndev                   # more ranks than devices (the 2-ranks-on-one-GPU test of this path): ranks share a device
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
+    dist, backend = None, None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        # RCCL needs one device per rank; with fewer devices than ranks the (tiny) exchange goes through gloo and host memory
+        backend = os.environ.get('ABOPT_BENCH_BACKEND', 'nccl' if ndev >= world else 'gloo')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ab_opt_amd import hip
+    from ab_opt_amd.sampler import all_gather_candidates
     hip.lib()
-    N, L, T, K, W = args.batch, args.length, 100, args.steps, args.warmup
+    N, L, T, K, W, R = args.batch, args.length, 100, args.steps, args.warmup, max(1, args.repeats)
     assert 1 <= K <= T and W <= T
-    log('building workload', dict(N=N, L=L, T=T, K=K, W=W), hip.device_info())
+    use_graph = args.graph == 'on'
+    log('building workload', dict(N=N, L=L, T=T, K=K, W=W, repeats=R, graph=use_graph), hip.device_info())
     dpm, state, res_feat, pair_feat, gen, mres = build_workload(dev, N, L, T, seed=2022 + rank)
     log('workload ready')
-    run = lambda n: dpm._run(state, T, res_feat, pair_feat, gen, mres, True, True, True, None, 1234 + rank, rank * N * L, False, stop_after=n)
+    run = lambda n, graph=False: dpm._run(state, T, res_feat, pair_feat, gen, mres, True, True, True, None, 1234 + rank, rank * N * L, False,
+                                          stop_after=n, graph=graph)
 
     # the network outputs of the first step (same launch geometry as the timed steps), kept for the oracle check below
     first = None
@@ -255,55 +271,103 @@ def main():
     if W > 0:
         run(W)
     torch.cuda.synchronize()
+    graph_events = False
+    if use_graph:
+        # capture (outside the timed region, like the warmup): K steps of the loop, the one-off pair-bias cache build included
+        t_cap = time.perf_counter()
+        hip.GRAPH_CAPTURE_EVENTS = bool(args.graph_events and not args.no_prof)
+        run(K, graph=True)
+        torch.cuda.synchronize()
+        graph_events = hip.GRAPH_CAPTURE_EVENTS
+        log('graph captured + first replay: %.3f s' % (time.perf_counter() - t_cap))
     log('warmup done')
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    hip.prof_enable(True)
-    t0 = time.perf_counter()
-    tv, tp, ts, _, _ = run(K)
-    if dist is not None:
-        # batched-sampling reduction: gather generated-residue CA candidates of every rank (design_for_pdb.py:326-336)
-        cand = tp[T - K][gen].reshape(N, -1, 3).contiguous()
-        allc = [torch.empty_like(cand) for _ in range(world)]
-        dist.all_gather(allc, cand)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    log('timed region done: %.3f s' % dt)
-    launches, ipa_ms = hip.prof_collect()
-    hip.prof_enable(False)
-    assert torch.isfinite(tp[T - K]).all()
 
-    if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def timed_pass(graph, events):
+        """One K-step timed region: barrier + synchronize on both sides, max over ranks."""
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        if not graph:
+            hip.prof_enable(events)
+        t0 = time.perf_counter()
+        tv, tp, ts, _, _ = run(K, graph=graph)
+        if dist is not None:
+            # batched-sampling reduction: gather generated-residue CA candidates of every rank (design_for_pdb.py:326-336)
+            cand = tp[T - K][gen].reshape(N, -1, 3).contiguous()
+            all_gather_candidates(cand)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(tp[T - K]).all()
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    # ---- the timed region, R times.  Eager mode: HIP events around every IPA-core launch inside it.  Graph mode: host-recorded
+    # event pairs cannot live in a replayed graph, so the kernel is timed in ONE extra eager pass of the same K steps right after
+    # the repeats (same process, same box, same clocks), unless --graph-events put the records into the graph itself.
+    times, launches, ipa_ms = [], 0, 0.0
+    for r in range(R):
+        times.append(timed_pass(use_graph, events=not args.no_prof))
+        if not use_graph and not args.no_prof:
+            n_, ms_ = hip.prof_collect()
+            launches, ipa_ms = launches + n_, ipa_ms + ms_
+        elif graph_events:
+            n_, ms_ = hip.prof_collect(keep=True)
+            launches, ipa_ms = launches + n_, ipa_ms + ms_
+    hip.prof_enable(False)
+    log('timed region x%d: %s ms per step' % (R, ', '.join('%.4f' % (t / K * 1e3) for t in times)))
+    instrumented = None
+    if use_graph and not graph_events and not args.no_prof:
+        dt_i = timed_pass(False, events=True)
+        launches, ipa_ms = hip.prof_collect()
+        hip.prof_enable(False)
+        instrumented = round(dt_i / K * 1e3, 4)
+        log('instrumented eager pass: %.4f ms per step' % instrumented)
+
     if rank == 0:
+        ts_sorted = sorted(times)
+        dt = ts_sorted[len(ts_sorted) // 2] if R % 2 else 0.5 * (ts_sorted[R // 2 - 1] + ts_sorted[R // 2])
         per_launch_ms = ipa_ms / max(launches, 1)
         alg = ipa_algorithmic_bytes(N, L)
         ach = alg / (per_launch_ms * 1e-3) / 1e9 if launches else 0.0
         step_s = dt / K
         traffic, traffic_src = MEASURED_TRAFFIC.get((N, L), (None, None))
+        timing = ('HIP events on the launch stream around every ipa_core launch, all %d repeats of the timed region' % R) if not use_graph else (
+            'HIP event records captured into the replayed graph around every ipa_core launch' if graph_events else
+            'HIP events on the launch stream around every ipa_core launch in one eager pass of the same K steps run right after the '
+            'timed graph replays (host-recorded events cannot be placed inside a replayed graph); that pass took instrumented_ms_per_step')
         line = {
             'metric': 'denoising steps/sec (256-res complex, 100-step sampler)', 'value': round(world * N * K / dt, 2),
             'unit': 'sample-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(step_s * 1e3, 4),
+            'repeats': R, 'ms_per_step_min': round(ts_sorted[0] / K * 1e3, 4), 'ms_per_step_max': round(ts_sorted[-1] / K * 1e3, 4),
+            'value_min': round(world * N * K / ts_sorted[-1], 2), 'value_max': round(world * N * K / ts_sorted[0], 2),
+            'aggregate': 'median of the repeats; each repeat times exactly K steps (barrier + synchronize on both sides, max over ranks)',
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'AbDesign codesign_single model block (F=128, C=64, 6 IPA layers, T=100), L={L}, 6 CDR segments, '
                                    f'batch {N} per GPU, distinct pair features per sample, device Philox RNG',
-                       'samples_per_gpu': N, 'residues': L, 'sampler_steps': T, 'parallelism': f'independent samples x{world}'},
+                       'samples_per_gpu': N, 'residues': L, 'sampler_steps': T, 'parallelism': f'independent samples x{world}',
+                       'launch': ('hipGraph replay of the K-step loop (captured once, before the timed region; Philox position from device memory)'
+                                  if use_graph else 'eager launches'),
+                       'backend': backend, 'ranks_per_device': (world + ndev - 1) // ndev if world > 1 else 1},
             'roofline': {'bound': 'hbm', 'kernel': 'ipa_core', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src, 'launches': launches,
-                         'avg_launch_ms': round(per_launch_ms, 4), 'algorithmic_bytes_per_launch': alg,
+                         'avg_launch_ms': round(per_launch_ms, 4), 'timing': timing, 'instrumented_ms_per_step': instrumented,
+                         'algorithmic_bytes_per_launch': alg,
                          'algorithmic_bytes_formula': 'N*(256*L^2 + 1076*L)  [SURVEY 8(d)]',
                          'kernel_io_bytes_per_launch': ipa_kernel_io_bytes(N, L),
                          'kernel_io_frac': round(ipa_kernel_io_bytes(N, L) / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if launches else 0.0,
                          'step': {'algorithmic_bytes': step_algorithmic_bytes(N, L), 'hbm_frac': round(step_algorithmic_bytes(N, L) / step_s / 1e9 / HBM_PEAK_GBS, 4),
                                   'flops': step_flops(N, L), 'tflops': round(step_flops(N, L) / step_s / 1e12, 2),
                                   'fp32_peak_tflops': FP32_PEAK_TFLOPS, 'flop_frac': round(step_flops(N, L) / step_s / 1e12 / FP32_PEAK_TFLOPS, 4),
-                                  'ipa_core_share_of_step': round(per_launch_ms * launches / K / (step_s * 1e3), 4) if launches else None}},
+                                  'ipa_core_share_of_step': round(per_launch_ms * NUM_LAYERS / (step_s * 1e3), 4) if launches else None}},
         }
         if world == 1 and not args.no_cpu_baseline:
             log('cpu baseline on', os.cpu_count(), 'cores ...')
@@ -311,6 +375,9 @@ def main():
             line['cpu_baseline'] = cpu_baseline(L, T, check=check)
         if world == 1 and not args.no_secondary:
             log('secondary configs ...')
+            del dpm._graphs
+            dpm._graphs = {}
+            torch.cuda.empty_cache()
             try:
                 line['secondary'] = secondary_measurements(dev, L)
             except Exception as e:           # never lose the headline line to a secondary measurement

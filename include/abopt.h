@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 23
+#define ABOPT_ABI_VERSION 24
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -211,7 +211,11 @@ int abopt_denoise_step(const abopt_step_params* sp, const abopt_step_noise* nois
                        const uint8_t* mask_generate,
                        const float* igso3_X, const float* igso3_cdf, int igso3_bins, int num_bins,
                        float* v_next, float* p_next, int64_t* s_next, float* prmsd, float* perplexity,
-                       float* post_out, float* p_next_norm, int N, int L, abopt_stream stream);
+                       float* post_out, float* p_next_norm,
+                       const uint64_t* seed_offset_dev /* optional DEVICE pointer to {seed, offset}: read by the kernel instead of the
+                                                          two by-value arguments, so a captured hipGraph of the loop can be replayed
+                                                          with a fresh stream position (the values are read at execution time) */,
+                       int N, int L, abopt_stream stream);
 
 /* Initial state of FullDPM.sample (dpm_full.py:255-269): q4 [N,L,4], pn [N,L,3], sr [N,L] are the
  * reference's three draws (NULL => Philox).  p in/out in Angstrom.  position_mean is a HOST pointer to 3 floats. */
@@ -226,7 +230,7 @@ int abopt_sample_init(const float* v, const float* p, const int64_t* s, const ui
  * fwd_cdf [T+1,bins-1] only for the device-RNG path.  p_0 / p_noisy in Angstrom.  noise: reference draw order
  * randn(N,L,3) axis, multinomial bin, rand ubin, randn gauss | randn(N,L,3) pos | multinomial s_noisy; all NULL => Philox.
  * c_noisy (optional, [N,L,20]): the categorical c_t the sequence sample is drawn from (transition.py:196-198), whether or not
- * the sample itself is injected. */
+ * the sample itself is injected; with noise_sequence = 0 it is onehot(s_0), the reference's c_0 (all-zero rows for s_0 outside 0..19). */
 typedef struct {
     const float* axis; const int64_t* bin; const float* ubin; const float* gauss;   /* rotation (so3.py:141-146) */
     const float* pos;                                                               /* e_rand (transition.py:75) */
@@ -238,14 +242,18 @@ int abopt_add_noise(const int64_t* t, const float* alpha_bars, const float* fwd_
                     const abopt_addnoise_noise* noise, uint64_t seed, uint64_t offset,
                     const float* v_0, const float* p_0, const int64_t* s_0, const uint8_t* mask_generate,
                     float position_scale, const float* position_mean, int noise_structure, int noise_sequence, int grad_mode,
-                    float* v_noisy, float* p_noisy, int64_t* s_noisy, float* eps_p, float* c_noisy, int N, int L, abopt_stream stream);
+                    float* v_noisy, float* p_noisy, int64_t* s_noisy, float* eps_p, float* c_noisy,
+                    const uint64_t* seed_offset_dev /* optional device {seed, offset}, as in abopt_denoise_step */,
+                    int N, int L, abopt_stream stream);
 
 /* ---- DockQ scoring of docked candidates: D/tools/runner/design_for_pdb.py:316-321 calls calc_DockQ(model, native, use_CA_only=True)
  * (AbDock/DockQ/DockQ.py:98-385) per candidate, which runs the `fnat` program twice (DockQ/src/fnat.c:100-252: residue contacts over
  * all heavy atoms, 5 A for Fnat, 10 A for the interface) and superimposes CA atoms twice (interface -> iRMS; receptor -> LRMS).
  * Structures are tensors with the batch's residue indexing: pos [L,A,3] Angstrom, mask [L,A], group [L] (0 = not in the file,
  * 1 / 2 = the two chains); atom slot 1 = CA.  model_pos [S,L,A,3]; model_mask [S,L,A], or [L,A] with model_mask_shared = 1.
- * out [S,4] = (fnat, irms, Lrms, DockQ).  ws: abopt_dockq_workspace_bytes(L). */
+ * out [S,4] = (fnat, irms, Lrms, DockQ).  ws: abopt_dockq_workspace_bytes(L).
+ * A candidate whose interface, receptor or ligand has NO CA atom present in both model and native has no superposition: its irms /
+ * Lrms (and DockQ) come back as -1 (the reference asserts on such inputs); with 1 or 2 common atoms the fit is degenerate but defined. */
 size_t abopt_dockq_workspace_bytes(int L);
 int abopt_dockq_lite(const float* model_pos, const uint8_t* model_mask, int model_mask_shared, const float* native_pos,
                      const uint8_t* native_mask, const int32_t* group, int S, int L, int A, float* out,
@@ -362,8 +370,10 @@ int abopt_commonness_score(const float* structs, float* score, int B, int n, abo
  * by hipEvents on the stream it is launched on; abopt_prof_collect synchronises those events and returns the number
  * of launches and their summed duration since the last enable.  Process-global, off by default, not for concurrent
  * use from several host threads (the only global state in the library). */
-int abopt_prof_enable(int on);
+int abopt_prof_enable(int on);   /* 1: on (forgets earlier pairs), 0: off (forgets), 2: off but keep the recorded pairs */
 int abopt_prof_collect(int* launches, double* total_ms);
+/* The same sum without forgetting the event pairs: records captured into a hipGraph are re-recorded by every replay. */
+int abopt_prof_peek(int* launches, double* total_ms);
 
 #ifdef __cplusplus
 }

@@ -14,9 +14,14 @@ indexing for model and native; `group` is the chain (1 or 2; 0 = residue not in 
 
 Pinning: Fnat, the contact counts and the interface list are checked against the reference's own `fnat` binary built from its
 sources (oracle/Makefile -> oracle/_ref/fnat) on PDB files written from the same tensors (tests/golden/make_golden.py::case_dockq).
-The superposition part (Bio.PDB.Superimposer / SVDSuperimposer, DockQ.py:296-353) is the textbook SVD (Kabsch) fit; Biopython is
-not installed here, so that part is pinned to the published algorithm only and cross-checked against scipy's
-Rotation.align_vectors in the golden generator ("parity unpinned" at Biopython level).
+The superposition part (Bio.PDB.Superimposer / SVDSuperimposer, DockQ.py:296-353) is the textbook SVD (Kabsch) fit with the
+reflection correction Biopython applies (flip the last right-singular vector when det < 0).  Biopython is not installed here, so that
+part is pinned to published algorithms instead: `kabsch` (SVD) and `qcp` below (Theobald 2005 / Liu, Agrafiotis & Theobald 2010: the
+largest root of the quartic characteristic polynomial of the 4x4 key matrix by Newton iteration, rotation from the adjugate of
+K - lambda I) are two INDEPENDENT derivations of the same optimum -- no shared linear-algebra routine -- and must agree on every
+fixture, including near-degenerate fits (collinear CA atoms, 3-residue interfaces) and mirror-image candidates
+(tests/test_oracle_golden.py::test_dockq_superposition_two_algorithms); scipy's Rotation.align_vectors is a third check in the golden
+generator.  What stays unpinned is only Biopython's own floating-point path, not the optimum it computes.
 """
 import numpy as np
 
@@ -48,6 +53,58 @@ def kabsch(x, y):
     D = np.diag([1.0, 1.0, d])
     R = Vt.T @ D @ U.T
     return R, cx - R @ cy
+
+
+def qcp(x, y, iters=100, tol=1e-15):
+    """Quaternion characteristic polynomial superposition (Theobald, Acta Cryst. A61 (2005) 478; Liu, Agrafiotis & Theobald,
+    J. Comput. Chem. 31 (2010) 1561): -> (rmsd, R, t) with the same convention as `kabsch` (R y + t ~ x), WITHOUT an SVD or an
+    eigen-solver.  lambda_max of the key matrix is the largest root of  l^4 + C2 l^2 + C1 l + C0  (C2 = -2 tr(S^T S), C1 = -8 det S,
+    C0 = det K), found by Newton's iteration from the upper bound E0 = (|x|^2 + |y|^2) / 2; the optimal quaternion is any non-zero
+    column of adj(K - lambda I)."""
+    x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    n = x.shape[0]
+    cx, cy = x.mean(0), y.mean(0)
+    xc, yc = x - cx, y - cy
+    S = yc.T @ xc                                    # S[a, b] = sum y_a x_b
+    Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz = S.reshape(-1)
+    K = np.array([[Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx],
+                  [Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz],
+                  [Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy],
+                  [Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz]])
+    E0 = 0.5 * ((xc ** 2).sum() + (yc ** 2).sum())
+    C2 = -2.0 * (S ** 2).sum()
+    C1 = -8.0 * (Sxx * (Syy * Szz - Syz * Szy) - Sxy * (Syx * Szz - Syz * Szx) + Sxz * (Syx * Szy - Syy * Szx))
+
+    def det3(m):
+        return (m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0])
+                + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]))
+
+    def minor(m, i, j):
+        return det3(np.delete(np.delete(m, i, 0), j, 1))
+    C0 = sum((-1) ** j * K[0, j] * minor(K, 0, j) for j in range(4))
+    lam = E0
+    for _ in range(iters):
+        l2 = lam * lam
+        p = l2 * l2 + C2 * l2 + C1 * lam + C0
+        dp = 4 * l2 * lam + 2 * C2 * lam + C1
+        if dp == 0:
+            break
+        step = p / dp
+        lam -= step
+        if abs(step) < tol * max(abs(lam), 1.0):
+            break
+    rmsd = float(np.sqrt(max(0.0, 2.0 * (E0 - lam) / n)))
+    M = K - lam * np.eye(4)
+    adj = np.array([[(-1) ** (i + j) * minor(M, j, i) for j in range(4)] for i in range(4)])
+    q = adj[:, np.argmax((adj ** 2).sum(0))]          # the column of largest norm: a multiple of the eigenvector
+    nq = np.linalg.norm(q)
+    if nq < 1e-300:                                   # lambda_max is a multiple root (degenerate fit): any proper rotation attaining it
+        return rmsd, None, None
+    a, b, c, d = q / nq
+    R = np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                  [2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b)],
+                  [2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d]])
+    return rmsd, R, cx - R @ cy
 
 
 def rmsd_after_fit(x, y):

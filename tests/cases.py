@@ -3,29 +3,8 @@
 import torch
 from ab_opt_amd.utils import synth
 
-MODEL_CFG_ABDOCK = dict(
-    type='diffab', res_feat_dim=128, pair_feat_dim=64,
-    diffusion=dict(num_steps=100, eps_net_opt=dict(num_layers=6), obj='pred_x0'),
-    train_structure=True, train_sequence=False, num_bins=40, dist_min=0.5, dist_max=19.5,
-)   # AbDock/configs/train/dock_single.yml:2-17
-
-
-def cfg_abdock(num_steps=100, **over):
-    c = {k: (dict(v) if isinstance(v, dict) else v) for k, v in MODEL_CFG_ABDOCK.items()}
-    c['diffusion'] = dict(c['diffusion'], num_steps=num_steps, eps_net_opt=dict(num_layers=6))
-    c.update(over)
-    return c
-
-
-def mask_from_lengths(lengths, L):
-    return torch.stack([torch.arange(L) < n for n in lengths], 0)
-
-
-def gen_from_ranges(N, L, ranges):
-    g = torch.zeros(N, L, dtype=torch.bool)
-    for a, b in ranges:
-        g[:, a:b] = True
-    return g
+# the model configuration, masks and the denoiser inputs live in the package (bench.py and smoke() use them without the test tree)
+from ab_opt_amd.utils.synth import MODEL_CFG_ABDOCK, cfg_abdock, mask_from_lengths, gen_from_ranges, eps_inputs  # noqa: F401,E402
 
 
 def ipa_inputs(N, L, lengths, salt=100, F=128, C=64):
@@ -37,20 +16,6 @@ def ipa_inputs(N, L, lengths, salt=100, F=128, C=64):
     x = synth.hash_tensor((N, L, F), salt + 2, scale=2.0)
     z = synth.hash_tensor((N, L, L, C), salt + 3, scale=2.0)
     return R, t, x, z, mask_from_lengths(lengths, L)
-
-
-def eps_inputs(N, L, lengths, gen_ranges, salt=200, F=128, C=64, t=37, num_steps=100):
-    from oracle.dpm import variance_schedule
-    v = synth.hash_tensor((N, L, 3), salt + 0, scale=4.0)
-    p = synth.hash_tensor((N, L, 3), salt + 1, scale=3.0)
-    s = (synth.hash_tensor((N, L), salt + 2) + 0.5).mul(21).long().clamp(0, 20)
-    mres = mask_from_lengths(lengths, L)
-    s = torch.where(mres, s, torch.full_like(s, 21))
-    res_feat = synth.hash_tensor((N, L, F), salt + 3, scale=2.0)
-    pair_feat = synth.hash_tensor((N, L, L, C), salt + 4, scale=2.0)
-    beta = variance_schedule(num_steps)['betas'][t].expand([N]).clone()
-    gen = gen_from_ranges(N, L, gen_ranges) & mres
-    return v, p, s, res_feat, pair_feat, beta, gen, mres
 
 
 SO3_EDGE_W = torch.tensor([
@@ -95,3 +60,61 @@ def dockq_case(S=6, seed=31):
         m[ab] = (pos[ab] - cen) @ rot.T + cen + shift + synth.hash_tensor(tuple(pos[ab].shape), 970 + k, scale=0.15 * k)
         models.append((m * 1000).round() / 1000)
     return pos, mask, group, torch.stack(models, 0)
+
+
+def dockq_edge_cases():
+    """Superposition corner cases of the DockQ scorer, each a dict(name, pos, mask, group, models, lrms_defined):
+      mirror          candidates that are MIRROR IMAGES of the native (plus a rigid motion): an unconstrained SVD would report RMSD 0;
+                      Biopython's SVDSuperimposer flips the last singular vector (proper rotations only), and so must everything here
+      tiny_interface  the antibody pulled away until only 3..4 residues are left in the 10 A interface: a (near-)planar point set
+      collinear       CA-only chains laid end to end on one line: the covariance has rank 1, the optimal rotation is not unique
+                      (iRMS and Fnat are still defined; LRMS is not -- the roll about the line is arbitrary -- and is not compared)"""
+    import numpy as np
+    from oracle import dockq as DQ
+    pos, mask, group, models = dockq_case()
+    out = []
+    # ---- mirror images
+    cen = pos[mask[:, 1] & (group > 0)][:, 1].mean(0)
+    mir = (pos - cen) * torch.tensor([1.0, 1.0, -1.0]) + cen
+    from oracle.geometry import so3_exp
+    Q = so3_exp(torch.tensor([[0.9, -0.3, 0.5]]))[0]
+    mods = torch.stack([mir, (mir - cen) @ Q.T + cen + torch.tensor([2.0, -1.0, 4.0]), (models[2] - cen) * torch.tensor([1.0, 1.0, -1.0]) + cen], 0)
+    out.append(dict(name='mirror', pos=pos, mask=mask, group=group, models=((mods * 1000).round() / 1000), lrms_defined=True))
+    # ---- 3..4 interface residues: translate the antibody along the centroid axis in 0.5 A steps until the interface is that small
+    ab = group == 1
+    axis = pos[ab][:, 1].mean(0) - pos[group == 2][:, 1].mean(0)
+    axis = axis / axis.norm()
+    npos = None
+    for step in range(400):
+        cand = pos.clone()
+        cand[ab] = pos[ab] + 0.5 * step * axis
+        cand = (cand * 1000).round() / 1000
+        o = DQ.dockq(cand.numpy(), mask.numpy(), cand.numpy(), mask.numpy(), group.numpy())
+        if 3 <= o['n_interface'] <= 4:
+            npos = cand
+            break
+    assert npos is not None, 'no translation leaves a 3..4 residue interface'
+    mods = []
+    for k in range(3):
+        m = npos.clone()
+        rot = so3_exp(synth.hash_tensor((1, 3), 1900 + k, scale=0.1 * (k + 1)))[0]
+        c2 = npos[ab][:, 1].mean(0)
+        m[ab] = (npos[ab] - c2) @ rot.T + c2 + synth.hash_tensor((3,), 1950 + k, scale=0.8 * (k + 1)) + synth.hash_tensor(tuple(npos[ab].shape), 1970 + k, scale=0.2)
+        mods.append((m * 1000).round() / 1000)
+    out.append(dict(name='tiny_interface', pos=npos, mask=mask, group=group, models=torch.stack(mods, 0), lrms_defined=True))
+    # ---- collinear CA-only chains, end to end on the x axis
+    n1, n2, A = 12, 9, pos.shape[1]
+    L = n1 + n2
+    cpos = torch.zeros(L, A, 3)
+    cpos[:, 1, 0] = 3.8 * torch.arange(L)
+    cmask = torch.zeros(L, A, dtype=torch.bool)
+    cmask[:, 1] = True
+    cgroup = torch.cat([torch.full((n1,), 1), torch.full((n2,), 2)]).int()
+    mods = []
+    for k in range(3):
+        m = cpos.clone()
+        m[:n1, 1] += synth.hash_tensor((n1, 3), 2100 + k, scale=0.6 * (k + 1))            # chain 1 jittered off the line
+        m[n1:, 1, 0] += 0.4 * k                                                               # chain 2 slid along it
+        mods.append((m * 1000).round() / 1000)
+    out.append(dict(name='collinear', pos=cpos, mask=cmask, group=cgroup, models=torch.stack(mods, 0), lrms_defined=False))
+    return out

@@ -26,34 +26,7 @@ def golden():
     return load_golden
 
 
-class AttrDict(dict):
-    def __init__(self, d=None, **kw):
-        super().__init__()
-        for k, v in dict(d or {}, **kw).items():
-            self[k] = AttrDict(v) if isinstance(v, dict) else v
-    __getattr__ = dict.__getitem__
-    __setattr__ = dict.__setitem__
-
-
-_MODELS = {}
-
-
-def build_model(num_steps, seed, flavour='abdock', device='cpu'):
-    """Product model with hash-filled weights (same fill as the reference got in make_golden.py)."""
-    import cases
-    from ab_opt_amd import get_model
-    from ab_opt_amd.utils import synth
-    key = (num_steps, seed, flavour, str(device))
-    if key not in _MODELS:
-        cfg = cases.cfg_abdock(num_steps)
-        if flavour == 'abdesign':
-            for k in ('num_bins', 'dist_min', 'dist_max'):
-                cfg.pop(k)
-            cfg['diffusion'].pop('obj')
-        m = get_model(AttrDict(cfg)).eval()
-        synth.fill_module_(m, seed=seed)
-        _MODELS[key] = m.to(device)
-    return _MODELS[key]
+from ab_opt_amd.utils.synth import AttrDict, build_model  # noqa: F401,E402  (kept importable from here for the tests)
 
 
 @pytest.fixture(scope='session')

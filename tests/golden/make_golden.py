@@ -511,12 +511,51 @@ def case_dockq():
     save('dockq_small', **{k: np.asarray(v) for k, v in out.items()})
 
 
+def case_dockq_edge():
+    """Superposition corner cases (cases.dockq_edge_cases): expected Fnat / iRMS / LRMS / DockQ from the oracle, accepted only where its
+    two independent superposition algorithms (SVD-Kabsch and QCP) and scipy agree; Fnat also from the reference's `fnat` binary."""
+    import subprocess, tempfile
+    from scipy.spatial.transform import Rotation
+    from oracle import dockq as DQ
+    subprocess.run(['make', '-C', os.path.join(ROOT, 'oracle')], check=True)
+    fnat_bin = os.path.join(ROOT, 'oracle', '_ref', 'fnat')
+    out = {}
+    for c in cases.dockq_edge_cases():
+        pos, mask, group, models = c['pos'].numpy().astype(np.float64), c['mask'].numpy(), c['group'].numpy(), c['models'].numpy().astype(np.float64)
+        rows = []
+        with tempfile.TemporaryDirectory() as d:
+            DQ.write_pdb(d + '/native.pdb', pos, mask, group)
+            for k in range(models.shape[0]):
+                o = DQ.dockq(models[k], mask, pos, mask, group)
+                DQ.write_pdb(d + '/model.pdb', models[k], mask, group)
+                r5 = DQ.parse_reference_fnat(subprocess.run([fnat_bin, d + '/model.pdb', d + '/native.pdb', '5', '-all'], capture_output=True, text=True, check=True).stdout)
+                assert (o['nat_correct'], o['nat_total']) == (r5['nat_correct'], r5['nat_total']), c['name']
+                both = mask[:, 1] & (group > 0)
+                sel = o['interface'] & both
+                x, y = pos[:, 1], models[k][:, 1]
+                q_rmsd, _, _ = DQ.qcp(x[sel], y[sel])
+                assert abs(q_rmsd - o['irms']) < 2e-6, (c['name'], q_rmsd, o['irms'])
+                _, rssd = Rotation.align_vectors(x[sel] - x[sel].mean(0), y[sel] - y[sel].mean(0))
+                assert abs(rssd / np.sqrt(sel.sum()) - o['irms']) < 2e-6
+                if c['lrms_defined']:
+                    n1, n2 = (both & (group == 1)).sum(), (both & (group == 2)).sum()
+                    rec, lig = (1, 2) if n1 > n2 else (2, 1)
+                    rs, ls = both & (group == rec), both & (group == lig)
+                    _, Rq, tq = DQ.qcp(x[rs], y[rs])
+                    lr = np.sqrt((((y[ls] @ Rq.T + tq) - x[ls]) ** 2).sum(-1).mean())
+                    assert abs(lr - o['Lrms']) < 1e-6, (c['name'], lr, o['Lrms'])
+                rows.append([o['fnat'], o['irms'], o['Lrms'] if c['lrms_defined'] else -1.0, o['DockQ'] if c['lrms_defined'] else -1.0, o['n_interface']])
+        out[c['name']] = np.asarray(rows)
+        print(c['name'], out[c['name']])
+    save('dockq_edge', **out)
+
+
 if __name__ == '__main__':
     assert os.path.isdir(REF), 'reference mount not present: goldens can only be generated in the build container'
     sys.path.insert(0, os.path.join(REF, 'AbDock'))
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['so3', 'ga_block', 'eps_net', 'schedule_tables', 'trajectory', 'structonly', 'abdesign_sample',
-                             'training', 'training_abdesign', 'encode', 'rank', 'reconstruct', 'posterior', 'dockq']
+                             'training', 'training_abdesign', 'encode', 'rank', 'reconstruct', 'posterior', 'dockq', 'dockq_edge']
     for w in which:
         print('==', w)
         globals()['case_' + w]()

@@ -378,3 +378,41 @@ def test_dockq_vs_reference_scorer():
             DQ.write_pdb(d + '/model.pdb', models[3].numpy(), mask.numpy(), group.numpy())
             r5 = DQ.parse_reference_fnat(subprocess.run([fnat_bin, d + '/model.pdb', d + '/native.pdb', '5', '-all'], capture_output=True, text=True).stdout)
         assert (r5['nat_correct'], r5['nat_total']) == (int(g['nat_correct'][3]), int(g['nat_total'][3]))
+
+
+def test_dockq_superposition_two_algorithms():
+    """iRMS / LRMS of the oracle are pinned by two independent published algorithms -- SVD-Kabsch with Biopython's reflection rule and
+    the quaternion characteristic polynomial (Theobald 2005) -- on the regular candidates and on the corner cases (mirror images,
+    3..4-residue interfaces, collinear CA atoms), and the corner-case fixture dockq_edge holds the agreed values."""
+    import numpy as np
+    from oracle import dockq as DQ
+    g = load_golden('dockq_edge')
+    pos, mask, group, models = cases.dockq_case()
+    all_cases = [dict(name='regular', pos=pos, mask=mask, group=group, models=models, lrms_defined=True)] + cases.dockq_edge_cases()
+    for c in all_cases:
+        p, m, gr = c['pos'].numpy().astype(np.float64), c['mask'].numpy(), c['group'].numpy()
+        for k in range(c['models'].shape[0]):
+            y = c['models'][k].numpy().astype(np.float64)
+            o = DQ.dockq(y, m, p, m, gr)
+            both = m[:, 1] & (gr > 0)
+            sel = o['interface'] & both
+            q_rmsd, Rq, _ = DQ.qcp(p[sel, 1], y[sel, 1])
+            assert abs(q_rmsd - o['irms']) < 2e-6, (c['name'], k, q_rmsd, o['irms'])
+            if Rq is not None:
+                assert abs(np.linalg.det(Rq) - 1) < 1e-9                      # proper rotation, also for mirror-image candidates
+            if c['lrms_defined']:
+                n1, n2 = (both & (gr == 1)).sum(), (both & (gr == 2)).sum()
+                rec, lig = (1, 2) if n1 > n2 else (2, 1)
+                rs, ls = both & (gr == rec), both & (gr == lig)
+                _, Rr, tr = DQ.qcp(p[rs, 1], y[rs, 1])
+                lr = np.sqrt((((y[ls, 1] @ Rr.T + tr) - p[ls, 1]) ** 2).sum(-1).mean())
+                assert abs(lr - o['Lrms']) < 1e-6, (c['name'], k)
+            if c['name'] != 'regular':
+                row = g[c['name']][k]
+                assert abs(o['fnat'] - row[0].item()) < 1e-9 and abs(o['irms'] - row[1].item()) < 1e-9 and o['n_interface'] == int(row[4])
+                if c['lrms_defined']:
+                    assert abs(o['Lrms'] - row[2].item()) < 1e-9 and abs(o['DockQ'] - row[3].item()) < 1e-9
+    # a mirror image is NOT superimposable: the unconstrained SVD optimum (0) must not be what comes out
+    mir = [c for c in all_cases if c['name'] == 'mirror'][0]
+    assert g['mirror'][0][1].item() > 1.0
+    assert 3 <= int(g['tiny_interface'][0][4]) <= 4

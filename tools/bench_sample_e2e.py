@@ -4,7 +4,7 @@ import sys, time, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
-from conftest import build_model
+from ab_opt_amd.utils.synth import build_model
 from ab_opt_amd.utils.synth import make_batch, LAYOUT_256, LAYOUT_128
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 256

@@ -9,7 +9,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
-from conftest import build_model                      # get_model(cfg) + deterministic weights (no checkpoint exists offline)
+from ab_opt_amd.utils.synth import build_model                      # get_model(cfg) + deterministic weights (no checkpoint exists offline)
 from ab_opt_amd import sampler, geometry
 from ab_opt_amd.utils.synth import make_batch, LAYOUT_256, LAYOUT_128
 

@@ -4,7 +4,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
-from conftest import build_model
+from ab_opt_amd.utils.synth import build_model
 from ab_opt_amd import training, hip
 from ab_opt_amd.utils.synth import make_batch, LAYOUT_256
 N, L = 16, 256
