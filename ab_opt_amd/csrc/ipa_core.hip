@@ -40,6 +40,10 @@ __device__ long long g_core_timing[3][8];
 #else
 #define TSTAMP(k)
 #define TSYNC(kw, kb) __syncthreads();
+#ifdef PERSIST_TIMING   // developer build: per-role clocks of one persistent workgroup
+#include <cstdio>
+__device__ long long g_core_timing[3][8];
+#endif
 #endif
 
 namespace abopt {

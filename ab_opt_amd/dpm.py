@@ -124,6 +124,7 @@ class FullDPM(nn.Module):
                 del self._graphs[k]                                     # weights were repacked: those graphs point at dead copies
             g = self._graphs[key] = _LoopGraph(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure,
                                                sample_sequence, ppl_masked, stop_after, optimize_mode, use_bias_cache)
+        self.last_run_info = g.info
         return g.replay(state, res_feat, pair_feat, mask_generate, mask_res, seed, rng_offset)
 
     def _bias_cache_fits(self, n_pair, L, dev, graph=False):

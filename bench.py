@@ -68,7 +68,7 @@ def step_flops(N, L):
     return N * (NUM_LAYERS * (node + pair) + 0.09e9 * L / 256)
 
 
-def build_workload(dev, N, L, T, seed, abdesign=True):
+def build_workload(dev, N, L, T, seed, abdesign=True, shared_context=False, cdrs=None):
     from ab_opt_amd.dpm import FullDPM
     from ab_opt_amd.utils import synth
     kw = dict(_abdesign=True) if abdesign else dict(obj='pred_x0', num_bins=40, dist_min=0.5, dist_max=19.5)
@@ -76,13 +76,15 @@ def build_workload(dev, N, L, T, seed, abdesign=True):
     synth.fill_module_(dpm, seed=2)
     dpm = dpm.to(dev)
     g = torch.Generator(device=dev).manual_seed(seed)
-    layout = synth.LAYOUT_256 if L == 256 else synth.LAYOUT_128
+    if cdrs is None:
+        cdrs = (synth.LAYOUT_256 if L == 256 else synth.LAYOUT_128)['cdrs']
     gen = torch.zeros(N, L, dtype=torch.bool, device=dev)
-    for a, b in layout['cdrs']:
+    for a, b in cdrs:
         gen[:, a:b] = True
     mres = torch.ones(N, L, dtype=torch.bool, device=dev)
-    res_feat = torch.randn(N, L, 128, device=dev, generator=g)
-    pair_feat = torch.randn(N, L, L, 64, device=dev, generator=g)          # distinct per sample: no replication shortcut
+    Nc = 1 if shared_context else N                                        # shared_context: ONE complex, N poses of it (the reference's runners)
+    res_feat = torch.randn(Nc, L, 128, device=dev, generator=g)
+    pair_feat = torch.randn(Nc, L, L, 64, device=dev, generator=g)         # distinct per sample unless shared_context: no replication shortcut
     v = torch.randn(N, L, 3, device=dev, generator=g)
     p = torch.randn(N, L, 3, device=dev, generator=g) * 10
     s = torch.randint(0, 20, (N, L), device=dev, generator=g)
@@ -205,7 +207,44 @@ def secondary_measurements(dev, L):
     torch.cuda.synchronize()
     res['config3_sample_steps_per_s'] = round(N3 * K3 / (time.perf_counter() - t0), 1)
     res['config3_config'] = f'AbDock dock_single model block (prmsd head, pred_x0), structure-only sampling, N={N3} poses, L={L}, {K3} timed steps'
+    del dpm, state, res_feat, pair_feat
+    torch.cuda.empty_cache()
+    # ---- the reference's own headline invocation (AbDock/README.md:61: dock_pdb.py -n 1000 -b 1000 with configs/test/dock_cdr.yml): 1000 poses of
+    # ONE complex cropped to the CDR-H3 + 20 antigen residues (dock_single.yml:12-14 antigen_size 20, initial_patch_size 0) -> L ~ 30..48
+    res.update(poses_measurement(dev, 1000, 48, 'poses1000'))
+    # ---- small batches at L=256 (latency-bound regime)
+    res.update(poses_measurement(dev, 8, 256, 'n8_L256', abdesign=True))
     return res
+
+
+def poses_measurement(dev, N, L, key, abdesign=False, K=20):
+    """N poses of one complex of L residues (shared context: pair_feat (1,L,L,C)), AbDock dock flavour, structure-only sampling."""
+    T = 100
+    if abdesign:
+        dpm, state, res_feat, pair_feat, gen, mres = build_workload(dev, N, L, T, seed=79, abdesign=True)
+        flags = (True, True)
+    else:
+        dpm, state, res_feat, pair_feat, gen, mres = build_workload(dev, N, L, T, seed=78, abdesign=False, shared_context=True, cdrs=[(8, min(26, L))])
+        flags = (True, False)
+    run = lambda n, graph: dpm._run(state, T, res_feat, pair_feat, gen, mres, flags[0], flags[1], True, None, 99, 0, False, stop_after=n, graph=graph)
+    out = {}
+    run(3, False)
+    for mode, graph in (('eager', False), ('graph', True)):
+        run(K, graph)                                   # (graph: capture + first replay)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        run(K, graph)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[mode] = (round(N * K / dt, 1), round(dt / K * 1e3, 4))
+    best = max(out.values())
+    Nz = pair_feat.shape[0]
+    alg = NUM_LAYERS * (Nz * 256 * L * L + N * 1076 * L) + 13.0e6          # SURVEY 8(d) with z counted once per DISTINCT complex
+    return {f'{key}_sample_steps_per_s': best[0], f'{key}_ms_per_step': best[1], f'{key}_eager_vs_graph': out,
+            f'{key}_step_hbm_frac': round(alg / (best[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            f'{key}_step_tflops': round(step_flops(N, L) / (best[1] * 1e-3) / 1e12, 2),
+            f'{key}_config': (f'{"AbDesign codesign" if abdesign else "AbDock dock_single (prmsd head, pred_x0), structure-only"} sampling loop, '
+                              f'N={N}, L={L}, {"one complex shared by all poses" if Nz == 1 else "distinct complexes"}, {K} timed steps; '
+                              'step_hbm_frac = SURVEY 8(d) bytes (z once per distinct complex) / time / 8 TB/s; step_tflops = 8(d) FLOPs / time')}
 
 
 def log(*a):
