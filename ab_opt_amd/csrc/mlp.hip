@@ -215,7 +215,7 @@ int launch_fused_ln_mlp(const float* x, const float* u, int nslab, int64_t slab_
 #ifdef OT_TIMING   // developer build: section clocks of one workgroup, printed by the launcher
 }  // namespace abopt
 #include <cstdio>
-__device__ long long g_ot_timing[16][4];
+__device__ long long g_ot_timing[16][8];
 namespace abopt {
 #endif
 namespace {
@@ -232,6 +232,7 @@ static_assert(OT_K % 16 == 0 && OT_KC % 64 == 0 && MR == 32 && F == 128, "out_tr
 
 struct OtSmem {
     float ys[MR][XLD];                        // y = LayerNorm1(...) in fp32 (residual of the MLP)
+    float bias[3][F];                         // b_mlp0..2
     char ap[3 * AP_PLANE];                    // input of the current layer as [term][row][128 bf16 + pad]
     union {
         char stage[2][OT_STAGE];              // phase 1: feat chunks as [term][row][192 bf16 + pad]
@@ -287,10 +288,65 @@ __device__ __forceinline__ void mlp_partial(const char* ap, const MlpW& w, float
 }
 }  // namespace
 
+// ---- phase-2 layer weights for the 16x16x32 form: wmf [layer][ct 8][k-step 4][lane 64] x 8 fp32, lane (m = lane & 15, kq = lane >> 4)
+// holds W[16 ct + m][32 s + 8 kq + i].  fp32 (4 bytes per weight instead of the 6 of three bf16 terms): the phase is bound by how fast a
+// CU can pull the three layers from L2, and the split costs 176 VALU operations per wave and layer.  Eight waves compute (wave = column
+// tile ct, both row tiles with the same weight registers); a layer's fragment is 32 registers, requested one layer ahead.
+namespace {
+struct MlpRaw { f32x4 v[4][2]; };
+__device__ __forceinline__ MlpRaw load_mlp_raw(const float* __restrict__ wm, int layer, int ct, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(wm) + ((int64_t)((layer * 8 + ct) * 4) * 64 + lane) * 2;
+    MlpRaw w;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { w.v[s][0] = p[s * 128]; w.v[s][1] = p[s * 128 + 1]; }
+    return w;
+}
+// [16 output columns of tile ct] x [32 rows] of one layer, K = 128, no K split: o[rt] register r of lane (n, kq) = output column
+// 16 ct + 4 kq + r of row 16 rt + n.  (Splitting the whole layer before the barrier that publishes its input, with the LDS reads one
+// k-step ahead, was measured: 128 VGPRs + 52 bytes of scratch per lane, no faster.)
+__device__ __forceinline__ void mlp16_layer(const char* ap, const MlpRaw& w, int lane, f32x4 (&o)[2]) {
+    f32x4 a[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) { a[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; a[rt][1] = a[rt][0]; }
+    const char* xp = ap + (lane & 15) * AP_ROW + (lane >> 4) * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const Split3 w3 = split3(w.v[s][0], w.v[s][1]);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {   // smallest terms first; two accumulators per row tile so consecutive MFMAs never depend on each other
+            const char* xr = xp + rt * 16 * AP_ROW + s * 64;
+            const u32x4 xh = *reinterpret_cast<const u32x4*>(xr), xm = *reinterpret_cast<const u32x4*>(xr + AP_PLANE),
+                        xl = *reinterpret_cast<const u32x4*>(xr + 2 * AP_PLANE);
+            a[rt][0] = mfma_bf(w3.h, xl, a[rt][0]); a[rt][1] = mfma_bf(w3.l, xh, a[rt][1]);
+            a[rt][0] = mfma_bf(w3.m, xm, a[rt][0]); a[rt][1] = mfma_bf(w3.h, xm, a[rt][1]);
+            a[rt][0] = mfma_bf(w3.m, xh, a[rt][0]); a[rt][1] = mfma_bf(w3.h, xh, a[rt][1]);
+        }
+    }
+    o[0] = a[0][0] + a[0][1]; o[1] = a[1][0] + a[1][1];
+}
+// one pair of adjacent fp32 values -> its three packed bf16 term words
+__device__ __forceinline__ void split_pair(float e0, float e1, unsigned& h, unsigned& m, unsigned& l) {
+    h = pk_bf16(e0, e1);
+    const float r0 = e0 - __uint_as_float(h << 16), r1 = e1 - __uint_as_float(h & 0xffff0000u);
+    m = pk_bf16(r0, r1);
+    l = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
+}  // namespace
+
 // DUMP (training): also writes what the backward needs, five [rows,128] slabs: pre-LayerNorm1 sum | y | h0 | h1 | pre-LayerNorm2 sum
+//
+// Schedule (round 3; -DOT_TIMING clocks: prologue 3.5k + phase 1 42k + phase 2 21k cycles before, at EVERY batch size -- the kernel was
+// bound by its own issue order, not by the W_out stream):
+//  phase 1  a wave's k-steps form one software pipeline across the chunk barriers: while the six MFMAs of k-step i issue, the VALU splits
+//           the fp32 W_out fragment of k-step i + 1 into its bf16 terms (it used to do that right after every barrier, all 16 waves at
+//           once, with the matrix pipe idle) and the loader threads split / stage the next feat chunk; raw W fragments are requested
+//           three k-steps ahead.
+//  phase 2  each of the 16 waves owns a 16 x 16 output tile of a layer over the full K = 128 (v_mfma_f32_16x16x32_bf16, the layer's
+//           weights in 48 registers, requested while the previous layer finishes): no K-group partial sums, one barrier per layer
+//           instead of two, activations ping-pong between two sets of bf16 planes.
 template <bool DUMP>
 __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restrict__ feat, const float* __restrict__ wof /* W_out terms, operand order */,
-                                                           const float* __restrict__ wmf /* W_mlp0..2 terms, operand order */,
+                                                           const float* __restrict__ wmf /* W_mlp0..2 terms, 16x16x32 operand order */,
                                                            const float* __restrict__ x, const float* __restrict__ ubias, const uint8_t* __restrict__ mask,
                                                            const float* __restrict__ g1, const float* __restrict__ be1,
                                                            const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2,
@@ -318,17 +374,22 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
         *reinterpret_cast<u32x4*>(d) = sp.h; *reinterpret_cast<u32x4*>(d + OT_PLANE) = sp.m; *reinterpret_cast<u32x4*>(d + 2 * OT_PLANE) = sp.l;
     };
     const int cb = wave & 3, kg = wave >> 2;
-    // this wave's W_out stream: fp32 in operand order, [cb][k-step][lane][8 floats], lane (column lane & 31, k half lane >> 5); split here
+    // this wave's W_out stream: fp32 in operand order, [cb][k-step][lane][8 floats], lane (column lane & 31, k half lane >> 5).
+    // Its k-steps, in order: chunk c, slot j -> k-step 12 c + 3 kg + j (c < 10, j < 3; past 113: nothing to do -- a clamped reload keeps the code uniform)
     const f32x4* wfr = reinterpret_cast<const f32x4*>(wof) + ((int64_t)cb * OT_ST * 64 + lane) * 2;
-    f32x4 wq[OT_SPW][2];
+    auto kstep = [&](int i) { return min((i / OT_SPW) * OT_SPC + kg * OT_SPW + (i % OT_SPW), OT_ST - 1); };
+    f32x4 raw[OT_SPW][2];                                                                                 // ring: k-step i lives in slot i % 3
 #pragma unroll
-    for (int j = 0; j < OT_SPW; ++j) { wq[j][0] = wfr[(kg * OT_SPW + j) * 128]; wq[j][1] = wfr[(kg * OT_SPW + j) * 128 + 1]; }
+    for (int j = 0; j < OT_SPW; ++j) { raw[j][0] = wfr[kstep(j) * 128]; raw[j][1] = wfr[kstep(j) * 128 + 1]; }
     f32x4 fv0 = (f32x4){0.f, 0.f, 0.f, 0.f}, fv1 = fv0;
     if (chunk_ok(0)) {
         fv0 = *reinterpret_cast<const f32x4*>(fsrc); fv1 = *reinterpret_cast<const f32x4*>(fsrc + 4);
         stage_store(0, fv0, fv1);
     }
     if (chunk_ok(1)) { fv0 = *reinterpret_cast<const f32x4*>(fsrc + OT_KC); fv1 = *reinterpret_cast<const f32x4*>(fsrc + OT_KC + 4); }
+    u32x4 nH, nM, nL;                                                                                     // terms of the NEXT k-step
+    { const Split3 w3 = split3(raw[0][0], raw[0][1]); nH = w3.h; nM = w3.m; nL = w3.l; }
+    raw[0][0] = wfr[kstep(OT_SPW) * 128]; raw[0][1] = wfr[kstep(OT_SPW) * 128 + 1];
     __syncthreads();
 #ifdef OT_TIMING
     const long long tc1 = clock64();
@@ -338,57 +399,78 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
     const char* xrd = &sm.stage[0][0] + (lane & 31) * OT_SROW + (kg * OT_SPW) * 32 + (lane >> 5) * 16;
     for (int c = 0; c < OT_NCH; ++c) {
         const int b = c & 1;
-        if (c * OT_SPC + kg * OT_SPW < OT_ST) {                                                         // the last chunk has work for K groups 0 and 1 only
+        // the last chunk has work for K groups 0 and 1 only (and nothing left to stage): the others go straight to the barrier
+        if (c * OT_SPC + kg * OT_SPW < OT_ST) {
 #pragma unroll
-            for (int j = 0; j < OT_SPW; ++j) {
-                const int64_t nst = min((c + 1) * OT_SPC + kg * OT_SPW + j, OT_ST - 1);               // next chunk's k-step of this slot (past the end: a reload)
-                const Split3 w3 = split3(wq[j][0], wq[j][1]);
-                const u32x4 wH = w3.h, wM = w3.m, wL = w3.l;
-#if !(OT_ABL & 1)
-                wq[j][0] = wfr[nst * 128]; wq[j][1] = wfr[nst * 128 + 1];
-#endif
-                const char* xp = xrd + b * OT_STAGE + j * 32;
-#if OT_ABL & 8
-                const u32x4 xh = wM, xm = wL, xl = wH; (void)xp;
-#else
-                const u32x4 xh = *reinterpret_cast<const u32x4*>(xp), xm = *reinterpret_cast<const u32x4*>(xp + OT_PLANE),
-                            xl = *reinterpret_cast<const u32x4*>(xp + 2 * OT_PLANE);
-#endif
-                // smallest terms first; two accumulators so consecutive MFMAs never depend on each other
-                acc0 = mfma_bf32(wH, xl, acc0); acc1 = mfma_bf32(wL, xh, acc1);
-                acc0 = mfma_bf32(wM, xm, acc0); acc1 = mfma_bf32(wH, xm, acc1);
-                acc0 = mfma_bf32(wM, xh, acc0); acc1 = mfma_bf32(wH, xh, acc1);
+        for (int j = 0; j < OT_SPW; ++j) {
+            const int i = c * OT_SPW + j;
+            const u32x4 wH = nH, wM = nM, wL = nL;
+            const char* xp = xrd + b * OT_STAGE + j * 32;
+            const u32x4 xh = *reinterpret_cast<const u32x4*>(xp), xm = *reinterpret_cast<const u32x4*>(xp + OT_PLANE),
+                        xl = *reinterpret_cast<const u32x4*>(xp + 2 * OT_PLANE);
+            // the fragment of k-step i + 1 (slot (j + 1) % 3, requested three k-steps ago) is split pair by pair between the MFMAs of k-step i
+            const f32x4 r0 = raw[(j + 1) % OT_SPW][0], r1 = raw[(j + 1) % OT_SPW][1];
+            acc0 = mfma_bf32(wH, xl, acc0); acc1 = mfma_bf32(wL, xh, acc1);
+            { unsigned h_, m_, l_; split_pair(r0[0], r0[1], h_, m_, l_); nH[0] = h_; nM[0] = m_; nL[0] = l_; }
+            acc0 = mfma_bf32(wM, xm, acc0);
+            { unsigned h_, m_, l_; split_pair(r0[2], r0[3], h_, m_, l_); nH[1] = h_; nM[1] = m_; nL[1] = l_; }
+            acc1 = mfma_bf32(wH, xm, acc1);
+            { unsigned h_, m_, l_; split_pair(r1[0], r1[1], h_, m_, l_); nH[2] = h_; nM[2] = m_; nL[2] = l_; }
+            acc0 = mfma_bf32(wM, xh, acc0);
+            { unsigned h_, m_, l_; split_pair(r1[2], r1[3], h_, m_, l_); nH[3] = h_; nM[3] = m_; nL[3] = l_; }
+            acc1 = mfma_bf32(wH, xh, acc1);
+            { const int64_t nst = kstep(i + 1 + OT_SPW); raw[(j + 1) % OT_SPW][0] = wfr[nst * 128]; raw[(j + 1) % OT_SPW][1] = wfr[nst * 128 + 1]; }
+            if (j == 0) {                                                                               // feat staging in the shadow of this chunk's MFMAs
+                if (chunk_ok(c + 1)) stage_store(b ^ 1, fv0, fv1);                                      // chunk c + 1 -> the other buffer
+                if (chunk_ok(c + 2)) { fv0 = *reinterpret_cast<const f32x4*>(fsrc + (c + 2) * OT_KC); fv1 = *reinterpret_cast<const f32x4*>(fsrc + (c + 2) * OT_KC + 4); }
             }
         }
-        if (!(OT_ABL & 2)) {
-            if (chunk_ok(c + 1)) stage_store(b ^ 1, fv0, fv1);                                          // chunk c + 1 -> the other buffer
-            if (chunk_ok(c + 2)) { fv0 = *reinterpret_cast<const f32x4*>(fsrc + (c + 2) * OT_KC); fv1 = *reinterpret_cast<const f32x4*>(fsrc + (c + 2) * OT_KC + 4); }
         }
         __syncthreads();
     }
 #ifdef OT_TIMING
     const long long tc2 = clock64();
+    long long tp2 = 0;
 #endif
-    MlpW mw = load_mlp_w(wmf, 0, cb, kg, lane);
-    store_partial(sm.part[kg], acc0, acc1, cb, lane);                                                   // the staging planes are dead: the loop ended on a barrier
-    __syncthreads();
     // ---------------------------------------------------------------- phase 2: LayerNorm1 (each wave 2 rows), MLP, LayerNorm2
     constexpr int RW = MR / OT_NW;
+    const int fm = lane & 15, kq = lane >> 4;
+    const bool mlpw = wave < 8;                                                                          // waves 0..7 own the eight 16-column tiles
+    const int ct = wave & 7;
+    // what LayerNorm1 needs from global memory goes out FIRST: loads return in order, and the layer weights behind them are a 64 KB burst
+    float2 xv_[RW];
+    bool keep_[RW];
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int64_t row = min(row0 + wave * RW + rr, rows - 1);
+        keep_[rr] = mask ? (mask[row] != 0) : true;
+        xv_[rr] = reinterpret_cast<const float2*>(x + row * F)[lane];
+    }
+    const float2 bb = ubias ? reinterpret_cast<const float2*>(ubias)[lane] : make_float2(0.f, 0.f);
+    const float2 g1v = reinterpret_cast<const float2*>(g1)[lane], be1v = reinterpret_cast<const float2*>(be1)[lane];
+    MlpRaw mw;
+    if (mlpw) mw = load_mlp_raw(wmf, 0, ct, lane);
+    store_partial(sm.part[kg], acc0, acc1, cb, lane);                                                   // the staging planes are dead: the loop ended on a barrier
+    if (tid < 3 * F / 4) {                                                                               // the three bias vectors -> LDS (read per layer by the compute waves)
+        const float* bsrc = tid < F / 4 ? b0 : (tid < F / 2 ? b1 : b2);
+        *reinterpret_cast<f32x4*>(&sm.bias[tid >> 5][(tid & 31) * 4]) = *reinterpret_cast<const f32x4*>(bsrc + (tid & 31) * 4);
+    }
+    const int ocol = ct * 16 + kq * 4;                                                                   // this lane's four output columns in every layer
+    __syncthreads();
+    char* apA = sm.ap;                                                                                   // planes: LayerNorm1 output, later layer-1 output
+    char* apB = reinterpret_cast<char*>(&sm.part[2][0][0]);                                              // second set (layer-0 output): part[2..3] are free after LayerNorm1
+    static_assert(3 * AP_PLANE <= (int)(2 * MR * XLD * sizeof(float)), "second activation plane set must fit into two K-group slabs");
     {
-        const float2 bb = ubias ? reinterpret_cast<const float2*>(ubias)[lane] : make_float2(0.f, 0.f);
-        const float2 g = reinterpret_cast<const float2*>(g1)[lane], bt = reinterpret_cast<const float2*>(be1)[lane];
+        const float2 g = g1v, bt = be1v;
         float a_[RW], b_[RW], mean[RW], var[RW];
 #pragma unroll
         for (int rr = 0; rr < RW; ++rr) {
             const int rl = wave * RW + rr;
-            const int64_t row = min(row0 + rl, rows - 1);
-            const bool keep = mask ? (mask[row] != 0) : true;
-            const float2 xv = reinterpret_cast<const float2*>(x + row * F)[lane];
             const float2 u0 = *reinterpret_cast<const float2*>(&sm.part[0][rl][2 * lane]), u1 = *reinterpret_cast<const float2*>(&sm.part[1][rl][2 * lane]);
             const float2 u2 = *reinterpret_cast<const float2*>(&sm.part[2][rl][2 * lane]), u3 = *reinterpret_cast<const float2*>(&sm.part[3][rl][2 * lane]);
             float2 us = make_float2(((u0.x + u1.x) + (u2.x + u3.x)) + bb.x, ((u0.y + u1.y) + (u2.y + u3.y)) + bb.y);
-            if (!keep) us = make_float2(0.f, 0.f);
-            a_[rr] = xv.x + us.x; b_[rr] = xv.y + us.y;
+            if (!keep_[rr]) us = make_float2(0.f, 0.f);
+            a_[rr] = xv_[rr].x + us.x; b_[rr] = xv_[rr].y + us.y;
             if (DUMP && row0 + rl < rows) reinterpret_cast<float2*>(dump + (row0 + rl) * F)[lane] = make_float2(a_[rr], b_[rr]);
         }
 #pragma unroll
@@ -401,53 +483,58 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
             const float sd = sqrtf(var[rr] + 1e-10f);
             const float y0 = a_[rr] / sd * g.x + bt.x, y1 = b_[rr] / sd * g.y + bt.y;
             *reinterpret_cast<float2*>(&sm.ys[rl][2 * lane]) = make_float2(y0, y1);
-            store_terms2(sm.ap, rl * AP_ROW + lane * 4, y0, y1);
+            store_terms2(apA, rl * AP_ROW + lane * 4, y0, y1);
             if (DUMP && row0 + rl < rows) reinterpret_cast<float2*>(dump + slab + (row0 + rl) * F)[lane] = make_float2(y0, y1);
         }
     }
-    __syncthreads();
-    // one pass after each layer: thread -> (row tid >> 5, columns 4 (tid & 31) ..): sum of the four K groups + bias
-    const int er = tid >> 5, ec = (tid & 31) * 4;
-    auto gather = [&](const float* __restrict__ bias) {
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&sm.part[0][er][ec]), p1 = *reinterpret_cast<const f32x4*>(&sm.part[1][er][ec]);
-        const f32x4 p2 = *reinterpret_cast<const f32x4*>(&sm.part[2][er][ec]), p3 = *reinterpret_cast<const f32x4*>(&sm.part[3][er][ec]);
-        return ((p0 + p1) + (p2 + p3)) + *reinterpret_cast<const f32x4*>(bias + ec);
-    };
-    // ---- layer 0: relu(W0 y + b0)
-    mlp_partial(sm.ap, mw, sm.part[kg], cb, kg, lane);
-    mw = load_mlp_w(wmf, 1, cb, kg, lane);
-    __syncthreads();
-    {
-        const f32x4 v = gather(b0);
-        const f32x4 hv = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-        store_terms2(sm.ap, er * AP_ROW + ec * 2, hv[0], hv[1]);
-        store_terms2(sm.ap, er * AP_ROW + ec * 2 + 4, hv[2], hv[3]);
-        if (DUMP && row0 + er < rows) *reinterpret_cast<f32x4*>(dump + 2 * slab + (row0 + er) * F + ec) = hv;
+    __syncthreads();                                                                                     // y planes complete; every read of part[] is done
+#ifdef OT_TIMING
+    const long long tp1 = clock64();
+#endif
+    // ---- layer 0: relu(W0 y + b0) -> planes B ; layer 1: relu(W1 h + b1) -> planes A (their last readers passed the barrier in between)
+#pragma unroll
+    for (int layer = 0; layer < 2; ++layer) {
+        if (mlpw) {
+            const char* src = layer == 0 ? apA : apB;
+            char* dst = layer == 0 ? apB : apA;
+            const MlpRaw nxt = load_mlp_raw(wmf, layer + 1, ct, lane);                                  // the next layer's fragment travels while this one computes
+            f32x4 o[2];
+            mlp16_layer(src, mw, lane, o);
+            mw = nxt;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(&sm.bias[layer][ocol]);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int orow = rt * 16 + fm;
+                const f32x4 v = o[rt] + bias;
+                const f32x4 hv = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                store_terms2(dst, orow * AP_ROW + ocol * 2, hv[0], hv[1]);
+                store_terms2(dst, orow * AP_ROW + ocol * 2 + 4, hv[2], hv[3]);
+                if (DUMP && row0 + orow < rows) *reinterpret_cast<f32x4*>(dump + (2 + layer) * slab + (row0 + orow) * F + ocol) = hv;
+            }
+        }
+        __syncthreads();
+#ifdef OT_TIMING
+        if (layer == 0) tp2 = clock64();
+#endif
+    }
+    // ---- layer 2 + residual (in place in ys: every element has exactly one owner), then LayerNorm2
+    if (mlpw) {
+        f32x4 o[2];
+        mlp16_layer(apA, mw, lane, o);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(&sm.bias[2][ocol]);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int orow = rt * 16 + fm;
+            f32x4 yv = *reinterpret_cast<const f32x4*>(&sm.ys[orow][ocol]);
+            yv += o[rt] + bias;
+            *reinterpret_cast<f32x4*>(&sm.ys[orow][ocol]) = yv;
+            if (DUMP && row0 + orow < rows) *reinterpret_cast<f32x4*>(dump + 4 * slab + (row0 + orow) * F + ocol) = yv;
+        }
     }
     __syncthreads();
-    // ---- layer 1: relu(W1 h + b1)
-    mlp_partial(sm.ap, mw, sm.part[kg], cb, kg, lane);
-    mw = load_mlp_w(wmf, 2, cb, kg, lane);
-    __syncthreads();
-    {
-        const f32x4 v = gather(b1);
-        const f32x4 hv = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-        store_terms2(sm.ap, er * AP_ROW + ec * 2, hv[0], hv[1]);
-        store_terms2(sm.ap, er * AP_ROW + ec * 2 + 4, hv[2], hv[3]);
-        if (DUMP && row0 + er < rows) *reinterpret_cast<f32x4*>(dump + 3 * slab + (row0 + er) * F + ec) = hv;
-    }
-    __syncthreads();
-    // ---- layer 2 + residual (in place in ys), then LayerNorm2
-    mlp_partial(sm.ap, mw, sm.part[kg], cb, kg, lane);
-    __syncthreads();
-    {
-        const f32x4 v = gather(b2);
-        f32x4 yv = *reinterpret_cast<const f32x4*>(&sm.ys[er][ec]);
-        yv += v;
-        *reinterpret_cast<f32x4*>(&sm.ys[er][ec]) = yv;
-        if (DUMP && row0 + er < rows) *reinterpret_cast<f32x4*>(dump + 4 * slab + (row0 + er) * F + ec) = yv;
-    }
-    __syncthreads();
+#ifdef OT_TIMING
+    const long long tp3 = clock64();
+#endif
     {
         const float2 g = reinterpret_cast<const float2*>(g2)[lane], bt = reinterpret_cast<const float2*>(be2)[lane];
         float2 v[RW];
@@ -464,7 +551,7 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
         }
     }
 #ifdef OT_TIMING
-    if (blockIdx.x == 17 && lane == 0) { long long* o = g_ot_timing[wave]; o[0] = tc1 - tc0; o[1] = tc2 - tc1; o[2] = clock64() - tc2; }
+    if (blockIdx.x == 17 && lane == 0) { long long* o = g_ot_timing[wave]; o[0] = tc1 - tc0; o[1] = tc2 - tc1; o[2] = clock64() - tc2; o[3] = tp1 - tc2; o[4] = tp2 - tp1; o[5] = tp3 - tp2; }
 #endif
 }
 
@@ -491,52 +578,59 @@ int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, con
                         : launch_out_ln_mlp_t<false>(feat, wof, wmf, x, ubias, mask, g1, be1, b0, b1, b2, g2, be2, out, dump, rows, st);
 #ifdef OT_TIMING
     {
-        long long hh[16][4];
+        long long hh[16][8];
         (void)hipDeviceSynchronize();
         (void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_ot_timing), sizeof(hh));
         static int calls = 0;
         if (++calls == 8)
-            for (int w = 0; w < 16; w += 5) fprintf(stderr, "[ot timing WG 17 wave %d] prologue %lld | phase 1 loop %lld | phase 2 %lld\n", w, hh[w][0], hh[w][1], hh[w][2]);
+            for (int w = 0; w < 16; w += 5) fprintf(stderr, "[ot timing WG 17 wave %d] prologue %lld | phase 1 loop %lld | phase 2 %lld (partials + LayerNorm1 %lld, layer 0 %lld, layers 1 + 2 %lld)\n", w, hh[w][0], hh[w][1], hh[w][2], hh[w][3], hh[w][4], hh[w][5]);
     }
 #endif
     return rc;
 }
 
 // =====================================================================================================================
-// Weights of the tail as bf16 terms in MFMA operand order, packed on the device (one launch per block): W_out -> wof
-// [4][114][3][64], W_mlp0..2 -> wmf [3][4][8][3][64], and their transposes -> wmt (operands of the backward chain).  One thread
-// per (matrix, cb, step, lane): 8 values -> three 16-byte vectors.  Layout: include/abopt.h (w_out_frag, w_mlp_frag).
+// Weights of the tail in MFMA operand order, packed on the device (one launch per block): W_out -> wof [4][114][64][8] fp32 (32x32x16
+// operand order; the tail kernel splits it in registers), W_mlp0..2 -> wmf [3][8][4][64][8] fp32 (16x16x32 operand order, split in
+// registers too; the buffer keeps the size of wmt, its unused third is zeroed), and the TRANSPOSED MLP weights -> wmt [3][4][8][3][64] x 8
+// bf16 (32x32x16 operand order, three bf16 terms: operands of the backward chain).
+// One thread per (matrix, block, step, lane): 8 values -> up to three 16-byte vectors.  Layout: include/abopt.h (w_out_frag, w_mlp_frag).
 __global__ __launch_bounds__(256) void pack_tail_weights_kernel(const float* __restrict__ w_out, const float* __restrict__ w0, const float* __restrict__ w1,
                                                                 const float* __restrict__ w2, float* __restrict__ wof, float* __restrict__ wmf,
                                                                 float* __restrict__ wmt) {
-    constexpr int NOUT = 4 * OT_ST * 64, NMLP = 4 * OT_MS * 64;
+    constexpr int NOUT = 4 * OT_ST * 64, NMLP = 4 * OT_MS * 64;          // NMLP = 2048 = 8 ct * 4 k-steps * 64 lanes as well
     int id = blockIdx.x * 256 + threadIdx.x;
-    const float* src; u32x4* dst; int K, rs, cs, steps;
-    if (id < NOUT) { src = w_out; dst = reinterpret_cast<u32x4*>(wof); K = OT_K; rs = OT_K; cs = 1; steps = OT_ST; }
-    else {
-        id -= NOUT;
-        if (id >= 6 * NMLP) return;
-        const int m = id / NMLP; id %= NMLP;
-        const int layer = m % 3; const bool tr = m >= 3;
-        if (tr && !wmt) return;
-        src = layer == 0 ? w0 : (layer == 1 ? w1 : w2);
-        dst = reinterpret_cast<u32x4*>(tr ? wmt : wmf) + layer * (NMLP * 3);
-        K = F; steps = OT_MS;
-        rs = tr ? 1 : F; cs = tr ? F : 1;                                        // transposed: element (row, k) = w[k][row]
-    }
-    (void)K;
-    const int lane = id & 63, st = (id >> 6) % steps, cb = (id >> 6) / steps;
-    const float* p = src + (int64_t)(cb * 32 + (lane & 31)) * rs + (int64_t)(st * 16 + (lane >> 5) * 8) * cs;
-    f32x4 lo, hi;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { lo[i] = p[(int64_t)i * cs]; hi[i] = p[(int64_t)(i + 4) * cs]; }
-    if (src == w_out) {                                                          // W_out stays fp32 (the tail kernel splits it in registers)
-        f32x4* d32 = reinterpret_cast<f32x4*>(wof) + ((int64_t)(cb * steps + st) * 64 + lane) * 2;
-        d32[0] = lo; d32[1] = hi;
+    if (id < NOUT) {                                                     // W_out stays fp32
+        const int lane = id & 63, st = (id >> 6) % OT_ST, cb = (id >> 6) / OT_ST;
+        const float* p = w_out + (int64_t)(cb * 32 + (lane & 31)) * OT_K + st * 16 + (lane >> 5) * 8;
+        f32x4* d32 = reinterpret_cast<f32x4*>(wof) + ((int64_t)(cb * OT_ST + st) * 64 + lane) * 2;
+        d32[0] = *reinterpret_cast<const f32x4*>(p); d32[1] = *reinterpret_cast<const f32x4*>(p + 4);
         return;
     }
+    id -= NOUT;
+    if (id >= 6 * NMLP) return;
+    const int m = id / NMLP; id %= NMLP;
+    const int layer = m % 3; const bool tr = m >= 3;
+    if (tr && !wmt) return;
+    const float* src = layer == 0 ? w0 : (layer == 1 ? w1 : w2);
+    const int lane = id & 63;
+    f32x4 lo, hi;
+    u32x4* d;
+    if (!tr) {                                                           // forward: fp32 [layer][ct][s][lane (m, kq)][i] = W[16 ct + m][32 s + 8 kq + i]
+        const int st = (id >> 6) % 4, ct = (id >> 6) / 4;
+        const float* p = src + (int64_t)(ct * 16 + (lane & 15)) * F + st * 32 + (lane >> 4) * 8;
+        f32x4* d32 = reinterpret_cast<f32x4*>(wmf) + ((int64_t)((layer * 8 + ct) * 4 + st) * 64 + lane) * 2;
+        d32[0] = *reinterpret_cast<const f32x4*>(p); d32[1] = *reinterpret_cast<const f32x4*>(p + 4);
+        reinterpret_cast<f32x4*>(wmf)[3 * NMLP * 2 + layer * NMLP + id] = (f32x4){0.f, 0.f, 0.f, 0.f};     // the unused third of the buffer
+        return;
+    } else {                                                             // backward: [cb][s][term][lane (c, kh)] = W[16 s + 8 kh + i][32 cb + c]
+        const int st = (id >> 6) % OT_MS, cb = (id >> 6) / OT_MS;
+        const float* p = src + (int64_t)(st * 16 + (lane >> 5) * 8) * F + cb * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lo[i] = p[(int64_t)i * F]; hi[i] = p[(int64_t)(i + 4) * F]; }
+        d = reinterpret_cast<u32x4*>(wmt) + layer * (NMLP * 3) + ((int64_t)(cb * OT_MS + st) * 3) * 64 + lane;
+    }
     const Split3 sp = split3(lo, hi);
-    u32x4* d = dst + ((int64_t)(cb * steps + st) * 3) * 64 + lane;
     d[0] = sp.h; d[64] = sp.m; d[128] = sp.l;
 }
 

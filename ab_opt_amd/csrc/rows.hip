@@ -152,19 +152,34 @@ int launch_heads_epilogue(const float* R, const float* v_t, const float* eps_crd
     return ABOPT_OK;
 }
 
-// prmsd_logits.mean(dim=1) over ALL L rows incl. padding (dpm_full.py:110).
-__global__ void mean_over_L_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int B) {
-    const int n = blockIdx.x, b = threadIdx.x;
-    if (b >= B) return;
-    float s = 0.f;
-    for (int l = 0; l < L; ++l) s += in[((int64_t)n * L + l) * B + b];
-    out[(int64_t)n * B + b] = s / (float)L;
+// prmsd_logits.mean(dim=1) over ALL L rows incl. padding (dpm_full.py:110).  One workgroup per sample: thread (bin b, slice p of 16)
+// sums rows p, p + 16, ... with the loads of four rows in flight, the slices meet in LDS (fixed order: deterministic).
+__global__ __launch_bounds__(1024) void mean_over_L_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int B) {
+    __shared__ float part[16][64];
+    const int n = blockIdx.x, b = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const float* src = in + (int64_t)n * L * B + b;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (b < B) {
+        int l = p;
+        for (; l + 48 < L; l += 64) {
+            s0 += src[(int64_t)l * B]; s1 += src[(int64_t)(l + 16) * B]; s2 += src[(int64_t)(l + 32) * B]; s3 += src[(int64_t)(l + 48) * B];
+        }
+        for (; l < L; l += 16) s0 += src[(int64_t)l * B];
+    }
+    part[p][b] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (p == 0 && b < B) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += part[q][b];
+        out[(int64_t)n * B + b] = s / (float)L;
+    }
 }
 
 int launch_mean_over_L(const float* in, float* out, int N, int L, int B, hipStream_t st) {
     if (N == 0) return ABOPT_OK;
-    ABOPT_CHECK_ARG(B <= 1024, "mean_over_L: B=%d too large", B);
-    hipLaunchKernelGGL(mean_over_L_kernel, dim3(N), dim3(((B + 63) / 64) * 64), 0, st, in, out, L, B);
+    ABOPT_CHECK_ARG(B <= 64, "mean_over_L: B=%d too large (at most 64 bins)", B);
+    hipLaunchKernelGGL(mean_over_L_kernel, dim3(N), dim3(1024), 0, st, in, out, L, B);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

@@ -268,8 +268,11 @@ def pack_out_weights(w_out):
 
 
 def pack_mlp_weights(w0, w1, w2):
-    """three [128, 128] layers -> w_mlp_frag [3, 4, 8, 3, 64, 4] (include/abopt.h: abopt_ga_weights.w_mlp_frag)."""
-    return torch.stack([pack_mfma_operand(w) for w in (w0, w1, w2)], 0).contiguous()
+    """three [128, 128] layers -> w_mlp_frag (include/abopt.h: abopt_ga_weights.w_mlp_frag): fp32 in 16x16x32 MFMA operand order,
+    [layer][ct][s][lane = 16 kq + m][i] = w[16 ct + m][32 s + 8 kq + i], zero-padded to abopt_mlp_frag_floats() floats."""
+    out = [w.float().reshape(8, 16, 4, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1) for w in (w0, w1, w2)]       # [ct, m, s, kq, i] -> [ct, s, kq, m, i]
+    flat = torch.cat(out)
+    return torch.cat([flat, torch.zeros(lib().abopt_mlp_frag_floats() - flat.numel(), dtype=torch.float32, device=flat.device)])
 
 
 _NODE_FRAG_INDEX = None

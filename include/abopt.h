@@ -62,9 +62,9 @@ typedef struct {
     const float* w_out_frag;    /* optional [4, 114, 64, 8]: w_out as fp32 in MFMA operand order: [cb][s][lane = 32 kh + c][i] = w_out[32 cb + c][16 s + 8 kh + i]
                                    (the kernel splits it into bf16 terms in registers);
                                    when given together with w_mlp_frag, out_transform runs inside the LayerNorm/MLP kernel (no split-K partial slabs) */
-    const float* w_mlp_frag;    /* optional [3, 4, 8, 3, 64, 4]: w_mlp0, w_mlp1, w_mlp2 in the same operand order, every weight as three bf16 terms
-                                   (h + m + l == w, as w_node_frag): [layer][cb][s][term][lane] is a 16-byte vector of 8 bf16, entry i =
-                                   term(w[32 cb + c][16 s + 8 kh + i]); the fused tail kernel reads its weights from here */
+    const float* w_mlp_frag;    /* optional, abopt_mlp_frag_floats() floats: w_mlp0, w_mlp1, w_mlp2 as fp32 in 16x16x32 MFMA operand order,
+                                   [layer][ct][s][lane = 16 kq + m][i] = w[16 ct + m][32 s + 8 kq + i] (3 * 8 * 4 * 64 * 8 floats, the rest of
+                                   the buffer is zero); the fused tail kernel reads its weights from here and splits them into bf16 terms */
 } abopt_ga_weights;
 
 /* Host-side description of the w_node_frag layout (used by the binding to pack weights once): for head h, tile T (0,1 q | 2,3 k |
