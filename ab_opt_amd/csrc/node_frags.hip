@@ -34,7 +34,7 @@ __device__ long long g_nf_timing[16][8];
 namespace abopt {
 
 constexpr int NF_F = 128;                                       // node feature width (ga.py:54-66 with node_feat_dim = 128)
-constexpr int NF_TILES = 12, NF_HT = NF_TILES / 2, NF_WAVES = 8;
+constexpr int NF_TILES = 12, NF_HT = NF_TILES / 2, NF_WAVES = 12;       // 12 waves = 3 per SIMD (152 VGPRs): the task epilogues of one wave hide behind the MFMAs of two others (8 -> 12 waves: 35.8 -> 34.9 us at M = 8192, 205 -> 188 us at M = 48000, same box)
 constexpr int NF_KS = NF_F / 32, NF_SPL = 3;                // k-steps of 32, bf16 terms per fp32 value
 constexpr int NF_HEAD_VEC = NF_TILES * NF_KS * NF_SPL * 64;    // 16-byte vectors (8 bf16) per head: [tile][k-step][term][lane]
 
