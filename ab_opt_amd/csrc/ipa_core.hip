@@ -499,6 +499,11 @@ __device__ __attribute__((noinline)) void persist_point_epilogue(const float* __
     }
 }
 
+// Short crops (L <= 64, the reference's CDR + 20 antigen residues: a block is over after 2..4 positions and the per-block pieces set the
+// pace -- at L = 48, by -DPERSIST_TIMING barrier waits per interval class: the A waves' point epilogue ~10k cycles, their q' swap ~6k,
+// the C waves' block epilogue ~7k on top of 3 x 9k of positions, the pair waves waiting at 60 % of the barriers) were tried in a
+// specialised form in round 3: point epilogue on the pair waves (208 bytes of scratch per lane: 4.36 -> 4.87 ms per 1000-pose step)
+// and z requests after the position's MFMAs instead of before (neutral).  Neither is kept.
 __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __restrict__ qfrag, const float* __restrict__ kvfrag, const float* __restrict__ z,
                                                                const uint8_t* __restrict__ mask, const float* __restrict__ R, const float* __restrict__ t,
                                                                float* __restrict__ feat, const float* __restrict__ pbc, int L, int nib, int total_blocks,
@@ -516,10 +521,13 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x;
 #ifdef PERSIST_TIMING
-    long long pt_wait = 0, pt_mem = 0, pt_lds = 0, pt_mf = 0, pt_start = clock64();
-#define PSYNC() { const long long a_ = clock64(); __syncthreads(); pt_wait += clock64() - a_; }
+    long long pt_wait = 0, pt_mem = 0, pt_lds = 0, pt_mf = 0, pt_start = clock64(), pt_wk[3] = {0, 0, 0};
+    int pt_cls = 0;                                                     // class of the current interval: 0 first chunk of a block, 2 last, 1 between
+#define PSYNC() { const long long a_ = clock64(); __syncthreads(); const long long d_ = clock64() - a_; pt_wait += d_; pt_wk[pt_cls] += d_; }
+#define PCLS(G) { const int c_ = (G) % nchunk; pt_cls = c_ == 0 ? 0 : (c_ == nchunk - 1 ? 2 : 1); }
 #else
 #define PSYNC() __syncthreads();
+#define PCLS(G)
 #endif
     const int nb = (total_blocks - (int)blockIdx.x + G - 1) / G;        // blocks of this workgroup (>= 1)
     const int gtot = nb * nchunk;                                       // positions
@@ -643,6 +651,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
         };
 #define PP_STEP(K, G)                                                                                                    \
     {                                                                                                                    \
+        PCLS(G)                                                                                                          \
         if (c == 0) block_begin();                                                                                       \
         PP_CHUNK(K, c, (G) & 1)                                                                                          \
         if (c == nchunk - 1) { block_end(); c = 0; ++j; } else ++c;                                                      \
@@ -702,6 +711,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
         PSYNC()                                                    // S(0) ready
         int bufn = 1;                                                       // buffer of position g + 1
         for (int g = 0; g < gtot; ++g) {
+            PCLS(g)
             const int gn = g + 1;
             if (gn < gtot) {
                 if (gn % nchunk == 0) {
@@ -726,7 +736,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
                 produce(bufn, kvx, chx);
                 bufn = (bufn == 2) ? 0 : bufn + 1;
             }
-            if (g >= nchunk && g % nchunk == 1) {                          // second interval of a block: the C waves wrote the previous block's points last interval
+            if (g >= nchunk && g % nchunk == 1) {                // second interval of a block: the C waves wrote the previous block's points last interval
                 const PBlk bp = blk(g / nchunk - 1);
                 persist_point_epilogue(ptsb, R, t, feat, bp.rowbase, bp.i0, L, atid, 4 * 64);
             }
@@ -816,6 +826,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
         PSYNC()                                                    // B_0: P(0) ready
         int buf = 0;                                                        // buffer of position g - 1
         for (int g = 1; g <= gtot; ++g) {
+            PCLS(g)
             const int p = g - 1;
             const f32x4* kvx; int chx;
             kv_pos(g, kvx, chx);
@@ -832,10 +843,11 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
 #ifdef PERSIST_TIMING
     if (blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == NPW || wave == NPW + 4)) {
         long long* o = g_core_timing[wave == 0 ? 0 : (wave == NPW ? 1 : 2)];
-        o[0] = clock64() - pt_start; o[1] = pt_wait; o[2] = pt_mem; o[3] = pt_lds; o[4] = pt_mf;
+        o[0] = clock64() - pt_start; o[1] = pt_wait; o[2] = pt_mem; o[3] = pt_lds; o[4] = pt_mf; o[5] = pt_wk[0]; o[6] = pt_wk[1]; o[7] = pt_wk[2];
     }
 #endif
 #undef PSYNC
+#undef PCLS
 #undef PC_ISSUE
 }
 
@@ -948,7 +960,7 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
                 static int calls = 0;
                 if (++calls == 8)
                     for (int r = 0; r < 3; ++r)
-                        fprintf(stderr, "[persist timing, cycles of WG 17] %s: total %lld | barrier wait %lld | waiting for its fragment loads %lld | (C) LDS reads %lld, scale + MFMA issue %lld\n", r == 0 ? "pair" : (r == 1 ? "A   " : "C   "), h[r][0], h[r][1], h[r][2], h[r][3], h[r][4]);
+                        fprintf(stderr, "[persist timing, cycles of WG 17] %s: total %lld | barrier wait %lld | waiting for its fragment loads %lld | (C) LDS reads %lld, scale + MFMA issue %lld | barrier wait by interval class (first / middle / last chunk of a block) %lld / %lld / %lld\n", r == 0 ? "pair" : (r == 1 ? "A   " : "C   "), h[r][0], h[r][1], h[r][2], h[r][3], h[r][4], h[r][5], h[r][6], h[r][7]);
             }
 #endif
             return ABOPT_OK;

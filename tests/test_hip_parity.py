@@ -1191,15 +1191,16 @@ def test_ga_block_and_cache_above_2048_residues():
         assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize('N,L,lengths', [(32, 256, None), (40, 100, None), (24, 250, 'ragged')])
+@pytest.mark.parametrize('N,L,lengths', [(32, 256, None), (40, 100, None), (24, 250, 'ragged'), (96, 48, 'ragged'), (136, 32, None), (72, 64, 'ragged')])
 def test_persistent_core_is_bit_identical(N, L, lengths):
     """With the pair-bias cache and more query blocks than CUs the sampler's core runs as ONE persistent workgroup per CU that walks
     several query blocks with the roles' pipeline kept across block boundaries (csrc/ipa_core.hip: ipa_core_persist_kernel).  Same
     arithmetic in the same order: every sample must come out bit-identical to the same sample run in a small batch (one block per
-    workgroup, the plain kernel) -- odd block counts per workgroup, chunk counts not divisible by 3 and ragged lengths included."""
+    workgroup, the plain kernel) -- odd block counts per workgroup, chunk counts not divisible by 3 and ragged lengths included.
+    L <= 64: blocks of 2..4 positions, where the per-block pieces (q swap, epilogues) dominate."""
     from ab_opt_amd import hip
     d = standalone_abdesign_dpm(100, 2).to(DEV)
-    lens = [L] * N if lengths is None else [L - (7 * i) % 60 for i in range(N)]
+    lens = [L] * N if lengths is None else [L - (7 * i) % min(60, L // 2) for i in range(N)]
     v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lens, 5200 + N, [(5, 14), (22, 30)])
     beta = d.trans_pos.var_sched.betas[37].expand([N]).contiguous()
     arr, ew = d.eps_net.encoder.packed_array(), d.eps_net.packed()
@@ -1325,3 +1326,45 @@ def test_dockq_superposition_corner_cases():
             assert max_abs(out['DockQ'].cpu(), want[:, 3]) < 1e-5, c['name']
         else:
             assert torch.isfinite(out['Lrms']).all()
+
+
+def test_eps_net_reference_headline_shape_vs_oracle():
+    """The reference's own headline invocation (AbDock/README.md:61: dock_pdb.py -n 1000 -b 1000; configs/train/dock_single.yml:12-14
+    crops the CDR plus 20 antigen residues): N = 1000 poses of ONE complex, L = 48, AbDock flavour, the context passed once
+    (pair_feat (1,L,L,C), shared pair-bias cache) -- the persistent core with 3000 three-position query blocks on 256 workgroups.  Per-pose masks
+    are ragged (the kernels take one per pose).  A subset of the poses against the oracle; then the whole batch must be bit-identical
+    to the same poses evaluated in small batches through the plain kernel."""
+    from ab_opt_amd import hip
+    from oracle import dpm
+    N, L, T, t = 1000, 48, 100, 63
+    d_cpu = build_model(T, 2).diffusion
+    d = build_model(T, 2, device=DEV).diffusion
+    sd = {k: v.cpu() for k, v in d_cpu.state_dict().items()}
+    lens = [L - (5 * i) % 17 for i in range(N)]
+    v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lens, 7100, [(8, 26)])
+    rf1, pf1 = rf[:1].contiguous(), pf[:1].contiguous()                       # one complex
+    beta = d.trans_pos.var_sched.betas[t].expand([N]).contiguous()
+    arr, ew = d.eps_net.encoder.packed_array(), d.eps_net.packed()
+    pbc = hip.pair_bias_cache(arr, 6, pf1)
+    rfN = rf1.expand(N, -1, -1).contiguous()
+    net = hip.eps_net_forward(ew, v, p, s, rfN, pf1, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc, pair_feat_shared=True)
+    net = {k: (a.clone() if a is not None else None) for k, a in net.items()}
+    ids = [0, 1, 499, 998, 999]
+    ix = torch.tensor(ids, device=DEV)
+    c = lambda a: a[ix].cpu()
+    inv = d_cpu.trans_rot.angular_distrib_inv
+    den = dpm.Denoiser(sd, num_steps=T, variant='abdock', obj='pred_x0', mode='mm', pre='',
+                       tables=(None, dict(stddevs=inv.stddevs, approx_flag=inv.approx_flag, X=inv.X, Y=None)))
+    k5 = len(ids)
+    ref = den._eps(c(v), c(p), c(s), rf1.cpu().expand(k5, -1, -1), pf1.cpu().expand(k5, -1, -1, -1), c(beta), c(gen), c(mres), False)
+    assert max_abs(c(net['R_next']), ref[1]) < 3e-5
+    assert max_abs(c(net['eps_pos']), ref[2]) < 3e-5
+    assert max_abs(c(net['c']), ref[3]) < 1e-5
+    assert max_abs(c(net['prmsd_logits']), ref[4]) < 3e-5
+    for lo in (0, 497, N - 3):                                                # 3 poses: 9 query blocks, the plain one-block kernel
+        sl = slice(lo, lo + 3)
+        cc = lambda a: a[sl].contiguous()
+        small = hip.eps_net_forward(ew, cc(v), cc(p), cc(s), cc(rfN), pf1, cc(beta), cc(gen), cc(mres), d.abdock, d.num_bins, False,
+                                    pair_bias_cache=pbc, pair_feat_shared=True)
+        for k in ('R_next', 'eps_pos', 'c'):
+            assert torch.equal(net[k][sl], small[k]), (k, lo)
