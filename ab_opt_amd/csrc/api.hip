@@ -281,13 +281,14 @@ extern "C" int abopt_ipa_backward_assemble(const float* P1, const float* P2, con
 
 extern "C" int abopt_ipa_pair_backward(const float* pair_feat, const float* alpha, const float* dalpha_node, const float* delta,
                                        const float* dfeat, int ld_dfeat, const float* w_pair_bias, float* g, float* dpair_feat,
-                                       float* dw_pair_bias_rows, int N, int L, int Cd, abopt_stream stream) {
+                                       float* dw_pair_bias_rows, int dpair_feat_accumulate, int N, int L, int Cd, abopt_stream stream) {
     int rc;
     if ((rc = check_dims(N, L, F, Cd))) return rc;
     if ((int64_t)N * L == 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(pair_feat && alpha && dalpha_node && delta && dfeat && w_pair_bias && g && dpair_feat && dw_pair_bias_rows && ld_dfeat >= ABOPT_HEADS * 64 && (ld_dfeat % 4) == 0,
                     "ipa_pair_backward: bad argument");
-    return launch_ipa_pair_backward(pair_feat, alpha, dalpha_node, delta, dfeat, ld_dfeat, w_pair_bias, g, dpair_feat, dw_pair_bias_rows, N, L, (hipStream_t)stream);
+    return launch_ipa_pair_backward(pair_feat, alpha, dalpha_node, delta, dfeat, ld_dfeat, w_pair_bias, g, dpair_feat, dw_pair_bias_rows, N, L, (hipStream_t)stream,
+                                    dpair_feat_accumulate ? 1 : 0);
 }
 
 extern "C" int abopt_ga_block_forward(const abopt_ga_weights* w, const float* R, const float* t, const float* x, const float* z,

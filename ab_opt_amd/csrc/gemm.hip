@@ -128,4 +128,209 @@ int launch_linear(const float* X, int ldx, const float* W, int ldw, const float*
     return ABOPT_OK;
 }
 
+
+
+// =====================================================================================================================
+// General strided-batched fp32 GEMM for the TRAINING path (round 3): C[b] = A[b] . B[b]^T with either operand stored k-contiguous
+// ("X W^T" form) or k-strided (transposed), exact fp32 on v_mfma_f32_16x16x4_f32.  It replaces the library GEMMs of the denoiser's
+// backward: the projection gradients (ga.py:54-66), the four (N,12,L,L)-sized contractions of the IPA backward (training.IpaCore),
+// the out_transform / MLP gradients of the block tail (ga.py:174-177), the heads and the mixer.
+//   A(m,k) = AT ? A[k*lda + m] : A[m*lda + k]      B(n,k) = BT ? B[k*ldb + n] : B[n*ldb + k]      C(m,n) = C[m*ldc + n]
+// 64x64 tile per 256-thread workgroup, K in tiles of 32 through LDS; a k-strided operand is staged as [k][m] and read with four 4-byte
+// LDS loads per fragment instead of one 16-byte load.  Leading dimensions that are not multiples of 4 (the 56/57-wide IPA operands)
+// take a scalar load / store path.  blockIdx.z = batch * ksplit + slice: split-K slices write their partial tile to slab `slice` of C
+// (stride slab_stride); the caller sums the slabs in a fixed order (deterministic, no atomics).
+constexpr int GLT = GBM + 4;          // row stride of a [k][m] staged tile
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256) void gemm_batched_kernel(const float* __restrict__ A, int lda, int64_t sa, const float* __restrict__ B, int ldb, int64_t sb,
+                                                           float* __restrict__ C, int ldc, int64_t sc, int M, int N, int K, int ksplit, int kchunk,
+                                                           int64_t slab_stride, float alpha) {
+    __shared__ __attribute__((aligned(16))) float As[GBM * GLD > GBK * GLT ? GBM * GLD : GBK * GLT];
+    __shared__ __attribute__((aligned(16))) float Bs[GBN * GLD > GBK * GLT ? GBN * GLD : GBK * GLT];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int batch = blockIdx.z / ksplit, slice = blockIdx.z % ksplit;
+    A += (int64_t)batch * sa; B += (int64_t)batch * sb; C += (int64_t)batch * sc + (int64_t)slice * slab_stride;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int fm = lane & 15, kq = lane >> 4;
+    const int kbeg = slice * kchunk, kend = min(K, kbeg + kchunk);
+    const bool avec = (lda % 4) == 0 && ((uintptr_t)A % 16) == 0, bvec = (ldb % 4) == 0 && ((uintptr_t)B % 16) == 0;
+    // staging registers: two float4 per operand and K tile.  k-contiguous: thread -> (row tid >> 3 (+32), k 4 (tid & 7));
+    // k-strided: thread -> (k tid >> 4 (+16), m 4 (tid & 15))
+    auto load_op = [&](const float* __restrict__ P, int ld, bool vec, bool T, int r0, int R, int k0, f32x4 (&v)[2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!T) {
+                const int r = r0 + (tid >> 3) + 32 * p, k = k0 + (tid & 7) * 4;
+                if (r < R && k < kend) {
+                    const float* q = P + (int64_t)r * ld + k;
+                    if (vec && k + 3 < kend) x = *reinterpret_cast<const f32x4*>(q);
+                    else { for (int i = 0; i < 4; ++i) if (k + i < kend) x[i] = q[i]; }
+                }
+            } else {
+                const int k = k0 + (tid >> 4) + 16 * p, r = r0 + (tid & 15) * 4;
+                if (k < kend && r < R) {
+                    const float* q = P + (int64_t)k * ld + r;
+                    if (vec && r + 3 < R) x = *reinterpret_cast<const f32x4*>(q);
+                    else { for (int i = 0; i < 4; ++i) if (r + i < R) x[i] = q[i]; }
+                }
+            }
+            v[p] = x;
+        }
+    };
+    auto store_op = [&](float* S, bool T, const f32x4 (&v)[2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (!T) *reinterpret_cast<f32x4*>(&S[((tid >> 3) + 32 * p) * GLD + (tid & 7) * 4]) = v[p];
+            else    *reinterpret_cast<f32x4*>(&S[((tid >> 4) + 16 * p) * GLT + (tid & 15) * 4]) = v[p];
+        }
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 av[2], bv[2];
+    if (kbeg < kend) { load_op(A, lda, avec, AT, m0, M, kbeg, av); load_op(B, ldb, bvec, BT, n0, N, kbeg, bv); }
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+        __syncthreads();
+        store_op(As, AT, av); store_op(Bs, BT, bv);
+        __syncthreads();
+        if (k0 + GBK < kend) { load_op(A, lda, avec, AT, m0, M, k0 + GBK, av); load_op(B, ldb, bvec, BT, n0, N, k0 + GBK, bv); }
+#pragma unroll
+        for (int ks = 0; ks < GBK; ks += 16) {
+            f32x4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!AT) a[i] = *reinterpret_cast<const f32x4*>(&As[(wm + i * 16 + fm) * GLD + ks + kq * 4]);
+                else { for (int kk = 0; kk < 4; ++kk) a[i][kk] = As[(ks + kq * 4 + kk) * GLT + wm + i * 16 + fm]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!BT) b[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn + j * 16 + fm) * GLD + ks + kq * 4]);
+                else { for (int kk = 0; kk < 4; ++kk) b[j][kk] = Bs[(ks + kq * 4 + kk) * GLT + wn + j * 16 + fm]; }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)      // B as the MFMA A operand: a lane ends up with 4 consecutive output columns of one row
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][kk], a[i][kk], acc[i][j], 0, 0, 0);
+        }
+    }
+    const bool cvec = (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = m0 + wm + i * 16 + fm, col = n0 + wn + j * 16 + kq * 4;
+            if (row >= M || col >= N) continue;
+            const f32x4 v = acc[i][j] * alpha;
+            float* cp = C + (int64_t)row * ldc + col;
+            if (cvec && col + 3 < N) *reinterpret_cast<f32x4*>(cp) = v;
+            else { for (int r = 0; r < 4; ++r) if (col + r < N) cp[r] = v[r]; }
+        }
+}
+
+// out[e] = sum over slabs s of in[s * stride + e]  (fixed order)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int slabs, int64_t stride) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s = in[e];
+    for (int k = 1; k < slabs; ++k) s += in[(int64_t)k * stride + e];
+    out[e] = s;
+}
+
+// column sums of a row-major [rows, ld] matrix (bias gradients, per-row partials of weight gradients): slice s of the rows -> part[s][cols],
+// then slab_sum_kernel adds the slices in a fixed order.  Thread -> (4 consecutive columns, row phase tid / 32 of 8)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ld, int64_t rows, int cols, int64_t rows_per_slice,
+                                                            float* __restrict__ part) {
+    __shared__ f32x4 red[8][32];
+    const int c4 = blockIdx.x * 32 + (threadIdx.x & 31), ph = threadIdx.x >> 5;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool vec = (ld % 4) == 0 && ((uintptr_t)x % 16) == 0;
+    if (c4 * 4 < cols)
+        for (int64_t r = r0 + ph; r < r1; r += 8) {
+            const float* p = x + r * ld + c4 * 4;
+            if (vec && c4 * 4 + 3 < cols) s += *reinterpret_cast<const f32x4*>(p);
+            else { for (int i = 0; i < 4; ++i) if (c4 * 4 + i < cols) s[i] += p[i]; }
+        }
+    red[ph][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (ph == 0 && c4 * 4 < cols) {
+        f32x4 t = red[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+        float* o = part + (int64_t)blockIdx.y * cols + c4 * 4;
+        for (int i = 0; i < 4; ++i) if (c4 * 4 + i < cols) o[i] = t[i];
+    }
+}
+
+int launch_colsum(const float* x, int ld, int64_t rows, int cols, float* out, float* ws, size_t ws_floats, hipStream_t st) {
+    if (cols <= 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(rows >= 0 && ld >= cols, "colsum: bad dimensions rows=%lld cols=%d ld=%d", (long long)rows, cols, ld);
+    const int cblocks = (cols + 127) / 128;
+    int64_t want = rows / 256;
+    if (want < 1) want = 1;
+    const int cap = 1024 / cblocks > 1 ? 1024 / cblocks : 1;
+    int slices = want < cap ? (int)want : cap;
+    if (!ws) slices = 1;
+    while (slices > 1 && (size_t)slices * cols > ws_floats) --slices;
+    const int64_t rps = (rows + slices - 1) / slices;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cblocks, slices), dim3(256), 0, st, x, ld, rows, cols, rps, slices > 1 ? ws : out);
+    ABOPT_LAUNCH_CHECK();
+    if (slices > 1) {
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, ws, out, (int64_t)cols, slices, (int64_t)cols);
+        ABOPT_LAUNCH_CHECK();
+    }
+    return ABOPT_OK;
+}
+
+int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const float* B, int ldb, int64_t sb, int b_t, float* C, int ldc, int64_t sc,
+                        int M, int N, int K, int batch, float alpha, float* ws, size_t ws_floats, hipStream_t st) {
+    if (M <= 0 || N <= 0 || batch <= 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(K >= 0 && lda >= 1 && ldb >= 1 && ldc >= N, "gemm: bad dimensions M=%d N=%d K=%d lda=%d ldb=%d ldc=%d", M, N, K, lda, ldb, ldc);
+    const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN) * batch;
+    // split K when the output alone cannot fill the chip (weight gradients: K = number of residues, a few dozen output tiles)
+    int ksplit = 1;
+    if (tiles < 128 && K >= 1024 && ws) {
+        ksplit = min(min(512 / max(tiles, 1), K / 512), 256);
+        while (ksplit > 1 && (size_t)ksplit * batch * M * ldc > ws_floats) --ksplit;
+        ksplit = max(ksplit, 1);
+    }
+    const int kchunk = ksplit == 1 ? max(K, 1) : ((K + ksplit * GBK - 1) / (ksplit * GBK)) * GBK;
+    float* out = ksplit == 1 ? C : ws;
+    const int64_t slab = (int64_t)batch * M * ldc;
+    ABOPT_CHECK_ARG(ksplit == 1 || sc == (int64_t)M * ldc, "gemm: split-K needs densely packed batches of C");
+    dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM, batch * ksplit);
+#define ABOPT_GEMM(AT_, BT_) hipLaunchKernelGGL((gemm_batched_kernel<AT_, BT_>), grid, dim3(256), 0, st, A, lda, sa, B, ldb, sb, out, ldc, sc, M, N, K, ksplit, \
+                                                 kchunk, slab, alpha)
+    if (a_t) { if (b_t) ABOPT_GEMM(true, true); else ABOPT_GEMM(true, false); }
+    else     { if (b_t) ABOPT_GEMM(false, true); else ABOPT_GEMM(false, false); }
+#undef ABOPT_GEMM
+    ABOPT_LAUNCH_CHECK();
+    if (ksplit > 1) {
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, ws, C, slab, ksplit, slab);
+        ABOPT_LAUNCH_CHECK();
+    }
+    return ABOPT_OK;
+}
+
 }  // namespace abopt
+
+extern "C" int abopt_colsum(const float* x, int ld, int64_t rows, int cols, float* out, void* ws, size_t ws_bytes, abopt_stream stream) {
+    ABOPT_CHECK_ARG(x && out, "colsum: NULL argument");
+    return abopt::launch_colsum(x, ld, rows, cols, out, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
+}
+
+extern "C" int abopt_gemm(const float* A, int lda, int64_t stride_a, int a_transposed, const float* B, int ldb, int64_t stride_b, int b_transposed,
+                          float* C, int ldc, int64_t stride_c, int M, int N, int K, int batch, float alpha, void* ws, size_t ws_bytes,
+                          abopt_stream stream) {
+    ABOPT_CHECK_ARG(A && B && C, "gemm: NULL operand");
+    return abopt::launch_gemm_batched(A, lda, stride_a, a_transposed, B, ldb, stride_b, b_transposed, C, ldc, stride_c, M, N, K, batch, alpha,
+                                      (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
+}

@@ -33,7 +33,7 @@ struct PairBwdSmem {
 __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __restrict__ z, const float* __restrict__ alpha,
                                                                 const float* __restrict__ dalpha_node, const float* __restrict__ delta,
                                                                 const float* __restrict__ dfeat, int ld_dfeat, const float* __restrict__ Wb,
-                                                                float* __restrict__ g_out, float* __restrict__ dz, float* __restrict__ dwb_part, int L) {
+                                                                float* __restrict__ g_out, float* __restrict__ dz, float* __restrict__ dwb_part, int L, int dz_accumulate) {
     __shared__ __attribute__((aligned(16))) PairBwdSmem sm;
     const int64_t row = blockIdx.x;                                        // n * L + i
     const int64_t n = row / L;
@@ -122,7 +122,10 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
 #pragma unroll
                 for (int s = 0; s < 4; ++s) o = mfma4(aq[s], bq[blk][s], o);
             }
-            if (jok) *reinterpret_cast<f32x4*>(dzj + ct * 16) = o;
+            if (jok) {                                                             // dz_accumulate: the blocks of an encoder share one d pair_feat buffer
+                if (dz_accumulate) o += *reinterpret_cast<const f32x4*>(dzj + ct * 16);
+                *reinterpret_cast<f32x4*>(dzj + ct * 16) = o;
+            }
         }
     }
     // ---- the row's d Wb partial: accumulator tile mt holds channels 4 fm' + mt (rows 4 kq + r = fm') of head fm
@@ -322,9 +325,9 @@ int launch_ipa_backward_assemble(const float* P1, const float* P2, const float* 
 }
 
 int launch_ipa_pair_backward(const float* z, const float* alpha, const float* dalpha_node, const float* delta, const float* dfeat, int ld_dfeat,
-                             const float* Wb, float* g_out, float* dz, float* dwb_part, int N, int L, hipStream_t st) {
+                             const float* Wb, float* g_out, float* dz, float* dwb_part, int N, int L, hipStream_t st, int dz_accumulate) {
     if ((int64_t)N * L == 0) return ABOPT_OK;
-    hipLaunchKernelGGL(ipa_pair_backward_kernel, dim3((unsigned)((int64_t)N * L)), dim3(256), 0, st, z, alpha, dalpha_node, delta, dfeat, ld_dfeat, Wb, g_out, dz, dwb_part, L);
+    hipLaunchKernelGGL(ipa_pair_backward_kernel, dim3((unsigned)((int64_t)N * L)), dim3(256), 0, st, z, alpha, dalpha_node, delta, dfeat, ld_dfeat, Wb, g_out, dz, dwb_part, L, dz_accumulate);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

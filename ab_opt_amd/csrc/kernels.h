@@ -11,6 +11,12 @@ namespace abopt {
 int launch_linear(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
                   int M, int N, int K, bool relu, hipStream_t st, int ksplit = 1, int64_t slab_stride = 0);
 
+// C[b] = alpha A[b] . B[b]^T, operands k-contiguous or k-strided (training path); ws: split-K scratch (optional)
+int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const float* B, int ldb, int64_t sb, int b_t, float* C, int ldc, int64_t sc,
+                        int M, int N, int K, int batch, float alpha, float* ws, size_t ws_floats, hipStream_t st);
+
+int launch_colsum(const float* x, int ld, int64_t rows, int cols, float* out, float* ws, size_t ws_floats, hipStream_t st);
+
 // ipa.hip / ipa_core.hip ----------------------------------------------------------------------
 // proj [N*L, NP = 2048]: q|k|v|qp|kp|vp (2016 used), points still in the residue frames (the six bias-free projections of ga.py:54-66).
 // launch_ipa_frags moves the point sets to the global frame and lays the IPA core's operands out in MFMA fragment order:
@@ -77,7 +83,7 @@ int launch_ipa_backward_assemble(const float* P1, const float* P2, const float* 
                                  const float* spatial_coef, float* dproj, float* e, int N, int L, hipStream_t st);
 int launch_ipa_pair_backward(const float* z, const float* alpha, const float* dalpha_node, const float* delta, const float* dfeat, int ld_dfeat,
                              const float* Wb, float* g_out, float* dz, float* dwb_part /* [N*L, 12*C] per-row partials of d proj_pair_bias.weight */,
-                             int N, int L, hipStream_t st);
+                             int N, int L, hipStream_t st, int dz_accumulate = 0 /* 1: dz += (the blocks of an encoder share one buffer) */);
 
 // embed.hip: encode() ----------------------------------------------------------------------------
 size_t residue_embed_ws_bytes(int N, int L, int A, int hotspot);

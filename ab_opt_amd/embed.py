@@ -22,6 +22,8 @@ AA_UNK, ATOM_N, ATOM_CA, ATOM_C = 20, 0, 1, 2
 def _splitk_tn(a, b, chunk=4096):
     """a^T @ b for tall a (M, I), b (M, J): batched over row chunks so the library runs many K=chunk GEMMs instead of one skinny
     K=M GEMM, then a short sum."""
+    if a.is_cuda and a.dtype == torch.float32:
+        return hip.gemm(a.t(), b.t())[0]            # abopt_gemm: both operands read k-strided in place, split-K partials summed in a fixed order
     M = a.shape[0]
     S = M // chunk
     out = None
@@ -40,14 +42,19 @@ class _TallLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
+        if x.is_cuda and x.dtype == torch.float32:
+            y = hip.gemm(x.reshape(-1, x.shape[-1]), weight)[0].view(x.shape[:-1] + (weight.shape[0],))
+            return y if bias is None else y.add_(bias)
         return F.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
-        dx = (dy2 @ weight).view_as(x) if ctx.needs_input_grad[0] else None
-        return dx, _splitk_tn(dy2, x2), dy2.sum(0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (hip.gemm(dy2, weight.t())[0] if dy2.is_cuda and dy2.dtype == torch.float32 else dy2 @ weight).view_as(x)
+        return dx, _splitk_tn(dy2, x2), hip.colsum(dy2)
 
 
 def _tall_mlp(seq, x):
@@ -140,7 +147,7 @@ class _PairEmbedFn(torch.autograd.Function):
         y, a2 = dys.view(M, -1), acts.view(M, -1)
         do2, do1, do0, dh1, dh0 = (y[:, 64 * k:64 * (k + 1)] for k in range(5))
         h0, h1, dih, o0, o1 = a2[:, :64], a2[:, 64:128], a2[:, 128:154], a2[:, 160:224], a2[:, 224:288]
-        db = y.sum(0)                                                               # the five bias gradients at once
+        db = hip.colsum(y)                                                          # the five bias gradients at once
         dbo2, dbo1, dbo0, dbd1, dbd0 = (db[64 * k:64 * (k + 1)] for k in range(5))
         dwo2, dwo1, dwd1 = _splitk_tn(do2, o1), _splitk_tn(do1, o0), _splitk_tn(dh1, h0)
         # out_mlp.0 columns: [aa-pair embedding | relpos embedding x same-chain | f_dist | f_dih]
@@ -264,7 +271,7 @@ class ResidueEmbedding(nn.Module):
         if self.hotspot_embed is not None:
             hs = hotspot if hotspot is not None else torch.zeros_like(aa)
             feats.append(embed_rows(self.hotspot_embed, hs))
-        return self.mlp(torch.cat(feats, dim=-1)) * mres[:, :, None]
+        return _tall_mlp(self.mlp, torch.cat(feats, dim=-1)) * mres[:, :, None]
 
 
 class PairEmbedding(nn.Module):

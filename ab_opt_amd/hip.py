@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,7 +73,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_add_noise', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
+           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
@@ -123,6 +123,9 @@ def lib():
         L.abopt_add_noise.argtypes = [c_i64, c_f, c_f, c_u8, c_f, c_f, C.c_int, C.c_int, C.POINTER(AddNoiseNoise), C.c_uint64, C.c_uint64,
                                       c_f, c_f, c_i64, c_u8, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,
                                       c_f, c_f, c_i64, c_f, c_f, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.abopt_gemm.argtypes = [c_f, C.c_int, C.c_int64, C.c_int, c_f, C.c_int, C.c_int64, C.c_int, c_f, C.c_int, C.c_int64,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_colsum.argtypes = [c_f, C.c_int, C.c_int64, C.c_int, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_prof_enable.argtypes = [C.c_int]
         L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.abopt_prof_peek.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
@@ -133,7 +136,7 @@ def lib():
         L.abopt_ipa_points_backward.argtypes = [c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_void_p]
         L.abopt_ipa_backward_operands.argtypes = [c_f] * 6 + [C.c_int, C.c_int, C.c_void_p]
         L.abopt_ipa_backward_assemble.argtypes = [c_f] * 9 + [C.c_int, C.c_int, C.c_void_p]
-        L.abopt_ipa_pair_backward.argtypes = [c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.abopt_ipa_pair_backward.argtypes = [c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.abopt_residue_embed_workspace_bytes.restype = C.c_size_t
         L.abopt_residue_embed_workspace_bytes.argtypes = [C.c_int] * 4
         L.abopt_pair_embed_workspace_bytes.restype = C.c_size_t
@@ -171,8 +174,8 @@ def _check(rc):
 _DT = {torch.float32: 'f32', torch.int64: 'i64', torch.bool: 'u8', torch.uint8: 'u8'}
 
 
-def ptr(t, dtype=None, optional=False):
-    """Device pointer of a contiguous HIP tensor (None -> NULL when optional)."""
+def ptr(t, dtype=None, optional=False, strided=False):
+    """Device pointer of a contiguous HIP tensor (None -> NULL when optional).  strided=True: the caller passes the strides itself."""
     if t is None:
         if optional:
             return None
@@ -183,7 +186,7 @@ def ptr(t, dtype=None, optional=False):
         raise RuntimeError(f'tensor lives on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}: kernels launch on '
                            'the current device/stream -- call torch.cuda.set_device() (one process per GPU) or wrap the call in '
                            '`with torch.cuda.device(tensor.device):`')
-    if not t.is_contiguous():
+    if not strided and not t.is_contiguous():
         raise ValueError('tensor must be contiguous')
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f'expected {dtype}, got {t.dtype}')
@@ -501,17 +504,18 @@ def ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, spatial_coef):
     return dproj, e
 
 
-def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias):
-    """alpha, dalpha_node head-major (N,12,L,L) -> g (N,12,L,L), dz (N,L,L,C), dWb (12,C)  (include/abopt.h: abopt_ipa_pair_backward)."""
+def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias, dz_into=None):
+    """alpha, dalpha_node head-major (N,12,L,L) -> g (N,12,L,L), dz (N,L,L,C), dWb (12,C)  (include/abopt.h: abopt_ipa_pair_backward).
+    dz_into: an existing d pair_feat buffer this block's gradient is ADDED to (returned as dz)."""
     N, L = z.shape[:2]
     g = torch.empty_like(alpha)
-    dz = torch.empty_like(z)
+    dz = torch.empty_like(z) if dz_into is None else dz_into
     dwb_rows = torch.empty(N * L, 12 * z.shape[-1], device=z.device)
     z, alpha, dalpha_node, delta, dfeat, w_pair_bias = _contig(z, alpha, dalpha_node, delta, dfeat, w_pair_bias)
     _check(lib().abopt_ipa_pair_backward(ptr(z, torch.float32), ptr(alpha, torch.float32), ptr(dalpha_node, torch.float32),
                                          ptr(delta, torch.float32), ptr(dfeat, torch.float32), dfeat.shape[-1],
-                                         ptr(w_pair_bias, torch.float32), ptr(g), ptr(dz), ptr(dwb_rows), N, L, z.shape[-1], stream()))
-    return g, dz, dwb_rows.sum(0).view(12, z.shape[-1])
+                                         ptr(w_pair_bias, torch.float32), ptr(g), ptr(dz), ptr(dwb_rows), int(dz_into is not None), N, L, z.shape[-1], stream()))
+    return g, dz, colsum(dwb_rows).view(12, z.shape[-1])
 
 
 def encode_inputs(aa, res_nb, chain_nb, pos_atoms, mask_atoms, atoms, fragment_type=None, hotspot=None, structure_mask=None, sequence_mask=None):
@@ -653,7 +657,53 @@ def block_tail_backward(dout, saved, wmt, mask, g1, g2):
     f = lambda t: ptr(t, torch.float32)
     _check(lib().abopt_block_tail_backward(f(dout), f(saved), f(wmt), ptr(mask, torch.bool), f(g1), f(g2), ptr(dpre), ptr(da1), ptr(du), ptr(colpart),
                                            rows, stream()))
-    return dpre, da1, du, colpart.sum(0)
+    return dpre, da1, du, colsum(colpart.view(colpart.shape[0], -1)).view(8, 128)
+
+
+def _operand(t):
+    """(tensor, ld, batch stride, transposed) of a 2-D / 3-D fp32 operand whose matrices are row- or column-major; anything else is copied."""
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    b, r, c = t.shape
+    sb, sr, sc_ = t.stride()
+    if b == 1:
+        sb = 0
+    if sc_ == 1 and sr >= max(c, 1):
+        return t, sr, sb, 0
+    if sr == 1 and sc_ >= max(r, 1):
+        return t, sc_, sb, 1
+    t = t.contiguous()
+    return t, t.stride(1), (t.stride(0) if b > 1 else 0), 0
+
+
+def gemm(a, b, alpha=1.0, out=None):
+    """C = alpha * a @ b^T on libabopt_hip.so (include/abopt.h: abopt_gemm).  a (M,K) or (B,M,K); b (N,K) or (B,N,K); either may be
+    a transposed VIEW (x.t(), x.transpose(1, 2)): the kernel reads k-strided operands in place.  Batch broadcasting: a 2-D operand
+    serves every batch."""
+    nb = max(a.shape[0] if a.dim() == 3 else 1, b.shape[0] if b.dim() == 3 else 1)
+    a, lda, sa, at = _operand(a.float())
+    b, ldb, sb, bt = _operand(b.float())
+    M, K, N = a.shape[1], a.shape[2], b.shape[1]
+    assert b.shape[2] == K, (a.shape, b.shape)
+    c = torch.empty(nb, M, N, dtype=torch.float32, device=a.device) if out is None else out
+    tiles = ((M + 63) // 64) * ((N + 63) // 64) * nb
+    ws = None
+    if tiles < 128 and K >= 1024:
+        ws = Workspace.get(min(256, max(K // 512, 1)) * nb * M * N * 4, a.device)
+    _check(lib().abopt_gemm(ptr(a, torch.float32, strided=True), lda, sa, at, ptr(b, torch.float32, strided=True), ldb, sb, bt, ptr(c), N, M * N, M, N, K, nb, float(alpha),
+                            ptr(ws, optional=True), ws.numel() if ws is not None else 0, stream()))
+    return c
+
+
+def colsum(x):
+    """x.sum(0) for a 2-D fp32 tensor with unit column stride (a row-sliced / column-sliced view is read in place): abopt_colsum."""
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32 or not x.is_cuda or x.shape[0] == 0:
+        return x.sum(0)
+    rows, cols = x.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    ws = Workspace.get(1024 * max(cols, 128) * 4, x.device)
+    _check(lib().abopt_colsum(ptr(x, torch.float32, strided=True), x.stride(0), rows, cols, ptr(out), ptr(ws), ws.numel(), stream()))
+    return out
 
 
 def prof_enable(on=True):

@@ -75,6 +75,48 @@ def _ln(x, mod):
     return F.layer_norm(x, (x.shape[-1],), mod.gamma, mod.beta, eps=mod.epsilon)
 
 
+# ------------------------------------------------------------------ dense layers on the library's own GEMM (csrc/gemm.hip: gemm_batched_kernel)
+class NativeLinear(torch.autograd.Function):
+    """y = x W^T (+ b) with forward and both gradients on abopt_gemm: d x = d y W, d W = d y^T x (split-K over the rows, summed in a
+    fixed order), d b = column sums.  Stands where the reference's nn.Linear modules call ATen under autograd (ga.py:54-66,
+    dpm_full.py:39-59)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b=None):
+        from . import hip
+        x2 = x.reshape(-1, x.shape[-1])
+        y = hip.gemm(x2, w)[0]
+        if b is not None:
+            y += b
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = b is not None
+        return y.view(x.shape[:-1] + (w.shape[0],))
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, dy):
+        from . import hip
+        x2, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        dx = hip.gemm(dy2, w.t())[0].view(dy.shape[:-1] + (w.shape[1],)) if ctx.needs_input_grad[0] else None
+        dw = hip.gemm(dy2.t(), x2.t())[0]
+        return dx, dw, (hip.colsum(dy2) if ctx.has_bias else None)
+
+
+def _linear(mod, x):
+    """nn.Linear `mod` applied through NativeLinear on the device (plain F.linear for CPU tensors: the float64 / CPU checkers)."""
+    if x.is_cuda and x.dtype == torch.float32:
+        return NativeLinear.apply(x, mod.weight, mod.bias)
+    return F.linear(x, mod.weight, mod.bias)
+
+
+def _mlp(seq, x):
+    """nn.Sequential of Linear / ReLU / Softmax modules with the Linear layers on NativeLinear."""
+    for m in seq:
+        x = _linear(m, x) if isinstance(m, torch.nn.Linear) else m(x)
+    return x
+
+
 # ------------------------------------------------------------------ IPA core as an autograd function on the HIP kernels
 class IpaCore(torch.autograd.Function):
     """feat = IPA(proj, z): ga.py:81-147 between the six projections and out_transform.
@@ -83,10 +125,13 @@ class IpaCore(torch.autograd.Function):
     (they come from the noised state)."""
 
     @staticmethod
-    def forward(ctx, proj, z, R, t, mask, w_pair_bias, spatial_coef, pbc=None):
+    def forward(ctx, proj, z, R, t, mask, w_pair_bias, spatial_coef, pbc=None, zsink=None):
         from . import hip
         feat, alpha = hip.ipa_core_train_forward(proj, R, t, z, mask, w_pair_bias, spatial_coef.reshape(-1), pbc)
         ctx.save_for_backward(proj, z, R, t, w_pair_bias, spatial_coef, feat, alpha)
+        ctx.zsink = zsink
+        if zsink is not None:
+            zsink['users'] += 1
         return feat
 
     @staticmethod
@@ -101,18 +146,31 @@ class IpaCore(torch.autograd.Function):
         # points epilogue backward (ga.py:136-139), head-major [d feat_node | d agg_pts] and delta_ih = <dfeat, feat>: one kernel
         dout_cat, delta = hip.ipa_points_backward(dfeat, feat, R, t)
         T = lambda a: a.transpose(-1, -2)
-        da_node = dout_cat @ T(Av)                                                  # (N,H,L,L)
-        g, dz, dWb = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb)     # the z-streaming part (incl. d proj_pair_bias.weight)
+        b3 = lambda a: a.reshape(N * H, a.shape[-2], a.shape[-1])                   # (N,H,.,.) -> batch of N*H matrices (a view)
+        mm = lambda a, b_nk: hip.gemm(b3(a), b3(b_nk)).view(N, H, a.shape[-2], b_nk.shape[-2])      # a @ b_nk^T, operands read in place
+        da_node = mm(dout_cat, Av)                                                  # (N,H,L,L) = dout_cat Av^T
+        # the z-streaming part (incl. d proj_pair_bias.weight).  The blocks of one encoder pass share ONE d pair_feat buffer (zsink): each
+        # backward adds into it in the kernel and only the last one to run hands it to autograd -- instead of six 268 MB tensors and five
+        # elementwise additions
+        sink = ctx.zsink if (ctx.zsink is not None and ctx.zsink['users'] > 0) else None       # (a second backward over a retained graph: no sharing)
+        g, dz, dWb = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb, dz_into=sink['buf'] if sink is not None else None)
+        if sink is not None:
+            sink['buf'] = dz
+            sink['users'] -= 1
+            if sink['users'] > 0:
+                dz = None
+            else:
+                sink['buf'] = None
         del da_node
-        # every (N,12,L,L) matrix is multiplied ONCE from each side:
-        P1 = g @ Ak                                                                 # sum_j g_ij [k_j | kg_j | 1]
-        P2 = T(g) @ Aq                                                              # sum_i g_ij [q_i | qg_i | 1]
-        P3 = T(alpha) @ dout_cat                                                    # sum_i alpha_ij [dfn_i | dag_i]
+        # every (N,12,L,L) matrix is multiplied ONCE from each side (abopt_gemm reads the transposed views in place):
+        P1 = mm(g, T(Ak))                                                           # sum_j g_ij [k_j | kg_j | 1]
+        P2 = mm(T(g), T(Aq))                                                        # sum_i g_ij [q_i | qg_i | 1]
+        P3 = mm(T(alpha), T(dout_cat))                                              # sum_i alpha_ij [dfn_i | dag_i]
         # scale, spatial-term chain rule, rotation back to the residue frames, re-layout to (N,L,2016): one kernel
         dproj, e = hip.ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, gamma_raw.reshape(-1))
         gam = gamma_raw.reshape(-1)
         dgamma = (e.sum((0, 1)) * (-torch.sigmoid(gam) * (math.sqrt(2 / (9 * P)) / 2))).reshape(gamma_raw.shape)
-        return dproj, dz, None, None, None, dWb, dgamma, None
+        return dproj, dz, None, None, None, dWb, dgamma, None, None
 
 
 NATIVE_IPA = True      # tests flip this to compare the native path with the plain torch statement
@@ -139,9 +197,9 @@ class BlockTail(torch.autograd.Function):
         from . import hip
         feat2, mask, saved, wmt, w_out, g1, g2 = ctx.saved_tensors
         dpre, da1, du, cs = hip.block_tail_backward(dout.reshape(-1, 128), saved, wmt, mask.reshape(-1), g1, g2)
-        dfeat = (du @ w_out).view(dout.shape[:-1] + (w_out.shape[1],))
-        dw_out = du.t() @ feat2
-        dw0, dw1, dw2 = torch.bmm(dpre.transpose(1, 2), saved[1:4]).unbind(0)      # d W_l = d pre_l^T . input_l, one batched launch
+        dfeat = hip.gemm(du, w_out.t())[0].view(dout.shape[:-1] + (w_out.shape[1],))
+        dw_out = hip.gemm(du.t(), feat2.t())[0]
+        dw0, dw1, dw2 = hip.gemm(dpre.transpose(1, 2), saved[1:4].transpose(1, 2)).unbind(0)      # d W_l = d pre_l^T . input_l, one batched launch
         #      x               feat   mask  w_out   b_out  g1     be1    w0   b0     w1   b1     w2   b2     g2     be2
         return da1.view(dout.shape), dfeat, None, dw_out, cs[7], cs[6], cs[5], dw0, cs[4], dw1, cs[3], dw2, cs[2], cs[1], cs[0]
 
@@ -158,14 +216,14 @@ def _block_tail(blk, x, feat, mask, native=True):
 
 
 # ------------------------------------------------------------------ network
-def ga_block(blk, R, t, x, z, mask, native=None, pbc=None):
+def ga_block(blk, R, t, x, z, mask, native=None, pbc=None, zsink=None):
     """pbc: this block's slice of hip.pair_bias_cache_layers (forward-only shortcut: the core reads proj_pair_bias(z) instead of
     recomputing it; gradients of z and the weight still come from the backward kernel)."""
     N, L, _ = x.shape
     if NATIVE_IPA if native is None else native:
         w_node = torch.cat([blk.proj_query.weight, blk.proj_key.weight, blk.proj_value.weight,
                             blk.proj_query_point.weight, blk.proj_key_point.weight, blk.proj_value_point.weight], dim=0)
-        feat = IpaCore.apply(x @ w_node.t(), z, R.detach(), t.detach(), mask, blk.proj_pair_bias.weight, blk.spatial_coef, pbc)
+        feat = IpaCore.apply(NativeLinear.apply(x, w_node), z, R.detach(), t.detach(), mask, blk.proj_pair_bias.weight, blk.spatial_coef, pbc, zsink)
         return _block_tail(blk, x, feat, mask)
     q = blk.proj_query(x).view(N, L, H, D)
     k = blk.proj_key(x).view(N, L, H, D)
@@ -197,26 +255,27 @@ def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_r
     N, L = mask_res.shape
     R = so3_exp(v_t)
     from .embed import embed_rows
-    x = net.res_feat_mixer(torch.cat([res_feat, embed_rows(net.current_sequence_embedding, s_t)], dim=-1))
+    x = _mlp(net.res_feat_mixer, torch.cat([res_feat, embed_rows(net.current_sequence_embedding, s_t)], dim=-1))
     caches = [None] * len(net.encoder.blocks)
     if NATIVE_IPA and pair_feat.is_cuda:
         # proj_pair_bias(pair_feat) of all blocks in one pass over pair_feat (the sampler's per-call cache, rebuilt every training step)
         from . import hip
         caches = hip.pair_bias_cache_layers([blk.proj_pair_bias.weight for blk in net.encoder.blocks], pair_feat.detach())
+    zsink = dict(buf=None, users=0) if (NATIVE_IPA and pair_feat.is_cuda and pair_feat.requires_grad) else None
     for blk, pbc in zip(net.encoder.blocks, caches):
-        x = ga_block(blk, R, p_t, x, pair_feat, mask_res, pbc=pbc)
+        x = ga_block(blk, R, p_t, x, pair_feat, mask_res, pbc=pbc, zsink=zsink)
     temb = torch.stack([beta, torch.sin(beta), torch.cos(beta)], dim=-1)[:, None, :].expand(N, L, 3)
     feat = torch.cat([x, temb], dim=-1)
     gen3 = mask_generate[:, :, None].expand(N, L, 3)
-    eps_crd = net.eps_crd_net(feat)
+    eps_crd = _mlp(net.eps_crd_net, feat)
     eps_pos = torch.where(gen3, torch.einsum('nlab,nlb->nla', R, eps_crd), torch.zeros_like(eps_crd))
-    R_next = R @ quat1ijk_to_rot(net.eps_rot_net(feat))
+    R_next = R @ quat1ijk_to_rot(_mlp(net.eps_rot_net, feat))
     v_next = torch.where(gen3, so3_log(R_next), v_t)
-    c = net.eps_seq_net(feat)
+    c = _mlp(net.eps_seq_net, feat)
     if net.no_bins is None:
         return v_next, R_next, eps_pos, c
     pp = net.prmsd_predictor
-    h = pp.linear_3(pp.linear_2(pp.linear_1(_ln(feat, pp.layer_norm)).relu()).relu())
+    h = _linear(pp.linear_3, _linear(pp.linear_2, _linear(pp.linear_1, _ln(feat, pp.layer_norm)).relu()).relu())
     return v_next, R_next, eps_pos, c, h.mean(dim=1)
 
 

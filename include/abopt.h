@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 24
+#define ABOPT_ABI_VERSION 25
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -288,6 +288,8 @@ int abopt_ipa_backward_assemble(const float* P1, const float* P2, const float* P
 int abopt_ipa_pair_backward(const float* pair_feat, const float* alpha, const float* dalpha_node, const float* delta,
                             const float* dfeat, int ld_dfeat, const float* w_pair_bias, float* g, float* dpair_feat,
                             float* dw_pair_bias_rows /* [N*L, 12*C]: per-query-row partials of d proj_pair_bias.weight (sum over rows) */,
+                            int dpair_feat_accumulate /* 1: dpair_feat += this block's gradient (the six blocks of the encoder share one
+                                                         buffer instead of six 268 MB tensors that autograd adds up); 0: overwrite */,
                             int N, int L, int C, abopt_stream stream);
 
 /* ---- encode(): D/models/diffab.py:39-83.  ResidueEmbedding.forward (D/modules/encoders/residue.py:26-92; the AbDesign
@@ -363,6 +365,18 @@ int abopt_reconstruct_backbone_partially(const float* pos_ctx, const float* R_ne
                                          const int64_t* chain_nb, const int64_t* res_nb, const uint8_t* mask_atoms,
                                          const uint8_t* mask_recons, const float* bb_table, const float* o_table,
                                          float* pos_new, uint8_t* mask_new, int N, int L, int A, abopt_stream stream);
+
+/* ---- Training path: general strided-batched fp32 GEMM, C[b] = alpha * A[b] . B[b]^T (exact fp32 FMA chains on the matrix cores).
+ *   A(m,k) = a_transposed ? A[k*lda + m] : A[m*lda + k]     B(n,k) = b_transposed ? B[k*ldb + n] : B[n*ldb + k]     C(m,n) = C[m*ldc + n]
+ * It stands where the reference's autograd calls ATen GEMMs in the backward of the denoiser (D/modules/encoders/ga.py:54-66,81-147,
+ * 174-177 and D/modules/diffusion/dpm_full.py:39-59 under torch.autograd).  ws (optional): scratch for split-K partial tiles, used when
+ * the output has too few tiles to fill the chip and K >= 1024 (weight gradients); partials are summed in a fixed order. */
+int abopt_gemm(const float* A, int lda, int64_t stride_a, int a_transposed, const float* B, int ldb, int64_t stride_b, int b_transposed,
+               float* C, int ldc, int64_t stride_c, int M, int N, int K, int batch, float alpha, void* ws, size_t ws_bytes, abopt_stream stream);
+
+/* out[c] = sum over rows of x[r*ld + c] (bias gradients and per-row partials of weight gradients on the training path); deterministic:
+ * row slices are summed in a fixed order.  ws (optional): slices * cols floats of scratch. */
+int abopt_colsum(const float* x, int ld, int64_t rows, int cols, float* out, void* ws, size_t ws_bytes, abopt_stream stream);
 
 int abopt_commonness_score(const float* structs, float* score, int B, int n, abopt_stream stream);
 

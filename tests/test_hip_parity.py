@@ -1368,3 +1368,40 @@ def test_eps_net_reference_headline_shape_vs_oracle():
                                     pair_bias_cache=pbc, pair_feat_shared=True)
         for k in ('R_next', 'eps_pos', 'c'):
             assert torch.equal(net[k][sl], small[k]), (k, lo)
+
+
+def test_training_step_config5_native_vs_plain_statement():
+    """BASELINE config 5 at full size (AbDesign flavour, N = 16, L = 256): one training forward + backward through the native path
+    (HIP noising, IPA core forward / backward, block tail, pair embedding, every GEMM on abopt_gemm, shared d pair_feat buffer) against
+    the plain torch statement of the same network (training.NATIVE_IPA = False) with the same step indices and noise: finite losses,
+    equal to 2e-5 relative, parameter gradients within 2e-4 of their own maximum from block 1 on (5e-3 upstream of it, see below)."""
+    from ab_opt_amd import training
+    m = build_model(100, 7, flavour='abdesign', device=DEV).train()
+    batch = {k: dev(v) for k, v in synth.make_batch(16, synth.LAYOUT_256, seed=21).items()}
+    out = {}
+    try:
+        for native in (True, False):
+            training.NATIVE_IPA = native
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(1234); torch.cuda.manual_seed(1234)
+            loss = m(dict(batch))
+            total = sum(loss.values())
+            total.backward()
+            out[native] = ({k: v.item() for k, v in loss.items()}, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    finally:
+        training.NATIVE_IPA = True
+        m.zero_grad(set_to_none=True); m.eval()
+    (la, ga), (lb, gb) = out[True], out[False]
+    assert set(la) == {'rot', 'pos', 'seq'} and all(math.isfinite(v) for v in la.values())
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-5 * max(abs(lb[k]), 1e-3), (k, la[k], lb[k])
+    assert set(ga) == set(gb) and len(ga) > 150
+    rel = sorted((((ga[n] - gb[n]).abs().max() / gb[n].abs().max().clamp_min(1e-12)).item(), n) for n in ga)
+    rl2 = sorted((((ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-12)).item(), n) for n in ga)
+    # Everything from block 1 to the heads agrees to ~1e-5 (asserted at 2e-4).  Block 0 -- the only block whose input is not layer-normalised
+    # (the raw mixer output: with the synthetic weights its point / distance logits are two orders of magnitude larger and their gradients
+    # are differences of nearly equal sums) -- and what lies upstream of it (mixer, embeddings) differ by ~2e-3 between the two fp32
+    # evaluations; the same code matches the REFERENCE's recorded gradients at 3e-4 on the small fixtures (test_training_*_vs_reference).
+    down = [a for a, n in rel if any(f'blocks.{b}.' in n for b in range(1, 6)) or 'eps_crd_net' in n or 'eps_rot_net' in n or 'eps_seq_net' in n]
+    assert len(down) > 100 and max(down) < 2e-4, max(down)
+    assert rel[-1][0] < 5e-3, rel[-3:]

@@ -24,10 +24,13 @@ def main(path):
         rows = list(con.execute('select name, total_calls, total_duration, average, percentage from top_kernels'))
         print(f'# {os.path.basename(db)}  (durations in microseconds, from rocprofv3 --kernel-trace --stats)')
         print(f'{"kernel":<92}{"calls":>7}{"total_us":>14}{"avg_us":>12}{"pct":>8}')
-        for n, c, tot, avg, pct in rows[:25]:
-            print(f'{short(n):<92}{c:>7}{tot:>14.1f}{avg:>12.2f}{pct:>8.2f}')
+        total = sum(r[2] for r in rows)
+        own = sum(r[2] for r in rows if 'abopt::' in r[0])
+        print(f'# GPU time in kernels: {total / 1e3:.1f} us total, {own / 1e3:.1f} us ({100 * own / max(total, 1):.1f} %) in abopt:: kernels; {len(rows)} distinct kernels')
+        for n, c, tot, avg, pct in (rows if '--all' in sys.argv else rows[:25])[:60]:
+            print(f'{short(n):<92}{c:>7}{tot / 1e3 if False else tot:>14.1f}{avg:>12.2f}{pct:>8.2f}')
         print()
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main([a for a in sys.argv[1:] if not a.startswith('--')][0])
