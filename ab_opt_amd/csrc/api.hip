@@ -59,7 +59,7 @@ struct Carver {
 constexpr int F = 128, FI = F + 4;
 constexpr int OUT_KSPLIT = 2;     // out_transform (K = 1824, N = 128) has only M/64 * 2 tiles: split K so it fills the chip
 
-struct GaScratch { float *proj, *feat, *u, *kvf, *qf; };
+struct GaScratch { float *proj, *feat, *u, *kvf, *qf, *split; size_t split_floats; };
 static GaScratch carve_ga(Carver& cv, int64_t M, int N, int L) {
     GaScratch s;
     s.proj = cv.f((size_t)M * NP);
@@ -67,6 +67,8 @@ static GaScratch carve_ga(Carver& cv, int64_t M, int N, int L) {
     s.u = cv.f((size_t)M * F * OUT_KSPLIT);
     s.kvf = cv.f(ipa_kvfrag_floats(N, L));
     s.qf = cv.f(ipa_qfrag_floats(N, L));
+    s.split_floats = ipa_split_ws_floats(N, L);
+    s.split = s.split_floats ? cv.f(s.split_floats) : nullptr;
     return s;
 }
 
@@ -83,7 +85,7 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     }
     float* feat = (dbg && dbg->feat) ? dbg->feat : s.feat;
     if ((rc = launch_ipa_core(s.qf, s.kvf, z, mask, R, t, w->w_pair_bias, feat,
-                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, N, L, st, z_shared))) return rc;
+                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, N, L, st, z_shared, s.split, s.split_floats))) return rc;
     // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
     if (w->w_out_frag && w->w_mlp_frag)
         return launch_out_ln_mlp(feat, w->w_out_frag, w->w_mlp_frag, x, w->b_out, mask, w->ln1_gamma, w->ln1_beta, w->b_mlp0, w->b_mlp1, w->b_mlp2,

@@ -22,6 +22,7 @@
 // chunk per SIMD), so the pipe stays fed while individual waves wait for HBM (pair waves) or L2 (A / C waves).
 // Operands arrive pre-arranged in MFMA fragment order (ipa.hip: ipa_frags_kernel): every global load of the A / C waves and
 // every LDS access of the S/P tile is a conflict-free, fully coalesced 16 bytes per lane.
+#include <cstdlib>
 #include "ipa_common.h"
 #include "kernels.h"
 
@@ -56,6 +57,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kSqrt13 = 0.5773502691896258f;   // sqrt(1/3), ga.py:165
 constexpr float kScale2 = kSqrt13 * kLog2e;            // logits are kept in base-2 units: p = exp2(l2 - m2)
 constexpr float kMask2 = 1e5f * kLog2e;           // the reference's additive -1e5 on masked pairs (ga.py:20-23), same units
+constexpr int SPLIT_ROW = H * C + H * D + H * P * 3;   // 1440 unnormalised accumulators per row and key slice
 
 // position of key group kq (keys 4 kq .. 4 kq + 3) inside head h's 16-key row of the S/P tile.  The rotation by h >> 1 makes the
 // pair waves' 16-byte reads AND writes (lane = (head, key group)) bank-conflict free; see DESIGN.md section 3.1.
@@ -78,12 +80,18 @@ __host__ __device__ constexpr size_t core_lds_fixed_bytes() {
 // DUMP (training / parity tests): the pair waves also write the scaled, UNMASKED logits x = logit * sqrt(1/3) * log2(e) head-major
 // (dump [N,12,L,L], one 16-byte store per lane and row chunk) and the final running maximum / sum of every (row, head)
 // (dump_stats [N*L,12,2]); alpha = mask ? exp2(x - m) / l : 0 is one elementwise pass later (ipa_train.hip: alpha_finalize).
-template <bool DUMP, bool CACHED>
+// SPLIT (small batches: fewer query blocks than half the CUs): blockIdx.x = block * nsplit + slice, a workgroup walks only the key chunks
+// [slice * nchunk / nsplit, (slice + 1) * nchunk / nsplit) and leaves its UNNORMALISED accumulators ([rows][1440]: 768 pair | 384 node |
+// 288 aggregated points) and the running maximum / sum of every (row, head) in `part` / `pstats`; ipa_split_merge_kernel combines the
+// slices (softmax merge) and applies the point epilogue.  A step's core is a 16-chunk serial loop (63 us) however few samples there are;
+// with 2..4 slices the loop is 8..4 chunks on twice / four times as many CUs.
+template <bool DUMP, bool CACHED, bool SPLIT = false>
 __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__ qfrag, const float* __restrict__ kvfrag, const float* __restrict__ z,
                                                        const uint8_t* __restrict__ mask, const float* __restrict__ R, const float* __restrict__ t,
                                                        const float* __restrict__ Wb, float* __restrict__ feat, float* __restrict__ dump,
                                                        float* __restrict__ dump_stats,
-                                                       const float* __restrict__ pbc, int N, int L, int nib, int xcd_remap, int z_shared) {
+                                                       const float* __restrict__ pbc, int N, int L, int nib, int xcd_remap, int z_shared,
+                                                       float* __restrict__ part = nullptr, float* __restrict__ pstats = nullptr, int nsplit = 1) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     CoreLds sm;
     {
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
     int n, ib;
     {   // all i-blocks of a sample on one XCD when N % 8 == 0 (blocks are dealt round-robin to the 8 XCDs): its key/value fragments stay
         // in that XCD's L2.  Speed only, never correctness.
-        const int b = blockIdx.x;
+        const int b = SPLIT ? blockIdx.x / nsplit : blockIdx.x;
         if (xcd_remap) { const int xcd = b & 7, k = b >> 3; n = xcd + 8 * (k / nib); ib = k % nib; }
         else { n = b / nib; ib = b % nib; }
     }
@@ -112,7 +120,10 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
     // Key chunks are visited in natural order by every query block of a sample: the 16 blocks then read the same 96 KB of key/value
     // fragments at about the same time and all but the first hit in the XCD's L2.  (A per-block rotated order was measured: L2 hit
     // rate of the fragments fell from ~90 % to ~25 %, FETCH_SIZE 0.75 -> 1.16 GB per launch, kernel 185 -> 199 us.)
-    const int c0 = (CORE_ABL & 512) ? ib % nchunk : 0;
+    const int slice = SPLIT ? blockIdx.x % nsplit : 0;
+    const int c_lo = SPLIT ? slice * nchunk / nsplit : 0, c_hi = SPLIT ? (slice + 1) * nchunk / nsplit : nchunk;
+    const int ncl = c_hi - c_lo;                                        // key chunks of this workgroup (all of them unless SPLIT)
+    const int c0 = SPLIT ? c_lo : ((CORE_ABL & 512) ? ib % nchunk : 0);
     auto chunk_of = [&](int it) { const int c = it + c0; return c < nchunk ? c : c - nchunk; };      // iteration -> key chunk
 #ifdef CORE_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();   // 0 prologue | 1 work | 2 barrier wait | 3 epilogue own | 4 F1/F2 waits | 5 common epilogue
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         const bool dfull = (L & 15) == 0;                                // no partial key chunk: every lane of heads 0..11 stores
 #define PW_ISSUE(SLOT, II, CH)                                                                                          \
     {                                                                                                                    \
-        const int ch_ = chunk_of(min((CH), nchunk - 1));                       /* past the end: harmless re-read */      \
+        const int ch_ = chunk_of(min((CH), ncl - 1));                          /* past the end: harmless re-read */      \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                \
             ring[SLOT][r_] = ZLOAD(reinterpret_cast<const f32x4*>(zrow[II] + ((unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b))); \
         if (CACHED && !(CORE_ABL & 64)) ringb[SLOT] = ZLOAD(reinterpret_cast<const f32x4*>(pbrow[II] + ((unsigned)ch_ * (unsigned)(H * JC * 4) + pb_lane))); \
@@ -254,10 +265,10 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         TSYNC(1, 2)                                                         /* barrier #(CH + 1) */                       \
     }
         int ch = 0;
-        for (; ch + 3 <= nchunk; ch += 3) { PW_CHUNK(0, ch) PW_CHUNK(1, ch + 1) PW_CHUNK(2, ch + 2) }
-        if (ch < nchunk) {
+        for (; ch + 3 <= ncl; ch += 3) { PW_CHUNK(0, ch) PW_CHUNK(1, ch + 1) PW_CHUNK(2, ch + 2) }
+        if (ch < ncl) {
             PW_CHUNK(0, ch)
-            if (ch + 1 < nchunk) PW_CHUNK(1, ch + 1)
+            if (ch + 1 < ncl) PW_CHUNK(1, ch + 1)
         }
         // alpha = P / l, zero for masked queries (ga.py:24-25); pair features out
 #pragma unroll
@@ -265,9 +276,12 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
             const int il = il0 + ii, i = i0 + il;
             if (kq == 0) sm.lsum[il * SCLD + fm] = l_run[ii];
             if (DUMP && kq == 0 && i < L && fm < H) *reinterpret_cast<float2*>(dump_stats + ((rowbase + i) * H + fm) * 2) = make_float2(m_run[ii], l_run[ii]);
+            if (SPLIT && kq == 0 && i < L && fm < H)
+                *reinterpret_cast<float2*>(pstats + (((int64_t)slice * N * L + rowbase + i) * H + fm) * 2) = make_float2(m_run[ii], l_run[ii]);
             if (i < L && fm < H) {
-                const float inv = mi_b[ii] ? 1.f / l_run[ii] : 0.f;
-                float* fo = feat + (rowbase + i) * FEAT + fm * C + kq * 16;        // accumulator row 4 kq + r of tile mt <-> channel 16 kq + 4 r + mt
+                const float inv = SPLIT ? 1.f : (mi_b[ii] ? 1.f / l_run[ii] : 0.f);
+                float* fo = SPLIT ? part + ((int64_t)slice * N * L + rowbase + i) * SPLIT_ROW + fm * C + kq * 16
+                                  : feat + (rowbase + i) * FEAT + fm * C + kq * 16;        // accumulator row 4 kq + r of tile mt <-> channel 16 kq + 4 r + mt
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     reinterpret_cast<f32x4*>(fo)[r] = (f32x4){accP[ii][0][r] * inv, accP[ii][1][r] * inv, accP[ii][2][r] * inv, accP[ii][3][r] * inv};
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         // load has a whole chunk period to arrive (no conditional loads: the compiler keeps exact vmcnt counts)
 #define AW_ISSUE(HH, CH)                                                                                                 \
     {                                                                                                                    \
-        const int c_ = chunk_of(min((CH), nchunk - 1));                                                                  \
+        const int c_ = chunk_of(min((CH), ncl - 1));                                                                     \
         const f32x4* fr_ = kvn + ((int64_t)c_ * H + h0 + (HH)) * 512 + lane;                                             \
         if (!(CORE_ABL & 128)) { _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) kf[HH][s_] = fr_[s_ * 64]; }           \
     }
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         __syncthreads();                                                    // barrier #0
         TSTAMP(0)
         int buf = 1;
-        for (int c = 1; c < nchunk; ++c) {
+        for (int c = 1; c < ncl; ++c) {
             produce(c, buf);
             buf = (buf == 2) ? 0 : buf + 1;
             TSYNC(1, 2)                                                     // barrier #c
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
             for (int k = 0; k < 2; ++k) { accV[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; accT[hh][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #define CW_ISSUE(HH, CH)                                                                                                 \
     {                                                                                                                    \
-        const f32x4* fr_ = kvn + ((int64_t)chunk_of(min((CH), nchunk - 1)) * H + h0 + (HH)) * 512 + 4 * 64 + lane;       \
+        const f32x4* fr_ = kvn + ((int64_t)chunk_of(min((CH), ncl - 1)) * H + h0 + (HH)) * 512 + 4 * 64 + lane;          \
         if (!(CORE_ABL & 256)) { _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) vf[HH][s_] = fr_[s_ * 64]; }           \
     }
 #define CW_ISSUE0(HH) { const f32x4* fr_ = kvn + ((int64_t)chunk_of(0) * H + h0 + (HH)) * 512 + 4 * 64 + lane;          \
@@ -372,32 +386,35 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         TSTAMP(0)
         TSYNC(1, 2)                                                         // barrier #1: P(0) ready
         int buf = 0;                                                        // buffer of the chunk being consumed
-        for (int c = 1; c < nchunk; ++c) {
+        for (int c = 1; c < ncl; ++c) {
             consume(c - 1, buf);
             buf = (buf == 2) ? 0 : buf + 1;
             TSYNC(1, 2)                                                     // barrier #(c + 1)
         }
-        consume(nchunk - 1, buf);
+        consume(ncl - 1, buf);
         TSYNC(3, 4)                                                         // F1
         float* pts = sm.sp;                                                 // [BI][H][24] aggregated global-frame points; the S/P tile is free now
         const int i = i0 + fm;
 #pragma unroll
         for (int hh = 0; hh < 3; ++hh) {
             const int h = h0 + hh;
-            const float inv = mi_c ? 1.f / sm.lsum[fm * SCLD + h] : 0.f;
+            const float inv = SPLIT ? 1.f : (mi_c ? 1.f / sm.lsum[fm * SCLD + h] : 0.f);
             // accumulator row 4 kq + r of tile k <-> value channel 16 k + 4 kq + r   /   coordinate r of point 4 k + kq (r = 3: padding)
+            float* prow = SPLIT ? part + ((int64_t)slice * N * L + rowbase + min(i, L - 1)) * SPLIT_ROW : nullptr;
             if (i < L) {
-                float* fo = feat + (rowbase + i) * FEAT + H * C + h * D + kq * 4;
+                float* fo = SPLIT ? prow + H * C + h * D + kq * 4 : feat + (rowbase + i) * FEAT + H * C + h * D + kq * 4;
                 *reinterpret_cast<f32x4*>(fo) = accV[hh][0] * inv;
                 *reinterpret_cast<f32x4*>(fo + 16) = accV[hh][1] * inv;
             }
-            float* po = pts + (fm * H + h) * (P * 3) + kq * 3;
+            float* po = (SPLIT ? prow + H * C + H * D + h * (P * 3) : pts + (fm * H + h) * (P * 3)) + kq * 3;
+            if (SPLIT && i >= L) continue;
 #pragma unroll
             for (int r = 0; r < 3; ++r) { po[r] = accT[hh][0][r] * inv; po[12 + r] = accT[hh][1][r] * inv; }
         }
         TSYNC(3, 4)                                                         // F2
     }
 
+    if (SPLIT) return;                                                      // the merge kernel finishes the rows
     // ---------------------------------------------------------------- all waves: local frame, norm, direction of the aggregated points (ga.py:136-139)
     // one thread per 4 consecutive points of a residue: 16-byte LDS reads and global stores
     const float* pts = sm.sp;
@@ -902,6 +919,56 @@ int launch_pair_bias_cache(const float* z, const float* const* wb, int num_layer
     return ABOPT_OK;
 }
 
+// Softmax merge of the key slices of a SPLIT launch + the point epilogue (ga.py:133-139): one workgroup per query row.
+//   w_s[h] = 2^(m_s - M) / sum_s' l_s' 2^(m_s' - M),  M = max_s m_s   (0 for a masked query row, ga.py:24-25)
+__global__ __launch_bounds__(256) void ipa_split_merge_kernel(const float* __restrict__ part, const float* __restrict__ pstats, const uint8_t* __restrict__ mask,
+                                                              const float* __restrict__ R, const float* __restrict__ t, float* __restrict__ feat,
+                                                              int64_t rows, int nsplit) {
+    __shared__ float w[4][16];
+    __shared__ float pts[H * P * 3];
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < H) {
+        float m[4], l[4], mx = -INFINITY;
+        for (int s_ = 0; s_ < nsplit; ++s_) {
+            const float2 ml = *reinterpret_cast<const float2*>(pstats + (((int64_t)s_ * rows + row) * H + tid) * 2);
+            m[s_] = ml.x; l[s_] = ml.y; mx = fmaxf(mx, ml.x);
+        }
+        float den = 0.f;
+        for (int s_ = 0; s_ < nsplit; ++s_) { m[s_] = __builtin_amdgcn_exp2f(m[s_] - mx); den += l[s_] * m[s_]; }
+        const float inv = mask[row] ? 1.f / den : 0.f;
+        for (int s_ = 0; s_ < nsplit; ++s_) w[s_][tid] = m[s_] * inv;
+    }
+    __syncthreads();
+    float* fo = feat + row * FEAT;
+    for (int idx = tid; idx < SPLIT_ROW; idx += 256) {
+        const int h = idx < H * C ? idx / C : (idx < H * C + H * D ? (idx - H * C) / D : (idx - H * C - H * D) / (P * 3));
+        float v = 0.f;
+        for (int s_ = 0; s_ < nsplit; ++s_) v += part[((int64_t)s_ * rows + row) * SPLIT_ROW + idx] * w[s_][h];
+        if (idx < H * C + H * D) fo[idx] = v; else pts[idx - H * C - H * D] = v;
+    }
+    __syncthreads();
+    if (tid < H * P) {
+        const float* Rr = R + row * 9;
+        const float* tr = t + row * 3;
+        const float dx = pts[3 * tid] - tr[0], dy = pts[3 * tid + 1] - tr[1], dz = pts[3 * tid + 2] - tr[2];
+        const float lx = Rr[0] * dx + Rr[3] * dy + Rr[6] * dz;            // R^T (a - t), geometry.py:94-117
+        const float ly = Rr[1] * dx + Rr[4] * dy + Rr[7] * dz;
+        const float lz = Rr[2] * dx + Rr[5] * dy + Rr[8] * dz;
+        const float d = sqrtf(lx * lx + ly * ly + lz * lz);
+        const float inv = 1.f / (d + 1e-4f);                              // ga.py:138-139
+        float* fp = fo + H * C + H * D;
+        fp[3 * tid] = lx; fp[3 * tid + 1] = ly; fp[3 * tid + 2] = lz;
+        fp[H * P * 3 + tid] = d;
+        fp[H * P * 3 + H * P + 3 * tid] = lx * inv; fp[H * P * 3 + H * P + 3 * tid + 1] = ly * inv; fp[H * P * 3 + H * P + 3 * tid + 2] = lz * inv;
+    }
+}
+
+size_t ipa_split_ws_floats(int N, int L) {
+    const int nib = (L + BI - 1) / BI;
+    return ((int64_t)N * nib * 2 <= 256) ? (size_t)4 * N * L * (SPLIT_ROW + 2 * H) : 0;
+}
+
 template <bool DUMP, bool CACHED>
 static int launch_core_variant(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                                const float* Wb, float* feat, float* dump, float* dump_stats, const float* pbc, int N, int L, hipStream_t st, int z_shared) {
@@ -932,7 +999,7 @@ static int launch_core_variant(const float* qfrag, const float* kvfrag, const fl
 
 int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                            const float* w_pair_bias, float* feat, float* dump, float* dump_stats, const float* pair_bias_cache, int N, int L, hipStream_t st,
-                           int z_shared) {
+                           int z_shared, float* split_ws, size_t split_ws_floats) {
     ABOPT_CHECK_ARG(!dump == !dump_stats, "ipa_core: the logits dump and its row statistics come together");
     ABOPT_CHECK_ARG(!dump || (int64_t)H * L * L * 4 < (1ll << 31), "ipa_core: L=%d too long for the logits dump", L);
     if (pair_bias_cache && !dump) {
@@ -966,6 +1033,30 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
             return ABOPT_OK;
         }
 #endif
+    }
+    if (pair_bias_cache && !dump && split_ws && !CORE_ABL && !getenv("ABOPT_CORE_NO_SPLIT")) {
+        // small batches: split the keys of every query block over 2 or 4 workgroups (see the SPLIT note at ipa_core_kernel)
+        const int nib = (L + BI - 1) / BI, nchunk = (L + JC - 1) / JC, total = N * nib;
+        int cus = 0;
+        if (int rc = device_cu_count(&cus)) return rc;
+        int nsplit = (total * 4 <= cus && nchunk >= 8) ? 4 : ((total * 2 <= cus && nchunk >= 4) ? 2 : 1);
+        const int64_t rows = (int64_t)N * L;
+        if (nsplit > 1 && (size_t)nsplit * rows * (SPLIT_ROW + 2 * H) <= split_ws_floats) {
+            float* part = split_ws;
+            float* pstats = split_ws + (size_t)nsplit * rows * SPLIT_ROW;
+            const size_t lds = core_lds_fixed_bytes<true>() + (size_t)nchunk * JC;
+            ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core: L=%d needs %zu bytes of LDS for the key mask (max 163840)", L, lds);
+            static LdsConfig lds_cfg;
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core_kernel<false, true, true>), lds, lds_cfg)) return rc;
+            prof::begin(st);
+            hipLaunchKernelGGL((ipa_core_kernel<false, true, true>), dim3((unsigned)(total * nsplit)), dim3(NTH), lds, st, qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat,
+                               nullptr, nullptr, pair_bias_cache, N, L, nib, (N % 8 == 0) ? 1 : 0, z_shared, part, pstats, nsplit);
+            ABOPT_LAUNCH_CHECK();
+            hipLaunchKernelGGL(ipa_split_merge_kernel, dim3((unsigned)rows), dim3(256), 0, st, part, pstats, mask, R, t, feat, rows, nsplit);
+            prof::end(st);
+            ABOPT_LAUNCH_CHECK();
+            return ABOPT_OK;
+        }
     }
     if (pair_bias_cache) {
         if (dump) return launch_core_variant<true, true>(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, dump, dump_stats, pair_bias_cache, N, L, st, z_shared);

@@ -27,7 +27,8 @@ size_t pair_bias_layer_floats(int N, int L);
 int launch_ipa_frags(const float* proj, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag, int N, int L, hipStream_t st);
 int launch_ipa_core(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                     const float* w_pair_bias, float* feat, float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache,
-                    int N, int L, hipStream_t st, int z_shared = 0 /* 1: z and the pair-bias cache hold ONE sample that every batch entry shares */);
+                    int N, int L, hipStream_t st, int z_shared = 0 /* 1: z and the pair-bias cache hold ONE sample that every batch entry shares */,
+                    float* split_ws = nullptr, size_t split_ws_floats = 0 /* scratch of the key-split form (small batches), ipa_split_ws_floats(N, L) */);
 
 // node_frags.hip: x [N*L,128] -> qfrag / kvfrag directly (projection GEMM + frame transform + fragment layout in one kernel)
 size_t node_wfrag_floats();

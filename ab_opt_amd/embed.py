@@ -108,8 +108,7 @@ def embed_rows(mod, idx):
     if mod.padding_idx is None:
         return oh @ w
     pad = mod.padding_idx
-    keep = torch.ones(w.shape[0], dtype=w.dtype, device=w.device)
-    keep[pad] = 0
+    keep = (torch.arange(w.shape[0], device=w.device) != pad).to(w.dtype)          # (no host scalar write: the step may be under graph capture)
     return (oh * keep) @ w + oh[..., pad:pad + 1] * w[pad].detach()
 
 

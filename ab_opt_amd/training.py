@@ -304,12 +304,14 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
     if t is None:
         t = torch.randint(0, dpm.num_steps, (N,), dtype=torch.long, device=dev)
     h = dpm._sched_host()
-    seed = dpm._new_seed() if seed is None else int(seed)
+    seed_dev = getattr(dpm, '_train_seed_dev', None)          # GraphedTrainStep: the Philox position comes from device memory (replayable)
+    seed = 0 if seed_dev is not None else (dpm._new_seed() if seed is None else int(seed))
     grad_mode = torch.is_grad_enabled()         # so3.py:12-16: the log map clamps at -0.999 under autograd, -1.0 in no_grad validation passes
     with torch.no_grad():                       # noising has no learnable parameters; native kernel (transition.py:62-78,120-144,179-200)
         v_n, p_n_ang, s_n, eps_p = hip.add_noise(t, vs.alpha_bars, dpm.trans_rot.angular_distrib_fwd, noise, seed, 0,
                                                  v_0.detach().float(), p_0.detach().float(), s_0, mask_generate, h['scale'], h['mean'],
-                                                 noise_structure=denoise_structure, noise_sequence=denoise_sequence, grad_mode=grad_mode, want_eps=True)
+                                                 noise_structure=denoise_structure, noise_sequence=denoise_sequence, grad_mode=grad_mode, want_eps=True,
+                                                 seed_dev=seed_dev if noise is None else None)
     p0n = dpm._normalize_position(p_0)
     p_n = dpm._normalize_position(p_n_ang)
     R_0 = so3_exp(v_0)
@@ -354,3 +356,63 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
     kl = F.kl_div(input=log_pred, target=post_true, reduction='none', log_target=False).sum(-1)
     loss['seq'] = (kl * genf).sum() / denom
     return loss
+
+
+# ------------------------------------------------------------------ the whole training step as one hipGraph
+class GraphedTrainStep:
+    """forward + backward + optimizer step of `model(batch)` captured ONCE into a hipGraph and replayed (BASELINE config 5: the step is
+    ~900 kernel launches; eager, ~1.4 ms of its 16.8 ms are gaps between them).
+
+    Everything on the path is capture-safe: the library allocates nothing per call, the step indices t come from torch's device
+    generator (graph-aware), the noising kernel reads its Philox position from a 16-byte device buffer refreshed before every replay,
+    and the optimizer must be built with capturable=True (torch.optim.Adam(..., capturable=True)).  The batch is copied into the
+    graph's static tensors; losses are returned as a dict of 0-d device tensors (valid until the next call).  Shapes, the set of
+    parameters and `loss_weights` are fixed at construction; build a new object when they change."""
+
+    def __init__(self, model, optimizer, batch, loss_weights=None, max_grad_norm=None, warmup=3):
+        from . import hip
+        self.model, self.opt = model, optimizer
+        self.weights, self.max_grad_norm = loss_weights, max_grad_norm
+        dev = next(model.parameters()).device
+        self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        dpm = model.diffusion
+        self.seed_dev = torch.zeros(2, dtype=torch.int64, device=dev)
+        dpm._train_seed_dev = self.seed_dev
+        self._set_seed(dpm)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                                  # warm-up on a side stream (torch's capture protocol)
+            for _ in range(warmup):
+                self._one_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        before = set(hip.Workspace._bufs)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.losses = self._one_step()
+        self.keep = [hip.Workspace._bufs.pop(k) for k in set(hip.Workspace._bufs) - before]     # scratch slabs owned by this graph's pool
+
+    def _set_seed(self, dpm):
+        self.seed_dev.copy_(torch.tensor([dpm._new_seed(), 0], dtype=torch.int64))
+
+    def _one_step(self):
+        self.opt.zero_grad(set_to_none=True)
+        losses = self.model(dict(self.static))
+        total = sum(v * (self.weights[k] if self.weights is not None else 1.0) for k, v in losses.items())
+        total.backward()
+        if self.max_grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+        self.opt.step()
+        return {k: v.detach() for k, v in losses.items()}
+
+    def __call__(self, batch):
+        for k, v in batch.items():
+            if torch.is_tensor(v) and k in self.static:
+                self.static[k].copy_(v)
+        self._set_seed(self.model.diffusion)
+        self.graph.replay()
+        return self.losses
+
+    def close(self):
+        self.model.diffusion._train_seed_dev = None

@@ -533,8 +533,9 @@ def _one_step(dpm_, state, t, res_feat, pair_feat, gen, mres, noise_t):
     return tv[t - 1], tp[t - 1], ts[t - 1], tpr[t - 1], tpp[t - 1]
 
 
-def test_pair_bias_cache_is_bit_identical():
+def test_pair_bias_cache_is_bit_identical(monkeypatch):
     """The per-call pair-bias cache (abopt_pair_bias_cache) must not change a single bit of a denoising step."""
+    monkeypatch.setenv('ABOPT_CORE_NO_SPLIT', '1')             # same kernel form on both sides (the cached path of a small batch may split the keys)
     g = load_golden('trajectory_abdock_T10')
     _, m, batch = _traj_setup()
     d = m.diffusion
@@ -1192,13 +1193,14 @@ def test_ga_block_and_cache_above_2048_residues():
 
 
 @pytest.mark.parametrize('N,L,lengths', [(32, 256, None), (40, 100, None), (24, 250, 'ragged'), (96, 48, 'ragged'), (136, 32, None), (72, 64, 'ragged')])
-def test_persistent_core_is_bit_identical(N, L, lengths):
+def test_persistent_core_is_bit_identical(N, L, lengths, monkeypatch):
     """With the pair-bias cache and more query blocks than CUs the sampler's core runs as ONE persistent workgroup per CU that walks
     several query blocks with the roles' pipeline kept across block boundaries (csrc/ipa_core.hip: ipa_core_persist_kernel).  Same
     arithmetic in the same order: every sample must come out bit-identical to the same sample run in a small batch (one block per
     workgroup, the plain kernel) -- odd block counts per workgroup, chunk counts not divisible by 3 and ragged lengths included.
     L <= 64: blocks of 2..4 positions, where the per-block pieces (q swap, epilogues) dominate."""
     from ab_opt_amd import hip
+    monkeypatch.setenv('ABOPT_CORE_NO_SPLIT', '1')             # the small batches below would otherwise take the key-split form (other summation order)
     d = standalone_abdesign_dpm(100, 2).to(DEV)
     lens = [L] * N if lengths is None else [L - (7 * i) % min(60, L // 2) for i in range(N)]
     v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lens, 5200 + N, [(5, 14), (22, 30)])
@@ -1405,3 +1407,41 @@ def test_training_step_config5_native_vs_plain_statement():
     down = [a for a, n in rel if any(f'blocks.{b}.' in n for b in range(1, 6)) or 'eps_crd_net' in n or 'eps_rot_net' in n or 'eps_seq_net' in n]
     assert len(down) > 100 and max(down) < 2e-4, max(down)
     assert rel[-1][0] < 5e-3, rel[-3:]
+
+
+@pytest.mark.parametrize('N,L,lengths', [(8, 256, 'ragged'), (3, 256, None), (2, 100, 'ragged'), (5, 128, None)])
+def test_key_split_core_vs_unsplit_and_oracle(N, L, lengths, monkeypatch):
+    """Small batches (fewer query blocks than half the CUs) run the cached core with the keys of every query block split over 2 or 4
+    workgroups and a softmax merge (csrc/ipa_core.hip: ipa_core_kernel<.., SPLIT>, ipa_split_merge_kernel).  Against the unsplit kernel
+    (ABOPT_CORE_NO_SPLIT=1) EpsilonNet agrees to fp32 rounding (another summation order, six layers deep), against the oracle to the
+    usual 3e-5 -- ragged lengths included."""
+    from ab_opt_amd import hip
+    from oracle import dpm
+    T, t = 100, 37
+    d_cpu = standalone_abdesign_dpm(T, 2)
+    d = standalone_abdesign_dpm(T, 2).to(DEV)
+    sd = {k: v.cpu() for k, v in d_cpu.state_dict().items()}
+    lens = [L] * N if lengths is None else [L - (37 * i) % (L // 2) for i in range(N)]
+    v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lens, 8200 + N, [(5, 14), (22, 30)])
+    beta = d.trans_pos.var_sched.betas[t].expand([N]).contiguous()
+    ew = d.eps_net.packed()
+    pbc = hip.pair_bias_cache(d.eps_net.encoder.packed_array(), 6, pf)
+    run = lambda: {k: a.clone() for k, a in hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, False, 0, False, pair_bias_cache=pbc).items() if a is not None}
+    split = run()
+    monkeypatch.setenv('ABOPT_CORE_NO_SPLIT', '1')
+    plain = run()
+    differs = False
+    for k in ('R_next', 'eps_pos', 'c'):
+        assert torch.isfinite(split[k]).all()
+        assert max_abs(split[k], plain[k]) < 1e-5, (k, max_abs(split[k], plain[k]))
+        differs |= not torch.equal(split[k], plain[k])
+    assert differs                                              # otherwise the split form did not run and this test tests nothing
+    ids = list(range(min(N, 3)))
+    c = lambda a: a[ids].cpu()
+    inv = d_cpu.trans_rot.angular_distrib_inv
+    den = dpm.Denoiser(sd, num_steps=T, variant='abdesign', obj='pred_noise', mode='mm', pre='',
+                       tables=(None, dict(stddevs=inv.stddevs, approx_flag=inv.approx_flag, X=inv.X, Y=None)))
+    ref = den._eps(c(v), c(p), c(s), c(rf), c(pf), c(beta), c(gen), c(mres), False)
+    assert max_abs(c(split['R_next']), ref[1]) < 3e-5
+    assert max_abs(c(split['eps_pos']), ref[2]) < 3e-5
+    assert max_abs(c(split['c']), ref[3]) < 1e-5
