@@ -168,16 +168,25 @@ def secondary_measurements(dev, L):
     model = build_model(100, 7, flavour='abdesign', device=dev).eval()
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(32, layout).items()}
     opt = {'sample_structure': True, 'sample_sequence': True, 'contig': ''}
-    model.sample(dict(batch), dict(opt))
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    model.sample(dict(batch), dict(opt))
-    torch.cuda.synchronize()
-    res['sample_e2e_ms'] = round((time.perf_counter() - t0) * 1e3, 2)
-    res['sample_e2e_config'] = f'model.sample, AbDesign flavour, N=32, L={L}, T=100, encode + cache + 100 steps + D2H of the trajectory'
-    # ---- config 5 training step
+    e2e = {}
+    for mode, g in (('eager', False), ('graph', True)):
+        model.sample(dict(batch), dict(opt, graph=g))                       # (graph: capture + first replay)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        model.sample(dict(batch), dict(opt, graph=g))
+        torch.cuda.synchronize()
+        e2e[mode] = round((time.perf_counter() - t0) * 1e3, 2)
+    res['sample_e2e_ms'] = min(e2e.values())
+    res['sample_e2e_eager_vs_graph_ms'] = e2e
+    res['sample_e2e_config'] = (f'model.sample, AbDesign flavour, N=32, L={L}, T=100: encode + pair-bias cache + 100 steps + D2H of the trajectory '
+                                '(graph: the loop replayed from a hipGraph captured by an earlier call, inputs copied into its static buffers)')
+    model.diffusion._graphs.clear()
+    torch.cuda.empty_cache()
+    # ---- config 5 training step: eager launches and the whole step replayed from one hipGraph (training.GraphedTrainStep)
+    from ab_opt_amd import training
     model.train()
-    tb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(16, layout).items()}
-    adam = torch.optim.Adam(model.parameters(), lr=1e-4)
+    NT = 16
+    tb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(NT, layout).items()}
+    adam = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
 
     def step():
         adam.zero_grad(set_to_none=True)
@@ -191,8 +200,34 @@ def secondary_measurements(dev, L):
     for _ in range(iters):
         step()
     torch.cuda.synchronize()
-    res['train_step_ms'] = round((time.perf_counter() - t0) / iters * 1e3, 2)
-    res['train_step_config'] = f'AbDesign flavour model(batch) fwd + bwd + Adam, N=16, L={L} (encode() inside, as train.py runs it)'
+    eager_ms = (time.perf_counter() - t0) / iters * 1e3
+    graph_ms = None
+    try:
+        gstep = training.GraphedTrainStep(model, adam, tb)
+        for _ in range(2):
+            gstep(tb)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(iters):
+            losses = gstep(tb)
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t0) / iters * 1e3
+        assert all(torch.isfinite(v) for v in losses.values())
+        gstep.close()
+        del gstep
+    except Exception as e:                   # the eager number stands on its own
+        res['train_graph_error'] = repr(e)
+    best = min(eager_ms, graph_ms) if graph_ms is not None else eager_ms
+    res['train_step_ms'] = round(best, 2)
+    res['train_step_eager_ms'], res['train_step_graph_ms'] = round(eager_ms, 2), (round(graph_ms, 2) if graph_ms is not None else None)
+    res['train_step_config'] = f'AbDesign flavour model(batch) fwd + bwd + Adam, N={NT}, L={L} (encode() inside, as train.py runs it); best of eager / hipGraph replay'
+    # SURVEY 8(d), "training (config 5) extra": per sample 285 MB (forward 102 MB + backward 6 z reads + 6 dz writes + 5 dz reads of 16.8 MB) and
+    # 3 x (4.15 GFLOP denoiser + 5.3 GFLOP encode) (backward = 2 x forward)
+    tb_bytes, tb_flops = NT * 285e6 * (L / 256) ** 2, NT * 3 * (4.15e9 + 5.3e9) * (L / 256) ** 2
+    res['train_roofline'] = {'algorithmic_bytes': tb_bytes, 'flops': tb_flops, 'ms': round(best, 2),
+                             'hbm_frac': round(tb_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             'tflops': round(tb_flops / (best * 1e-3) / 1e12, 2), 'flop_frac': round(tb_flops / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                             'bound': 'fp32 matrix / vector pipes (0.57 ms of HBM time against 2.9 ms of fp32 FLOPs at peak)',
+                             'kernel_share': 'profiles/r03_*_train_full_step_kernel_stats.txt: share of GPU time in abopt:: kernels'}
     model.zero_grad(set_to_none=True)
     model.eval()
     del adam, tb

@@ -32,5 +32,8 @@ for k in ipa_core node_frags_kernel out_ln_mlp_kernel; do
     python tools/pmc_summary.py $OUT/pmc --kernel $k; } > $OUT/pmc_$k.txt
 done
 rm -rf $OUT/stats $OUT/pmc
+# 4. the training step (config 5) and the shapes other than the bench's
+bash tools/r03_train_prof.sh $TAG/train > /dev/null 2>&1
+bash tools/r03_shapes.sh $TAG/shapes > /dev/null 2>&1
 tail -1 $OUT/bench_full.log | cut -c1-600
 head -14 $OUT/kernel_stats.txt | cut -c1-60,92-140

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.." && ROOT=$(pwd) && OUT=$ROOT/gpurun_out/${1:-shapes} && mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-for spec in "1000 48 --shared abdock" "1000 32 --shared abdock" "8 256 _ abdesign" "2 256 _ abdesign" "64 256 --shared abdock"; do
+for spec in "1000 48 --shared abdock" "8 256 _ abdesign" "2 256 _ abdesign" "64 256 --shared abdock"; do
   set -- $spec; n=$1; l=$2; sh=$3; fl=$4; [ "$sh" = "_" ] && sh=""
   tag=n${n}_l${l}
   python $ROOT/tools/run_shape.py --n $n --l $l $sh --flavour $fl --steps 10 >> $OUT/rates.txt 2>> $OUT/err.txt
