@@ -410,12 +410,11 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
     EpsScratch e = carve_eps(cv, M, N, L, 64);
     if (!cv.ok) { set_error("eps_net_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, abopt_eps_workspace_bytes(N, L, Fd, Cd)); return ABOPT_EWORKSPACE; }
 
-    // dpm_full.py:86  R = exp(v_t)
-    if ((rc = launch_so3_exp(v_t, e.R, M, st))) return rc;
-    // dpm_full.py:89  res_feat_mixer([res_feat | Embedding(s_t)])
+    // dpm_full.py:86  R = exp(v_t)   and   dpm_full.py:89  res_feat_mixer([res_feat | Embedding(s_t)])
     if (w->w_mix_frag && w->mix_table) {
-        if ((rc = launch_mixer(res_feat, s_t, w->w_mix_frag, w->mix_table, w->b_mix1, e.cat, M, st))) return rc;
+        if ((rc = launch_mixer(res_feat, s_t, w->w_mix_frag, w->mix_table, w->b_mix1, e.cat, M, st, v_t, e.R))) return rc;       // one launch for both
     } else {
+        if ((rc = launch_so3_exp(v_t, e.R, M, st))) return rc;
         if ((rc = launch_embed_concat(res_feat, s_t, w->seq_embed, e.cat, M, st))) return rc;
         if ((rc = launch_linear(e.cat, 2 * F, w->w_mix0, 2 * F, w->b_mix0, e.x0, F, (int)M, F, 2 * F, true, st))) return rc;
         if ((rc = launch_linear(e.x0, F, w->w_mix1, F, w->b_mix1, e.cat, F, (int)M, F, F, false, st))) return rc;   // reuse cat[:, :F] as x (ld = F)

@@ -141,13 +141,20 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
 // products on the same path as the heads.  Waves 0..3 own the four 32-column blocks of each layer.
 __global__ __launch_bounds__(HTH) void mixer_kernel(const float* __restrict__ res_feat, const int64_t* __restrict__ s_t, const float* __restrict__ wfrag,
                                                     const float* __restrict__ table, const float* __restrict__ b1, float* __restrict__ x_out,
-                                                    int64_t rows) {
+                                                    int64_t rows, const float* __restrict__ v_t, float* __restrict__ R_out) {
     extern __shared__ __attribute__((aligned(16))) char hd_raw[];
     HeadsSmem& sm = *reinterpret_cast<HeadsSmem*>(hd_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * HR;
     const u32x4* wf = reinterpret_cast<const u32x4*>(wfrag);
+    if (R_out && wave == 4 && lane < HR && row0 + lane < rows) {
+        // dpm_full.py:86  R = exp(v_t) of this workgroup's rows, on a wave that has no layer to compute (saves the so3_exp launch of a step)
+        const int64_t i = row0 + lane;
+        const Mat3 m = so3_exp(v_t[i * 3], v_t[i * 3 + 1], v_t[i * 3 + 2]);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R_out[i * 9 + k] = m.m[k];
+    }
     {
         const int r = tid >> 5, c = (tid & 31) * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(res_feat + min(row0 + r, rows - 1) * HF + c);
@@ -188,11 +195,11 @@ __global__ __launch_bounds__(HTH) void mixer_kernel(const float* __restrict__ re
 }
 
 int launch_mixer(const float* res_feat, const int64_t* s_t, const float* wfrag, const float* table, const float* b1, float* x_out, int64_t rows,
-                 hipStream_t st) {
+                 hipStream_t st, const float* v_t, float* R_out) {
     if (rows == 0) return ABOPT_OK;
     static LdsConfig lds_cfg;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(mixer_kernel), sizeof(HeadsSmem), lds_cfg)) return rc;
-    hipLaunchKernelGGL(mixer_kernel, dim3((unsigned)((rows + HR - 1) / HR)), dim3(HTH), sizeof(HeadsSmem), st, res_feat, s_t, wfrag, table, b1, x_out, rows);
+    hipLaunchKernelGGL(mixer_kernel, dim3((unsigned)((rows + HR - 1) / HR)), dim3(HTH), sizeof(HeadsSmem), st, res_feat, s_t, wfrag, table, b1, x_out, rows, v_t, R_out);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

@@ -51,7 +51,7 @@ int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, con
 size_t heads_wfrag_floats();
 size_t mixer_wfrag_floats();
 int launch_mixer(const float* res_feat, const int64_t* s_t, const float* wfrag, const float* table, const float* b1, float* x_out, int64_t rows,
-                 hipStream_t st);
+                 hipStream_t st, const float* v_t = nullptr, float* R_out = nullptr /* optional: R = exp(v_t) of the same rows, fused */);
 int launch_heads_mlp(const float* xe, const float* beta, const float* wfrag, const float* w1, int ld1, const float* b1, const float* b2c,
                      const float* b2r, const float* b2s, const float* b3c, const float* b3r, const float* b3s, float* out3, int64_t rows, int L,
                      hipStream_t st);
