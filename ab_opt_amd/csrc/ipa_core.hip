@@ -41,7 +41,7 @@ __device__ long long g_core_timing[3][8];
 #else
 #define TSTAMP(k)
 #define TSYNC(kw, kb) __syncthreads();
-#ifdef PERSIST_TIMING   // developer build: per-role clocks of one persistent workgroup
+#if defined(PERSIST_TIMING) || defined(C32_TIMING)   // developer builds: per-role clocks of one workgroup
 #include <cstdio>
 __device__ long long g_core_timing[3][8];
 #endif
@@ -481,8 +481,8 @@ __device__ __forceinline__ PBlk pblk_of(int b, int nib, int L, int xcd_remap, in
 // per-point epilogue of a finished block (ga.py:136-139): local frame, norm, direction of the aggregated points; one thread per 4
 // consecutive points of a residue.  Out of line on purpose: it runs once per block on waves whose hot loop must keep its registers.
 __device__ __attribute__((noinline)) void persist_point_epilogue(const float* __restrict__ ptsb, const float* __restrict__ R, const float* __restrict__ t,
-                                                                 float* __restrict__ feat, int64_t rowbase, int i0, int L, int th, int nth) {
-    for (int e = th; e < BI * (H * P / 4); e += nth) {
+                                                                 float* __restrict__ feat, int64_t rowbase, int i0, int L, int th, int nth, int nrows = BI) {
+    for (int e = th; e < nrows * (H * P / 4); e += nth) {
         const int il = e / (H * P / 4), g4 = e % (H * P / 4), i = i0 + il;
         if (i >= L) continue;
         const float* Rr = R + (rowbase + i) * 9;
@@ -868,6 +868,403 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
 #undef PC_ISSUE
 }
 
+// =====================================================================================================================
+// 32-row form of the cached core (round 3).  What bounds the 16-row kernels is the number of bytes a CU pulls through its L1 per query
+// row: a 16-row block reads its sample's key/value fragments (96 KB per key chunk) next to 80 KB of z and pair bias, 805 MB of 1.44 GB
+// per launch at the bench shape.  Here ONE workgroup owns 32 query rows, so a fragment read serves twice the rows (256 KB instead of
+// 352 KB per chunk and 32 rows).  The state of 32 rows does not fit 16 waves x 128 registers; it does fit
+// 8 waves x 256 (two per SIMD, the unified VGPR/AGPR file of gfx950):
+//   4 pair waves (8 query rows each)   128 accumulator registers + the 3-slot z ring (60)
+//   2 "A" waves (6 heads each)         q' of their heads for both row tiles LIVES IN REGISTERS (192; 96 KB of LDS otherwise), key fragments
+//                                      double buffered, one head ahead
+//   2 "C" waves (6 heads each)         192 accumulator registers (value / point aggregation of 32 rows), value fragments double buffered
+// Wave w and w + 4 share a SIMD: every SIMD hosts one pair wave and one A or C wave (308 / 320 MFMAs per chunk).  Same per-row
+// arithmetic in the same order as the 16-row kernels: results are bit-identical to them (test_persistent_core_is_bit_identical runs this
+// kernel for its large batches).  One block per workgroup; the sampler's bench shape (N = 32, L = 256) is exactly 256 blocks.
+#ifndef C32_RING
+#define C32_RING 3       // slots of the pair waves' z ring (3 or 4)
+#endif
+#ifndef C32_ABL
+#define C32_ABL 0        // developer ablations (timing only, results wrong): 1 no z / bias loads in the loop | 32 z / bias loads all from one L1-resident address | 64 no softmax arithmetic in rows 1..7 (P = S) | 128 no pair MFMAs | 256 / 512 no A / C MFMAs (nothing instead) | 2 no fragment loads in the loop | 4 / 8 / 16 pair / A / C MFMAs off
+#endif
+constexpr int BI2 = 32, NPW2 = 4, RPW2 = BI2 / NPW2, NTH2 = 512, HPW = 6;
+
+#ifdef C32_OLDMASK
+#define C32_L2(x, r) (((mk4_ >> (8 * (r))) & 0xffu) ? (x) * kScale2 : (x) * kScale2 - kMask2)
+#else
+#define C32_L2(x, r) __builtin_fmaf((x), kScale2, mterm_[r])
+#endif
+__global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restrict__ qfrag, const float* __restrict__ kvfrag, const float* __restrict__ z,
+                                                          const uint8_t* __restrict__ mask, const float* __restrict__ R, const float* __restrict__ t,
+                                                          float* __restrict__ feat, const float* __restrict__ pbc, int L, int nib2, int xcd_remap, int z_shared) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sp = reinterpret_cast<float*>(smem_raw);                     // [3][BI2][SROW]
+    float* scl = sp + 3 * BI2 * SROW;                                   // [2][BI2][SCLD]
+    float* lsum = scl + 2 * BI2 * SCLD;                                 // [BI2][SCLD]
+    float* mlr = lsum + BI2 * SCLD;                                     // [BI2][16][2]  running maximum / sum of every (row, head): the pair waves have no registers left for them
+    uint8_t* mk = reinterpret_cast<uint8_t*>(mlr + BI2 * 32);           // [nchunk * JC]
+    int n, ib;
+    {
+        const int b = blockIdx.x;
+        if (xcd_remap) { const int xcd = b & 7, k = b >> 3; n = xcd + 8 * (k / nib2); ib = k % nib2; }
+        else { n = b / nib2; ib = b % nib2; }
+    }
+    const int tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunk = (L + JC - 1) / JC, nib16 = (L + BI - 1) / BI;
+#ifdef C32_TIMING   // developer build: per-role clocks of workgroup 17: total | barrier waits in the chunk loop | wall clock (100 MHz ticks)
+    const long long t_begin = clock64(), w_begin = wall_clock64();
+    long long t_wait = 0;
+    if (blockIdx.x == 17 && lane == 0) g_core_timing[2][7 - 0] = 0;
+    if (blockIdx.x == 17 && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g_core_timing[0][4 + (wave >> 2)]) + 0, (unsigned long long)__builtin_amdgcn_s_getreg(2308) << (8 * (wave & 3)));   // SIMD of every wave
+#define C32_SYNC() { const long long t0_ = clock64(); __syncthreads(); t_wait += clock64() - t0_; }
+#define C32_REPORT(ROLE) if (blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == NPW2 || wave == NPW2 + 2)) { g_core_timing[ROLE][0] = clock64() - t_begin; g_core_timing[ROLE][1] = t_wait; g_core_timing[ROLE][2] = wall_clock64() - w_begin; }
+#else
+#define C32_SYNC() __syncthreads();
+#define C32_REPORT(ROLE) {}
+#endif
+    const int i0 = ib * BI2;
+    const int64_t rowbase = (int64_t)n * L;
+    const int64_t zbase = z_shared ? 0 : rowbase;
+    auto fill_mask = [&]() { for (int e = tid; e < nchunk * JC; e += NTH2) mk[e] = (e < L) ? mask[rowbase + e] : 0; };
+
+    if (wave < NPW2) {
+        // =========================================================================================== pair waves: 8 rows each
+        const int il0 = wave * RPW2;
+        // z and the bias cache are read through buffer descriptors of this sample's slabs: a request is ONE instruction -- descriptor (SGPRs),
+        // the row's byte offset (an SGPR, added by the hardware) and the lane's offset inside a row (a VGPR that lives for a whole chunk)
+        const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(z + zbase * (int64_t)L * C), 0, L * L * C * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pbc + zbase * (int64_t)nchunk * (H * JC)), 0, L * nchunk * (H * JC) * 4, 0x00020000);
+        int zrow[RPW2], pbrow[RPW2];
+#pragma unroll
+        for (int ii = 0; ii < RPW2; ++ii) {
+            const int row = min(i0 + il0 + ii, L - 1);
+            zrow[ii] = row * L * (C * 4);
+            pbrow[ii] = row * nchunk * (H * JC * 4);
+        }
+        const unsigned lane_b = (unsigned)fm * 16u;
+        const unsigned pb_lane = (unsigned)(min(fm, H - 1) * JC + kq * 4) * 4u;
+        f32x4 ring[C32_RING][4], ringb[4];                                  // z ring: requests run C32_RING - 1 positions ahead; the bias (needed one position earlier, see below) 3 ahead
+        // byte offsets of the lane's four key rows / of its bias quad inside a row, for the chunk the requests currently go to: computed once
+        // per chunk, so a request is one instruction (SGPR row base + VGPR offset) and no address arithmetic rides in the hot loop
+        unsigned koff_[4], boff_;
+#define P2_KOFF(CH)                                                                                                      \
+    {                                                                                                                    \
+        const int ch_ = (C32_ABL & 32) ? 0 : min((CH), nchunk - 1);             /* past the end: harmless re-read */      \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) koff_[r_] = (unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b; \
+    }
+#define P2_BOFF(CH) boff_ = (unsigned)((C32_ABL & 32) ? 0 : min((CH), nchunk - 1)) * (unsigned)(H * JC * 4) + pb_lane;
+#ifdef C32_OLDLOAD
+        const char* zslab = reinterpret_cast<const char*>(z + zbase * (int64_t)L * C);
+        const char* bslab = reinterpret_cast<const char*>(pbc + zbase * (int64_t)nchunk * (H * JC));
+#define P2_ISSUE_Z(SLOT, II)                                                                                            \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                \
+            ring[SLOT][r_] = ZLOAD(reinterpret_cast<const f32x4*>(zslab + zrow[II] + koff_[r_]));
+#define P2_ISSUE_B(SLOT, II) ringb[SLOT] = ZLOAD(reinterpret_cast<const f32x4*>(bslab + pbrow[II] + boff_));
+#else
+#define P2_ISSUE_Z(SLOT, II)                                                                                            \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                \
+            ring[SLOT][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, koff_[r_], zrow[(C32_ABL & 32) ? 0 : II], 2));   /* aux 2 = nt, as ZLOAD */
+#define P2_ISSUE_B(SLOT, II) ringb[SLOT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, boff_, pbrow[(C32_ABL & 32) ? 0 : II], 2));
+#endif
+        P2_KOFF(0) P2_BOFF(0)
+        P2_ISSUE_B(0, 0) P2_ISSUE_Z(0, 0) P2_ISSUE_B(1, 1) P2_ISSUE_Z(1, 1) P2_ISSUE_B(2, 2)
+        if (C32_RING == 4) P2_ISSUE_Z(2, 2)
+        fill_mask();
+        f32x4 accP[RPW2][4];
+        float* mlw = mlr + (il0 * 16 + fm) * 2;                             // this wave's rows; all four key groups of a lane column keep the same value
+#pragma unroll
+        for (int ii = 0; ii < RPW2; ++ii) {
+            if (kq == 0) *reinterpret_cast<float2*>(mlw + ii * 32) = make_float2(-INFINITY, 0.f);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) accP[ii][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int spo = sp_off(fm, kq);
+        __syncthreads();                                                    // key mask visible
+        __syncthreads();                                                    // barrier #0: S(0) ready
+        // Position (chunk CH, row II) is number 8 CH + II; its z sits in ring slot (8 CH + II) % C32_RING, its bias in slot II % 4.
+        // With two waves on a SIMD nobody else fills the ~40 dependent VALU / LDS steps of a row's softmax, so a row's softmax runs
+        // in the shadow of the PREVIOUS row's 16 MFMAs (software pipeline inside a chunk; a chunk's first row waits for its barrier).
+        // softmax of row II of the chunk in sp[BUF] -> pvn_, scn_ (P, the rescale factor and the running maximum / sum go to LDS)
+#define P2_SM(II, BUF)                                                                                                   \
+    {                                                                                                                    \
+        const int il_ = il0 + (II);                                                                                      \
+        float* spp_ = sp + ((BUF) * BI2 + il_) * SROW + spo;                                                             \
+        f32x4 sv_ = *reinterpret_cast<const f32x4*>(spp_);                                                               \
+        const float2 ml_ = *reinterpret_cast<const float2*>(mlw + (II) * 32);                                            \
+        sv_ += ringb[(II) & 3];                                                                                          \
+        float l2_[4];                                                                                                    \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) l2_[r_] = C32_L2(sv_[r_], r_);          \
+        const float mx_ = rows_max(fmaxf(fmaxf(l2_[0], l2_[1]), fmaxf(l2_[2], l2_[3])));                                 \
+        const float mn_ = fmaxf(ml_.x, mx_);                                                                             \
+        scn_ = __builtin_amdgcn_exp2f(ml_.x - mn_);                                                                      \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) pvn_[r_] = __builtin_amdgcn_exp2f(l2_[r_] - mn_);               \
+        const float ps_ = rows_sum((pvn_[0] + pvn_[1]) + (pvn_[2] + pvn_[3]));                                           \
+        const float ln_ = ml_.y * scn_ + ps_;                                                                            \
+        *reinterpret_cast<f32x4*>(spp_) = pvn_;                                                                          \
+        if (kq == 0) { scl[((CHPAR) * BI2 + il_) * SCLD + fm] = scn_; *reinterpret_cast<float2*>(mlw + (II) * 32) = make_float2(mn_, ln_); } \
+    }
+        // one MFMA of row II (k-step K_ >> 2, channel tile K_ & 3) and a fence: the source order below IS the issue order
+#define P2_MF(SLOT, II, K_)                                                                                              \
+        if (!(C32_ABL & 128)) accP[II][(K_) & 3] = mfma4(ring[SLOT][(K_) >> 2][(K_) & 3], pvc_[(K_) >> 2], accP[II][(K_) & 3]);                \
+        __builtin_amdgcn_sched_barrier(0);
+        // rows 0..6 of a chunk: the 16 MFMAs of row II, each followed by a piece of row II + 1's softmax and accumulator rescale
+        // (an MFMA holds the pipe for 32 cycles; 3..8 dependent VALU steps ride in its shadow)
+#define P2_POS(SLOT, II, CH, BUF)                                                                                        \
+    {                                                                                                                    \
+        const f32x4 pvc_ = pvn_;                                                                                         \
+        if ((II) + 3 == 8) P2_BOFF((CH) + 1)                                /* the requests move on to the next chunk */ \
+        if ((II) + C32_RING - 1 == 8) P2_KOFF((CH) + 1)                                                                  \
+        if (!(C32_ABL & 1)) {                                                                                            \
+            P2_ISSUE_B(((II) + 3) & 3, ((II) + 3) & 7)                                                                   \
+            P2_ISSUE_Z(((SLOT) + C32_RING - 1) % C32_RING, ((II) + C32_RING - 1) & 7)                                    \
+        }                                                                                                                \
+        const int il_ = il0 + (II) + 1;                                                                                  \
+        float* spp_ = sp + ((BUF) * BI2 + il_) * SROW + spo;                                                             \
+        f32x4 sv_ = *reinterpret_cast<const f32x4*>(spp_);                                                               \
+        const float2 ml_ = *reinterpret_cast<const float2*>(mlw + ((II) + 1) * 32);                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        P2_MF(SLOT, II, 0) P2_MF(SLOT, II, 1)                                                                            \
+        if (C32_ABL & 64) { pvn_ = sv_; scn_ = 1.f; *reinterpret_cast<f32x4*>(spp_) = pvn_;                              \
+            P2_MF(SLOT, II, 2) P2_MF(SLOT, II, 3) P2_MF(SLOT, II, 4) P2_MF(SLOT, II, 5) P2_MF(SLOT, II, 6) P2_MF(SLOT, II, 7) P2_MF(SLOT, II, 8) P2_MF(SLOT, II, 9) \
+            P2_MF(SLOT, II, 10) P2_MF(SLOT, II, 11) P2_MF(SLOT, II, 12) P2_MF(SLOT, II, 13) P2_MF(SLOT, II, 14) P2_MF(SLOT, II, 15) } else {   \
+        sv_ += ringb[((II) + 1) & 3];                                                                                    \
+        P2_MF(SLOT, II, 2)                                                                                               \
+        float l2_[4];                                                                                                    \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) l2_[r_] = C32_L2(sv_[r_], r_);          \
+        P2_MF(SLOT, II, 3)                                                                                               \
+        float mx_ = fmaxf(fmaxf(l2_[0], l2_[1]), fmaxf(l2_[2], l2_[3]));                                                 \
+        { auto a_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx_), __float_as_uint(mx_), false, false);          \
+          mx_ = fmaxf(__uint_as_float(a_[0]), __uint_as_float(a_[1])); }                                                 \
+        P2_MF(SLOT, II, 4)                                                                                               \
+        { auto b_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx_), __float_as_uint(mx_), false, false);          \
+          mx_ = fmaxf(__uint_as_float(b_[0]), __uint_as_float(b_[1])); }                                                 \
+        const float mn_ = fmaxf(ml_.x, mx_);                                                                             \
+        scn_ = __builtin_amdgcn_exp2f(ml_.x - mn_);                                                                      \
+        P2_MF(SLOT, II, 5)                                                                                               \
+        pvn_[0] = __builtin_amdgcn_exp2f(l2_[0] - mn_); pvn_[1] = __builtin_amdgcn_exp2f(l2_[1] - mn_);                  \
+        P2_MF(SLOT, II, 6)                                                                                               \
+        pvn_[2] = __builtin_amdgcn_exp2f(l2_[2] - mn_); pvn_[3] = __builtin_amdgcn_exp2f(l2_[3] - mn_);                  \
+        float ps_ = (pvn_[0] + pvn_[1]) + (pvn_[2] + pvn_[3]);                                                           \
+        P2_MF(SLOT, II, 7)                                                                                               \
+        { auto a_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(ps_), __float_as_uint(ps_), false, false);          \
+          ps_ = __uint_as_float(a_[0]) + __uint_as_float(a_[1]); }                                                       \
+        P2_MF(SLOT, II, 8)                                                                                               \
+        { auto b_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps_), __float_as_uint(ps_), false, false);          \
+          ps_ = __uint_as_float(b_[0]) + __uint_as_float(b_[1]); }                                                       \
+        const float ln_ = ml_.y * scn_ + ps_;                                                                            \
+        P2_MF(SLOT, II, 9)                                                                                               \
+        *reinterpret_cast<f32x4*>(spp_) = pvn_;                                                                          \
+        P2_MF(SLOT, II, 10)                                                                                              \
+        if (kq == 0) { scl[((CHPAR) * BI2 + il_) * SCLD + fm] = scn_; *reinterpret_cast<float2*>(mlw + ((II) + 1) * 32) = make_float2(mn_, ln_); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        P2_MF(SLOT, II, 11)                                                                                              \
+        accP[(II) + 1][0] *= scn_;                                                                                       \
+        P2_MF(SLOT, II, 12)                                                                                              \
+        accP[(II) + 1][1] *= scn_;                                                                                       \
+        P2_MF(SLOT, II, 13)                                                                                              \
+        accP[(II) + 1][2] *= scn_;                                                                                       \
+        P2_MF(SLOT, II, 14)                                                                                              \
+        accP[(II) + 1][3] *= scn_;                                                                                       \
+        P2_MF(SLOT, II, 15) }                                                                                            \
+    }
+        // the last row of a chunk: nothing to overlap with (the next chunk's logits are behind the barrier)
+#define P2_POS_LAST(SLOT, II, CH)                                                                                        \
+    {                                                                                                                    \
+        const f32x4 pvc_ = pvn_;                                                                                         \
+        if ((II) + 3 == 8) P2_BOFF((CH) + 1)                                /* the requests move on to the next chunk */ \
+        if ((II) + C32_RING - 1 == 8) P2_KOFF((CH) + 1)                                                                  \
+        if (!(C32_ABL & 1)) {                                                                                            \
+            P2_ISSUE_B(((II) + 3) & 3, ((II) + 3) & 7)                                                                   \
+            P2_ISSUE_Z(((SLOT) + C32_RING - 1) % C32_RING, ((II) + C32_RING - 1) & 7)                                    \
+        }                                                                                                                \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                 \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[II][mt_] = mfma4(ring[SLOT][r_][mt_], pvc_[r_], accP[II][mt_]); \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }
+#define P2_SLOT(K, II) ((8 * (K) + (II)) % C32_RING)
+#define P2_CHUNK(K, CH)                                                                                                  \
+    {                                                                                                                    \
+        const uint32_t mk4_ = *reinterpret_cast<const uint32_t*>(&mk[(CH) * JC + kq * 4]);                               \
+        float mterm_[4];                                                    /* x k + (0 | -1e5 log2 e) in one fma: the values of the 16-row kernels' (mask ? x k : x k - 1e5 log2 e), whose second form the compiler contracts to the same fma */ \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) mterm_[r_] = ((mk4_ >> (8 * r_)) & 0xffu) ? 0.f : -kMask2;      \
+        const int CHPAR = (CH) & 1;                                                                                      \
+        f32x4 pvn_; float scn_;                                                                                          \
+        P2_SM(0, K)                                                                                                      \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[0][mt_] *= scn_;                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        P2_POS(P2_SLOT(K, 0), 0, CH, K) P2_POS(P2_SLOT(K, 1), 1, CH, K) P2_POS(P2_SLOT(K, 2), 2, CH, K) P2_POS(P2_SLOT(K, 3), 3, CH, K) \
+        P2_POS(P2_SLOT(K, 4), 4, CH, K) P2_POS(P2_SLOT(K, 5), 5, CH, K) P2_POS(P2_SLOT(K, 6), 6, CH, K) P2_POS_LAST(P2_SLOT(K, 7), 7, CH) \
+        C32_SYNC()                                                          /* barrier #(CH + 1) */                      \
+    }
+        int ch = 0;
+        for (; ch + 3 <= nchunk; ch += 3) { P2_CHUNK(0, ch) P2_CHUNK(1, ch + 1) P2_CHUNK(2, ch + 2) }
+        if (ch < nchunk) {
+            P2_CHUNK(0, ch)
+            if (ch + 1 < nchunk) P2_CHUNK(1, ch + 1)
+        }
+#undef P2_CHUNK
+#undef P2_SLOT
+#undef P2_POS
+#undef P2_POS_LAST
+#undef P2_MF
+#undef P2_SM
+#undef P2_ISSUE_Z
+#undef P2_ISSUE_B
+#undef P2_KOFF
+#undef P2_BOFF
+        // alpha = P / l, zero for masked queries (ga.py:24-25); pair features out
+#pragma unroll
+        for (int ii = 0; ii < RPW2; ++ii) {
+            const int il = il0 + ii, i = i0 + il;
+            const float l_fin = mlw[ii * 32 + 1];                           // written by this lane column's kq == 0 lane of this very wave
+            if (kq == 0) lsum[il * SCLD + fm] = l_fin;
+            if (i < L && fm < H) {
+                const bool mi = mk[i] != 0;
+                const float inv = mi ? 1.f / l_fin : 0.f;
+                float* fo = feat + (rowbase + i) * FEAT + fm * C + kq * 16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    reinterpret_cast<f32x4*>(fo)[r] = (f32x4){accP[ii][0][r] * inv, accP[ii][1][r] * inv, accP[ii][2][r] * inv, accP[ii][3][r] * inv};
+            }
+        }
+        C32_REPORT(0)
+        __syncthreads();                                                    // F1: lsum visible, C waves done with the last chunk
+        __syncthreads();                                                    // F2: aggregated points in LDS
+    } else if (wave < NPW2 + 2) {
+        // =========================================================================================== A waves: S(t + 1), 6 heads x 2 row tiles
+        const int h0 = (wave - NPW2) * HPW;
+        const f32x4* kvn = reinterpret_cast<const f32x4*>(kvfrag) + (int64_t)n * nchunk * H * 512;
+        f32x4 qr[HPW][2][4];                                                // q' of this wave's heads, both row tiles: stays in registers
+#pragma unroll
+        for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const f32x4* qg = reinterpret_cast<const f32x4*>(qfrag) + (((int64_t)n * nib16 + min(2 * ib + rt, nib16 - 1)) * H + h0 + hh) * (4 * 64) + lane;
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) qr[hh][rt][s_] = qg[s_ * 64];
+            }
+        f32x4 kf[2][4];
+#define A2_ISSUE(B, HH, CH) { const f32x4* fr_ = kvn + ((int64_t)min((CH), nchunk - 1) * H + h0 + (HH)) * 512 + lane;   \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) kf[B][s_] = fr_[s_ * 64]; }
+        auto produce = [&](int c, int buf) {                                // S(c) -> sp[buf]; the key fragments of the NEXT head are requested first
+#pragma unroll
+            for (int hh = 0; hh < HPW; ++hh) {
+                const int h = h0 + hh;
+                if (!(C32_ABL & 2)) { if (hh + 1 < HPW) { if (hh & 1) A2_ISSUE(0, hh + 1, c) else A2_ISSUE(1, hh + 1, c) } else A2_ISSUE(0, 0, c + 1) }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const f32x4 q0 = qr[hh][rt][0], q1 = qr[hh][rt][1], q2 = qr[hh][rt][2], q3 = qr[hh][rt][3];
+                    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                    if (C32_ABL & 8) { acc0 = kf[hh & 1][0] * q0 + kf[hh & 1][1] * q1; acc1 = kf[hh & 1][2] * q2 + kf[hh & 1][3] * q3; }
+                    else if (C32_ABL & 256) { acc0 = kf[hh & 1][0]; acc1 = q0; }
+                    else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { acc0 = mfma4(kf[hh & 1][0][s], q0[s], acc0); acc1 = mfma4(kf[hh & 1][2][s], q2[s], acc1); }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { acc0 = mfma4(kf[hh & 1][1][s], q1[s], acc0); if (s < 3) acc1 = mfma4(kf[hh & 1][3][s], q3[s], acc1); }
+                    }
+                    const f32x4 sres = acc0 + acc1;
+                    *reinterpret_cast<f32x4*>(sp + (buf * BI2 + rt * 16 + fm) * SROW + sp_off(h, kq)) = sres;
+                }
+                __builtin_amdgcn_sched_barrier(0);                          // keep the per-head order
+            }
+        };
+        A2_ISSUE(0, 0, 0)
+        fill_mask();
+        __syncthreads();
+        produce(0, 0);
+        __syncthreads();                                                    // barrier #0
+        int buf = 1;
+        for (int c = 1; c < nchunk; ++c) {
+            produce(c, buf);
+            buf = (buf == 2) ? 0 : buf + 1;
+            C32_SYNC()                                                      // barrier #c
+        }
+        C32_SYNC()                                                          // barrier #nchunk
+        C32_REPORT(1)
+        __syncthreads();                                                    // F1
+        __syncthreads();                                                    // F2
+#undef A2_ISSUE
+    } else {
+        // =========================================================================================== C waves: aggregation of chunk t - 1, 6 heads x 2 row tiles
+        const int h0 = (wave - NPW2 - 2) * HPW;
+        const f32x4* kvn = reinterpret_cast<const f32x4*>(kvfrag) + (int64_t)n * nchunk * H * 512;
+        f32x4 vf[2][4];
+        f32x4 accV[HPW][2][2], accT[HPW][2][2];
+#pragma unroll
+        for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { accV[hh][rt][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; accT[hh][rt][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#define C2_ISSUE(B, HH, CH) { const f32x4* fr_ = kvn + ((int64_t)min((CH), nchunk - 1) * H + h0 + (HH)) * 512 + 4 * 64 + lane; \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) vf[B][s_] = fr_[s_ * 64]; }
+        auto consume = [&](int c, int buf) {
+            const int par = c & 1;
+#pragma unroll
+            for (int hh = 0; hh < HPW; ++hh) {
+                const int h = h0 + hh;
+                if (!(C32_ABL & 2)) { if (hh + 1 < HPW) { if (hh & 1) C2_ISSUE(0, hh + 1, c) else C2_ISSUE(1, hh + 1, c) } else C2_ISSUE(0, 0, c + 1) }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const float sc = scl[(par * BI2 + rt * 16 + fm) * SCLD + h];
+                    const f32x4 pa = *reinterpret_cast<const f32x4*>(sp + (buf * BI2 + rt * 16 + fm) * SROW + sp_off(h, kq));
+                    accV[hh][rt][0] *= sc; accV[hh][rt][1] *= sc; accT[hh][rt][0] *= sc; accT[hh][rt][1] *= sc;
+                    if (C32_ABL & 512) { accV[hh][rt][0] += pa; }
+                    else if (C32_ABL & 16) { accV[hh][rt][0] += vf[hh & 1][0] * pa; accV[hh][rt][1] += vf[hh & 1][1] * pa; accT[hh][rt][0] += vf[hh & 1][2] * pa; accT[hh][rt][1] += vf[hh & 1][3] * pa; }
+                    else
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        accV[hh][rt][0] = mfma4(vf[hh & 1][s][0], pa[s], accV[hh][rt][0]);
+                        accV[hh][rt][1] = mfma4(vf[hh & 1][s][1], pa[s], accV[hh][rt][1]);
+                        accT[hh][rt][0] = mfma4(vf[hh & 1][s][2], pa[s], accT[hh][rt][0]);
+                        accT[hh][rt][1] = mfma4(vf[hh & 1][s][3], pa[s], accT[hh][rt][1]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        C2_ISSUE(0, 0, 0)
+        fill_mask();
+        __syncthreads();
+        __syncthreads();                                                    // barrier #0
+        C32_SYNC()                                                          // barrier #1: P(0) ready
+        int buf = 0;
+        for (int c = 1; c < nchunk; ++c) {
+            consume(c - 1, buf);
+            buf = (buf == 2) ? 0 : buf + 1;
+            C32_SYNC()                                                      // barrier #(c + 1)
+        }
+        consume(nchunk - 1, buf);
+        C32_REPORT(2)
+        __syncthreads();                                                    // F1
+        float* pts = sp;                                                    // [BI2][H][24] aggregated global-frame points; the S/P tile is free now
+#pragma unroll
+        for (int hh = 0; hh < HPW; ++hh) {
+            const int h = h0 + hh;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int il = rt * 16 + fm, i = i0 + il;
+                const bool mi = (i < L) && mk[min(i, L - 1)] != 0;
+                const float inv = mi ? 1.f / lsum[il * SCLD + h] : 0.f;
+                if (i < L) {
+                    float* fo = feat + (rowbase + i) * FEAT + H * C + h * D + kq * 4;
+                    *reinterpret_cast<f32x4*>(fo) = accV[hh][rt][0] * inv;
+                    *reinterpret_cast<f32x4*>(fo + 16) = accV[hh][rt][1] * inv;
+                }
+                float* po = pts + (il * H + h) * (P * 3) + kq * 3;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { po[r] = accT[hh][rt][0][r] * inv; po[12 + r] = accT[hh][rt][1][r] * inv; }
+            }
+        }
+        __syncthreads();                                                    // F2
+#undef C2_ISSUE
+    }
+    // ---------------------------------------------------------------- all waves: local frame, norm, direction of the aggregated points (ga.py:136-139)
+    persist_point_epilogue(sp, R, t, feat, rowbase, i0, L, tid, NTH2, BI2);
+}
+
 // Pair-bias cache: lp[l][n,i,j,h] = z[n,i,j,:] . Wb_l[h,:] for every layer l in ONE pass over z (ga.py:88-90).  z and the weights do
 // not change during the 100 steps of FullDPM.sample, so the sampler builds this once per call and the per-step kernel reads 48
 // bytes per (i,j) instead of spending 64 more MFMAs per (row, chunk) and an LDS transpose on it.
@@ -997,11 +1394,53 @@ static int launch_core_variant(const float* qfrag, const float* kvfrag, const fl
     return ABOPT_OK;
 }
 
+// The 32-row kernel runs one block per workgroup, so it pays where its N * ceil(L / 32) workgroups fill the CUs in whole rounds: one
+// round at least 70 % full (N = 24, L = 256: 145 us against 155 us of the persistent 16-row kernel; N = 32: 167 against 175), or
+// several rounds at least 95 % full (N = 64: 335 against 345).  A half-empty last round loses (N = 48: 288 against 259; N = 20, L = 400:
+// 385 against 258), short lengths gain nothing (L = 128: equal; L = 64: 134 against 128), and small batches belong to the key-split
+// form (N = 16: 124 against 90).  Measured in tools/r03_c32_sweep.sh.  ABOPT_CORE32=0 / 1 overrides (1: whenever L > 16).
+static bool use_core32(int N, int L, int cus) {
+    const char* e = getenv("ABOPT_CORE32");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return L > BI;
+    if (L < 192 || cus < 8) return false;
+    const int64_t total = (int64_t)N * ((L + BI2 - 1) / BI2), rounds = (total + cus - 1) / cus;
+    return rounds == 1 ? total * 10 >= (int64_t)cus * 7 : total * 100 >= rounds * cus * 95;
+}
+
 int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                            const float* w_pair_bias, float* feat, float* dump, float* dump_stats, const float* pair_bias_cache, int N, int L, hipStream_t st,
                            int z_shared, float* split_ws, size_t split_ws_floats) {
     ABOPT_CHECK_ARG(!dump == !dump_stats, "ipa_core: the logits dump and its row statistics come together");
     ABOPT_CHECK_ARG(!dump || (int64_t)H * L * L * 4 < (1ll << 31), "ipa_core: L=%d too long for the logits dump", L);
+    int cus32 = 0;
+    if (pair_bias_cache && !dump && !CORE_ABL) { if (int rc = device_cu_count(&cus32)) return rc; }
+    if (pair_bias_cache && !dump && !CORE_ABL && use_core32(N, L, cus32)) {
+        const int nib2 = (L + BI2 - 1) / BI2, nchunk = (L + JC - 1) / JC;
+        const size_t lds = sizeof(float) * (3 * BI2 * SROW + 2 * BI2 * SCLD + BI2 * SCLD + BI2 * 32) + (size_t)nchunk * JC;
+        ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core: L=%d needs %zu bytes of LDS for the key mask (max 163840)", L, lds);
+        static LdsConfig lds_cfg;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel), lds, lds_cfg)) return rc;
+        prof::begin(st);
+        hipLaunchKernelGGL(ipa_core32_kernel, dim3((unsigned)(N * nib2)), dim3(NTH2), lds, st, qfrag, kvfrag, z, mask, R, t, feat, pair_bias_cache, L, nib2,
+                           (N % 8 == 0) ? 1 : 0, z_shared);
+        prof::end(st);
+        ABOPT_LAUNCH_CHECK();
+#ifdef C32_TIMING
+        {
+            long long h[3][8];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_core_timing), sizeof(h));
+            static int calls = 0;
+            if (++calls == 8)
+                for (int r = 0; r < 3; ++r)
+                    fprintf(stderr, "[core32 timing, WG 17] %s: %lld cycles to the end of its chunk loop, %lld of them at barriers; %lld wall ticks of 10 ns -> %.2f GHz\n",
+                            r == 0 ? "pair" : (r == 1 ? "A   " : "C   "), h[r][0], h[r][1], h[r][2], h[r][0] / (10.0 * h[r][2]));
+            if (calls == 8) fprintf(stderr, "[core32 timing] SIMD of waves 0..7 (summed over launches, byte per wave): %llx %llx\n", (unsigned long long)h[0][4], (unsigned long long)h[0][5]);
+        }
+#endif
+        return ABOPT_OK;
+    }
     if (pair_bias_cache && !dump) {
         const int nib = (L + BI - 1) / BI, nchunk = (L + JC - 1) / JC;
         int cus = 0;

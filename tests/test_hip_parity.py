@@ -1201,6 +1201,7 @@ def test_persistent_core_is_bit_identical(N, L, lengths, monkeypatch):
     L <= 64: blocks of 2..4 positions, where the per-block pieces (q swap, epilogues) dominate."""
     from ab_opt_amd import hip
     monkeypatch.setenv('ABOPT_CORE_NO_SPLIT', '1')             # the small batches below would otherwise take the key-split form (other summation order)
+    monkeypatch.setenv('ABOPT_CORE32', '0')                    # ... and the full-round batches the 32-row kernel (test_core32_is_bit_identical)
     d = standalone_abdesign_dpm(100, 2).to(DEV)
     lens = [L] * N if lengths is None else [L - (7 * i) % min(60, L // 2) for i in range(N)]
     v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lens, 5200 + N, [(5, 14), (22, 30)])
@@ -1214,6 +1215,27 @@ def test_persistent_core_is_bit_identical(N, L, lengths, monkeypatch):
                                     pair_bias_cache=hip.pair_bias_cache(arr, 6, c(pf)))
         for k in ('R_next', 'eps_pos', 'c'):
             assert torch.isfinite(big[k]).all() and torch.equal(big[k][sl], small[k]), (k, lo)
+
+
+@pytest.mark.parametrize('N,L,lengths', [(32, 256, None), (3, 100, None), (5, 250, 'ragged'), (8, 48, 'ragged'), (4, 40, None), (2, 33, None), (16, 64, 'ragged'), (9, 130, None)])
+def test_core32_is_bit_identical(N, L, lengths, monkeypatch):
+    """The 32-row form of the cached core (csrc/ipa_core.hip: ipa_core32_kernel, 8 waves x 256 registers, q' in registers) does the
+    per-row arithmetic of the 16-row kernels in the same order: the whole EpsilonNet output must be bit-identical with and without it --
+    lengths that leave the second row tile of the last block empty or partial, chunk counts not divisible by 3, ragged masks."""
+    from ab_opt_amd import hip
+    monkeypatch.setenv('ABOPT_CORE_NO_SPLIT', '1')
+    d = standalone_abdesign_dpm(100, 2).to(DEV)
+    lens = [L] * N if lengths is None else [L - (7 * i) % min(60, L // 2) for i in range(N)]
+    v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lens, 6100 + N, [(5, 14), (22, 30)])
+    beta = d.trans_pos.var_sched.betas[37].expand([N]).contiguous()
+    arr, ew = d.eps_net.encoder.packed_array(), d.eps_net.packed()
+    pbc = hip.pair_bias_cache(arr, 6, pf)
+    monkeypatch.setenv('ABOPT_CORE32', '0')
+    ref = hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc)
+    monkeypatch.setenv('ABOPT_CORE32', '1')
+    got = hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc)
+    for k in ('R_next', 'eps_pos', 'c'):
+        assert torch.isfinite(got[k]).all() and torch.equal(got[k], ref[k]), k
 
 
 # ------------------------------------------------------------------------------------------ round 3: graph replay, bench N>1 path, edge cases
