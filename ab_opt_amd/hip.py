@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,7 +73,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
+           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
@@ -148,6 +148,9 @@ def lib():
         L.abopt_pair_embed_backward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, c_f, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_node_frag_source_row.argtypes = [C.c_int] * 3
         L.abopt_node_frag_floats.restype = C.c_size_t
+        L.abopt_adam_ws_floats.restype = C.c_size_t
+        L.abopt_adam_ws_floats.argtypes = [C.c_int, C.c_void_p]
+        L.abopt_adam_step.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 6 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.abopt_dockq_workspace_bytes.restype = C.c_size_t
         L.abopt_dockq_workspace_bytes.argtypes = [C.c_int]
         L.abopt_dockq_lite.argtypes = [c_f, c_u8, C.c_int, c_f, c_u8, C.c_void_p, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -704,6 +707,32 @@ def colsum(x):
     ws = Workspace.get(1024 * max(cols, 128) * 4, x.device)
     _check(lib().abopt_colsum(ptr(x, torch.float32, strided=True), x.stride(0), rows, cols, ptr(out), ptr(ws), ws.numel(), stream()))
     return out
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay=0.0, max_grad_norm=None, grad_norm_out=None, ws=None):
+    """clip_grad_norm_ + torch.optim.Adam.step for a list of fp32 tensors in a handful of launches (abopt_adam_step; A/train.py:116-117).
+    step: int64 device tensor of one element, incremented by the call.  grad_norm_out (1 float on the device) receives the unclipped norm
+    when max_grad_norm is given.  The gradient tensors are read, not rewritten.  ws: the caller's scratch (adam_ws_bytes), else the shared one."""
+    n = len(params)
+    if n == 0:
+        return
+    for group in (params, grads, exp_avg, exp_avg_sq):
+        for t in group:
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise TypeError('adam_step: contiguous fp32 HIP tensors only')
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    numel = (C.c_int64 * n)(*[t.numel() for t in params])
+    need = lib().abopt_adam_ws_floats(n, numel)
+    if ws is None or ws.numel() * ws.element_size() < need * 4:
+        ws = Workspace.get(need * 4, params[0].device)
+    _check(lib().abopt_adam_step(n, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), numel, lr, beta1, beta2, eps, weight_decay,
+                                 float(max_grad_norm) if max_grad_norm is not None else 0.0, ptr(step, torch.int64), ptr(ws), need,
+                                 ptr(grad_norm_out, torch.float32, optional=True), stream()))
+
+
+def adam_ws_bytes(params):
+    n = len(params)
+    return 4 * lib().abopt_adam_ws_floats(n, (C.c_int64 * n)(*[t.numel() for t in params])) if n else 0
 
 
 def prof_enable(on=True):

@@ -359,13 +359,73 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
 
 
 # ------------------------------------------------------------------ the whole training step as one hipGraph
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (no amsgrad / maximize) with the gradient clipping of the reference's training loop folded in, as a handful of HIP
+    launches for the whole parameter list (csrc/optim.hip; A/train.py:116-118, A/diffab/utils/train.py:28-36):
+
+        opt = FusedAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0)
+        loss.backward(); grad_norm = opt.step(max_grad_norm=100.0); opt.zero_grad()
+
+    step(max_grad_norm) returns the UNCLIPPED gradient norm as a 1-element device tensor (what clip_grad_norm_ returns), or None without
+    clipping; the .grad tensors themselves are not rescaled.  The state keeps torch's layout ('step', 'exp_avg', 'exp_avg_sq' per parameter,
+    `step` a device tensor shared by a group), so state_dict()s interchange with torch.optim.Adam(capturable=True).  Capturable into a
+    hipGraph as it is (the step counter lives on the device)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError('FusedAdam: invalid hyper-parameters')
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._steps, self._ws, self._norm = {}, {}, {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._steps.clear()                                    # re-read from the loaded per-parameter 'step' at the next step()
+
+    @torch.no_grad()
+    def step(self, closure=None, max_grad_norm=None):
+        from . import hip
+        if closure is not None:
+            raise NotImplementedError('FusedAdam: closures are not supported')
+        norms = []
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group['params'] if p.grad is not None]
+            if not ps:
+                continue
+            dev = ps[0].device
+            if gi not in self._steps:
+                # ONE counter per group (every parameter is expected to receive a gradient in every step, as all 207 of the reference's
+                # model do); a loaded state_dict (ours or torch.optim.Adam's) continues from its count
+                loaded = [self.state[p]['step'] for p in group['params'] if 'step' in self.state.get(p, {})]
+                first = int(torch.as_tensor(loaded[0]).reshape(-1)[0].item()) if loaded else 0
+                self._steps[gi] = torch.full((1,), first, dtype=torch.int64, device=dev)
+                self._norm[gi] = torch.zeros(1, dtype=torch.float32, device=dev)
+            for p in ps:
+                st = self.state[p]
+                if st.get('step') is not self._steps[gi]:
+                    st['step'] = self._steps[gi]
+                if 'exp_avg' not in st:
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            need = hip.adam_ws_bytes(ps)
+            if gi not in self._ws or self._ws[gi].numel() < need:
+                self._ws[gi] = torch.empty(need, dtype=torch.uint8, device=dev)
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            hip.adam_step([p.data for p in ps], grads, [self.state[p]['exp_avg'] for p in ps], [self.state[p]['exp_avg_sq'] for p in ps],
+                          self._steps[gi], group['lr'], group['betas'][0], group['betas'][1], group['eps'], group['weight_decay'],
+                          max_grad_norm=max_grad_norm, grad_norm_out=self._norm[gi] if max_grad_norm is not None else None, ws=self._ws[gi])
+            norms.append(self._norm[gi])
+        if max_grad_norm is None or not norms:
+            return None
+        return norms[0] if len(norms) == 1 else torch.linalg.vector_norm(torch.cat(norms))
+
+
 class GraphedTrainStep:
     """forward + backward + optimizer step of `model(batch)` captured ONCE into a hipGraph and replayed (BASELINE config 5: the step is
     ~900 kernel launches; eager, ~1.4 ms of its 16.8 ms are gaps between them).
 
     Everything on the path is capture-safe: the library allocates nothing per call, the step indices t come from torch's device
     generator (graph-aware), the noising kernel reads its Philox position from a 16-byte device buffer refreshed before every replay,
-    and the optimizer must be built with capturable=True (torch.optim.Adam(..., capturable=True)).  The batch is copied into the
+    and the optimizer must be capturable: training.FusedAdam, or torch.optim.Adam(..., capturable=True).  The batch is copied into the
     graph's static tensors; losses are returned as a dict of 0-d device tensors (valid until the next call).  Shapes, the set of
     parameters and `loss_weights` are fixed at construction; build a new object when they change."""
 
@@ -401,9 +461,12 @@ class GraphedTrainStep:
         losses = self.model(dict(self.static))
         total = sum(v * (self.weights[k] if self.weights is not None else 1.0) for k, v in losses.items())
         total.backward()
-        if self.max_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
-        self.opt.step()
+        if isinstance(self.opt, FusedAdam):
+            self.opt.step(max_grad_norm=self.max_grad_norm)
+        else:
+            if self.max_grad_norm is not None:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+            self.opt.step()
         return {k: v.detach() for k, v in losses.items()}
 
     def __call__(self, batch):

@@ -186,13 +186,13 @@ def secondary_measurements(dev, L):
     model.train()
     NT = 16
     tb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(NT, layout).items()}
-    adam = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
+    adam = training.FusedAdam(model.parameters(), lr=1e-4)       # clip_grad_norm_ + torch.optim.Adam of A/train.py:116-117 as one native call
 
     def step():
         adam.zero_grad(set_to_none=True)
         loss = sum(model(dict(tb)).values())
         loss.backward()
-        adam.step()
+        adam.step(max_grad_norm=100.0)                              # codesign_single.yml:21
     for _ in range(3):
         step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -203,7 +203,7 @@ def secondary_measurements(dev, L):
     eager_ms = (time.perf_counter() - t0) / iters * 1e3
     graph_ms = None
     try:
-        gstep = training.GraphedTrainStep(model, adam, tb)
+        gstep = training.GraphedTrainStep(model, adam, tb, max_grad_norm=100.0)
         for _ in range(2):
             gstep(tb)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -219,7 +219,7 @@ def secondary_measurements(dev, L):
     best = min(eager_ms, graph_ms) if graph_ms is not None else eager_ms
     res['train_step_ms'] = round(best, 2)
     res['train_step_eager_ms'], res['train_step_graph_ms'] = round(eager_ms, 2), (round(graph_ms, 2) if graph_ms is not None else None)
-    res['train_step_config'] = f'AbDesign flavour model(batch) fwd + bwd + Adam, N={NT}, L={L} (encode() inside, as train.py runs it); best of eager / hipGraph replay'
+    res['train_step_config'] = f'AbDesign flavour model(batch) fwd + bwd + gradient clipping + Adam (training.FusedAdam), N={NT}, L={L} (encode() inside, as train.py runs it); best of eager / hipGraph replay'
     # SURVEY 8(d), "training (config 5) extra": per sample 285 MB (forward 102 MB + backward 6 z reads + 6 dz writes + 5 dz reads of 16.8 MB) and
     # 3 x (4.15 GFLOP denoiser + 5.3 GFLOP encode) (backward = 2 x forward)
     tb_bytes, tb_flops = NT * 285e6 * (L / 256) ** 2, NT * 3 * (4.15e9 + 5.3e9) * (L / 256) ** 2

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 25
+#define ABOPT_ABI_VERSION 26
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -377,6 +377,22 @@ int abopt_gemm(const float* A, int lda, int64_t stride_a, int a_transposed, cons
 /* out[c] = sum over rows of x[r*ld + c] (bias gradients and per-row partials of weight gradients on the training path); deterministic:
  * row slices are summed in a fixed order.  ws (optional): slices * cols floats of scratch. */
 int abopt_colsum(const float* x, int ld, int64_t rows, int cols, float* out, void* ws, size_t ws_bytes, abopt_stream stream);
+
+/* ---- Training path: gradient clipping + Adam for a whole parameter list in a handful of launches.  Replaces, with the same arithmetic,
+ *   orig_grad_norm = clip_grad_norm_(model.parameters(), config.train.max_grad_norm); optimizer.step()
+ * of A/train.py:116-117 / D/train.py:112-113 with torch.optim.Adam(lr, betas, weight_decay) (A/diffab/utils/train.py:28-36; eps as given,
+ * no amsgrad, no maximize), which torch runs as ~1000 small launches for the model's 207 tensors.
+ *   params / grads / exp_avg / exp_avg_sq / numel : HOST arrays of `count` device pointers / element counts (fp32, contiguous)
+ *   step  : device int64, the number of steps taken so far; incremented by the call (bias corrections use the incremented value)
+ *   max_grad_norm > 0 : gradients are scaled by min(1, max_grad_norm / (||g||_2 + 1e-6)) inside the update (the gradient tensors themselves
+ *                       are NOT rewritten) and the unclipped norm is stored in grad_norm_out[0] (device, may be NULL); <= 0: no clipping
+ *   ws    : device scratch of abopt_adam_ws_floats(count, numel) floats.
+ * Hyper-parameters are doubles, as Python holds them: 1 - beta and the bias corrections are formed in double and rounded once, as torch does.
+ * Deterministic (block partials of the norm are summed in a fixed order); capturable into a hipGraph (pointers travel as kernel arguments). */
+size_t abopt_adam_ws_floats(int count, const int64_t* numel);
+int abopt_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const int64_t* numel, double lr, double beta1, double beta2, double eps, double weight_decay, double max_grad_norm,
+                    int64_t* step, float* ws, size_t ws_floats, float* grad_norm_out, abopt_stream stream);
 
 int abopt_commonness_score(const float* structs, float* score, int B, int n, abopt_stream stream);
 

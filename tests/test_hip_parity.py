@@ -1238,6 +1238,51 @@ def test_core32_is_bit_identical(N, L, lengths, monkeypatch):
         assert torch.isfinite(got[k]).all() and torch.equal(got[k], ref[k]), k
 
 
+@pytest.mark.parametrize('weight_decay,max_norm', [(0.0, None), (0.0, 0.5), (0.01, 100.0)])
+def test_fused_adam_vs_torch_adam(weight_decay, max_norm):
+    """training.FusedAdam (csrc/optim.hip: clip_grad_norm_ + Adam for the whole parameter list in a handful of launches) against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.Adam, the pair the reference's training loop runs (A/train.py:116-117,
+    A/diffab/utils/train.py:28-36): six steps on 40 tensors from 1 element to 300k (more tensors than one launch carries, sizes that are
+    not multiples of the block), parameters / moments / returned norm equal to fp32 rounding."""
+    from ab_opt_amd import training
+    g = torch.Generator().manual_seed(31)
+    shapes = [(1,), (3,), (128,), (127, 3), (4096,), (4097,), (300, 1000), (64, 64), (2016, 128)] + [(17 + i, 5) for i in range(31)]
+    ref = [torch.nn.Parameter(torch.randn(sh, generator=g).to(DEV)) for sh in shapes]
+    got = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    a = torch.optim.Adam(ref, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay)
+    b = training.FusedAdam(got, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay)
+    for it in range(6):
+        grads = [torch.randn(sh, generator=g).to(DEV) * (0.1 + it) for sh in shapes]
+        for p, q, gr in zip(ref, got, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, max_norm) if max_norm is not None else None
+        a.step()
+        n_got = b.step(max_grad_norm=max_norm)
+        if max_norm is not None:
+            assert abs(n_got.item() - n_ref.item()) <= 2e-6 * n_ref.item()
+            assert torch.equal(got[0].grad, grads[0])          # gradients are read, not rescaled in place
+        else:
+            assert n_got is None
+        for p, q in zip(ref, got):
+            assert (p - q).abs().max().item() <= 2e-6 * max(1.0, p.abs().max().item()), it
+    for p, q in zip(ref, got):
+        sa, sb = a.state[p], b.state[q]
+        if 'exp_avg' in sb:
+            assert (sa['exp_avg'] - sb['exp_avg']).abs().max().item() <= 1e-6 * max(1.0, sa['exp_avg'].abs().max().item())
+            assert (sa['exp_avg_sq'] - sb['exp_avg_sq']).abs().max().item() <= 1e-6 * max(1.0, sa['exp_avg_sq'].abs().max().item())
+    assert int(b.state[got[0]]['step'].item()) == 6
+    import copy
+    sd = copy.deepcopy(b.state_dict())                          # torch's layout (as if it had been to disk: load_state_dict shares tensors otherwise)
+    cp = [torch.nn.Parameter(p.detach().clone()) for p in got]
+    c = training.FusedAdam(cp, lr=3e-3, weight_decay=weight_decay)
+    c.load_state_dict(sd)
+    grads = [torch.randn(sh, generator=g).to(DEV) for sh in shapes]
+    for p, q, gr in zip(got, cp, grads):
+        p.grad, q.grad = gr.clone(), gr.clone()
+    b.step(max_grad_norm=max_norm); c.step(max_grad_norm=max_norm)                 # the reloaded optimizer continues at step 7, bit for bit
+    assert all(torch.equal(p, q) for p, q in zip(got, cp)) and int(c.state[cp[0]]['step'].item()) == 7
+
+
 # ------------------------------------------------------------------------------------------ round 3: graph replay, bench N>1 path, edge cases
 def test_graph_replay_is_bit_identical_to_eager_launches():
     """FullDPM._run(graph=True): the captured hipGraph of the sampling loop must reproduce the eager loop bit for bit, for the seed

@@ -11,13 +11,13 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 dev = torch.device('cuda:0')
 model = build_model(100, 7, flavour='abdesign', device=dev).train()
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(N, LAYOUT_256 if L == 256 else LAYOUT_128).items()}
-opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
+opt = training.FusedAdam(model.parameters(), lr=1e-4)
 
 
 def eager():
     opt.zero_grad(set_to_none=True)
     sum(model(dict(batch)).values()).backward()
-    opt.step()
+    opt.step(max_grad_norm=100.0)
 
 
 for _ in range(3):
@@ -28,7 +28,7 @@ for _ in range(iters):
 torch.cuda.synchronize()
 print('eager  : %.2f ms per step' % ((time.perf_counter() - t0) / iters * 1e3))
 t0 = time.perf_counter()
-g = training.GraphedTrainStep(model, opt, batch)
+g = training.GraphedTrainStep(model, opt, batch, max_grad_norm=100.0)
 torch.cuda.synchronize()
 print('capture: %.1f ms' % ((time.perf_counter() - t0) * 1e3))
 for _ in range(2):

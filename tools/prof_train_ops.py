@@ -1,29 +1,32 @@
-"""Operator-level view of one training step (torch.profiler, device time by aten op / autograd function): N=16, L=256."""
-import sys, os
+"""Which torch operators own the non-native GPU time of a training step?  torch.profiler over two eager steps (config 5), aggregated by
+operator and input shapes:  python tools/prof_train_ops.py [N] [L]"""
+import os
+import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT)
 import torch
 from torch.profiler import profile, ProfilerActivity
-from ab_opt_amd.utils.synth import build_model
-from ab_opt_amd.utils.synth import make_batch, LAYOUT_256
-N = 16
+from ab_opt_amd import training
+from ab_opt_amd.utils.synth import build_model, make_batch, LAYOUT_256, LAYOUT_128
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = torch.device('cuda:0')
 model = build_model(100, 7, flavour='abdesign', device=dev).train()
-batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(N, LAYOUT_256).items()}
-opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(N, LAYOUT_256 if L == 256 else LAYOUT_128).items()}
+opt = training.FusedAdam(model.parameters(), lr=1e-4)
 
 
 def step():
     opt.zero_grad(set_to_none=True)
     sum(model(dict(batch)).values()).backward()
-    opt.step()
+    opt.step(max_grad_norm=100.0)
 
 
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-    for _ in range(3):
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
+    for _ in range(2):
         step()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by='self_cuda_time_total', row_limit=45, max_name_column_width=60))
+print(prof.key_averages(group_by_input_shape=True).table(sort_by='self_cuda_time_total', row_limit=45, max_name_column_width=42, max_shapes_column_width=70))
