@@ -290,6 +290,48 @@ int launch_colsum(const float* x, int ld, int64_t rows, int cols, float* out, fl
     return ABOPT_OK;
 }
 
+// out[b][c] = sum over the rows r with idx[r] == b of x[r*ld + c]  (idx < 0: the row is skipped): the gradient of an embedding table that
+// was looked up per ROW of a tall activation matrix (relative-position table of the pair embedding: 65 buckets over N L^2 rows), without
+// the [rows, buckets] one-hot matrix.  One wave walks its rows in order and adds each into its own LDS accumulator [nb][64] (lane = column);
+// the two waves of a workgroup, then the slices, are summed in a fixed order: deterministic.
+constexpr int BKT_MAX = 96;
+__global__ __launch_bounds__(128) void bucket_colsum_kernel(const float* __restrict__ x, int ld, int64_t rows, int cols, const int* __restrict__ idx, int nb,
+                                                            int64_t rows_per_slice, float* __restrict__ part) {
+    __shared__ float acc[2][BKT_MAX][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+    for (int b = 0; b < nb; ++b) acc[w][b][lane] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
+    if (c < cols)
+        for (int64_t r = r0 + w; r < r1; r += 2) {
+            const int b = __builtin_amdgcn_readfirstlane(idx[r]);
+            if (b >= 0 && b < nb) acc[w][b][lane] += x[r * ld + c];
+        }
+    __syncthreads();
+    if (c < cols)
+        for (int b = w; b < nb; b += 2) part[((int64_t)blockIdx.y * nb + b) * cols + c] = acc[0][b][lane] + acc[1][b][lane];
+}
+
+int launch_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const int* idx, int nb, float* out, float* ws, size_t ws_floats, hipStream_t st) {
+    if (cols <= 0 || nb <= 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(rows >= 0 && ld >= cols && nb <= BKT_MAX, "bucket_colsum: rows=%lld cols=%d ld=%d buckets=%d (max %d)", (long long)rows, cols, ld, nb, BKT_MAX);
+    const int cblocks = (cols + 63) / 64;
+    int64_t want = rows / 1024;
+    if (want < 1) want = 1;
+    const int64_t cap = 1024 / cblocks > 1 ? 1024 / cblocks : 1;
+    int slices = (int)(want < cap ? want : cap);
+    if (!ws) slices = 1;
+    while (slices > 1 && (size_t)slices * nb * cols > ws_floats) --slices;
+    const int64_t rps = (rows + slices - 1) / slices;
+    hipLaunchKernelGGL(bucket_colsum_kernel, dim3(cblocks, slices), dim3(128), 0, st, x, ld, rows, cols, idx, nb, rps, slices > 1 ? ws : out);
+    ABOPT_LAUNCH_CHECK();
+    if (slices > 1) {
+        const int64_t n = (int64_t)nb * cols;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, out, n, slices, n);
+        ABOPT_LAUNCH_CHECK();
+    }
+    return ABOPT_OK;
+}
+
 int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const float* B, int ldb, int64_t sb, int b_t, float* C, int ldc, int64_t sc,
                         int M, int N, int K, int batch, float alpha, float* ws, size_t ws_floats, hipStream_t st) {
     if (M <= 0 || N <= 0 || batch <= 0) return ABOPT_OK;
@@ -321,6 +363,12 @@ int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const floa
 }
 
 }  // namespace abopt
+
+extern "C" int abopt_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const int32_t* idx, int buckets, float* out, void* ws, size_t ws_bytes,
+                                   abopt_stream stream) {
+    ABOPT_CHECK_ARG(x && out && idx, "bucket_colsum: NULL argument");
+    return abopt::launch_bucket_colsum(x, ld, rows, cols, idx, buckets, out, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
+}
 
 extern "C" int abopt_colsum(const float* x, int ld, int64_t rows, int cols, float* out, void* ws, size_t ws_bytes, abopt_stream stream) {
     ABOPT_CHECK_ARG(x && out, "colsum: NULL argument");

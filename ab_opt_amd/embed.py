@@ -151,11 +151,16 @@ class _PairEmbedFn(torch.autograd.Function):
         dwo2, dwo1, dwd1 = _splitk_tn(do2, o1), _splitk_tn(do1, o0), _splitk_tn(dh1, h0)
         # out_mlp.0 columns: [aa-pair embedding | relpos embedding x same-chain | f_dist | f_dih]
         oh = F.one_hot(aa, nt).to(dout.dtype)
-        pair_sum = lambda x4: torch.einsum('nia,nibc->abc', oh, torch.einsum('njb,nijc->nibc', oh, x4)).reshape(nt * nt, -1)
+        # sum over (n, i, j) by the pair of residue types (a of i, b of j).  i is contracted FIRST: x4[n] is then read in place as an
+        # [L, L c] matrix (contracting j first costs a permuted copy of the whole tensor -- 1 GB for ds)
+        pair_sum = lambda x4: torch.einsum('njb,najc->abc', oh, torch.bmm(oh.transpose(1, 2), x4.reshape(N, L, -1)).view(N, nt, L, -1)).reshape(nt * nt, -1)
         s_aap = pair_sum(do0.reshape(N, L, L, C))
         rel = torch.clamp(res_nb[:, :, None] - res_nb[:, None, :], min=-ctx.max_relpos, max=ctx.max_relpos) + ctx.max_relpos
-        same = (chain_nb[:, :, None] == chain_nb[:, None, :]).reshape(M, 1)
-        s_rel = _splitk_tn(F.one_hot(rel.reshape(M), 2 * ctx.max_relpos + 1).to(dout.dtype) * same, do0)
+        same = chain_nb[:, :, None] == chain_nb[:, None, :]
+        if do0.is_cuda:           # rows summed by relative-position bucket (other-chain pairs skipped): abopt_bucket_colsum, no one-hot matrix
+            s_rel = hip.bucket_colsum(do0, torch.where(same, rel, -1).reshape(M).to(torch.int32), 2 * ctx.max_relpos + 1)
+        else:
+            s_rel = _splitk_tn(F.one_hot(rel.reshape(M), 2 * ctx.max_relpos + 1).to(dout.dtype) * same.reshape(M, 1), do0)
         dwo0 = torch.cat([s_aap.t() @ E_aap, s_rel.t() @ E_rel, _splitk_tn(do0, h1), _splitk_tn(do0, dih)], dim=1)
         dE_aap, dE_rel = s_aap @ wo0[:, :C], s_rel @ wo0[:, C:2 * C]
         unpad = lambda m: m.reshape(m.shape[0], A, 16)[:, :, :A].reshape(m.shape[0], A * A)          # [.., a, 16] -> [.., a*A + b]

@@ -73,7 +73,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
+           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
@@ -706,6 +706,18 @@ def colsum(x):
     out = torch.empty(cols, dtype=torch.float32, device=x.device)
     ws = Workspace.get(1024 * max(cols, 128) * 4, x.device)
     _check(lib().abopt_colsum(ptr(x, torch.float32, strided=True), x.stride(0), rows, cols, ptr(out), ptr(ws), ws.numel(), stream()))
+    return out
+
+
+def bucket_colsum(x, idx, buckets):
+    """out[b] = sum of the rows of x (2-D fp32, unit column stride, read in place) whose idx is b; rows with idx < 0 are skipped."""
+    rows, cols = x.shape
+    if x.stride(1) != 1 or x.dtype != torch.float32 or not x.is_cuda or idx.dtype != torch.int32 or idx.numel() != rows:
+        raise TypeError('bucket_colsum: fp32 [rows, cols] with unit column stride and an int32 index per row')
+    out = torch.empty(buckets, cols, dtype=torch.float32, device=x.device)
+    ws = Workspace.get(1024 * buckets * max(cols, 64) * 4, x.device)
+    _check(lib().abopt_bucket_colsum(ptr(x, torch.float32, strided=True), x.stride(0), rows, cols, ptr(idx.contiguous(), torch.int32), buckets, ptr(out),
+                                     ptr(ws), ws.numel(), stream()))
     return out
 
 

@@ -378,6 +378,12 @@ int abopt_gemm(const float* A, int lda, int64_t stride_a, int a_transposed, cons
  * row slices are summed in a fixed order.  ws (optional): slices * cols floats of scratch. */
 int abopt_colsum(const float* x, int ld, int64_t rows, int cols, float* out, void* ws, size_t ws_bytes, abopt_stream stream);
 
+/* out[b*cols + c] = sum over the rows r with idx[r] == b of x[r*ld + c] (rows with idx outside [0, buckets) are skipped; buckets <= 96):
+ * the gradient of an embedding table looked up once per row of a tall activation matrix -- the relative-position table of
+ * D/modules/encoders/pair.py:46-53 over its N L^2 pair rows -- without the [rows, buckets] one-hot matrix autograd builds.  Deterministic. */
+int abopt_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const int32_t* idx, int buckets, float* out, void* ws, size_t ws_bytes,
+                        abopt_stream stream);
+
 /* ---- Training path: gradient clipping + Adam for a whole parameter list in a handful of launches.  Replaces, with the same arithmetic,
  *   orig_grad_norm = clip_grad_norm_(model.parameters(), config.train.max_grad_norm); optimizer.step()
  * of A/train.py:116-117 / D/train.py:112-113 with torch.optim.Adam(lr, betas, weight_decay) (A/diffab/utils/train.py:28-36; eps as given,
