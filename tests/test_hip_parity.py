@@ -1283,6 +1283,24 @@ def test_fused_adam_vs_torch_adam(weight_decay, max_norm):
     assert all(torch.equal(p, q) for p, q in zip(got, cp)) and int(c.state[cp[0]]['step'].item()) == 7
 
 
+def test_bucket_colsum_vs_index_add():
+    """abopt_bucket_colsum (the relative-position table's gradient on the training path, D/modules/encoders/pair.py:46-53 under autograd):
+    rows of a strided column slice summed by bucket, rows with a negative index skipped, against torch.index_add_ in fp64; deterministic."""
+    from ab_opt_amd import hip
+    g = torch.Generator().manual_seed(77)
+    for rows, cols, nb, ld in ((70000, 64, 65, 320), (1000, 128, 96, 128), (5, 64, 3, 64), (4097, 20, 7, 33)):
+        y = torch.randn(rows, ld, generator=g).to(DEV)
+        x = y[:, ld - cols:]                                     # a column slice, read in place
+        idx = torch.randint(-1, nb, (rows,), generator=g).to(torch.int32).to(DEV)
+        out = hip.bucket_colsum(x, idx, nb)
+        keep = idx >= 0
+        ref = torch.zeros(nb, cols, dtype=torch.float64, device=DEV).index_add_(0, idx[keep].long(), x[keep].double())
+        assert (out.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (rows, cols, nb)
+        assert torch.equal(out, hip.bucket_colsum(x, idx, nb))
+    with pytest.raises(RuntimeError):
+        hip.bucket_colsum(torch.zeros(4, 64, device=DEV), torch.zeros(4, dtype=torch.int32, device=DEV), 97)
+
+
 # ------------------------------------------------------------------------------------------ round 3: graph replay, bench N>1 path, edge cases
 def test_graph_replay_is_bit_identical_to_eager_launches():
     """FullDPM._run(graph=True): the captured hipGraph of the sampling loop must reproduce the eager loop bit for bit, for the seed
