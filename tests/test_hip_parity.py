@@ -1236,6 +1236,9 @@ def test_core32_is_bit_identical(N, L, lengths, monkeypatch):
     got = hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc)
     for k in ('R_next', 'eps_pos', 'c'):
         assert torch.isfinite(got[k]).all() and torch.equal(got[k], ref[k]), k
+    monkeypatch.delenv('ABOPT_CORE32')                          # the library's own choice (the 32-row kernel at the bench shape): same bits either way
+    auto = hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc)
+    assert all(torch.equal(auto[k], ref[k]) for k in ('R_next', 'eps_pos', 'c'))
 
 
 @pytest.mark.parametrize('weight_decay,max_norm', [(0.0, None), (0.0, 0.5), (0.01, 100.0)])

@@ -30,3 +30,8 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
         step()
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by='self_cuda_time_total', row_limit=45, max_name_column_width=42, max_shapes_column_width=70))
+if len(sys.argv) > 3:          # a third argument: only the operators whose name contains it, with their shapes (e.g. copy_)
+    rows = [e for e in prof.key_averages(group_by_input_shape=True) if sys.argv[3] in e.key]
+    rows.sort(key=lambda e: -e.self_device_time_total)
+    for e in rows[:25]:
+        print('%-28s %9.1f us  x%-4d %s' % (e.key, e.self_device_time_total, e.count, str(e.input_shapes)[:150]))
