@@ -1401,6 +1401,7 @@ static int launch_core_variant(const float* qfrag, const float* kvfrag, const fl
 // form (N = 16: 124 against 90).  Measured in tools/r03_c32_sweep.sh.  ABOPT_CORE32=0 / 1 overrides (1: whenever L > 16).
 static bool use_core32(int N, int L, int cus) {
     const char* e = getenv("ABOPT_CORE32");
+    if (L > 2048) return false;                                 // its buffer descriptors address a sample's z slab (L^2 * 256 bytes) with 32-bit offsets
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return L > BI;
     if (L < 192 || cus < 8) return false;
