@@ -189,7 +189,7 @@ extern "C" int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abo
     if ((int64_t)in->N * in->L == 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(w && w->aa_pair_embed && w->relpos_embed && w->aapair_to_distcoef && w->freq_bands && w->wd0 && w->bd0 && w->wd1 && w->bd1 &&
                     w->wo0 && w->bo0 && w->wo1 && w->bo1 && w->wo2 && w->bo2 && pair_feat && ws, "pair_embed_forward: NULL argument");
-    ABOPT_CHECK_ARG((gauss == nullptr) == (dgauss == nullptr), "pair_embed_forward: gauss and dgauss go together");
+    ABOPT_CHECK_ARG(gauss || !dgauss, "pair_embed_forward: dgauss needs gauss");
     return launch_pair_embed(in, w, pair_feat, activations, gauss, dgauss, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -201,7 +201,7 @@ extern "C" int abopt_pair_embed_backward(const abopt_encode_inputs* in, const ab
     int rc;
     if ((rc = check_encode_inputs(in, "pair_embed_backward"))) return rc;
     if ((int64_t)in->N * in->L == 0) return ABOPT_OK;
-    ABOPT_CHECK_ARG(w && w->wd0 && w->wd1 && w->wo0 && w->wo1 && w->wo2 && dpair_feat && activations && dgauss && dys && dsoftplus && ws,
+    ABOPT_CHECK_ARG(w && w->wd0 && w->wd1 && w->wo0 && w->wo1 && w->wo2 && dpair_feat && activations && dys && dsoftplus && ws && w->aapair_to_distcoef && w->aa_pair_embed && w->relpos_embed,
                     "pair_embed_backward: NULL argument");
     return launch_pair_embed_backward(in, w, dpair_feat, activations, dgauss, dys, dsoftplus, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
                     if (j_ < L) {
                         const int64_t o_ = (((row_i * L) + j_) * A + at) * 16 + kq * 4;
                         *reinterpret_cast<f32x4*>(a.gsave + o_) = g[mt];
-                        *reinterpret_cast<f32x4*>(a.tsave + o_) = tq;
+                        if (a.tsave) *reinterpret_cast<f32x4*>(a.tsave + o_) = tq;
                     }
                 }
             }
@@ -496,6 +496,7 @@ struct PairBwdArgs {
     const float* dout; const float* acts; const float* tsave; const uint8_t* flags;
     const f32x4* wo2t; const f32x4* wo1t; const f32x4* wo0dt; const f32x4* wd1t; const f32x4* wd0t;
     float* dys; float* ds; int N, L, A, has_struct;
+    const f32x4* atoms4; const int* aa_eff; const float* sp;      // tsave == NULL: T = -d^2 g is recomputed from the atoms, as the forward does
 };
 constexpr int PAIR_DY = 320;
 
@@ -565,6 +566,18 @@ __global__ __launch_bounds__(256, 2) void pair_embed_backward_kernel(PairBwdArgs
     PAIR_BACK(da, db, b.wd1t, act)
     PAIR_STORE_DY(da, 256)
     // d G = Wd0^T dY_d0 per atom block a (operand rows = the 16 padded b), times T = dG / d softplus(coef)
+    f32x4 pj[PMT][4];
+    int aap[PMT];
+    if (!b.tsave) {
+        const int aa_i = b.aa_eff[row_i];
+#pragma unroll
+        for (int mt = 0; mt < PMT; ++mt) {
+            const int64_t jr = base + jc[mt];
+            aap[mt] = aa_i * AAT + b.aa_eff[jr];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pj[mt][q] = b.atoms4[jr * 16 + kq * 4 + q];
+        }
+    }
 #pragma unroll 1
     for (int at = 0; at < A; ++at) {
         f32x4 acc[PMT];
@@ -582,13 +595,29 @@ __global__ __launch_bounds__(256, 2) void pair_embed_backward_kernel(PairBwdArgs
         for (int mt = 0; mt < PMT; ++mt) {
             if (j0 + mt * 16 + fm < L) {
                 const int64_t o_ = (((row_i * L) + jc[mt]) * A + at) * 16 + kq * 4;
-                *reinterpret_cast<f32x4*>(b.ds + o_) = acc[mt] * *reinterpret_cast<const f32x4*>(b.tsave + o_);
+                f32x4 tq;
+                if (b.tsave) tq = *reinterpret_cast<const f32x4*>(b.tsave + o_);
+                else {                                                                              // the forward's arithmetic (pair_embed_kernel), bit for bit
+                    const f32x4 pi = b.atoms4[row_i * 16 + at];
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(b.sp + ((int64_t)aap[mt] * A + at) * 16 + kq * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float dx = pi[0] - pj[mt][q][0], dy = pi[1] - pj[mt][q][1], dz = pi[2] - pj[mt][q][2];
+                        const float d = sqrtf(dx * dx + dy * dy + dz * dz) / 10.f;
+                        const float gv = expf(-1.f * c4[q] * (d * d));
+                        tq[q] = -(d * d) * ((pi[3] != 0.f && pj[mt][q][3] != 0.f) ? gv : 0.f);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(b.ds + o_) = acc[mt] * tq;
             }
         }
     }
 }
 
-size_t pair_embed_backward_ws_bytes(int N, int L, int A) { return pack_bytes((int64_t)N * L) + al256((size_t)(4 * 4 + 4 * A) * 1024 * 4 + 4096); }
+static size_t pair_tables_floats(int A) { return (size_t)AAT * AAT * EC + (size_t)NREL * EC + (size_t)AAT * AAT * A * 16; }
+size_t pair_embed_backward_ws_bytes(int N, int L, int A) {
+    return pack_bytes((int64_t)N * L) + al256((size_t)(4 * 4 + 4 * A) * 1024 * 4 + 4096) + al256(pair_tables_floats(A) * 4);
+}
 
 int launch_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dout, const float* acts, const float* tsave,
                                float* dys, float* ds, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -609,6 +638,16 @@ int launch_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_e
     hipLaunchKernelGGL(swizzle_wd0_transposed_kernel, dim3(A), dim3(256), 0, st, w->wd0, A, wd0t);
     ABOPT_LAUNCH_CHECK();
     PairBwdArgs b;
+    b.atoms4 = pb.atoms4; b.aa_eff = pb.aa_eff; b.sp = nullptr;
+    if (!tsave) {                                                   // softplus(coef) table, as the forward builds it
+        float* tab = (float*)((char*)pb.end + al256((size_t)(4 * 4 + 4 * A) * 1024 * 4 + 4096));
+        float* sp = tab + AAT * AAT * EC + NREL * EC;
+        const int n = (int)pair_tables_floats(A);
+        hipLaunchKernelGGL(pair_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w->aa_pair_embed, w->relpos_embed, w->aapair_to_distcoef, w->wo0, 3 * EC + 26, A,
+                           tab, tab + AAT * AAT * EC, sp);
+        ABOPT_LAUNCH_CHECK();
+        b.sp = sp;
+    }
     b.dout = dout; b.acts = acts; b.tsave = tsave; b.flags = pb.flags;
     b.wo2t = wo2t; b.wo1t = wo1t; b.wo0dt = wo0dt; b.wd1t = wd1t; b.wd0t = wd0t;
     b.dys = dys; b.ds = ds; b.N = N; b.L = L; b.A = A; b.has_struct = in->structure_mask ? 1 : 0;

@@ -126,7 +126,7 @@ class _PairEmbedFn(torch.autograd.Function):
         t = [x.detach().contiguous() for x in (E_aap, E_rel, coef, freq, wd0, bd0, wd1, bd1, wo0, bo0, wo1, bo1, wo2, bo2)]
         w = hip.PairEmbedWeights(*[hip.ptr(x, torch.float32) for x in t])
         out, acts, G, T = hip.pair_embed_forward(inp, w, save_activations=True)
-        ctx.save_for_backward(aa, res_nb, chain_nb, pos, matom, acts, G, T, *t)
+        ctx.save_for_backward(aa, res_nb, chain_nb, pos, matom, acts, G, *t)
         ctx.structure_mask = structure_mask
         ctx.n_types, ctx.max_relpos = n_types, max_relpos
         return out
@@ -134,15 +134,15 @@ class _PairEmbedFn(torch.autograd.Function):
     @staticmethod
     @torch.no_grad()
     def backward(ctx, dout):
-        aa, res_nb, chain_nb, pos, matom, acts, G, T = ctx.saved_tensors[:8]
-        t = list(ctx.saved_tensors[8:])
+        aa, res_nb, chain_nb, pos, matom, acts, G = ctx.saved_tensors[:7]
+        t = list(ctx.saved_tensors[7:])
         E_aap, E_rel, coef, wo0 = t[0], t[1], t[2], t[8]
         N, L = aa.shape
         A = pos.shape[2]
         M, C, nt = N * L * L, dout.shape[-1], ctx.n_types
         inp, keep = hip.encode_inputs(aa, res_nb, chain_nb, pos, matom, A, structure_mask=ctx.structure_mask)
         w = hip.PairEmbedWeights(*[hip.ptr(x, torch.float32) for x in t])
-        dys, ds = hip.pair_embed_backward(inp, w, dout, acts, T)
+        dys, ds = hip.pair_embed_backward(inp, w, dout, acts)            # T = dg / d softplus(coef) is recomputed from the atoms in the kernel
         y, a2 = dys.view(M, -1), acts.view(M, -1)
         do2, do1, do0, dh1, dh0 = (y[:, 64 * k:64 * (k + 1)] for k in range(5))
         h0, h1, dih, o0, o1 = a2[:, :64], a2[:, 64:128], a2[:, 128:154], a2[:, 160:224], a2[:, 224:288]

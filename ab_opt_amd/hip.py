@@ -547,15 +547,17 @@ def residue_embed_forward(inp, weights, has_hotspot):
 PAIR_ACT = 288
 
 
-def pair_embed_forward(inp, weights, save_activations=False):
-    """-> pair_feat (N,L,L,64) [, activations (N,L,L,288), G, T (N,L,L,atoms*16) for the training backward]."""
+def pair_embed_forward(inp, weights, save_activations=False, save_T=False):
+    """-> pair_feat (N,L,L,64) [, activations (N,L,L,288), G, T (N,L,L,atoms*16) for the training backward; T is None unless save_T:
+    the backward recomputes it from the atoms]."""
     N, L = inp.N, inp.L
     dev = torch.device('cuda', torch.cuda.current_device())
     pair_feat = torch.empty(N, L, L, 64, device=dev)
     acts = G = T = None
     if save_activations:
         acts = torch.empty(N, L, L, PAIR_ACT, device=dev)
-        G, T = torch.empty(N, L, L, inp.atoms * 16, device=dev), torch.empty(N, L, L, inp.atoms * 16, device=dev)
+        G = torch.empty(N, L, L, inp.atoms * 16, device=dev)
+        T = torch.empty(N, L, L, inp.atoms * 16, device=dev) if save_T else None
     nb = lib().abopt_pair_embed_workspace_bytes(N, L, inp.atoms)
     buf = Workspace.get(nb, dev)
     _check(lib().abopt_pair_embed_forward(C.byref(inp), C.byref(weights), ptr(pair_feat), ptr(acts, optional=True), ptr(G, optional=True),
@@ -566,8 +568,8 @@ def pair_embed_forward(inp, weights, save_activations=False):
 PAIR_DY = 320
 
 
-def pair_embed_backward(inp, weights, dpair_feat, acts, T):
-    """-> dys (N,L,L,320), ds (N,L,L,atoms*16)  (include/abopt.h: abopt_pair_embed_backward)."""
+def pair_embed_backward(inp, weights, dpair_feat, acts, T=None):
+    """-> dys (N,L,L,320), ds (N,L,L,atoms*16)  (include/abopt.h: abopt_pair_embed_backward).  T None: recomputed in the kernel."""
     N, L = inp.N, inp.L
     dev = acts.device
     dys = torch.empty(N, L, L, PAIR_DY, device=dev)
@@ -576,7 +578,7 @@ def pair_embed_backward(inp, weights, dpair_feat, acts, T):
     buf = Workspace.get(nb, dev)
     dpair_feat, = _contig(dpair_feat)
     _check(lib().abopt_pair_embed_backward(C.byref(inp), C.byref(weights), ptr(dpair_feat, torch.float32), ptr(acts, torch.float32),
-                                           ptr(T, torch.float32), ptr(dys), ptr(ds), ptr(buf), buf.numel(), stream()))
+                                           ptr(T, torch.float32, optional=True), ptr(dys), ptr(ds), ptr(buf), buf.numel(), stream()))
     return dys, ds
 
 

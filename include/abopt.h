@@ -343,14 +343,16 @@ size_t abopt_pair_embed_workspace_bytes(int N, int L, int atoms);
  * pair, relu(distance_embed.0) (64) | f_dist = relu(distance_embed.2) x structure mask (64) | f_dih (26, padded to 32) |
  * relu(out_mlp.0) (64) | relu(out_mlp.2) (64): what the backward of the five linears needs (pair.py:74-99). */
 enum { ABOPT_PAIR_ACT = 288 };
-/* gauss / dgauss (both or neither, training): [N,L,L,atoms,16] -- the Gaussian atom-pair features g (pair.py:62-73, atom b of
- * residue j padded to 16) and T = dg / d softplus(coef) = -d^2 g. */
+/* gauss / dgauss (training): [N,L,L,atoms,16] -- the Gaussian atom-pair features g (pair.py:62-73, atom b of residue j padded to 16)
+ * and T = dg / d softplus(coef) = -d^2 g.  dgauss may be NULL with gauss given: the backward then recomputes T from the atoms (1 GB
+ * less to write and to read back at N = 16, L = 256). */
 int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* activations,
                              float* gauss, float* dgauss, void* ws, size_t ws_bytes, abopt_stream stream);
 /* Backward chain of the five linears for the training path: from dpair_feat [N,L,L,64] and the saved activations writes, per pair,
  * dys [N,L,L,ABOPT_PAIR_DY] = d loss / d pre-activation of out_mlp.4 | out_mlp.2 | out_mlp.0 | distance_embed.2 |
  * distance_embed.0 (64 each), and dsoftplus [N,L,L,atoms,16] = d loss / d softplus(aapair_to_distcoef) per atom pair.  The
- * weight gradients are tall GEMMs of dys against the activations (host side). */
+ * weight gradients are tall GEMMs of dys against the activations (host side).  dgauss NULL: T is recomputed in the kernel with the
+ * forward's arithmetic (same bits). */
 enum { ABOPT_PAIR_DY = 320 };
 size_t abopt_pair_embed_backward_workspace_bytes(int N, int L, int atoms);
 int abopt_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dpair_feat,
