@@ -1394,11 +1394,15 @@ static int launch_core_variant(const float* qfrag, const float* kvfrag, const fl
     return ABOPT_OK;
 }
 
-// The 32-row kernel runs one block per workgroup, so it pays where its N * ceil(L / 32) workgroups fill the CUs in whole rounds: one
-// round at least 70 % full (N = 24, L = 256: 145 us against 155 us of the persistent 16-row kernel; N = 32: 167 against 175), or
-// several rounds at least 95 % full (N = 64: 335 against 345).  A half-empty last round loses (N = 48: 288 against 259; N = 20, L = 400:
-// 385 against 258), short lengths gain nothing (L = 128: equal; L = 64: 134 against 128), and small batches belong to the key-split
-// form (N = 16: 124 against 90).  Measured in tools/r03_c32_sweep.sh.  ABOPT_CORE32=0 / 1 overrides (1: whenever L > 16).
+// The 32-row kernel runs one block per workgroup, so it pays where its N * ceil(L / 32) workgroups fill the CUs in whole rounds
+// (tools/r03_c32_sweep.sh, r03_c32_sweep2.sh; microseconds per launch against the 16-row kernels on the same box):
+//   one round, more than half full, where the 16-row blocks no longer fit one round themselves (N L / 16 > CUs: the persistent kernel
+//   then walks two blocks per CU):  N = 23 / 24 / 28 / 32 at L = 256: 145 / 145 / 154 / 167 against 156 / 155 / 168 / 175; N = 32,
+//   L = 200: 123 against 132.  Up to N L / 16 = CUs the one-block 16-row kernel is the faster one (N = 16: 90 against 124).
+//   several rounds at least 95 % full:  N = 62 / 64: 334 / 335 against 344 / 345.  A half-empty last round loses (N = 48: 288 against
+//   259; N = 20, L = 400: 385 against 258).
+//   short lengths gain nothing (L = 128: equal; L = 64: 134 against 128).
+// ABOPT_CORE32=0 / 1 overrides (1: whenever 16 < L <= 2048).
 static bool use_core32(int N, int L, int cus) {
     const char* e = getenv("ABOPT_CORE32");
     if (L > 2048) return false;                                 // its buffer descriptors address a sample's z slab (L^2 * 256 bytes) with 32-bit offsets
@@ -1406,7 +1410,8 @@ static bool use_core32(int N, int L, int cus) {
     if (e && e[0] == '1') return L > BI;
     if (L < 192 || cus < 8) return false;
     const int64_t total = (int64_t)N * ((L + BI2 - 1) / BI2), rounds = (total + cus - 1) / cus;
-    return rounds == 1 ? total * 10 >= (int64_t)cus * 7 : total * 100 >= rounds * cus * 95;
+    if (rounds == 1) return total * 100 >= (int64_t)cus * 53 && (int64_t)N * ((L + BI - 1) / BI) > cus;
+    return total * 100 >= rounds * cus * 95;
 }
 
 int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
