@@ -196,14 +196,14 @@ extern "C" int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abo
 extern "C" size_t abopt_pair_embed_backward_workspace_bytes(int N, int L, int atoms) { return pair_embed_backward_ws_bytes(N, L, atoms); }
 
 extern "C" int abopt_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dpair_feat,
-                                         const float* activations, const float* dgauss, float* dys, float* dsoftplus,
+                                         const float* activations, const float* dgauss, float* dys, float* dsoftplus, float* dys_colsum,
                                          void* ws, size_t ws_bytes, abopt_stream stream) {
     int rc;
     if ((rc = check_encode_inputs(in, "pair_embed_backward"))) return rc;
     if ((int64_t)in->N * in->L == 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(w && w->wd0 && w->wd1 && w->wo0 && w->wo1 && w->wo2 && dpair_feat && activations && dys && dsoftplus && ws && w->aapair_to_distcoef && w->aa_pair_embed && w->relpos_embed,
                     "pair_embed_backward: NULL argument");
-    return launch_pair_embed_backward(in, w, dpair_feat, activations, dgauss, dys, dsoftplus, ws, ws_bytes, (hipStream_t)stream);
+    return launch_pair_embed_backward(in, w, dpair_feat, activations, dgauss, dys, dsoftplus, dys_colsum, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int abopt_reconstruct_backbone_partially(const float* pos_ctx, const float* R_new, const float* t_new, const int64_t* aa,

@@ -496,6 +496,7 @@ struct PairBwdArgs {
     const float* dout; const float* acts; const float* tsave; const uint8_t* flags;
     const f32x4* wo2t; const f32x4* wo1t; const f32x4* wo0dt; const f32x4* wd1t; const f32x4* wd0t;
     float* dys; float* ds; int N, L, A, has_struct;
+    float* dsum;                                                  // [units][PAIR_DY] per-wave column sums of dys (the five bias gradients), or NULL
     const f32x4* atoms4; const int* aa_eff; const float* sp;      // tsave == NULL: T = -d^2 g is recomputed from the atoms, as the forward does
 };
 constexpr int PAIR_DY = 320;
@@ -510,6 +511,18 @@ constexpr int PAIR_DY = 320;
         if (j0 + mt * 16 + fm < L) {                                                                                      \
             float* d_ = b.dys + ((row_i * L) + jc[mt]) * PAIR_DY + (OFF) + kq * 4;                                        \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(d_ + nt * 16) = SRC[mt][nt];       \
+        }                                                                                                                 \
+    }                                                                                                                     \
+    if (b.dsum) {                                                       /* the strip's column sums: tiles, then the 16 pairs of a tile (one DPP row) */ \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                                \
+            f32x4 t_ = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                       \
+            _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt) if (j0 + mt * 16 + fm < L) t_ += SRC[mt][nt];              \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                               \
+                float v_ = t_[r];                                                                                         \
+                v_ += ABOPT_DPP_ROR(v_, 8); v_ += ABOPT_DPP_ROR(v_, 4); v_ += ABOPT_DPP_ROR(v_, 2); v_ += ABOPT_DPP_ROR(v_, 1); \
+                t_[r] = v_;                                                                                               \
+            }                                                                                                             \
+            if (fm == 0) *reinterpret_cast<f32x4*>(b.dsum + unit * PAIR_DY + (OFF) + nt * 16 + kq * 4) = t_;              \
         }                                                                                                                 \
     }
 // DST = (W^T . SRC) masked by ACT > 0
@@ -615,12 +628,16 @@ __global__ __launch_bounds__(256, 2) void pair_embed_backward_kernel(PairBwdArgs
 }
 
 static size_t pair_tables_floats(int A) { return (size_t)AAT * AAT * EC + (size_t)NREL * EC + (size_t)AAT * AAT * A * 16; }
+static int64_t pair_units(int N, int L) { return (int64_t)N * L * ((L + 16 * PMT - 1) / (16 * PMT)); }
 size_t pair_embed_backward_ws_bytes(int N, int L, int A) {
-    return pack_bytes((int64_t)N * L) + al256((size_t)(4 * 4 + 4 * A) * 1024 * 4 + 4096) + al256(pair_tables_floats(A) * 4);
+    return pack_bytes((int64_t)N * L) + al256((size_t)(4 * 4 + 4 * A) * 1024 * 4 + 4096) + al256(pair_tables_floats(A) * 4) +
+           al256((size_t)pair_units(N, L) * PAIR_DY * 4) + al256((size_t)1024 * PAIR_DY * 4);
 }
 
+int launch_colsum(const float* x, int ld, int64_t rows, int cols, float* out, float* ws, size_t ws_floats, hipStream_t st);    // gemm.hip
+
 int launch_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dout, const float* acts, const float* tsave,
-                               float* dys, float* ds, void* ws, size_t ws_bytes, hipStream_t st) {
+                               float* dys, float* ds, float* dy_colsum, void* ws, size_t ws_bytes, hipStream_t st) {
     const int N = in->N, L = in->L, A = in->atoms;
     ABOPT_CHECK_ARG(A >= 3 && A <= 15 && A <= in->atoms_in, "pair_embed_backward: atoms=%d must be in [3, min(15, atoms_in=%d)]", A, in->atoms_in);
     const int64_t rows = (int64_t)N * L;
@@ -648,12 +665,16 @@ int launch_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_e
         ABOPT_LAUNCH_CHECK();
         b.sp = sp;
     }
+    float* partials = (float*)((char*)pb.end + al256((size_t)(4 * 4 + 4 * A) * 1024 * 4 + 4096) + al256(pair_tables_floats(A) * 4));
+    float* cs_ws = (float*)((char*)partials + al256((size_t)pair_units(N, L) * PAIR_DY * 4));
+    b.dsum = dy_colsum ? partials : nullptr;
     b.dout = dout; b.acts = acts; b.tsave = tsave; b.flags = pb.flags;
     b.wo2t = wo2t; b.wo1t = wo1t; b.wo0dt = wo0dt; b.wd1t = wd1t; b.wd0t = wd0t;
     b.dys = dys; b.ds = ds; b.N = N; b.L = L; b.A = A; b.has_struct = in->structure_mask ? 1 : 0;
     const int jblocks = (L + 16 * PMT - 1) / (16 * PMT);
     hipLaunchKernelGGL(pair_embed_backward_kernel, dim3((unsigned)((rows * jblocks + 3) / 4)), dim3(256), 0, st, b);
     ABOPT_LAUNCH_CHECK();
+    if (dy_colsum) return launch_colsum(partials, PAIR_DY, pair_units(N, L), PAIR_DY, dy_colsum, cs_ws, (size_t)1024 * PAIR_DY, st);
     return ABOPT_OK;
 }
 

@@ -301,11 +301,22 @@ __global__ __launch_bounds__(128) void bucket_colsum_kernel(const float* __restr
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
     for (int b = 0; b < nb; ++b) acc[w][b][lane] = 0.f;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
-    if (c < cols)
-        for (int64_t r = r0 + w; r < r1; r += 2) {
+    if (c < cols) {
+        // eight rows per trip: their indices and values are requested together (one row at a time the loop is a chain of memory round trips)
+        int64_t r = r0 + w;
+        for (; r + 14 < r1; r += 16) {
+            int bb[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { bb[u] = __builtin_amdgcn_readfirstlane(idx[r + 2 * u]); v[u] = x[(r + 2 * u) * ld + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (bb[u] >= 0 && bb[u] < nb) acc[w][bb[u]][lane] += v[u];
+        }
+        for (; r < r1; r += 2) {
             const int b = __builtin_amdgcn_readfirstlane(idx[r]);
             if (b >= 0 && b < nb) acc[w][b][lane] += x[r * ld + c];
         }
+    }
     __syncthreads();
     if (c < cols)
         for (int b = w; b < nb; b += 2) part[((int64_t)blockIdx.y * nb + b) * cols + c] = acc[0][b][lane] + acc[1][b][lane];
@@ -315,9 +326,9 @@ int launch_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const i
     if (cols <= 0 || nb <= 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(rows >= 0 && ld >= cols && nb <= BKT_MAX, "bucket_colsum: rows=%lld cols=%d ld=%d buckets=%d (max %d)", (long long)rows, cols, ld, nb, BKT_MAX);
     const int cblocks = (cols + 63) / 64;
-    int64_t want = rows / 1024;
+    int64_t want = rows / 512;
     if (want < 1) want = 1;
-    const int64_t cap = 1024 / cblocks > 1 ? 1024 / cblocks : 1;
+    const int64_t cap = 2048 / cblocks > 1 ? 2048 / cblocks : 1;
     int slices = (int)(want < cap ? want : cap);
     if (!ws) slices = 1;
     while (slices > 1 && (size_t)slices * nb * cols > ws_floats) --slices;

@@ -95,7 +95,7 @@ int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weig
                       void* ws, size_t ws_bytes, hipStream_t st);
 size_t pair_embed_backward_ws_bytes(int N, int L, int A);
 int launch_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dout, const float* acts, const float* tsave,
-                               float* dys, float* ds, void* ws, size_t ws_bytes, hipStream_t st);
+                               float* dys, float* ds, float* dy_colsum, void* ws, size_t ws_bytes, hipStream_t st);
 
 int launch_reconstruct_backbone(const float* pos_ctx, const float* R_new, const float* t_new, const int64_t* aa, const int64_t* chain_nb,
                                 const int64_t* res_nb, const uint8_t* mask_atoms, const uint8_t* mask_recons, const float* bb_table,

@@ -142,11 +142,10 @@ class _PairEmbedFn(torch.autograd.Function):
         M, C, nt = N * L * L, dout.shape[-1], ctx.n_types
         inp, keep = hip.encode_inputs(aa, res_nb, chain_nb, pos, matom, A, structure_mask=ctx.structure_mask)
         w = hip.PairEmbedWeights(*[hip.ptr(x, torch.float32) for x in t])
-        dys, ds = hip.pair_embed_backward(inp, w, dout, acts)            # T = dg / d softplus(coef) is recomputed from the atoms in the kernel
+        dys, ds, db = hip.pair_embed_backward(inp, w, dout, acts, colsum=True)     # T = dg / d softplus(coef) recomputed in the kernel; bias gradients from its per-wave sums
         y, a2 = dys.view(M, -1), acts.view(M, -1)
         do2, do1, do0, dh1, dh0 = (y[:, 64 * k:64 * (k + 1)] for k in range(5))
         h0, h1, dih, o0, o1 = a2[:, :64], a2[:, 64:128], a2[:, 128:154], a2[:, 160:224], a2[:, 224:288]
-        db = hip.colsum(y)                                                          # the five bias gradients at once
         dbo2, dbo1, dbo0, dbd1, dbd0 = (db[64 * k:64 * (k + 1)] for k in range(5))
         dwo2, dwo1, dwd1 = _splitk_tn(do2, o1), _splitk_tn(do1, o0), _splitk_tn(dh1, h0)
         # out_mlp.0 columns: [aa-pair embedding | relpos embedding x same-chain | f_dist | f_dih]

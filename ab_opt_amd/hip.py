@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -145,7 +145,7 @@ def lib():
         L.abopt_pair_embed_forward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_pair_embed_backward_workspace_bytes.restype = C.c_size_t
         L.abopt_pair_embed_backward_workspace_bytes.argtypes = [C.c_int] * 3
-        L.abopt_pair_embed_backward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, c_f, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_pair_embed_backward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, c_f, c_f, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_node_frag_source_row.argtypes = [C.c_int] * 3
         L.abopt_node_frag_floats.restype = C.c_size_t
         L.abopt_adam_ws_floats.restype = C.c_size_t
@@ -568,18 +568,20 @@ def pair_embed_forward(inp, weights, save_activations=False, save_T=False):
 PAIR_DY = 320
 
 
-def pair_embed_backward(inp, weights, dpair_feat, acts, T=None):
-    """-> dys (N,L,L,320), ds (N,L,L,atoms*16)  (include/abopt.h: abopt_pair_embed_backward).  T None: recomputed in the kernel."""
+def pair_embed_backward(inp, weights, dpair_feat, acts, T=None, colsum=False):
+    """-> dys (N,L,L,320), ds (N,L,L,atoms*16) [, column sums of dys (320) when colsum]  (include/abopt.h: abopt_pair_embed_backward).
+    T None: recomputed in the kernel."""
     N, L = inp.N, inp.L
     dev = acts.device
     dys = torch.empty(N, L, L, PAIR_DY, device=dev)
     ds = torch.empty(N, L, L, inp.atoms * 16, device=dev)
+    db = torch.empty(PAIR_DY, device=dev) if colsum else None
     nb = lib().abopt_pair_embed_backward_workspace_bytes(N, L, inp.atoms)
     buf = Workspace.get(nb, dev)
     dpair_feat, = _contig(dpair_feat)
     _check(lib().abopt_pair_embed_backward(C.byref(inp), C.byref(weights), ptr(dpair_feat, torch.float32), ptr(acts, torch.float32),
-                                           ptr(T, torch.float32, optional=True), ptr(dys), ptr(ds), ptr(buf), buf.numel(), stream()))
-    return dys, ds
+                                           ptr(T, torch.float32, optional=True), ptr(dys), ptr(ds), ptr(db, optional=True), ptr(buf), buf.numel(), stream()))
+    return (dys, ds, db) if colsum else (dys, ds)
 
 
 _BB_TABLES = {}
@@ -717,7 +719,7 @@ def bucket_colsum(x, idx, buckets):
     if x.stride(1) != 1 or x.dtype != torch.float32 or not x.is_cuda or idx.dtype != torch.int32 or idx.numel() != rows:
         raise TypeError('bucket_colsum: fp32 [rows, cols] with unit column stride and an int32 index per row')
     out = torch.empty(buckets, cols, dtype=torch.float32, device=x.device)
-    ws = Workspace.get(1024 * buckets * max(cols, 64) * 4, x.device)
+    ws = Workspace.get(2048 * buckets * max(cols, 64) * 4, x.device)
     _check(lib().abopt_bucket_colsum(ptr(x, torch.float32, strided=True), x.stride(0), rows, cols, ptr(idx.contiguous(), torch.int32), buckets, ptr(out),
                                      ptr(ws), ws.numel(), stream()))
     return out

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 26
+#define ABOPT_ABI_VERSION 27
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -352,11 +352,12 @@ int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_emb
  * dys [N,L,L,ABOPT_PAIR_DY] = d loss / d pre-activation of out_mlp.4 | out_mlp.2 | out_mlp.0 | distance_embed.2 |
  * distance_embed.0 (64 each), and dsoftplus [N,L,L,atoms,16] = d loss / d softplus(aapair_to_distcoef) per atom pair.  The
  * weight gradients are tall GEMMs of dys against the activations (host side).  dgauss NULL: T is recomputed in the kernel with the
- * forward's arithmetic (same bits). */
+ * forward's arithmetic (same bits).  dys_colsum (optional, [ABOPT_PAIR_DY]): the column sums of dys = the five bias gradients, formed from
+ * per-wave partial sums inside the kernel instead of a second pass over the 1.3 GB of dys. */
 enum { ABOPT_PAIR_DY = 320 };
 size_t abopt_pair_embed_backward_workspace_bytes(int N, int L, int atoms);
 int abopt_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dpair_feat,
-                              const float* activations, const float* dgauss, float* dys, float* dsoftplus,
+                              const float* activations, const float* dgauss, float* dys, float* dsoftplus, float* dys_colsum,
                               void* ws, size_t ws_bytes, abopt_stream stream);
 
 /* ---- reconstruct_backbone_partially: D/modules/common/geometry.py:404-480 (called on every saved frame right after the

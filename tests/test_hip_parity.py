@@ -1258,9 +1258,12 @@ def test_pair_embed_backward_recomputes_T_bit_identically():
     assert T2 is None and torch.equal(out, out2) and torch.equal(G, G2) and torch.equal(acts, acts2)
     dout = dev(synth.hash_tensor(tuple(out.shape), 5, scale=1.0))
     dys_a, ds_a = hip.pair_embed_backward(inp, w, dout, acts, T)
-    dys_b, ds_b = hip.pair_embed_backward(inp, w, dout, acts)
+    dys_b, ds_b, db = hip.pair_embed_backward(inp, w, dout, acts, colsum=True)
     assert torch.isfinite(ds_b).all() and ds_a.abs().max().item() > 0
     assert torch.equal(dys_a, dys_b) and torch.equal(ds_a, ds_b)
+    # the five bias gradients from the kernel's per-wave partial sums = column sums of dys (fp64 reference; padded rows of the strips excluded)
+    ref = dys_a.double().reshape(-1, hip.PAIR_DY).sum(0)
+    assert (db.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize('weight_decay,max_norm', [(0.0, None), (0.0, 0.5), (0.01, 100.0)])
