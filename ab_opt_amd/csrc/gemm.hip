@@ -244,6 +244,38 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     out[e] = s;
 }
 
+// The same for many slabs of few elements (split-K partials of a 64 x 64 weight gradient: 256 slabs of 4096 floats; bucket sums: 2048
+// slabs of 4160): a thread per element walks a serial chain of strided loads on a handful of CUs (60 us for 4 MB).  Here 64 elements x G
+// slab groups per workgroup: group g adds slabs g, g + G, ... with four loads in flight, the groups are then added in a fixed order.
+template <int G>
+__global__ __launch_bounds__(64 * G) void slab_sum_groups_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int slabs, int64_t stride) {
+    __shared__ float red[G][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < n) {
+        int k = g;
+        for (; k + 3 * G < slabs; k += 4 * G) {
+            s0 += in[(int64_t)k * stride + e]; s1 += in[(int64_t)(k + G) * stride + e];
+            s2 += in[(int64_t)(k + 2 * G) * stride + e]; s3 += in[(int64_t)(k + 3 * G) * stride + e];
+        }
+        for (; k < slabs; k += G) s0 += in[(int64_t)k * stride + e];
+    }
+    red[g][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && e < n) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int j = 1; j < G; ++j) t += red[j][lane];
+        out[e] = t;
+    }
+}
+static void launch_slab_sum(const float* in, float* out, int64_t n, int slabs, int64_t stride, hipStream_t st) {
+    if (slabs >= 128 && n <= (1 << 16)) hipLaunchKernelGGL(slab_sum_groups_kernel<16>, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, in, out, n, slabs, stride);
+    else if (slabs >= 16 && n <= (1 << 18)) hipLaunchKernelGGL(slab_sum_groups_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, in, out, n, slabs, stride);
+    else hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n, slabs, stride);
+}
+
 // column sums of a row-major [rows, ld] matrix (bias gradients, per-row partials of weight gradients): slice s of the rows -> part[s][cols],
 // then slab_sum_kernel adds the slices in a fixed order.  Thread -> (4 consecutive columns, row phase tid / 32 of 8)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ld, int64_t rows, int cols, int64_t rows_per_slice,
@@ -284,7 +316,7 @@ int launch_colsum(const float* x, int ld, int64_t rows, int cols, float* out, fl
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cblocks, slices), dim3(256), 0, st, x, ld, rows, cols, rps, slices > 1 ? ws : out);
     ABOPT_LAUNCH_CHECK();
     if (slices > 1) {
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, ws, out, (int64_t)cols, slices, (int64_t)cols);
+        launch_slab_sum(ws, out, (int64_t)cols, slices, (int64_t)cols, st);
         ABOPT_LAUNCH_CHECK();
     }
     return ABOPT_OK;
@@ -337,7 +369,7 @@ int launch_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const i
     ABOPT_LAUNCH_CHECK();
     if (slices > 1) {
         const int64_t n = (int64_t)nb * cols;
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, out, n, slices, n);
+        launch_slab_sum(ws, out, n, slices, n, st);
         ABOPT_LAUNCH_CHECK();
     }
     return ABOPT_OK;
@@ -367,7 +399,7 @@ int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const floa
 #undef ABOPT_GEMM
     ABOPT_LAUNCH_CHECK();
     if (ksplit > 1) {
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, ws, C, slab, ksplit, slab);
+        launch_slab_sum(ws, C, slab, ksplit, slab, st);
         ABOPT_LAUNCH_CHECK();
     }
     return ABOPT_OK;
