@@ -206,6 +206,18 @@ extern "C" int abopt_pair_embed_backward(const abopt_encode_inputs* in, const ab
     return launch_pair_embed_backward(in, w, dpair_feat, activations, dgauss, dys, dsoftplus, dys_colsum, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" int abopt_heads_epilogue_forward(const float* R, const float* v_t, const float* eps_crd, const float* eps_rot, const uint8_t* mask_generate,
+                                            float* v_next, float* R_next, float* eps_pos, int64_t rows, int grad_mode, abopt_stream stream) {
+    ABOPT_CHECK_ARG(rows >= 0 && R && eps_crd && eps_rot && mask_generate && R_next && eps_pos && (!v_next || v_t), "heads_epilogue_forward: NULL argument");
+    return launch_heads_epilogue(R, v_t, eps_crd, eps_rot, nullptr, 3, 0, mask_generate, v_next, R_next, eps_pos, nullptr, rows, grad_mode, (hipStream_t)stream);
+}
+
+extern "C" int abopt_heads_epilogue_backward(const float* R, const float* eps_rot, const uint8_t* mask_generate, const float* dR_next, const float* deps_pos,
+                                             float* deps_crd, float* deps_rot, int64_t rows, abopt_stream stream) {
+    ABOPT_CHECK_ARG(rows >= 0 && R && eps_rot && mask_generate && deps_crd && deps_rot, "heads_epilogue_backward: NULL argument");
+    return launch_heads_epilogue_backward(R, eps_rot, 3, mask_generate, dR_next, deps_pos, deps_crd, deps_rot, rows, (hipStream_t)stream);
+}
+
 extern "C" int abopt_reconstruct_backbone_partially(const float* pos_ctx, const float* R_new, const float* t_new, const int64_t* aa,
                                                     const int64_t* chain_nb, const int64_t* res_nb, const uint8_t* mask_atoms,
                                                     const uint8_t* mask_recons, const float* bb_table, const float* o_table,

@@ -128,10 +128,13 @@ __global__ __launch_bounds__(256) void heads_epilogue_kernel(const float* __rest
     const Mat3 Rn = matmul3(Rm, U);
 #pragma unroll
     for (int k = 0; k < 9; ++k) R_next[i * 9 + k] = Rn.m[k];
-    const Vec3 w = so3_log(Rn, grad_mode != 0);
-    v_next[i * 3 + 0] = gen ? w.x : v_t[i * 3 + 0];
-    v_next[i * 3 + 1] = gen ? w.y : v_t[i * 3 + 1];
-    v_next[i * 3 + 2] = gen ? w.z : v_t[i * 3 + 2];
+    if (v_next) {
+        const Vec3 w = so3_log(Rn, grad_mode != 0);
+        v_next[i * 3 + 0] = gen ? w.x : v_t[i * 3 + 0];
+        v_next[i * 3 + 1] = gen ? w.y : v_t[i * 3 + 1];
+        v_next[i * 3 + 2] = gen ? w.z : v_t[i * 3 + 2];
+    }
+    if (!seq_logits) return;                                        // training path: the sequence head's softmax stays in the autograd graph
     float lgt[ABOPT_AA], mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < ABOPT_AA; ++k) { lgt[k] = seq_logits[i * ldseq + k]; mx = fmaxf(mx, lgt[k]); }
@@ -148,6 +151,54 @@ int launch_heads_epilogue(const float* R, const float* v_t, const float* eps_crd
     if (rows == 0) return ABOPT_OK;
     hipLaunchKernelGGL(heads_epilogue_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, R, v_t, eps_crd, eps_rot, seq_logits,
                        ld3, ldseq, mask_generate, v_next, R_next, eps_pos, c_den, rows, grad_mode);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+// Backward of the geometric epilogue for the training path (dpm_full.py:95-101 under autograd): from d R_next and d eps_pos to the
+// gradients of the two 3-vectors the heads produce.  R_next = R U(e), U the rotation of the quaternion (1 + b i + c j + d k) / s:
+//   dL/dU = R^T dL/dR_next;  dL/dq_k = sum_ij (dL/dU)_ij dU_ij/dq_k (U is quadratic in the unit quaternion q = (1, b, c, d) / s);
+//   dL/d(b, c, d) = J^T dL/dq with dq_0/dx = -x / s^3, dq_x/dx = 1/s - x^2 / s^3, dq_x/dy = -x y / s^3.
+// eps_pos = gen ? R eps_crd : 0  ->  d eps_crd = gen ? R^T d eps_pos : 0.
+__global__ __launch_bounds__(256) void heads_epilogue_backward_kernel(const float* __restrict__ R, const float* __restrict__ eps_rot, int ld3,
+                                                                      const uint8_t* __restrict__ mask_generate, const float* __restrict__ dR_next,
+                                                                      const float* __restrict__ deps_pos, float* __restrict__ deps_crd,
+                                                                      float* __restrict__ deps_rot, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    float Rm[9], G[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { Rm[k] = R[i * 9 + k]; G[k] = dR_next ? dR_next[i * 9 + k] : 0.f; }
+    const bool gen = mask_generate[i] != 0;
+    const float px = deps_pos ? deps_pos[i * 3] : 0.f, py = deps_pos ? deps_pos[i * 3 + 1] : 0.f, pz = deps_pos ? deps_pos[i * 3 + 2] : 0.f;
+    deps_crd[i * 3 + 0] = gen ? (Rm[0] * px + Rm[3] * py + Rm[6] * pz) : 0.f;
+    deps_crd[i * 3 + 1] = gen ? (Rm[1] * px + Rm[4] * py + Rm[7] * pz) : 0.f;
+    deps_crd[i * 3 + 2] = gen ? (Rm[2] * px + Rm[5] * py + Rm[8] * pz) : 0.f;
+    float U[9];                                                         // dL/dU = R^T G
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) U[r * 3 + c] = Rm[r] * G[c] + Rm[3 + r] * G[3 + c] + Rm[6 + r] * G[6 + c];
+    const float qb = eps_rot[i * ld3], qc = eps_rot[i * ld3 + 1], qd = eps_rot[i * ld3 + 2];
+    const float s = sqrtf(1.f + qb * qb + qc * qc + qd * qd), is = 1.f / s, is3 = is * is * is;
+    const float a = is, b = qb * is, c = qc * is, d = qd * is;
+    // dL/dq: the four derivative matrices of quat1ijk_to_rot's entries contracted with dL/dU
+    const float ga = 2.f * (a * U[0] - d * U[1] + c * U[2] + d * U[3] + a * U[4] - b * U[5] - c * U[6] + b * U[7] + a * U[8]);
+    const float gb = 2.f * (b * U[0] + c * U[1] + d * U[2] + c * U[3] - b * U[4] - a * U[5] + d * U[6] + a * U[7] - b * U[8]);
+    const float gc = 2.f * (-c * U[0] + b * U[1] + a * U[2] + b * U[3] + c * U[4] + d * U[5] - a * U[6] + d * U[7] - c * U[8]);
+    const float gd = 2.f * (-d * U[0] - a * U[1] + b * U[2] + a * U[3] - d * U[4] + c * U[5] + b * U[6] + c * U[7] + d * U[8]);
+    // q = (1, qb, qc, qd) / s:  dL/dx = -x / s^3 (ga + qb gb + qc gc + qd gd) + g_x / s
+    const float dot = ga + qb * gb + qc * gc + qd * gd;
+    deps_rot[i * 3 + 0] = gb * is - qb * is3 * dot;
+    deps_rot[i * 3 + 1] = gc * is - qc * is3 * dot;
+    deps_rot[i * 3 + 2] = gd * is - qd * is3 * dot;
+}
+
+int launch_heads_epilogue_backward(const float* R, const float* eps_rot, int ld3, const uint8_t* mask_generate, const float* dR_next, const float* deps_pos,
+                                   float* deps_crd, float* deps_rot, int64_t rows, hipStream_t st) {
+    if (rows == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(heads_epilogue_backward_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, R, eps_rot, ld3, mask_generate, dR_next, deps_pos,
+                       deps_crd, deps_rot, rows);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,7 +73,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
+           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
@@ -711,6 +711,28 @@ def colsum(x):
     ws = Workspace.get(1024 * max(cols, 128) * 4, x.device)
     _check(lib().abopt_colsum(ptr(x, torch.float32, strided=True), x.stride(0), rows, cols, ptr(out), ptr(ws), ws.numel(), stream()))
     return out
+
+
+def heads_epilogue_forward(R, eps_crd, eps_rot, mask_generate):
+    """-> R_next (.., 3, 3), eps_pos (.., 3): dpm_full.py:95-101 without the log map (abopt_heads_epilogue_forward)."""
+    R, eps_crd, eps_rot, mask_generate = _contig(R.float(), eps_crd.float(), eps_rot.float(), mask_generate)
+    rows = mask_generate.numel()
+    R_next, eps_pos = torch.empty_like(R), torch.empty_like(eps_crd)
+    _check(lib().abopt_heads_epilogue_forward(ptr(R, torch.float32), None, ptr(eps_crd, torch.float32), ptr(eps_rot, torch.float32), ptr(mask_generate, torch.bool),
+                                              None, ptr(R_next), ptr(eps_pos), C.c_int64(rows), 0, stream()))
+    return R_next, eps_pos
+
+
+def heads_epilogue_backward(R, eps_rot, mask_generate, dR_next, deps_pos):
+    """-> d eps_crd, d eps_rot (.., 3) (abopt_heads_epilogue_backward); dR_next / deps_pos may be None (= zero)."""
+    R, eps_rot, mask_generate = _contig(R.float(), eps_rot.float(), mask_generate)
+    dR_next = None if dR_next is None else dR_next.float().contiguous()
+    deps_pos = None if deps_pos is None else deps_pos.float().contiguous()
+    rows = mask_generate.numel()
+    d_crd, d_rot = torch.empty_like(eps_rot), torch.empty_like(eps_rot)
+    _check(lib().abopt_heads_epilogue_backward(ptr(R, torch.float32), ptr(eps_rot, torch.float32), ptr(mask_generate, torch.bool), ptr(dR_next, torch.float32, optional=True),
+                                               ptr(deps_pos, torch.float32, optional=True), ptr(d_crd), ptr(d_rot), C.c_int64(rows), stream()))
+    return d_crd, d_rot
 
 
 def bucket_colsum(x, idx, buckets):

@@ -251,9 +251,35 @@ def ga_block(blk, R, t, x, z, mask, native=None, pbc=None, zsink=None):
     return _block_tail(blk, x, feat, mask, native=False)
 
 
-def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res):
+class HeadsEpilogue(torch.autograd.Function):
+    """eps_pos = gen ? R eps_crd : 0 and R_next = R U(eps_rot) (dpm_full.py:95-101) as one launch forward and one backward
+    (csrc/rows.hip: heads_epilogue_kernel / heads_epilogue_backward_kernel) instead of ~45 + ~90 elementwise kernels; R carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, R, eps_crd, eps_rot, mask_generate):
+        from . import hip
+        R_next, eps_pos = hip.heads_epilogue_forward(R, eps_crd, eps_rot, mask_generate)
+        ctx.save_for_backward(R, eps_rot, mask_generate)
+        return R_next, eps_pos
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, dR_next, deps_pos):
+        from . import hip
+        R, eps_rot, mask_generate = ctx.saved_tensors
+        d_crd, d_rot = hip.heads_epilogue_backward(R, eps_rot, mask_generate, dR_next, deps_pos)
+        return None, d_crd, d_rot, None
+
+
+def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res, want_v=True):
+    """EpsilonNet.forward under autograd.  want_v=False skips v_next = log(R_next) (the training losses use R_next only)."""
     N, L = mask_res.shape
-    R = so3_exp(v_t)
+    native = NATIVE_IPA and v_t.is_cuda and not v_t.requires_grad
+    if native:
+        from . import hip
+        R = hip.so3_exp(v_t.detach().float())
+    else:
+        R = so3_exp(v_t)
     from .embed import embed_rows
     x = _mlp(net.res_feat_mixer, torch.cat([res_feat, embed_rows(net.current_sequence_embedding, s_t)], dim=-1))
     caches = [None] * len(net.encoder.blocks)
@@ -268,9 +294,12 @@ def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_r
     feat = torch.cat([x, temb], dim=-1)
     gen3 = mask_generate[:, :, None].expand(N, L, 3)
     eps_crd = _mlp(net.eps_crd_net, feat)
-    eps_pos = torch.where(gen3, torch.einsum('nlab,nlb->nla', R, eps_crd), torch.zeros_like(eps_crd))
-    R_next = R @ quat1ijk_to_rot(_mlp(net.eps_rot_net, feat))
-    v_next = torch.where(gen3, so3_log(R_next), v_t)
+    if native:
+        R_next, eps_pos = HeadsEpilogue.apply(R, eps_crd, _mlp(net.eps_rot_net, feat), mask_generate)
+    else:
+        eps_pos = torch.where(gen3, torch.einsum('nlab,nlb->nla', R, eps_crd), torch.zeros_like(eps_crd))
+        R_next = R @ quat1ijk_to_rot(_mlp(net.eps_rot_net, feat))
+    v_next = torch.where(gen3, so3_log(R_next), v_t) if want_v else None
     c = _mlp(net.eps_seq_net, feat)
     if net.no_bins is None:
         return v_next, R_next, eps_pos, c
@@ -314,9 +343,12 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
                                                  seed_dev=seed_dev if noise is None else None)
     p0n = dpm._normalize_position(p_0)
     p_n = dpm._normalize_position(p_n_ang)
-    R_0 = so3_exp(v_0)
+    if NATIVE_IPA and v_0.is_cuda and not v_0.requires_grad:
+        R_0 = hip.so3_exp(v_0.detach().float())
+    else:
+        R_0 = so3_exp(v_0)
     beta = vs.betas[t]
-    out = eps_net(dpm.eps_net, v_n, p_n, s_n, res_feat, pair_feat, beta, mask_generate, mask_res)
+    out = eps_net(dpm.eps_net, v_n, p_n, s_n, res_feat, pair_feat, beta, mask_generate, mask_res, want_v=False)
     v_pred, R_pred, p_pred, c_den = out[:4]
     genf = mask_generate.float()
     denom = genf.sum() + 1e-8

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 27
+#define ABOPT_ABI_VERSION 28
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -359,6 +359,17 @@ size_t abopt_pair_embed_backward_workspace_bytes(int N, int L, int atoms);
 int abopt_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dpair_feat,
                               const float* activations, const float* dgauss, float* dys, float* dsoftplus, float* dys_colsum,
                               void* ws, size_t ws_bytes, abopt_stream stream);
+
+/* ---- Training path: the geometric epilogue of the heads on its own, D/modules/diffusion/dpm_full.py:95-101 (A: 86-92), and its backward.
+ *   eps_pos = gen ? R eps_crd : 0;   R_next = R U(eps_rot) with U the rotation of the quaternion 1 + b i + c j + d k (geometry.py:215-233);
+ *   v_next = gen ? log(R_next) : v_t  (optional: v_t / v_next may both be NULL -- the training losses do not use it).
+ * eps_crd / eps_rot [rows,3] are the outputs of eps_crd_net / eps_rot_net; the backward takes d R_next [rows,3,3] and d eps_pos [rows,3]
+ * (either may be NULL = zero) and writes d eps_crd, d eps_rot [rows,3].  In the reference these are ~45 elementwise ATen kernels forward
+ * and ~90 backward per step. */
+int abopt_heads_epilogue_forward(const float* R, const float* v_t, const float* eps_crd, const float* eps_rot, const uint8_t* mask_generate,
+                                 float* v_next, float* R_next, float* eps_pos, int64_t rows, int grad_mode, abopt_stream stream);
+int abopt_heads_epilogue_backward(const float* R, const float* eps_rot, const uint8_t* mask_generate, const float* dR_next, const float* deps_pos,
+                                  float* deps_crd, float* deps_rot, int64_t rows, abopt_stream stream);
 
 /* ---- reconstruct_backbone_partially: D/modules/common/geometry.py:404-480 (called on every saved frame right after the
  * sampler, D/tools/runner/design_for_pdb.py:166-223).  pos_ctx/pos_new [N,L,A,3], mask_atoms/mask_new [N,L,A], R_new [N,L,3,3],

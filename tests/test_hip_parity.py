@@ -1241,6 +1241,31 @@ def test_core32_is_bit_identical(N, L, lengths, monkeypatch):
     assert all(torch.equal(auto[k], ref[k]) for k in ('R_next', 'eps_pos', 'c'))
 
 
+def test_heads_epilogue_autograd_function_vs_torch_statement():
+    """training.HeadsEpilogue (abopt_heads_epilogue_forward / _backward: eps_pos = gen ? R eps_crd : 0, R_next = R U(eps_rot),
+    dpm_full.py:95-101 under autograd) against the torch statement of the same lines: values and both input gradients, small and
+    large quaternion vectors, masked rows."""
+    from ab_opt_amd import training, hip
+    g = torch.Generator().manual_seed(3)
+    N, L = 5, 77
+    R = hip.so3_exp(dev(torch.randn(N, L, 3, generator=g) * 1.5))
+    crd = dev(torch.randn(N, L, 3, generator=g)).requires_grad_()
+    rot = dev(torch.randn(N, L, 3, generator=g) * torch.tensor([0.01, 1.0, 8.0])[torch.randint(0, 3, (N, L, 1), generator=g)]).requires_grad_()
+    gen = dev(torch.rand(N, L, generator=g) < 0.7)
+    wR, wp = dev(torch.randn(N, L, 3, 3, generator=g)), dev(torch.randn(N, L, 3, generator=g))
+    Rn, ep = training.HeadsEpilogue.apply(R, crd, rot, gen)
+    ((Rn * wR).sum() + (ep * wp).sum()).backward()
+    got = (Rn.detach(), ep.detach(), crd.grad.clone(), rot.grad.clone())
+    crd.grad = rot.grad = None
+    gen3 = gen[:, :, None].expand(N, L, 3)
+    ep2 = torch.where(gen3, torch.einsum('nlab,nlb->nla', R, crd), torch.zeros_like(crd))
+    Rn2 = R @ training.quat1ijk_to_rot(rot)
+    ((Rn2 * wR).sum() + (ep2 * wp).sum()).backward()
+    for a, b, name in zip(got, (Rn2.detach(), ep2.detach(), crd.grad, rot.grad), ('R_next', 'eps_pos', 'd eps_crd', 'd eps_rot')):
+        assert (a - b).abs().max().item() <= 3e-6 * max(1.0, b.abs().max().item()), name
+    assert (got[2][~gen] == 0).all()
+
+
 def test_pair_embed_backward_recomputes_T_bit_identically():
     """abopt_pair_embed_backward without the saved T = dg / d softplus(coef) (pair.py:62-73 under autograd): the kernel recomputes it from
     the atoms with the forward's arithmetic -- dys and dsoftplus must equal, bit for bit, the run that reads the forward's dump
