@@ -182,6 +182,17 @@ extern "C" int abopt_residue_embed_forward(const abopt_encode_inputs* in, const 
     return launch_residue_embed(in, w, res_feat, R, p, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" size_t abopt_residue_features_workspace_bytes(int N, int L) { return residue_features_ws_bytes(N, L); }
+
+extern "C" int abopt_residue_features(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* features, float* R, float* p,
+                                      void* ws, size_t ws_bytes, abopt_stream stream) {
+    int rc;
+    if ((rc = check_encode_inputs(in, "residue_features"))) return rc;
+    if ((int64_t)in->N * in->L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(in->fragment_type && w && w->aatype_embed && w->type_embed && w->freq_bands && features && R && p && ws, "residue_features: NULL argument");
+    return launch_residue_features(in, w, features, R, p, ws, ws_bytes, (hipStream_t)stream);
+}
+
 extern "C" int abopt_pair_embed_forward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* activations,
                                         float* gauss, float* dgauss, void* ws, size_t ws_bytes, abopt_stream stream) {
     int rc;

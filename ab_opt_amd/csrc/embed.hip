@@ -783,6 +783,28 @@ int launch_residue_embed(const abopt_encode_inputs* in, const abopt_residue_embe
     return ABOPT_OK;
 }
 
+// The input features of ResidueEmbedding's MLP on their own (residue.py:33-88): [rows, ld] with ld = in_dim rounded up to 4, for the
+// training path (the MLP then runs under autograd on abopt_gemm).  Frames R and CA positions p come along as in the fused forward.
+size_t residue_features_ws_bytes(int N, int L) { return pack_bytes((int64_t)N * L) + 1024; }
+int launch_residue_features(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* feat, float* R, float* p, void* ws, size_t ws_bytes,
+                            hipStream_t st) {
+    const int N = in->N, L = in->L, A = in->atoms;
+    ABOPT_CHECK_ARG(A >= 3 && A <= 15 && A <= in->atoms_in, "residue_features: atoms=%d must be in [3, min(15, atoms_in=%d)]", A, in->atoms_in);
+    const int64_t rows = (int64_t)N * L;
+    if (rows == 0) return ABOPT_OK;
+    if (ws_bytes < residue_features_ws_bytes(N, L)) { set_error("residue_features: workspace too small"); return ABOPT_EWORKSPACE; }
+    const bool hs = w->hotspot_embed != nullptr;
+    const int ld = (residue_in_dim(A, hs) + 3) & ~3;
+    PackBufs pb = carve_pack((char*)ws, rows);
+    hipLaunchKernelGGL(residue_pack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(64), 0, st, in->aa, in->res_nb, in->chain_nb, in->pos_atoms, in->mask_atoms,
+                       in->structure_mask, in->sequence_mask, in->atoms_in, A, rows, pb.atoms4, pb.aa_eff, pb.resnb, pb.chain, pb.flags, R, p);
+    ABOPT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(residue_feat_kernel, dim3((unsigned)rows), dim3(256), 0, st, pb.atoms4, pb.aa_eff, pb.resnb, pb.chain, pb.flags, R, in->fragment_type,
+                       in->hotspot, w->aatype_embed, w->type_embed, w->hotspot_embed, w->freq_bands, A, L, in->structure_mask ? 1 : 0, feat, ld);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
 static size_t pair_weight_floats(int A) {
     return (size_t)AAT * AAT * EC + NREL * EC + (size_t)AAT * AAT * A * 16 + (size_t)(A + 4 + 6 + 4 + 4) * 4 * 64 * 4;
 }

@@ -96,6 +96,9 @@ size_t pair_embed_ws_bytes(int N, int L, int A);
 int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, float* pair_feat, float* acts, float* gsave, float* tsave,
                       void* ws, size_t ws_bytes, hipStream_t st);
 size_t pair_embed_backward_ws_bytes(int N, int L, int A);
+size_t residue_features_ws_bytes(int N, int L);
+int launch_residue_features(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* feat, float* R, float* p, void* ws, size_t ws_bytes,
+                            hipStream_t st);
 int launch_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_embed_weights* w, const float* dout, const float* acts, const float* tsave,
                                float* dys, float* ds, float* dy_colsum, void* ws, size_t ws_bytes, hipStream_t st);
 

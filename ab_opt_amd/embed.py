@@ -168,6 +168,51 @@ class _PairEmbedFn(torch.autograd.Function):
         return (None,) * 8 + (dE_aap, dE_rel, dcoef, None, dwd0, dbd0, dwd1, dbd1, dwo0, dbo0, dwo1, dbo1, dwo2, dbo2)
 
 
+NATIVE_FEATURES = True      # tests flip this to compare the native feature builder with the torch statement
+
+
+class _ResidueFeaturesFn(torch.autograd.Function):
+    """The inputs of ResidueEmbedding's MLP on the training path: one HIP launch pair (`abopt_residue_features`) instead of the ~120
+    elementwise kernels of the torch statement below (frames, per-type local coordinates, dihedrals, angular encoding, concatenation).
+    Only the embedding tables carry gradients: a bucketed row sum of the matching feature columns each (`abopt_bucket_colsum`)."""
+
+    @staticmethod
+    def forward(ctx, aa, res_nb, chain_nb, pos, matom, fragment_type, hotspot, structure_mask, sequence_mask, n_atoms, pad_type, pad_hot,
+                w_aa, w_type, w_hot, freq):
+        inp, keep = hip.encode_inputs(aa, res_nb, chain_nb, pos, matom, n_atoms, fragment_type=fragment_type, hotspot=hotspot,
+                                      structure_mask=structure_mask, sequence_mask=sequence_mask)
+        t = [x.detach().contiguous() for x in (w_aa, w_type, freq)]
+        hs = w_hot.detach().contiguous() if w_hot is not None else None
+        w = hip.ResidueEmbedWeights(hip.ptr(t[0], torch.float32), hip.ptr(t[1], torch.float32), hip.ptr(hs, torch.float32, optional=True),
+                                    hip.ptr(t[2], torch.float32), *([None] * 8))
+        F_ = w_aa.shape[1]
+        in_dim = F_ + w_aa.shape[0] * n_atoms * 3 + 39 + F_ + (F_ if w_hot is not None else 0)
+        feat, _, _ = hip.residue_features(inp, w, in_dim)
+        aa_eff = aa if sequence_mask is None else torch.where(sequence_mask, aa, torch.full_like(aa, AA_UNK))
+        hot = None if w_hot is None else (hotspot if hotspot is not None else torch.zeros_like(aa))
+        ctx.save_for_backward(aa_eff, fragment_type, hot)
+        ctx.dims = (w_aa.shape[0], w_type.shape[0], None if w_hot is None else w_hot.shape[0], F_, in_dim, pad_type, pad_hot)
+        return feat
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, dfeat):
+        aa_eff, ftype, hot = ctx.saved_tensors
+        n_aa, n_type, n_hot, F_, in_dim, pad_type, pad_hot = ctx.dims
+        idx = lambda t: t.reshape(-1).to(torch.int32)
+        d_aa = hip.bucket_colsum(dfeat[:, :F_], idx(aa_eff), n_aa)
+        off = in_dim - F_ - (F_ if n_hot is not None else 0)
+        d_type = hip.bucket_colsum(dfeat[:, off:off + F_], idx(ftype), n_type)
+        if pad_type is not None:
+            d_type[pad_type].zero_()                 # (no scalar index_put: the step may be under graph capture)
+        d_hot = None
+        if n_hot is not None:
+            d_hot = hip.bucket_colsum(dfeat[:, off + F_:off + 2 * F_], idx(hot), n_hot)
+            if pad_hot is not None:
+                d_hot[pad_hot].zero_()
+        return (None,) * 12 + (d_aa, d_type, d_hot, None)
+
+
 class AngularEncoding(nn.Module):
     def __init__(self, num_funcs=3):
         super().__init__()
@@ -253,6 +298,13 @@ class ResidueEmbedding(nn.Module):
         N, L = aa.size()
         A = self.max_num_atoms
         mres = mask_atoms[:, :, ATOM_CA]
+        if NATIVE_FEATURES and aa.is_cuda and not pos_atoms.requires_grad and pos_atoms.dtype == torch.float32 and self.aatype_embed.weight.dtype == torch.float32 \
+                and torch.is_grad_enabled():
+            x = _ResidueFeaturesFn.apply(aa, res_nb, chain_nb, pos_atoms, mask_atoms, fragment_type, hotspot, structure_mask, sequence_mask, A,
+                                         self.type_embed.padding_idx, None if self.hotspot_embed is None else self.hotspot_embed.padding_idx,
+                                         self.aatype_embed.weight, self.type_embed.weight, None if self.hotspot_embed is None else self.hotspot_embed.weight,
+                                         self.dihed_embed.freq_bands)
+            return _tall_mlp(self.mlp, x.view(N, L, -1)) * mres[:, :, None]
         pos, matom = pos_atoms[:, :, :A], mask_atoms[:, :, :A]
         if sequence_mask is not None:
             aa = torch.where(sequence_mask, aa, torch.full_like(aa, AA_UNK))

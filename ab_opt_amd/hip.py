@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,7 +73,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
+           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
@@ -138,6 +138,9 @@ def lib():
         L.abopt_ipa_backward_assemble.argtypes = [c_f] * 9 + [C.c_int, C.c_int, C.c_void_p]
         L.abopt_ipa_pair_backward.argtypes = [c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.abopt_residue_embed_workspace_bytes.restype = C.c_size_t
+        L.abopt_residue_features_workspace_bytes.restype = C.c_size_t
+        L.abopt_residue_features_workspace_bytes.argtypes = [C.c_int] * 2
+        L.abopt_residue_features.argtypes = [C.POINTER(EncodeInputs), C.POINTER(ResidueEmbedWeights), c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_residue_embed_workspace_bytes.argtypes = [C.c_int] * 4
         L.abopt_pair_embed_workspace_bytes.restype = C.c_size_t
         L.abopt_pair_embed_workspace_bytes.argtypes = [C.c_int] * 3
@@ -545,6 +548,20 @@ def residue_embed_forward(inp, weights, has_hotspot):
 
 
 PAIR_ACT = 288
+
+
+def residue_features(inp, weights, in_dim):
+    """-> features (N*L, in_dim) (a view of a buffer whose rows are padded to a multiple of 4 floats), R (N,L,3,3), p (N,L,3):
+    abopt_residue_features, the inputs of ResidueEmbedding's MLP (residue.py:33-88)."""
+    N, L = inp.N, inp.L
+    dev = torch.device('cuda', torch.cuda.current_device())
+    ld = (in_dim + 3) & ~3
+    feat = torch.empty(N * L, ld, device=dev)
+    R, p = torch.empty(N, L, 3, 3, device=dev), torch.empty(N, L, 3, device=dev)
+    nb = lib().abopt_residue_features_workspace_bytes(N, L)
+    buf = Workspace.get(nb, dev)
+    _check(lib().abopt_residue_features(C.byref(inp), C.byref(weights), ptr(feat), ptr(R), ptr(p), ptr(buf), buf.numel(), stream()))
+    return feat[:, :in_dim], R, p
 
 
 def pair_embed_forward(inp, weights, save_activations=False, save_T=False):

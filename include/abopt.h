@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 28
+#define ABOPT_ABI_VERSION 29
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -338,6 +338,12 @@ size_t abopt_residue_embed_workspace_bytes(int N, int L, int atoms, int hotspot)
 /* -> res_feat [N,L,128]; R [N,L,3,3] = construct_3d_basis(CA, C, N); p [N,L,3] = CA (diffab.py:76-83) */
 int abopt_residue_embed_forward(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* res_feat, float* R, float* p,
                                 void* ws, size_t ws_bytes, abopt_stream stream);
+/* Training path: the input features of the residue MLP on their own (residue.py:33-88: aa embedding | per-type local coordinates | dihedral
+ * encoding | fragment-type embedding [| hotspot embedding]) -> features [N*L, ld], ld = in_dim rounded up to a multiple of 4
+ * (in_dim = 128 + 22*atoms*3 + 39 + 128 [+ 128]); only the embedding tables and freq_bands of `w` are read.  R, p as in the fused forward. */
+size_t abopt_residue_features_workspace_bytes(int N, int L);
+int abopt_residue_features(const abopt_encode_inputs* in, const abopt_residue_embed_weights* w, float* features, float* R, float* p,
+                           void* ws, size_t ws_bytes, abopt_stream stream);
 size_t abopt_pair_embed_workspace_bytes(int N, int L, int atoms);
 /* -> pair_feat [N,L,L,64].  activations: NULL for inference; for training a [N,L,L,ABOPT_PAIR_ACT] buffer that receives, per
  * pair, relu(distance_embed.0) (64) | f_dist = relu(distance_embed.2) x structure mask (64) | f_dih (26, padded to 32) |

@@ -1241,6 +1241,41 @@ def test_core32_is_bit_identical(N, L, lengths, monkeypatch):
     assert all(torch.equal(auto[k], ref[k]) for k in ('R_next', 'eps_pos', 'c'))
 
 
+def test_residue_features_native_vs_torch_statement():
+    """ResidueEmbedding on the training path: features from abopt_residue_features (+ bucketed row sums for the embedding tables) against
+    the torch statement of residue.py:33-88 in the same module -- output and every parameter gradient, both flavours (hotspot table),
+    ragged lengths, two chains, structure / sequence masks."""
+    from ab_opt_amd import embed
+    for flavour in ('abdock', 'abdesign'):
+        m = build_model(10, 3, flavour=flavour, device=DEV).train()
+        re_ = m.residue_embed
+        b = {k: dev(v) for k, v in synth.make_batch(3, synth.LAYOUT_128, seed=31, lengths=[128, 77, 50]).items()}
+        b['chain_nb'][:, 40:] = 1
+        smask = b['mask'] & ~b['generate_flag']
+        args = (b['aa'], b['res_nb'], b['chain_nb'], b['pos_heavyatom'], b['mask_heavyatom'], b['fragment_type'])
+        kw = dict(structure_mask=smask, sequence_mask=smask)
+        if re_.hotspot_embed is not None:
+            kw['hotspot'] = (b['fragment_type'] == 3).long()
+        w = dev(synth.hash_tensor((3, 128, 128), 9, scale=1.0))
+        out = {}
+        try:
+            for native in (True, False):
+                embed.NATIVE_FEATURES = native
+                re_.zero_grad(set_to_none=True)
+                with torch.enable_grad():
+                    y = re_(*args, **kw)
+                    (y * w).sum().backward()
+                out[native] = (y.detach(), {n: p.grad.clone() for n, p in re_.named_parameters() if p.grad is not None})
+        finally:
+            embed.NATIVE_FEATURES = True
+            re_.zero_grad(set_to_none=True)
+        (ya, ga), (yb, gb) = out[True], out[False]
+        assert (ya - yb).abs().max().item() <= 2e-5 * max(1.0, yb.abs().max().item())
+        assert set(ga) == set(gb)
+        for n in ga:
+            assert (ga[n] - gb[n]).abs().max().item() <= 2e-4 * max(1e-6, gb[n].abs().max().item()), (flavour, n)
+
+
 def test_heads_epilogue_autograd_function_vs_torch_statement():
     """training.HeadsEpilogue (abopt_heads_epilogue_forward / _backward: eps_pos = gen ? R eps_crd : 0, R_next = R U(eps_rot),
     dpm_full.py:95-101 under autograd) against the torch statement of the same lines: values and both input gradients, small and

@@ -36,6 +36,6 @@ if len(sys.argv) > 3:          # a third argument: only the operators whose name
     for e in rows[:25]:
         print('%-28s %9.1f us  x%-4d %s' % (e.key, e.self_device_time_total, e.count, str(e.input_shapes)[:150]))
 if len(sys.argv) > 3 and sys.argv[3] == 'count':     # 'count': operators by number of calls (the ~500 three-microsecond launches of a step), with python source
-    rows = sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.count)
-    for e in rows[:40]:
+    rows = sorted((e for e in prof.key_averages(group_by_input_shape=True) if e.self_device_time_total > 0 and e.key.startswith('aten::')), key=lambda e: -e.count)
+    for e in rows[:45]:
         print('%-34s x%-5d %9.1f us  %s' % (e.key[:34], e.count, e.self_device_time_total, str(e.input_shapes)[:110]))
