@@ -217,6 +217,15 @@ extern "C" int abopt_pair_embed_backward(const abopt_encode_inputs* in, const ab
     return launch_pair_embed_backward(in, w, dpair_feat, activations, dgauss, dys, dsoftplus, dys_colsum, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" int abopt_dpm_losses(const float* R_pred, const float* R_0, const float* p_pred, const float* p_target, const float* c_denoised, const int64_t* s_t,
+                                const int64_t* s_0, const float* alpha_bar_t, const uint8_t* mask_generate, int N, int L, float* block_sums, float* dR_pred,
+                                float* dp_pred, float* dc_denoised, abopt_stream stream) {
+    ABOPT_CHECK_ARG(N >= 0 && L >= 0 && R_pred && R_0 && p_pred && p_target && c_denoised && s_t && s_0 && alpha_bar_t && mask_generate && block_sums && dR_pred &&
+                    dp_pred && dc_denoised, "dpm_losses: NULL argument");
+    return launch_dpm_losses(R_pred, R_0, p_pred, p_target, c_denoised, s_t, s_0, alpha_bar_t, mask_generate, N, L, block_sums, dR_pred, dp_pred, dc_denoised,
+                             (hipStream_t)stream);
+}
+
 extern "C" int abopt_heads_epilogue_forward(const float* R, const float* v_t, const float* eps_crd, const float* eps_rot, const uint8_t* mask_generate,
                                             float* v_next, float* R_next, float* eps_pos, int64_t rows, int grad_mode, abopt_stream stream) {
     ABOPT_CHECK_ARG(rows >= 0 && R && eps_crd && eps_rot && mask_generate && R_next && eps_pos && (!v_next || v_t), "heads_epilogue_forward: NULL argument");

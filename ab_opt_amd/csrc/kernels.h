@@ -69,6 +69,8 @@ int launch_build_infeat(const float* x, const float* beta, float* infeat, const 
 int launch_heads_epilogue(const float* R, const float* v_t, const float* eps_crd, const float* eps_rot, const float* seq_logits,
                           int ld3, int ldseq, const uint8_t* mask_generate, float* v_next, float* R_next, float* eps_pos, float* c_den,
                           int64_t rows, int grad_mode, hipStream_t st);
+int launch_dpm_losses(const float* R_pred, const float* R_0, const float* p_pred, const float* p_target, const float* c_den, const int64_t* s_t, const int64_t* s_0,
+                      const float* abar, const uint8_t* mask_generate, int N, int L, float* part, float* gR, float* gp, float* gc, hipStream_t st);
 int launch_heads_epilogue_backward(const float* R, const float* eps_rot, int ld3, const uint8_t* mask_generate, const float* dR_next, const float* deps_pos,
                                    float* deps_crd, float* deps_rot, int64_t rows, hipStream_t st);
 // out[n, b] = mean_l in[n, l, b]

@@ -203,6 +203,85 @@ int launch_heads_epilogue_backward(const float* R, const float* eps_rot, int ld3
     return ABOPT_OK;
 }
 
+// The three per-residue losses of FullDPM.forward (D/modules/diffusion/dpm_full.py:199-231; A: 156-190) and their gradients in one pass:
+//   rot  sum over the 3 columns of 1 - cos(R_pred[:, k], R_0[:, k])     (rotation_matrix_cosine_loss: F.cosine_embedding_loss, eps 1e-12 on the squared norms)
+//   pos  |p_pred - target|^2                                             (F.mse_loss(...).sum(-1))
+//   seq  KL(posterior(s_t, s_0) || posterior(s_t, c_den))                (F.kl_div(log(post_pred + 1e-8), post_true).sum(-1); transition.py:217-229: alpha_bar_t in both factors)
+// each summed over the generated residues.  part[block][3] receives the block's sums (added on the host side in a fixed order and divided
+// by sum(mask_generate) + 1e-8); gR / gp / gc receive d(sum)/d(input) of the row (zero outside the mask) -- the caller scales them by the
+// upstream gradient / denominator.  One thread per residue.
+__global__ __launch_bounds__(256) void dpm_losses_kernel(const float* __restrict__ R_pred, const float* __restrict__ R_0, const float* __restrict__ p_pred,
+                                                         const float* __restrict__ p_target, const float* __restrict__ c_den, const int64_t* __restrict__ s_t,
+                                                         const int64_t* __restrict__ s_0, const float* __restrict__ abar /* [N] alpha_bar_t */,
+                                                         const uint8_t* __restrict__ mask_generate, int L, int64_t rows, float* __restrict__ part,
+                                                         float* __restrict__ gR, float* __restrict__ gp, float* __restrict__ gc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float l_rot = 0.f, l_pos = 0.f, l_seq = 0.f;
+    if (i < rows) {
+        const bool gen = mask_generate[i] != 0;
+        float a[9], b[9], g[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { a[k] = R_pred[i * 9 + k]; b[k] = R_0[i * 9 + k]; g[k] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                                           // column c of both matrices
+            const float x0 = a[c], x1 = a[3 + c], x2 = a[6 + c], y0 = b[c], y1 = b[3 + c], y2 = b[6 + c];
+            const float prod = x0 * y0 + x1 * y1 + x2 * y2;
+            const float m1 = x0 * x0 + x1 * x1 + x2 * x2 + 1e-12f, m2 = y0 * y0 + y1 * y1 + y2 * y2 + 1e-12f;
+            const float den = sqrtf(m1 * m2), cs = prod / den;
+            l_rot += 1.f - cs;
+            // d(1 - cos)/dx = -(y / den - cos x / m1)
+            g[c] = -(y0 / den - cs * x0 / m1); g[3 + c] = -(y1 / den - cs * x1 / m1); g[6 + c] = -(y2 / den - cs * x2 / m1);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gR[i * 9 + k] = gen ? g[k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float d = p_pred[i * 3 + k] - p_target[i * 3 + k];
+            l_pos += d * d;
+            gp[i * 3 + k] = gen ? 2.f * d : 0.f;
+        }
+        // sequence: th_k = (ab ct_k + u)(ab c0_k + u), u = (1 - ab) / 20; post = th / (sum th + 1e-8)
+        const float ab = abar[i / L], u = (1.f - ab) / (float)ABOPT_AA;
+        const int st = (int)s_t[i], s0 = (int)s_0[i];
+        float fct[ABOPT_AA], thp[ABOPT_AA], tht[ABOPT_AA], sp = 0.f, stt = 0.f;
+#pragma unroll
+        for (int k = 0; k < ABOPT_AA; ++k) {
+            fct[k] = ab * ((k == st) ? 1.f : 0.f) + u;                           // _one_hot20: indices outside 0..19 give a zero row
+            tht[k] = fct[k] * (ab * ((k == s0) ? 1.f : 0.f) + u);
+            thp[k] = fct[k] * (ab * c_den[i * ABOPT_AA + k] + u);
+            stt += tht[k]; sp += thp[k];
+        }
+        const float zt = stt + 1e-8f, zp = sp + 1e-8f;
+        float dth[ABOPT_AA], dot = 0.f;                                          // d kl / d post_pred_k = -post_true_k / (post_pred_k + 1e-8)
+#pragma unroll
+        for (int k = 0; k < ABOPT_AA; ++k) {
+            const float pt = tht[k] / zt, pp = thp[k] / zp;
+            l_seq += (pt > 0.f ? pt * logf(pt) : 0.f) - pt * logf(pp + 1e-8f);   // xlogy(t, t) - t * input
+            dth[k] = -pt / (pp + 1e-8f);
+            dot += dth[k] * pp;
+        }
+#pragma unroll
+        for (int k = 0; k < ABOPT_AA; ++k)                                       // post = th / z: d/d th_k = (dpost_k - sum_j dpost_j post_j) / z;  th_k = fct_k (ab c0_k + u)
+            gc[i * ABOPT_AA + k] = gen ? (dth[k] - dot) / zp * fct[k] * ab : 0.f;
+        if (!gen) { l_rot = 0.f; l_pos = 0.f; l_seq = 0.f; }
+    }
+    __shared__ float red[3][4];
+    l_rot = wave_sum(l_rot); l_pos = wave_sum(l_pos); l_seq = wave_sum(l_seq);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = l_rot; red[1][threadIdx.x >> 6] = l_pos; red[2][threadIdx.x >> 6] = l_seq; }
+    __syncthreads();
+    if (threadIdx.x < 3) part[blockIdx.x * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+int launch_dpm_losses(const float* R_pred, const float* R_0, const float* p_pred, const float* p_target, const float* c_den, const int64_t* s_t, const int64_t* s_0,
+                      const float* abar, const uint8_t* mask_generate, int N, int L, float* part, float* gR, float* gp, float* gc, hipStream_t st) {
+    const int64_t rows = (int64_t)N * L;
+    if (rows == 0) return ABOPT_OK;
+    hipLaunchKernelGGL(dpm_losses_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, R_pred, R_0, p_pred, p_target, c_den, s_t, s_0, abar, mask_generate, L,
+                       rows, part, gR, gp, gc);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
 // prmsd_logits.mean(dim=1) over ALL L rows incl. padding (dpm_full.py:110).  One workgroup per sample: thread (bin b, slice p of 16)
 // sums rows p, p + 16, ... with the loads of four rows in flight, the slices meet in LDS (fixed order: deterministic).
 __global__ __launch_bounds__(1024) void mean_over_L_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int B) {

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,7 +73,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
+           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_dpm_losses', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
@@ -728,6 +728,20 @@ def colsum(x):
     ws = Workspace.get(1024 * max(cols, 128) * 4, x.device)
     _check(lib().abopt_colsum(ptr(x, torch.float32, strided=True), x.stride(0), rows, cols, ptr(out), ptr(ws), ws.numel(), stream()))
     return out
+
+
+def dpm_losses(R_pred, R_0, p_pred, p_target, c_den, s_t, s_0, abar_t, mask_generate):
+    """-> sums (3,) of (rot, pos, seq) over the generated residues, and d(sum)/d(R_pred, p_pred, c_den) (abopt_dpm_losses)."""
+    R_pred, R_0, p_pred, p_target, c_den, s_t, s_0, abar_t, mask_generate = _contig(R_pred.float(), R_0.float(), p_pred.float(), p_target.float(), c_den.float(),
+                                                                                    s_t, s_0, abar_t.float(), mask_generate)
+    N, L = mask_generate.shape
+    nblk = (N * L + 255) // 256
+    part = torch.empty(nblk, 3, dtype=torch.float32, device=R_pred.device)
+    gR, gp, gc = torch.empty_like(R_pred), torch.empty_like(p_pred), torch.empty_like(c_den)
+    _check(lib().abopt_dpm_losses(ptr(R_pred, torch.float32), ptr(R_0, torch.float32), ptr(p_pred, torch.float32), ptr(p_target, torch.float32), ptr(c_den, torch.float32),
+                                  ptr(s_t, torch.int64), ptr(s_0, torch.int64), ptr(abar_t, torch.float32), ptr(mask_generate, torch.bool), N, L, ptr(part), ptr(gR), ptr(gp),
+                                  ptr(gc), stream()))
+    return colsum(part), gR, gp, gc
 
 
 def heads_epilogue_forward(R, eps_crd, eps_rot, mask_generate):

@@ -169,7 +169,7 @@ class IpaCore(torch.autograd.Function):
         # scale, spatial-term chain rule, rotation back to the residue frames, re-layout to (N,L,2016): one kernel
         dproj, e = hip.ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, gamma_raw.reshape(-1))
         gam = gamma_raw.reshape(-1)
-        dgamma = (e.sum((0, 1)) * (-torch.sigmoid(gam) * (math.sqrt(2 / (9 * P)) / 2))).reshape(gamma_raw.shape)
+        dgamma = (hip.colsum(e.reshape(-1, e.shape[-1])) * (-torch.sigmoid(gam) * (math.sqrt(2 / (9 * P)) / 2))).reshape(gamma_raw.shape)
         return dproj, dz, None, None, None, dWb, dgamma, None, None
 
 
@@ -322,6 +322,24 @@ def _posterior(alpha_bars, x_t, x_0, t):
     return th / (th.sum(dim=-1, keepdim=True) + 1e-8)
 
 
+class DpmLosses(torch.autograd.Function):
+    """(rot, pos, seq) sums over the generated residues (dpm_full.py:199-231) and their gradients in ONE launch (csrc/rows.hip:
+    dpm_losses_kernel) instead of the ~50 forward and ~70 backward elementwise kernels of the statement in fulldpm_loss below."""
+
+    @staticmethod
+    def forward(ctx, R_pred, R_0, p_pred, p_target, c_den, s_t, s_0, abar_t, mask_generate):
+        from . import hip
+        sums, gR, gp, gc = hip.dpm_losses(R_pred, R_0, p_pred, p_target, c_den, s_t, s_0, abar_t, mask_generate)
+        ctx.save_for_backward(gR, gp, gc)
+        return sums
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, dsums):
+        gR, gp, gc = ctx.saved_tensors
+        return gR * dsums[0], None, gp * dsums[1], None, gc * dsums[2], None, None, None, None
+
+
 def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_res, denoise_structure, denoise_sequence,
                  t=None, noise=None, seed=None):
     """FullDPM.forward -> dict of scalar losses (AbDock: prmsd, dist (pred_x0), rot, pos, seq; AbDesign: rot, pos, seq)."""
@@ -377,6 +395,10 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
         pos_target = p_true
     else:
         pos_target = eps_p
+    if NATIVE_IPA and R_pred.is_cuda and R_pred.dtype == torch.float32 and not (R_0.requires_grad or pos_target.requires_grad):
+        sums = DpmLosses.apply(R_pred, R_0, p_pred, pos_target, c_den, s_n, s_0, vs.alpha_bars[t], mask_generate) / denom
+        loss['rot'], loss['pos'], loss['seq'] = sums[0], sums[1], sums[2]
+        return loss
     cp = R_pred.transpose(-2, -1).reshape(-1, 3)
     ct = R_0.transpose(-2, -1).reshape(-1, 3)
     lr = F.cosine_embedding_loss(cp, ct, torch.ones(cp.shape[0], dtype=torch.long, device=dev), reduction='none')

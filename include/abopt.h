@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 29
+#define ABOPT_ABI_VERSION 30
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -372,6 +372,14 @@ int abopt_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_em
  * eps_crd / eps_rot [rows,3] are the outputs of eps_crd_net / eps_rot_net; the backward takes d R_next [rows,3,3] and d eps_pos [rows,3]
  * (either may be NULL = zero) and writes d eps_crd, d eps_rot [rows,3].  In the reference these are ~45 elementwise ATen kernels forward
  * and ~90 backward per step. */
+/* The three per-residue losses of FullDPM.forward and their gradients in one pass (D/modules/diffusion/dpm_full.py:199-231, A: 156-190):
+ *   rot = sum_k 1 - cos(R_pred[:, k], R_0[:, k])  (rotation_matrix_cosine_loss, dpm_full.py:15-32);  pos = |p_pred - p_target|^2;
+ *   seq = KL(posterior(s_t, s_0) || posterior(s_t, c_denoised))  (transition.py:217-229),  each summed over the generated residues.
+ * block_sums [ceil(N L / 256)][3]: per-workgroup sums of (rot, pos, seq), to be added in order and divided by sum(mask_generate) + 1e-8;
+ * dR_pred [N,L,3,3], dp_pred [N,L,3], dc_denoised [N,L,20]: d(sum)/d(input) per residue, zero outside mask_generate. */
+int abopt_dpm_losses(const float* R_pred, const float* R_0, const float* p_pred, const float* p_target, const float* c_denoised, const int64_t* s_t,
+                     const int64_t* s_0, const float* alpha_bar_t, const uint8_t* mask_generate, int N, int L, float* block_sums, float* dR_pred,
+                     float* dp_pred, float* dc_denoised, abopt_stream stream);
 int abopt_heads_epilogue_forward(const float* R, const float* v_t, const float* eps_crd, const float* eps_rot, const uint8_t* mask_generate,
                                  float* v_next, float* R_next, float* eps_pos, int64_t rows, int grad_mode, abopt_stream stream);
 int abopt_heads_epilogue_backward(const float* R, const float* eps_rot, const uint8_t* mask_generate, const float* dR_next, const float* deps_pos,

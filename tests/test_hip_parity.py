@@ -10,6 +10,7 @@ Tolerances (fp32, stated per SURVEY.md section 8c / BASELINE.md section 4):
 import math
 import pytest
 import torch
+import torch.nn.functional as F
 
 import cases
 from conftest import load_golden, build_model, max_abs
@@ -1274,6 +1275,39 @@ def test_residue_features_native_vs_torch_statement():
         assert set(ga) == set(gb)
         for n in ga:
             assert (ga[n] - gb[n]).abs().max().item() <= 2e-4 * max(1e-6, gb[n].abs().max().item()), (flavour, n)
+
+
+def test_dpm_losses_autograd_function_vs_torch_statement():
+    """training.DpmLosses (abopt_dpm_losses: rotation cosine, position MSE and sequence KL losses of dpm_full.py:199-231 with their
+    gradients in one launch) against the torch statement of the same lines (cosine_embedding_loss, mse_loss, kl_div on the posteriors):
+    sums and the three input gradients; sequence states outside 0..19 and masked rows included."""
+    from ab_opt_amd import training, hip
+    g = torch.Generator().manual_seed(11)
+    N, L = 4, 100
+    R0 = hip.so3_exp(dev(torch.randn(N, L, 3, generator=g)))
+    Rp = (hip.so3_exp(dev(torch.randn(N, L, 3, generator=g))) + dev(torch.randn(N, L, 3, 3, generator=g) * 0.1)).requires_grad_()
+    pp = dev(torch.randn(N, L, 3, generator=g)).requires_grad_()
+    pt = dev(torch.randn(N, L, 3, generator=g))
+    cd = torch.softmax(dev(torch.randn(N, L, 20, generator=g) * 2), -1).requires_grad_()
+    st, s0 = dev(torch.randint(0, 22, (N, L), generator=g)), dev(torch.randint(0, 20, (N, L), generator=g))
+    ab = dev(torch.tensor([0.999, 0.7, 0.2, 0.011]))
+    gen = dev(torch.rand(N, L, generator=g) < 0.6)
+    w = dev(torch.tensor([0.7, -1.3, 2.1]))
+    sums = training.DpmLosses.apply(Rp, R0, pp, pt, cd, st, s0, ab, gen)
+    (sums * w).sum().backward()
+    got = (sums.detach(), Rp.grad.clone(), pp.grad.clone(), cd.grad.clone())
+    Rp.grad = pp.grad = cd.grad = None
+    genf = gen.float()
+    cp, ct = Rp.transpose(-2, -1).reshape(-1, 3), R0.transpose(-2, -1).reshape(-1, 3)
+    lr = F.cosine_embedding_loss(cp, ct, torch.ones(cp.shape[0], dtype=torch.long, device=DEV), reduction='none').reshape(N, L, 3).sum(-1)
+    t_idx = torch.arange(N, device=DEV)
+    post_true = training._posterior(ab, st, s0, t_idx)
+    log_pred = torch.log(training._posterior(ab, st, cd, t_idx) + 1e-8)
+    kl = F.kl_div(input=log_pred, target=post_true, reduction='none', log_target=False).sum(-1)
+    ref = torch.stack([(lr * genf).sum(), (F.mse_loss(pp, pt, reduction='none').sum(-1) * genf).sum(), (kl * genf).sum()])
+    (ref * w).sum().backward()
+    for a, b, name in zip(got, (ref.detach(), Rp.grad, pp.grad, cd.grad), ('sums', 'd R_pred', 'd p_pred', 'd c_den')):
+        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item()), (name, (a - b).abs().max().item())
 
 
 def test_heads_epilogue_autograd_function_vs_torch_statement():
