@@ -145,7 +145,7 @@ constexpr int GLT = GBM + 4;          // row stride of a [k][m] staged tile
 template <bool AT, bool BT>
 __global__ __launch_bounds__(256) void gemm_batched_kernel(const float* __restrict__ A, int lda, int64_t sa, const float* __restrict__ B, int ldb, int64_t sb,
                                                            float* __restrict__ C, int ldc, int64_t sc, int M, int N, int K, int ksplit, int kchunk,
-                                                           int64_t slab_stride, float alpha) {
+                                                           int64_t slab_stride, float alpha, const float* __restrict__ bias, int relu) {
     __shared__ __attribute__((aligned(16))) float As[GBM * GLD > GBK * GLT ? GBM * GLD : GBK * GLT];
     __shared__ __attribute__((aligned(16))) float Bs[GBN * GLD > GBK * GLT ? GBN * GLD : GBK * GLT];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -228,7 +228,9 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float* __restri
         for (int j = 0; j < 2; ++j) {
             const int row = m0 + wm + i * 16 + fm, col = n0 + wn + j * 16 + kq * 4;
             if (row >= M || col >= N) continue;
-            const f32x4 v = acc[i][j] * alpha;
+            f32x4 v = acc[i][j] * alpha;
+            if (bias) { for (int r = 0; r < 4; ++r) if (col + r < N) v[r] += bias[col + r]; }       // y = x W^T + b (and ReLU) in the product's epilogue
+            if (relu) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
             float* cp = C + (int64_t)row * ldc + col;
             if (cvec && col + 3 < N) *reinterpret_cast<f32x4*>(cp) = v;
             else { for (int r = 0; r < 4; ++r) if (col + r < N) cp[r] = v[r]; }
@@ -306,7 +308,7 @@ int launch_colsum(const float* x, int ld, int64_t rows, int cols, float* out, fl
     if (cols <= 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(rows >= 0 && ld >= cols, "colsum: bad dimensions rows=%lld cols=%d ld=%d", (long long)rows, cols, ld);
     const int cblocks = (cols + 127) / 128;
-    int64_t want = rows / 256;
+    int64_t want = rows / 64;
     if (want < 1) want = 1;
     const int cap = 1024 / cblocks > 1 ? 1024 / cblocks : 1;
     int slices = want < cap ? (int)want : cap;
@@ -358,7 +360,7 @@ int launch_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const i
     if (cols <= 0 || nb <= 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(rows >= 0 && ld >= cols && nb <= BKT_MAX, "bucket_colsum: rows=%lld cols=%d ld=%d buckets=%d (max %d)", (long long)rows, cols, ld, nb, BKT_MAX);
     const int cblocks = (cols + 63) / 64;
-    int64_t want = rows / 512;
+    int64_t want = rows / 64;                                   // (4096 rows in 8 slices: 30 us on 16 workgroups; in 64: latency of a 32-row walk)
     if (want < 1) want = 1;
     const int64_t cap = 2048 / cblocks > 1 ? 2048 / cblocks : 1;
     int slices = (int)(want < cap ? want : cap);
@@ -376,13 +378,13 @@ int launch_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const i
 }
 
 int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const float* B, int ldb, int64_t sb, int b_t, float* C, int ldc, int64_t sc,
-                        int M, int N, int K, int batch, float alpha, float* ws, size_t ws_floats, hipStream_t st) {
+                        int M, int N, int K, int batch, float alpha, float* ws, size_t ws_floats, hipStream_t st, const float* bias, int relu) {
     if (M <= 0 || N <= 0 || batch <= 0) return ABOPT_OK;
     ABOPT_CHECK_ARG(K >= 0 && lda >= 1 && ldb >= 1 && ldc >= N, "gemm: bad dimensions M=%d N=%d K=%d lda=%d ldb=%d ldc=%d", M, N, K, lda, ldb, ldc);
     const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN) * batch;
     // split K when the output alone cannot fill the chip (weight gradients: K = number of residues, a few dozen output tiles)
     int ksplit = 1;
-    if (tiles < 128 && K >= 1024 && ws) {
+    if (tiles < 128 && K >= 1024 && ws && !bias && !relu) {      // (an epilogue with bias / ReLU needs the whole sum in one workgroup)
         ksplit = min(min(512 / max(tiles, 1), K / 512), 256);
         while (ksplit > 1 && (size_t)ksplit * batch * M * ldc > ws_floats) --ksplit;
         ksplit = max(ksplit, 1);
@@ -393,7 +395,7 @@ int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const floa
     ABOPT_CHECK_ARG(ksplit == 1 || sc == (int64_t)M * ldc, "gemm: split-K needs densely packed batches of C");
     dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM, batch * ksplit);
 #define ABOPT_GEMM(AT_, BT_) hipLaunchKernelGGL((gemm_batched_kernel<AT_, BT_>), grid, dim3(256), 0, st, A, lda, sa, B, ldb, sb, out, ldc, sc, M, N, K, ksplit, \
-                                                 kchunk, slab, alpha)
+                                                 kchunk, slab, alpha, bias, relu)
     if (a_t) { if (b_t) ABOPT_GEMM(true, true); else ABOPT_GEMM(true, false); }
     else     { if (b_t) ABOPT_GEMM(false, true); else ABOPT_GEMM(false, false); }
 #undef ABOPT_GEMM
@@ -419,9 +421,9 @@ extern "C" int abopt_colsum(const float* x, int ld, int64_t rows, int cols, floa
 }
 
 extern "C" int abopt_gemm(const float* A, int lda, int64_t stride_a, int a_transposed, const float* B, int ldb, int64_t stride_b, int b_transposed,
-                          float* C, int ldc, int64_t stride_c, int M, int N, int K, int batch, float alpha, void* ws, size_t ws_bytes,
-                          abopt_stream stream) {
+                          float* C, int ldc, int64_t stride_c, int M, int N, int K, int batch, float alpha, const float* bias, int relu,
+                          void* ws, size_t ws_bytes, abopt_stream stream) {
     ABOPT_CHECK_ARG(A && B && C, "gemm: NULL operand");
     return abopt::launch_gemm_batched(A, lda, stride_a, a_transposed, B, ldb, stride_b, b_transposed, C, ldc, stride_c, M, N, K, batch, alpha,
-                                      (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
+                                      (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream, bias, relu);
 }

@@ -13,7 +13,7 @@ int launch_linear(const float* X, int ldx, const float* W, int ldw, const float*
 
 // C[b] = alpha A[b] . B[b]^T, operands k-contiguous or k-strided (training path); ws: split-K scratch (optional)
 int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const float* B, int ldb, int64_t sb, int b_t, float* C, int ldc, int64_t sc,
-                        int M, int N, int K, int batch, float alpha, float* ws, size_t ws_floats, hipStream_t st);
+                        int M, int N, int K, int batch, float alpha, float* ws, size_t ws_floats, hipStream_t st, const float* bias = nullptr, int relu = 0);
 
 int launch_colsum(const float* x, int ld, int64_t rows, int cols, float* out, float* ws, size_t ws_floats, hipStream_t st);
 

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -124,7 +124,7 @@ def lib():
                                       c_f, c_f, c_i64, c_u8, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,
                                       c_f, c_f, c_i64, c_f, c_f, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.abopt_gemm.argtypes = [c_f, C.c_int, C.c_int64, C.c_int, c_f, C.c_int, C.c_int64, C.c_int, c_f, C.c_int, C.c_int64,
-                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_colsum.argtypes = [c_f, C.c_int, C.c_int64, C.c_int, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_prof_enable.argtypes = [C.c_int]
         L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
@@ -700,10 +700,10 @@ def _operand(t):
     return t, t.stride(1), (t.stride(0) if b > 1 else 0), 0
 
 
-def gemm(a, b, alpha=1.0, out=None):
+def gemm(a, b, alpha=1.0, out=None, bias=None, relu=False):
     """C = alpha * a @ b^T on libabopt_hip.so (include/abopt.h: abopt_gemm).  a (M,K) or (B,M,K); b (N,K) or (B,N,K); either may be
     a transposed VIEW (x.t(), x.transpose(1, 2)): the kernel reads k-strided operands in place.  Batch broadcasting: a 2-D operand
-    serves every batch."""
+    serves every batch.  bias (N,) and relu: y = relu(a b^T + bias) in the product's epilogue."""
     nb = max(a.shape[0] if a.dim() == 3 else 1, b.shape[0] if b.dim() == 3 else 1)
     a, lda, sa, at = _operand(a.float())
     b, ldb, sb, bt = _operand(b.float())
@@ -712,10 +712,13 @@ def gemm(a, b, alpha=1.0, out=None):
     c = torch.empty(nb, M, N, dtype=torch.float32, device=a.device) if out is None else out
     tiles = ((M + 63) // 64) * ((N + 63) // 64) * nb
     ws = None
-    if tiles < 128 and K >= 1024:
+    if tiles < 128 and K >= 1024 and bias is None and not relu:
         ws = Workspace.get(min(256, max(K // 512, 1)) * nb * M * N * 4, a.device)
+    if bias is not None:
+        bias = bias.detach().float().contiguous()
+        assert bias.numel() == N
     _check(lib().abopt_gemm(ptr(a, torch.float32, strided=True), lda, sa, at, ptr(b, torch.float32, strided=True), ldb, sb, bt, ptr(c), N, M * N, M, N, K, nb, float(alpha),
-                            ptr(ws, optional=True), ws.numel() if ws is not None else 0, stream()))
+                            ptr(bias, torch.float32, optional=True), int(bool(relu)), ptr(ws, optional=True), ws.numel() if ws is not None else 0, stream()))
     return c
 
 

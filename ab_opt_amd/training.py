@@ -82,13 +82,12 @@ class NativeLinear(torch.autograd.Function):
     dpm_full.py:39-59)."""
 
     @staticmethod
-    def forward(ctx, x, w, b=None):
+    def forward(ctx, x, w, b=None, relu=False):
+        """relu=True: y = relu(x W^T + b) as ONE launch (bias and clamp in the product's epilogue); the backward masks d y with y > 0."""
         from . import hip
         x2 = x.reshape(-1, x.shape[-1])
-        y = hip.gemm(x2, w)[0]
-        if b is not None:
-            y += b
-        ctx.save_for_backward(x2, w)
+        y = hip.gemm(x2, w, bias=b, relu=relu)[0]
+        ctx.save_for_backward(x2, w, y if relu else None)
         ctx.has_bias = b is not None
         return y.view(x.shape[:-1] + (w.shape[0],))
 
@@ -96,24 +95,36 @@ class NativeLinear(torch.autograd.Function):
     @torch.no_grad()
     def backward(ctx, dy):
         from . import hip
-        x2, w = ctx.saved_tensors
-        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        x2, w, y = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dy2 = torch.ops.aten.threshold_backward(dy2.contiguous(), y, 0.0) if y is not None else dy2.contiguous()      # d relu: one kernel
         dx = hip.gemm(dy2, w.t())[0].view(dy.shape[:-1] + (w.shape[1],)) if ctx.needs_input_grad[0] else None
         dw = hip.gemm(dy2.t(), x2.t())[0]
-        return dx, dw, (hip.colsum(dy2) if ctx.has_bias else None)
+        return dx, dw, (hip.colsum(dy2) if ctx.has_bias else None), None
 
 
-def _linear(mod, x):
-    """nn.Linear `mod` applied through NativeLinear on the device (plain F.linear for CPU tensors: the float64 / CPU checkers)."""
+def _linear(mod, x, relu=False):
+    """nn.Linear `mod` (followed by a ReLU if asked) through NativeLinear on the device (plain F.linear for CPU tensors: the float64 /
+    CPU checkers)."""
     if x.is_cuda and x.dtype == torch.float32:
-        return NativeLinear.apply(x, mod.weight, mod.bias)
-    return F.linear(x, mod.weight, mod.bias)
+        return NativeLinear.apply(x, mod.weight, mod.bias, relu)
+    y = F.linear(x, mod.weight, mod.bias)
+    return y.relu() if relu else y
 
 
 def _mlp(seq, x):
-    """nn.Sequential of Linear / ReLU / Softmax modules with the Linear layers on NativeLinear."""
-    for m in seq:
-        x = _linear(m, x) if isinstance(m, torch.nn.Linear) else m(x)
+    """nn.Sequential of Linear / ReLU / Softmax modules with the Linear layers on NativeLinear (a Linear followed by a ReLU is one call)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, torch.nn.Linear):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU)
+            x = _linear(m, x, relu=fuse)
+            i += 2 if fuse else 1
+        else:
+            x = m(x)
+            i += 1
     return x
 
 
@@ -304,7 +315,7 @@ def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_r
     if net.no_bins is None:
         return v_next, R_next, eps_pos, c
     pp = net.prmsd_predictor
-    h = _linear(pp.linear_3, _linear(pp.linear_2, _linear(pp.linear_1, _ln(feat, pp.layer_norm)).relu()).relu())
+    h = _linear(pp.linear_3, _linear(pp.linear_2, _linear(pp.linear_1, _ln(feat, pp.layer_norm), relu=True), relu=True))
     return v_next, R_next, eps_pos, c, h.mean(dim=1)
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 30
+#define ABOPT_ABI_VERSION 31
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -398,9 +398,12 @@ int abopt_reconstruct_backbone_partially(const float* pos_ctx, const float* R_ne
  *   A(m,k) = a_transposed ? A[k*lda + m] : A[m*lda + k]     B(n,k) = b_transposed ? B[k*ldb + n] : B[n*ldb + k]     C(m,n) = C[m*ldc + n]
  * It stands where the reference's autograd calls ATen GEMMs in the backward of the denoiser (D/modules/encoders/ga.py:54-66,81-147,
  * 174-177 and D/modules/diffusion/dpm_full.py:39-59 under torch.autograd).  ws (optional): scratch for split-K partial tiles, used when
- * the output has too few tiles to fill the chip and K >= 1024 (weight gradients); partials are summed in a fixed order. */
+ * the output has too few tiles to fill the chip and K >= 1024 (weight gradients); partials are summed in a fixed order.
+ * bias (optional, [N]) is added to every row and relu != 0 clamps at zero in the product's epilogue: y = relu(x W^T + b), the nn.Linear +
+ * nn.ReLU pairs of the heads / mixer / residue MLPs as one launch (no split-K then). */
 int abopt_gemm(const float* A, int lda, int64_t stride_a, int a_transposed, const float* B, int ldb, int64_t stride_b, int b_transposed,
-               float* C, int ldc, int64_t stride_c, int M, int N, int K, int batch, float alpha, void* ws, size_t ws_bytes, abopt_stream stream);
+               float* C, int ldc, int64_t stride_c, int M, int N, int K, int batch, float alpha, const float* bias, int relu,
+               void* ws, size_t ws_bytes, abopt_stream stream);
 
 /* out[c] = sum over rows of x[r*ld + c] (bias gradients and per-row partials of weight gradients on the training path); deterministic:
  * row slices are summed in a fixed order.  ws (optional): slices * cols floats of scratch. */
