@@ -40,26 +40,39 @@ class _TallLinear(torch.autograd.Function):
     """F.linear for x with millions of rows; weight gradient through _splitk_tn."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        if x.is_cuda and x.dtype == torch.float32:
-            y = hip.gemm(x.reshape(-1, x.shape[-1]), weight)[0].view(x.shape[:-1] + (weight.shape[0],))
-            return y if bias is None else y.add_(bias)
-        return F.linear(x, weight, bias)
+    def forward(ctx, x, weight, bias, relu=False):
+        native = x.is_cuda and x.dtype == torch.float32
+        if native:              # bias and ReLU in the product's epilogue: one launch
+            y = hip.gemm(x.reshape(-1, x.shape[-1]), weight, bias=bias, relu=relu)[0].view(x.shape[:-1] + (weight.shape[0],))
+        else:
+            y = F.linear(x, weight, bias)
+            y = y.relu() if relu else y
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors
+        if y is not None:
+            dy = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0)
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = None
         if ctx.needs_input_grad[0]:
             dx = (hip.gemm(dy2, weight.t())[0] if dy2.is_cuda and dy2.dtype == torch.float32 else dy2 @ weight).view_as(x)
-        return dx, _splitk_tn(dy2, x2), hip.colsum(dy2)
+        return dx, _splitk_tn(dy2, x2), hip.colsum(dy2), None
 
 
 def _tall_mlp(seq, x):
-    for m in seq:
-        x = _TallLinear.apply(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+    mods, i = list(seq), 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = _TallLinear.apply(x, m.weight, m.bias, fuse)
+            i += 2 if fuse else 1
+        else:
+            x = m(x)
+            i += 1
     return x
 
 
