@@ -262,7 +262,8 @@ __global__ __launch_bounds__(128) void ipa_backward_operands_kernel(const float*
 
 // d proj [N,L,2016] (gradients wrt q|k|v and the LOCAL-frame points) from the three batched products
 //   P1 = g Ak = [sum_j g k_j | sum_j g kg_j | sum_j g],  P2 = g^T Aq,  P3 = alpha^T [d feat_node | d agg_pts]      (head-major, 57/57/56 wide)
-// and e[n,i,h] = |qg|^2 rowsum + |kg|^2 colsum - 2 <qg, sum_j g kg_j>, whose sum over (n, i) is d loss / d coef_h (ga.py:108-111)
+// and e[n,i,h] = (|qg|^2 rowsum + |kg|^2 colsum - 2 <qg, sum_j g kg_j>) x d coef_h / d spatial_coef_h, whose sum over (n, i) is
+// d loss / d spatial_coef_h (ga.py:108-111)
 __global__ __launch_bounds__(128) void ipa_backward_assemble_kernel(const float* __restrict__ P1, const float* __restrict__ P2, const float* __restrict__ P3,
                                                                     const float* __restrict__ Aq, const float* __restrict__ Ak, const float* __restrict__ R,
                                                                     const float* __restrict__ spatial_coef, float* __restrict__ dproj, float* __restrict__ e, int L) {
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(128) void ipa_backward_assemble_kernel(const float*
         outs[s3][2] = Rr[2] * gvec[0] + Rr[5] * gvec[1] + Rr[8] * gvec[2];
     }
     part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
-    if (p == 0) e[row * H + h] = part;
+    // d softplus(x)/dx = sigmoid(x); the logit coefficient is -softplus(coef) sqrt(2 / (9 P)) / 2 (ga.py:108-111): e sums to d loss / d spatial_coef
+    if (p == 0) e[row * H + h] = part * (-(1.f / (1.f + expf(-scv))) * 0.08333333333333333f);
 }
 
 int launch_ipa_backward_operands(const float* proj, const float* R, const float* t, float* Aq, float* Ak, float* Av, int N, int L, hipStream_t st) {

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -499,7 +499,7 @@ def ipa_backward_operands(proj_local, R, t):
 
 
 def ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, spatial_coef):
-    """-> d proj_local (N,L,2016), e (N,L,12)  (abopt_ipa_backward_assemble)."""
+    """-> d proj_local (N,L,2016), e (N,L,12) with e.sum((0, 1)) = d loss / d spatial_coef  (abopt_ipa_backward_assemble)."""
     N, _, L, _ = P1.shape
     dproj = torch.empty(N, L, 2016, device=P1.device)
     e = torch.empty(N, L, 12, device=P1.device)

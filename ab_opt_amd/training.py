@@ -179,8 +179,7 @@ class IpaCore(torch.autograd.Function):
         P3 = mm(T(alpha), T(dout_cat))                                              # sum_i alpha_ij [dfn_i | dag_i]
         # scale, spatial-term chain rule, rotation back to the residue frames, re-layout to (N,L,2016): one kernel
         dproj, e = hip.ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, gamma_raw.reshape(-1))
-        gam = gamma_raw.reshape(-1)
-        dgamma = (hip.colsum(e.reshape(-1, e.shape[-1])) * (-torch.sigmoid(gam) * (math.sqrt(2 / (9 * P)) / 2))).reshape(gamma_raw.shape)
+        dgamma = hip.colsum(e.reshape(-1, e.shape[-1])).reshape(gamma_raw.shape)      # the kernel applies d(-softplus(x) sqrt(2/(9P))/2)/dx
         return dproj, dz, None, None, None, dWb, dgamma, None, None
 
 

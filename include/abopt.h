@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 31
+#define ABOPT_ABI_VERSION 32
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -279,8 +279,8 @@ int abopt_ipa_core_train_forward(const float* proj_local, const float* R, const 
 int abopt_ipa_points_backward(const float* dfeat, int ld_dfeat, const float* feat, const float* R, const float* t,
                               float* dout_cat, float* delta, int N, int L, abopt_stream stream);
 /* head-major operands of the backward's batched GEMMs: Aq/Ak [N,12,L,57] = [q|k (32) | points in the global frame (24) | 1],
- * Av [N,12,L,56] = [v | v points]; and the final assembly of d proj_local [N,L,2016] (+ e [N,L,12], whose sum is
- * d loss / d(-softplus(spatial_coef) sqrt(2/(9P))/2)) from P1 = g Ak, P2 = g^T Aq, P3 = alpha^T dout_cat. */
+ * Av [N,12,L,56] = [v | v points]; and the final assembly of d proj_local [N,L,2016] (+ e [N,L,12], whose sum over (N, L) is
+ * d loss / d spatial_coef: the chain through -softplus(.) sqrt(2/(9P))/2 is applied in the kernel) from P1 = g Ak, P2 = g^T Aq, P3 = alpha^T dout_cat. */
 int abopt_ipa_backward_operands(const float* proj_local, const float* R, const float* t, float* Aq, float* Ak, float* Av,
                                 int N, int L, abopt_stream stream);
 int abopt_ipa_backward_assemble(const float* P1, const float* P2, const float* P3, const float* Aq, const float* Ak, const float* R,
