@@ -1405,6 +1405,30 @@ def test_fused_adam_vs_torch_adam(weight_decay, max_norm):
     assert all(torch.equal(p, q) for p, q in zip(got, cp)) and int(c.state[cp[0]]['step'].item()) == 7
 
 
+def test_abopt_gemm_views_splitk_bias_relu_vs_fp64():
+    """abopt_gemm (the training path's strided-batched fp32 product C = alpha a b^T): plain, transposed VIEWS read in place, batch
+    broadcasting, split-K (few output tiles, long K), and the bias / ReLU epilogue, against fp64 matmul; ragged sizes; deterministic."""
+    from ab_opt_amd import hip
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *sh: dev(torch.randn(*sh, generator=g))
+    ok = lambda got, ref: (got.double() - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+    a, b = rnd(70, 33), rnd(45, 33)
+    assert ok(hip.gemm(a, b)[0], a.double() @ b.double().t())
+    at, bt = rnd(33, 70), rnd(33, 45)                                            # both operands as transposed views
+    assert ok(hip.gemm(at.t(), bt.t(), alpha=0.5)[0], 0.5 * (at.double().t() @ bt.double()))
+    A3, B2 = rnd(6, 40, 129), rnd(17, 129)                                      # batch broadcasting of a 2-D operand
+    assert ok(hip.gemm(A3, B2), A3.double() @ B2.double().t())
+    x, dy = rnd(5000, 96), rnd(5000, 64)                                        # weight gradient: 2 output tiles over K = 5000 rows -> split-K
+    dw = hip.gemm(dy.t(), x.t())[0]
+    assert ok(dw, dy.double().t() @ x.double()) and torch.equal(dw, hip.gemm(dy.t(), x.t())[0])
+    w, bias = rnd(200, 96), rnd(200)                                            # y = relu(x W^T + b) in the epilogue
+    assert ok(hip.gemm(x, w, bias=bias)[0], x.double() @ w.double().t() + bias.double())
+    assert ok(hip.gemm(x, w, bias=bias, relu=True)[0], (x.double() @ w.double().t() + bias.double()).clamp_min(0))
+    assert ok(hip.gemm(x, w, relu=True)[0], (x.double() @ w.double().t()).clamp_min(0))
+    col = rnd(300, 320)[:, 64:128]                                              # a column slice (row stride 320) as operand
+    assert ok(hip.gemm(col, w[:10, :64])[0], col.double() @ w[:10, :64].double().t())
+
+
 def test_bucket_colsum_vs_index_add():
     """abopt_bucket_colsum (the relative-position table's gradient on the training path, D/modules/encoders/pair.py:46-53 under autograd):
     rows of a strided column slice summed by bucket, rows with a negative index skipped, against torch.index_add_ in fp64; deterministic."""
