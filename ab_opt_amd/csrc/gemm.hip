@@ -384,7 +384,10 @@ int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const floa
     const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN) * batch;
     // split K when the output alone cannot fill the chip (weight gradients: K = number of residues, a few dozen output tiles)
     int ksplit = 1;
-    if (tiles < 128 && K >= 1024 && ws && !bias && !relu) {      // (an epilogue with bias / ReLU needs the whole sum in one workgroup)
+    // The partial slabs have C's own layout and the slab sum writes every element of it: only for a densely packed C (ldc == N, batches
+    // back to back) -- a C that is a column slice of a wider matrix (ldc > N) or has gaps between batches takes the unsplit kernel
+    const bool dense_c = ldc == N && (batch == 1 || sc == (int64_t)M * ldc);
+    if (tiles < 128 && K >= 1024 && ws && !bias && !relu && dense_c) {      // (an epilogue with bias / ReLU needs the whole sum in one workgroup)
         ksplit = min(min(512 / max(tiles, 1), K / 512), 256);
         while (ksplit > 1 && (size_t)ksplit * batch * M * ldc > ws_floats) --ksplit;
         ksplit = max(ksplit, 1);
@@ -392,7 +395,6 @@ int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const floa
     const int kchunk = ksplit == 1 ? max(K, 1) : ((K + ksplit * GBK - 1) / (ksplit * GBK)) * GBK;
     float* out = ksplit == 1 ? C : ws;
     const int64_t slab = (int64_t)batch * M * ldc;
-    ABOPT_CHECK_ARG(ksplit == 1 || sc == (int64_t)M * ldc, "gemm: split-K needs densely packed batches of C");
     dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM, batch * ksplit);
 #define ABOPT_GEMM(AT_, BT_) hipLaunchKernelGGL((gemm_batched_kernel<AT_, BT_>), grid, dim3(256), 0, st, A, lda, sa, B, ldb, sb, out, ldc, sc, M, N, K, ksplit, \
                                                  kchunk, slab, alpha, bias, relu)

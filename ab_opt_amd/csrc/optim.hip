@@ -52,8 +52,11 @@ __global__ __launch_bounds__(AD_THREADS) void grad_sqsum_kernel(AdamChunk c, flo
 
 // ws[0] = total gradient norm, ws[1] = clip coefficient (torch.nn.utils.clip_grad_norm_: max_norm / (norm + 1e-6), clamped to 1);
 // the step counter moves on by one.  nparts == 0: no clipping.
+// hyper (optional, DEVICE): {lr, beta1, beta2, eps, weight_decay, max_grad_norm} as doubles, read at execution time instead of the by-value
+// arguments -- a captured hipGraph of the training step then follows a learning-rate scheduler (the host refreshes the buffer before a replay).
 __global__ __launch_bounds__(AD_THREADS) void adam_prepare_kernel(const float* __restrict__ partials, int nparts, float max_norm, float* __restrict__ ws,
-                                                                  int64_t* __restrict__ step, float* __restrict__ norm_out) {
+                                                                  int64_t* __restrict__ step, float* __restrict__ norm_out, const double* __restrict__ hyper) {
+    if (hyper) max_norm = (float)hyper[5];
     __shared__ double red[AD_THREADS];
     double s = 0.0;
     for (int i = threadIdx.x; i < nparts; i += AD_THREADS) s += (double)partials[i];
@@ -77,7 +80,8 @@ __global__ __launch_bounds__(AD_THREADS) void adam_prepare_kernel(const float* _
 //   grad (+= weight_decay * param);  exp_avg.lerp_(grad, 1 - beta1);  exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
 //   denom = exp_avg_sq.sqrt() / sqrt(1 - beta2^t) + eps;  param.addcdiv_(exp_avg, denom, value = -lr / (1 - beta1^t))
 __global__ __launch_bounds__(AD_THREADS) void adam_kernel(AdamChunk c, const float* __restrict__ ws, const int64_t* __restrict__ step, double lr, double beta1d,
-                                                          double beta2d, float eps, float weight_decay) {
+                                                          double beta2d, float eps, float weight_decay, const double* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; beta1d = hyper[1]; beta2d = hyper[2]; eps = (float)hyper[3]; weight_decay = (float)hyper[4]; }
     const int b = blockIdx.x, ti = chunk_tensor_of(c, b);
     const int64_t off = (int64_t)(b - c.blk0[ti]) * AD_BLK, n = c.n[ti];
     float* p = c.p[ti];
@@ -119,7 +123,7 @@ extern "C" size_t abopt_adam_ws_floats(int count, const int64_t* numel) { return
 
 extern "C" int abopt_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                                const int64_t* numel, double lr, double beta1, double beta2, double eps, double weight_decay, double max_grad_norm,
-                               int64_t* step, float* ws, size_t ws_floats, float* grad_norm_out, abopt_stream stream) {
+                               int64_t* step, float* ws, size_t ws_floats, float* grad_norm_out, const double* hyper_dev, abopt_stream stream) {
     hipStream_t st = (hipStream_t)stream;
     ABOPT_CHECK_ARG(count >= 0 && step && ws, "adam_step: step counter and workspace are required");
     ABOPT_CHECK_ARG(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0. && lr >= 0. && weight_decay >= 0., "adam_step: lr %g, betas (%g, %g), eps %g", lr, beta1, beta2, eps);
@@ -156,10 +160,10 @@ extern "C" int abopt_adam_step(int count, float* const* params, const float* con
                 return ABOPT_OK;
             })) return rc;
     }
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(AD_THREADS), 0, st, partials, clip ? (int)total_blocks : 0, (float)max_grad_norm, ws, step, grad_norm_out);
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(AD_THREADS), 0, st, partials, clip ? (int)total_blocks : 0, (float)max_grad_norm, ws, step, grad_norm_out, hyper_dev);
     ABOPT_LAUNCH_CHECK();
     return for_chunks([&](const AdamChunk& c, int blocks, int64_t) -> int {
-        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(AD_THREADS), 0, st, c, ws, step, lr, beta1, beta2, (float)eps, (float)weight_decay);
+        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(AD_THREADS), 0, st, c, ws, step, lr, beta1, beta2, (float)eps, (float)weight_decay, hyper_dev);
         ABOPT_LAUNCH_CHECK();
         return ABOPT_OK;
     });

@@ -12,7 +12,8 @@ deliberate and MI355X-first:
     shapes and options): every per-step scalar is a kernel argument baked into its node, the Philox stream position is read from a
     16-byte device buffer at execution time, inputs are copied into the graph's static buffers before a replay.
 """
-import functools
+import collections
+import weakref
 import torch
 import torch.nn as nn
 
@@ -41,14 +42,22 @@ class FullDPM(nn.Module):
         if self.abdock:
             self.prmsd = pRMSDCa(num_bins, dist_min=dist_min, dist_max=dist_max)
         self._host_sched = None
-        self._graphs, self._graph_seen = {}, set()
+        self._graphs, self._graph_seen = collections.OrderedDict(), set()
         self.graph_mode = 'auto'          # 'auto': eager first, captured from the second call with the same signature; True / False
+        self.max_graphs = 4               # captured loops kept (least recently used first out): each pins its own copy of pair_feat, the
+                                          # pair-bias cache, the trajectory and a scratch slab -- about 1.2 GB at N=32, L=256
 
     def __getstate__(self):
         """Captured graphs and host-side caches are per-process objects: a pickled / deep-copied model starts without them."""
         d = dict(self.__dict__)
-        d['_graphs'], d['_graph_seen'], d['_host_sched'] = {}, set(), None
+        d['_graphs'], d['_graph_seen'], d['_host_sched'] = collections.OrderedDict(), set(), None
         return d
+
+    def clear_graphs(self):
+        """Drop every captured loop (and the memory its private pool pins).  Runners that walk many structures of different padded
+        lengths can call this between structures; the cache is bounded by `max_graphs` anyway."""
+        self._graphs.clear()
+        self._graph_seen.clear()
 
     # ------------------------------------------------------------------ helpers
     def _normalize_position(self, p):
@@ -94,8 +103,8 @@ class FullDPM(nn.Module):
 
     # ------------------------------------------------------------------ training loss
     def forward(self, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_res, denoise_structure, denoise_sequence, t=None, noise=None):
-        """dpm_full.py:156-234.  Noising runs in the HIP kernel; the differentiable denoiser + losses currently run as torch
-        ops on the device so autograd supplies the backward (ab_opt_amd/training.py; interim until the IPA backward kernel)."""
+        """dpm_full.py:156-234.  Noising, the denoiser (forward and backward: custom autograd functions over libabopt_hip.so) and the
+        rot / pos / seq losses run in HIP kernels (ab_opt_amd/training.py; DESIGN.md section 7 lists what is still an ATen op)."""
         from .training import fulldpm_loss
         return fulldpm_loss(self, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_res, denoise_structure, denoise_sequence, t=t, noise=noise)
 
@@ -117,13 +126,18 @@ class FullDPM(nn.Module):
         g = self._graphs.get(key)
         if g is None:
             if graph == 'auto' and key not in self._graph_seen:         # a one-off call should not pay for a capture
+                if len(self._graph_seen) >= 64:
+                    self._graph_seen.clear()
                 self._graph_seen.add(key)
                 return self._run_eager(state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
                                        ppl_masked, noise, seed, rng_offset, pbar, stop_after, optimize_mode, use_bias_cache)
             for k in [k for k, v in self._graphs.items() if v.pack is not self.eps_net._pack]:
                 del self._graphs[k]                                     # weights were repacked: those graphs point at dead copies
+            while len(self._graphs) >= max(1, int(self.max_graphs)):
+                self._graphs.popitem(last=False)                        # least recently used: its pool goes back to the allocator
             g = self._graphs[key] = _LoopGraph(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure,
                                                sample_sequence, ppl_masked, stop_after, optimize_mode, use_bias_cache)
+        self._graphs.move_to_end(key)
         self.last_run_info = g.info
         return g.replay(state, res_feat, pair_feat, mask_generate, mask_res, seed, rng_offset)
 
@@ -289,13 +303,20 @@ class _LoopGraph:
         # the scratch slab the capture allocated on the capturing stream lives in this graph's pool: it must not serve another stream user
         self.keep = [hip.Workspace._bufs.pop(k) for k in set(hip.Workspace._bufs) - before]
         self.info = dict(dpm.last_run_info)
+        self._pf_src = None                                             # (weakref to the caller's pair_feat, its _version) of the last copy
 
     def replay(self, state, res_feat, pair_feat, mask_generate, mask_res, seed, rng_offset):
         for dst, src in zip(self.state, state):
             dst.copy_(src)
         self.res_feat.copy_(res_feat.expand_as(self.res_feat))
-        if pair_feat.data_ptr() != self.pair_feat.data_ptr():
+        # pair_feat is the one large input (537 MB at N=32, L=256): when the caller hands over the very tensor object of the last replay,
+        # unmodified (same _version), the static copy is still current.  Identity of the live OBJECT, not of the address: a freed tensor's
+        # address can come back from the allocator with other contents.
+        src = self._pf_src
+        same = src is not None and src[0]() is pair_feat and src[1] == pair_feat._version
+        if not same and pair_feat.data_ptr() != self.pair_feat.data_ptr():
             self.pair_feat.copy_(pair_feat)
+            self._pf_src = (weakref.ref(pair_feat), pair_feat._version)
         self.mask_generate.copy_(mask_generate)
         self.mask_res.copy_(mask_res)
         self.seed_dev.copy_(torch.tensor([int(seed), int(rng_offset)], dtype=torch.int64))

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -153,7 +153,7 @@ def lib():
         L.abopt_node_frag_floats.restype = C.c_size_t
         L.abopt_adam_ws_floats.restype = C.c_size_t
         L.abopt_adam_ws_floats.argtypes = [C.c_int, C.c_void_p]
-        L.abopt_adam_step.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 6 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.abopt_adam_step.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 6 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.abopt_dockq_workspace_bytes.restype = C.c_size_t
         L.abopt_dockq_workspace_bytes.argtypes = [C.c_int]
         L.abopt_dockq_lite.argtypes = [c_f, c_u8, C.c_int, c_f, c_u8, C.c_void_p, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -703,13 +703,20 @@ def _operand(t):
 def gemm(a, b, alpha=1.0, out=None, bias=None, relu=False):
     """C = alpha * a @ b^T on libabopt_hip.so (include/abopt.h: abopt_gemm).  a (M,K) or (B,M,K); b (N,K) or (B,N,K); either may be
     a transposed VIEW (x.t(), x.transpose(1, 2)): the kernel reads k-strided operands in place.  Batch broadcasting: a 2-D operand
-    serves every batch.  bias (N,) and relu: y = relu(a b^T + bias) in the product's epilogue."""
+    serves every batch.  bias (N,) and relu: y = relu(a b^T + bias) in the product's epilogue.  out (optional): (M,N) / (B,M,N) fp32 with
+    unit column stride; it may be a column slice of a wider matrix (ldc = its row stride > N) -- the other columns are left untouched."""
     nb = max(a.shape[0] if a.dim() == 3 else 1, b.shape[0] if b.dim() == 3 else 1)
     a, lda, sa, at = _operand(a.float())
     b, ldb, sb, bt = _operand(b.float())
     M, K, N = a.shape[1], a.shape[2], b.shape[1]
     assert b.shape[2] == K, (a.shape, b.shape)
     c = torch.empty(nb, M, N, dtype=torch.float32, device=a.device) if out is None else out
+    ldc, sc = N, M * N
+    if out is not None:
+        o3 = out if out.dim() == 3 else out.unsqueeze(0)
+        if o3.shape != (nb, M, N) or o3.stride(2) != 1 or out.dtype != torch.float32 or not out.is_cuda:
+            raise TypeError('gemm: out must be fp32 (B,M,N) on the device with unit column stride')
+        ldc, sc = o3.stride(1), (o3.stride(0) if nb > 1 else 0)
     tiles = ((M + 63) // 64) * ((N + 63) // 64) * nb
     ws = None
     if tiles < 128 and K >= 1024 and bias is None and not relu:
@@ -717,7 +724,7 @@ def gemm(a, b, alpha=1.0, out=None, bias=None, relu=False):
     if bias is not None:
         bias = bias.detach().float().contiguous()
         assert bias.numel() == N
-    _check(lib().abopt_gemm(ptr(a, torch.float32, strided=True), lda, sa, at, ptr(b, torch.float32, strided=True), ldb, sb, bt, ptr(c), N, M * N, M, N, K, nb, float(alpha),
+    _check(lib().abopt_gemm(ptr(a, torch.float32, strided=True), lda, sa, at, ptr(b, torch.float32, strided=True), ldb, sb, bt, ptr(c, torch.float32, strided=True), ldc, sc, M, N, K, nb, float(alpha),
                             ptr(bias, torch.float32, optional=True), int(bool(relu)), ptr(ws, optional=True), ws.numel() if ws is not None else 0, stream()))
     return c
 
@@ -781,10 +788,13 @@ def bucket_colsum(x, idx, buckets):
     return out
 
 
-def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay=0.0, max_grad_norm=None, grad_norm_out=None, ws=None):
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay=0.0, max_grad_norm=None, grad_norm_out=None, ws=None,
+              hyper_dev=None):
     """clip_grad_norm_ + torch.optim.Adam.step for a list of fp32 tensors in a handful of launches (abopt_adam_step; A/train.py:116-117).
     step: int64 device tensor of one element, incremented by the call.  grad_norm_out (1 float on the device) receives the unclipped norm
-    when max_grad_norm is given.  The gradient tensors are read, not rewritten.  ws: the caller's scratch (adam_ws_bytes), else the shared one."""
+    when max_grad_norm is given.  The gradient tensors are read, not rewritten.  ws: the caller's scratch (adam_ws_bytes), else the shared one.
+    hyper_dev: 6 float64 on the device {lr, beta1, beta2, eps, weight_decay, max_grad_norm}, read by the kernels instead of the scalars
+    (graph replays follow a scheduler)."""
     n = len(params)
     if n == 0:
         return
@@ -799,7 +809,7 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, w
         ws = Workspace.get(need * 4, params[0].device)
     _check(lib().abopt_adam_step(n, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), numel, lr, beta1, beta2, eps, weight_decay,
                                  float(max_grad_norm) if max_grad_norm is not None else 0.0, ptr(step, torch.int64), ptr(ws), need,
-                                 ptr(grad_norm_out, torch.float32, optional=True), stream()))
+                                 ptr(grad_norm_out, torch.float32, optional=True), ptr(hyper_dev, torch.float64, optional=True), stream()))
 
 
 def adam_ws_bytes(params):

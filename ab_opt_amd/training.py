@@ -361,7 +361,9 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
     if t is None:
         t = torch.randint(0, dpm.num_steps, (N,), dtype=torch.long, device=dev)
     h = dpm._sched_host()
-    seed_dev = getattr(dpm, '_train_seed_dev', None)          # GraphedTrainStep: the Philox position comes from device memory (replayable)
+    # GraphedTrainStep: the Philox position comes from device memory (replayable).  Only while that object runs its own step (its
+    # warm-up, capture): an eager model(batch) in between -- a validation pass -- draws a fresh seed, or takes the caller's, as always
+    seed_dev = getattr(dpm, '_train_seed_dev', None) if seed is None else None
     seed = 0 if seed_dev is not None else (dpm._new_seed() if seed is None else int(seed))
     grad_mode = torch.is_grad_enabled()         # so3.py:12-16: the log map clamps at -0.999 under autograd, -1.0 in no_grad validation passes
     with torch.no_grad():                       # noising has no learnable parameters; native kernel (transition.py:62-78,120-144,179-200)
@@ -440,6 +442,20 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError('FusedAdam: invalid hyper-parameters')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._steps, self._ws, self._norm = {}, {}, {}
+        self._hyper, self._hyper_host = {}, {}          # per group: 6 float64 on the device (what the kernels read) and the tuple last uploaded
+
+    def refresh_hyper(self, max_grad_norm=None):
+        """Upload lr / betas / eps / weight_decay (/ max_grad_norm) of every group to the device buffers the kernels read, if they changed.
+        step() calls this itself outside a graph capture; GraphedTrainStep calls it before every replay, so a scheduler's change to
+        param_groups takes effect in the replayed step (a host scalar baked into the captured launch would not)."""
+        for gi, group in enumerate(self.param_groups):
+            if gi not in self._hyper:
+                continue
+            vals = (float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']), float(group['weight_decay']),
+                    float(max_grad_norm) if max_grad_norm is not None else 0.0)
+            if self._hyper_host.get(gi) != vals:
+                self._hyper[gi].copy_(torch.tensor(vals, dtype=torch.float64))
+                self._hyper_host[gi] = vals
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -463,6 +479,8 @@ class FusedAdam(torch.optim.Optimizer):
                 first = int(torch.as_tensor(loaded[0]).reshape(-1)[0].item()) if loaded else 0
                 self._steps[gi] = torch.full((1,), first, dtype=torch.int64, device=dev)
                 self._norm[gi] = torch.zeros(1, dtype=torch.float32, device=dev)
+            if gi not in self._hyper:
+                self._hyper[gi] = torch.zeros(6, dtype=torch.float64, device=dev)
             for p in ps:
                 st = self.state[p]
                 if st.get('step') is not self._steps[gi]:
@@ -474,9 +492,16 @@ class FusedAdam(torch.optim.Optimizer):
             if gi not in self._ws or self._ws[gi].numel() < need:
                 self._ws[gi] = torch.empty(need, dtype=torch.uint8, device=dev)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            if not torch.cuda.is_current_stream_capturing():
+                self.refresh_hyper(max_grad_norm)
             hip.adam_step([p.data for p in ps], grads, [self.state[p]['exp_avg'] for p in ps], [self.state[p]['exp_avg_sq'] for p in ps],
                           self._steps[gi], group['lr'], group['betas'][0], group['betas'][1], group['eps'], group['weight_decay'],
-                          max_grad_norm=max_grad_norm, grad_norm_out=self._norm[gi] if max_grad_norm is not None else None, ws=self._ws[gi])
+                          max_grad_norm=max_grad_norm, grad_norm_out=self._norm[gi] if max_grad_norm is not None else None, ws=self._ws[gi],
+                          hyper_dev=self._hyper[gi])
+            # the kernel wrote the parameters through raw pointers: tell autograd / the packed-weight caches (modules.GABlock.packed keys
+            # its inference copies on _version) that they changed
+            if not torch.cuda.is_current_stream_capturing():
+                torch._C._increment_version(ps)
             norms.append(self._norm[gi])
         if max_grad_norm is None or not norms:
             return None
@@ -491,7 +516,10 @@ class GraphedTrainStep:
     generator (graph-aware), the noising kernel reads its Philox position from a 16-byte device buffer refreshed before every replay,
     and the optimizer must be capturable: training.FusedAdam, or torch.optim.Adam(..., capturable=True).  The batch is copied into the
     graph's static tensors; losses are returned as a dict of 0-d device tensors (valid until the next call).  Shapes, the set of
-    parameters and `loss_weights` are fixed at construction; build a new object when they change."""
+    parameters and `loss_weights` are fixed at construction; build a new object when they change.  Optimizer hyper-parameters (lr,
+    betas, eps, weight_decay, the clip norm) are NOT frozen with FusedAdam: its kernels read them from a device buffer this object
+    refreshes from `param_groups` before every replay, so ReduceLROnPlateau / MultiStepLR (A/diffab/utils/train.py:39-60) work
+    unchanged; with torch's capturable Adam a changed host-scalar lr raises instead of being ignored."""
 
     def __init__(self, model, optimizer, batch, loss_weights=None, max_grad_norm=None, warmup=3):
         from . import hip
@@ -501,7 +529,6 @@ class GraphedTrainStep:
         self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         dpm = model.diffusion
         self.seed_dev = torch.zeros(2, dtype=torch.int64, device=dev)
-        dpm._train_seed_dev = self.seed_dev
         self._set_seed(dpm)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -522,7 +549,12 @@ class GraphedTrainStep:
 
     def _one_step(self):
         self.opt.zero_grad(set_to_none=True)
-        losses = self.model(dict(self.static))
+        dpm = self.model.diffusion
+        dpm._train_seed_dev = self.seed_dev                            # for this step only (fulldpm_loss)
+        try:
+            losses = self.model(dict(self.static))
+        finally:
+            dpm._train_seed_dev = None
         total = sum(v * (self.weights[k] if self.weights is not None else 1.0) for k, v in losses.items())
         total.backward()
         if isinstance(self.opt, FusedAdam):
@@ -538,8 +570,24 @@ class GraphedTrainStep:
             if torch.is_tensor(v) and k in self.static:
                 self.static[k].copy_(v)
         self._set_seed(self.model.diffusion)
-        self.graph.replay()
+        if isinstance(self.opt, FusedAdam):
+            self.opt.refresh_hyper(self.max_grad_norm)                 # a scheduler may have moved lr since the last replay
+            self.graph.replay()
+            torch._C._increment_version([p for g in self.opt.param_groups for p in g['params']])   # raw-pointer writes inside the graph
+        else:
+            self._check_frozen_hyper()
+            self.graph.replay()
         return self.losses
+
+    def _check_frozen_hyper(self):
+        """torch.optim.Adam(capturable=True) keeps lr as a host scalar baked into the captured kernels unless lr is a tensor: refuse to
+        replay silently with a stale value."""
+        cur = [(g['lr'] if not torch.is_tensor(g['lr']) else None, g.get('betas'), g.get('eps'), g.get('weight_decay')) for g in self.opt.param_groups]
+        if getattr(self, '_hyper0', None) is None:
+            self._hyper0 = cur
+        elif cur != self._hyper0:
+            raise RuntimeError('GraphedTrainStep: optimizer hyper-parameters changed after capture; use training.FusedAdam (reads them from '
+                               'device memory at replay), a tensor lr, or build a new GraphedTrainStep')
 
     def close(self):
         self.model.diffusion._train_seed_dev = None

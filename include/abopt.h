@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 32
+#define ABOPT_ABI_VERSION 33
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -425,11 +425,15 @@ int abopt_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const in
  *                       are NOT rewritten) and the unclipped norm is stored in grad_norm_out[0] (device, may be NULL); <= 0: no clipping
  *   ws    : device scratch of abopt_adam_ws_floats(count, numel) floats.
  * Hyper-parameters are doubles, as Python holds them: 1 - beta and the bias corrections are formed in double and rounded once, as torch does.
+ *   hyper_dev (optional, DEVICE, 6 doubles {lr, beta1, beta2, eps, weight_decay, max_grad_norm}): read by the kernels at execution time
+ *   INSTEAD of the by-value arguments, so a captured hipGraph of the step follows a learning-rate scheduler (the reference's loops use
+ *   ReduceLROnPlateau / MultiStepLR, A/diffab/utils/train.py:39-60): the host rewrites the buffer before a replay.  Whether clipping
+ *   happens at all is still decided by the by-value max_grad_norm > 0 (it changes the launch list).
  * Deterministic (block partials of the norm are summed in a fixed order); capturable into a hipGraph (pointers travel as kernel arguments). */
 size_t abopt_adam_ws_floats(int count, const int64_t* numel);
 int abopt_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                     const int64_t* numel, double lr, double beta1, double beta2, double eps, double weight_decay, double max_grad_norm,
-                    int64_t* step, float* ws, size_t ws_floats, float* grad_norm_out, abopt_stream stream);
+                    int64_t* step, float* ws, size_t ws_floats, float* grad_norm_out, const double* hyper_dev, abopt_stream stream);
 
 int abopt_commonness_score(const float* structs, float* score, int B, int n, abopt_stream stream);
 

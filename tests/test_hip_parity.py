@@ -1405,6 +1405,82 @@ def test_fused_adam_vs_torch_adam(weight_decay, max_norm):
     assert all(torch.equal(p, q) for p, q in zip(got, cp)) and int(c.state[cp[0]]['step'].item()) == 7
 
 
+@pytest.mark.gpu
+def test_fused_adam_hyper_parameters_follow_the_scheduler_under_graph_replay():
+    """A captured step must not freeze lr (round-3 advisor finding): FusedAdam's kernels read {lr, betas, eps, weight_decay, clip norm}
+    from a device buffer that is refreshed from param_groups outside the capture.  Three replays with MultiStepLR-style changes of lr
+    against the same steps taken eagerly with torch.optim.Adam; and the parameters' _version moves (packed-weight caches key on it)."""
+    from ab_opt_amd import training
+    g = torch.Generator().manual_seed(3)
+    shapes = [(257,), (64, 33), (5,)]
+    ref = [torch.nn.Parameter(torch.randn(sh, generator=g).to(DEV)) for sh in shapes]
+    got = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    grads = [torch.randn(sh, generator=g).to(DEV) for sh in shapes]
+    for p, q, gr in zip(ref, got, grads):
+        p.grad, q.grad = gr.clone(), gr.clone()
+    a = torch.optim.Adam(ref, lr=1e-2)
+    b = training.FusedAdam(got, lr=1e-2)
+    b.step(max_grad_norm=1.0)                                                   # eager warm-up step (allocates state)
+    torch.nn.utils.clip_grad_norm_(ref, 1.0); a.step()
+    for p, gr in zip(ref, grads):
+        p.grad = gr.clone()
+    v0 = got[0]._version
+    graph = torch.cuda.CUDAGraph()
+    snap = [q.detach().clone() for q in got]
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        b.step(max_grad_norm=1.0)
+    for q, s0 in zip(got, snap):                                                # a capture records, it does not execute
+        assert torch.equal(q, s0)
+    for lr, clip in ((1e-2, 1.0), (1e-3, 1.0), (5e-4, 0.25)):
+        for grp in b.param_groups:
+            grp['lr'] = lr
+        for grp in a.param_groups:
+            grp['lr'] = lr
+        b.refresh_hyper(clip)
+        graph.replay()
+        for p, gr in zip(ref, grads):
+            p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, clip); a.step()
+        for p, q in zip(ref, got):
+            assert (p - q).abs().max().item() <= 2e-6 * max(1.0, p.abs().max().item()), (lr, clip)
+    assert int(b.state[got[0]]['step'].item()) == 4
+    b.step(max_grad_norm=1.0)
+    assert got[0]._version > v0
+
+
+@pytest.mark.gpu
+def test_loop_graph_cache_is_bounded_and_skips_unchanged_pair_feat():
+    """graph_mode='auto' keeps at most `max_graphs` captured loops (round-3 advisor finding: one pinned pool per shape seen twice, never
+    evicted) and a replay with the very same, unmodified pair_feat tensor skips the copy into the graph's static buffer -- but never
+    serves stale contents: an in-place change (new _version) or another tensor object is copied."""
+    m = build_model(10, 3, device=DEV)
+    dpm = m.diffusion
+    dpm.max_graphs = 2
+    outs = {}
+    for L in (32, 48, 64, 32):
+        args = synth.eps_inputs(2, L, [L, L - 5], [(4, 12)], num_steps=10, t=7)
+        v, p, s, rf, pf, beta, gen, mres = [dev(a) for a in args]
+        for rep in range(3):
+            tv = dpm.sample(v, p, s, rf, pf, gen, mres, seed=5, graph='auto')
+        outs[L] = tv[0][1].clone()
+        assert len(dpm._graphs) <= 2
+    assert len(dpm._graphs) == 2
+    g = next(reversed(dpm._graphs.values()))
+    assert g._pf_src is not None and g._pf_src[0]() is pf
+    ref = dpm.sample(v, p, s, rf, pf, gen, mres, seed=5, graph=False)[0][1]
+    assert torch.equal(ref, outs[32])
+    pf.mul_(0.5)                                                                # same object, new version: must be copied again
+    a = dpm.sample(v, p, s, rf, pf, gen, mres, seed=5, graph='auto')[0][1]
+    b = dpm.sample(v, p, s, rf, pf, gen, mres, seed=5, graph=False)[0][1]
+    assert torch.equal(a, b) and not torch.equal(a, ref)
+    pf2 = pf * 2.0                                                              # another object
+    a = dpm.sample(v, p, s, rf, pf2, gen, mres, seed=5, graph='auto')[0][1]
+    assert torch.equal(a, ref)
+    dpm.clear_graphs()
+    assert len(dpm._graphs) == 0
+
+
 def test_abopt_gemm_views_splitk_bias_relu_vs_fp64():
     """abopt_gemm (the training path's strided-batched fp32 product C = alpha a b^T): plain, transposed VIEWS read in place, batch
     broadcasting, split-K (few output tiles, long K), and the bias / ReLU epilogue, against fp64 matmul; ragged sizes; deterministic."""
@@ -1427,6 +1503,16 @@ def test_abopt_gemm_views_splitk_bias_relu_vs_fp64():
     assert ok(hip.gemm(x, w, relu=True)[0], (x.double() @ w.double().t()).clamp_min(0))
     col = rnd(300, 320)[:, 64:128]                                              # a column slice (row stride 320) as operand
     assert ok(hip.gemm(col, w[:10, :64])[0], col.double() @ w[:10, :64].double().t())
+    # C as a column slice of a wider matrix (ldc > N) with a split-K shape: the columns outside the slice, and the memory past the last
+    # row, stay untouched (round-3 advisor finding: the slab sum used to write all M * ldc elements)
+    wide = torch.full((64 + 1, 200), 7.0, device=DEV)
+    hip.gemm(dy.t(), x.t(), out=wide[:64, 50:146])
+    assert ok(wide[:64, 50:146], dy.double().t() @ x.double())
+    assert (wide[:64, :50] == 7).all() and (wide[:64, 146:] == 7).all() and (wide[64] == 7).all()
+    cb = torch.full((3, 20, 40), 7.0, device=DEV)                                # batched, gaps between the batches of C
+    a3, b3 = rnd(3, 20, 2048), rnd(3, 24, 2048)
+    hip.gemm(a3, b3, out=cb[:, :, 8:32])
+    assert ok(cb[:, :, 8:32], a3.double() @ b3.double().transpose(1, 2)) and (cb[:, :, :8] == 7).all() and (cb[:, :, 32:] == 7).all()
 
 
 def test_bucket_colsum_vs_index_add():
