@@ -83,6 +83,13 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
         if ((rc = launch_linear(x, F, w->w_node, F, nullptr, s.proj, NP, (int)M, ABOPT_NODE_PROJ, F, false, st))) return rc;
         if ((rc = launch_ipa_frags(s.proj, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st))) return rc;
     }
+    if (!dbg && pbc && w->w_out_terms && w->w_mlp_frag) {
+        // core + tail as one kernel (feat stays on the chip) wherever the 32-row core is the one to run; bit-identical to the two launches below
+        int fused = 0;
+        if ((rc = launch_ipa_block_fused(s.qf, s.kvf, z, mask, R, t, pbc, N, L, st, z_shared, w->w_out_terms, w->w_mlp_frag, x, w->b_out, w->ln1_gamma,
+                                         w->ln1_beta, w->b_mlp0, w->b_mlp1, w->b_mlp2, w->ln2_gamma, w->ln2_beta, x_out, &fused))) return rc;
+        if (fused) return ABOPT_OK;
+    }
     float* feat = (dbg && dbg->feat) ? dbg->feat : s.feat;
     if ((rc = launch_ipa_core(s.qf, s.kvf, z, mask, R, t, w->w_pair_bias, feat,
                               dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, N, L, st, z_shared, s.split, s.split_floats))) return rc;
@@ -126,6 +133,11 @@ extern "C" size_t abopt_heads_frag_floats(void) { return heads_wfrag_floats(); }
 extern "C" size_t abopt_mixer_frag_floats(void) { return mixer_wfrag_floats(); }
 extern "C" size_t abopt_out_frag_floats(void) { return out_wfrag_floats(); }
 extern "C" size_t abopt_mlp_frag_floats(void) { return mlp_wfrag_floats(); }
+extern "C" size_t abopt_out_terms_floats(void) { return out_wterms_floats(); }
+extern "C" int abopt_out_frag_terms(const float* w_out_frag, float* w_out_terms, abopt_stream stream) {
+    ABOPT_CHECK_ARG(w_out_frag && w_out_terms, "out_frag_terms: NULL argument");
+    return launch_out_frag_terms(w_out_frag, w_out_terms, (hipStream_t)stream);
+}
 extern "C" int abopt_pack_tail_weights(const float* w_out, const float* w_mlp0, const float* w_mlp1, const float* w_mlp2, float* w_out_frag,
                                        float* w_mlp_frag, float* w_mlpT_frag, abopt_stream stream) {
     ABOPT_CHECK_ARG(w_out && w_mlp0 && w_mlp1 && w_mlp2 && w_out_frag && w_mlp_frag, "pack_tail_weights: NULL argument");

@@ -23,7 +23,7 @@
 // Operands arrive pre-arranged in MFMA fragment order (ipa.hip: ipa_frags_kernel): every global load of the A / C waves and
 // every LDS access of the S/P tile is a conflict-free, fully coalesced 16 bytes per lane.
 #include <cstdlib>
-#include "ipa_common.h"
+#include "tail_common.h"
 #include "kernels.h"
 
 // Developer ablations (never in the shipped build): make CXXEXTRA=-DCORE_ABL=<bits>.  bit 0: pair waves load z only once;
@@ -62,6 +62,18 @@ constexpr int SPLIT_ROW = H * C + H * D + H * P * 3;   // 1440 unnormalised accu
 // position of key group kq (keys 4 kq .. 4 kq + 3) inside head h's 16-key row of the S/P tile.  The rotation by h >> 1 makes the
 // pair waves' 16-byte reads AND writes (lane = (head, key group)) bank-conflict free; see DESIGN.md section 3.1.
 __device__ __forceinline__ int sp_off(int h, int kq) { return h * JC + 4 * ((kq + (h >> 1)) & 3); }
+
+// Aggregated point back to the residue frame: l = R^T (a - t) (geometry.py:94-117), its norm and 1 / (norm + 1e-4) (ga.py:138-139), with the
+// operation order written out -- every kernel that produces these feature columns (one-block, persistent, 32-row, key-split merge, fused
+// core + tail) calls this, so their results agree bit for bit whatever the compiler would contract elsewhere.
+__device__ __forceinline__ void point_local(float dx, float dy, float dz, float r0, float r1, float r2, float r3, float r4, float r5, float r6, float r7,
+                                            float r8, float& lx, float& ly, float& lz, float& d, float& inv) {
+    lx = __builtin_fmaf(r6, dz, __builtin_fmaf(r3, dy, r0 * dx));
+    ly = __builtin_fmaf(r7, dz, __builtin_fmaf(r4, dy, r1 * dx));
+    lz = __builtin_fmaf(r8, dz, __builtin_fmaf(r5, dy, r2 * dx));
+    d = sqrtf(__builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx)));
+    inv = 1.f / (d + 1e-4f);
+}
 
 struct CoreLds {
     float* sp;      // [3][BI][SROW]
@@ -433,11 +445,8 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float dx = a[(3 * k) >> 2][(3 * k) & 3] - t0, dy = a[(3 * k + 1) >> 2][(3 * k + 1) & 3] - t1, dz = a[(3 * k + 2) >> 2][(3 * k + 2) & 3] - t2;
-            const float lx = r0 * dx + r3 * dy + r6 * dz;                // R^T (a - t), geometry.py:94-117
-            const float ly = r1 * dx + r4 * dy + r7 * dz;
-            const float lz = r2 * dx + r5 * dy + r8 * dz;
-            const float d = sqrtf(lx * lx + ly * ly + lz * lz);
-            const float inv = 1.f / (d + 1e-4f);                         // ga.py:138-139
+            float lx, ly, lz, d, inv;
+            point_local(dx, dy, dz, r0, r1, r2, r3, r4, r5, r6, r7, r8, lx, ly, lz, d, inv);
             loc[3 * k] = lx; loc[3 * k + 1] = ly; loc[3 * k + 2] = lz;
             dir[3 * k] = lx * inv; dir[3 * k + 1] = ly * inv; dir[3 * k + 2] = lz * inv;
             dist[k] = d;
@@ -497,11 +506,8 @@ __device__ __attribute__((noinline)) void persist_point_epilogue(const float* __
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float dx = a[(3 * k) >> 2][(3 * k) & 3] - t0, dy = a[(3 * k + 1) >> 2][(3 * k + 1) & 3] - t1, dz = a[(3 * k + 2) >> 2][(3 * k + 2) & 3] - t2;
-            const float lx = r0 * dx + r3 * dy + r6 * dz;                // R^T (a - t), geometry.py:94-117
-            const float ly = r1 * dx + r4 * dy + r7 * dz;
-            const float lz = r2 * dx + r5 * dy + r8 * dz;
-            const float d = sqrtf(lx * lx + ly * ly + lz * lz);
-            const float inv = 1.f / (d + 1e-4f);                         // ga.py:138-139
+            float lx, ly, lz, d, inv;
+            point_local(dx, dy, dz, r0, r1, r2, r3, r4, r5, r6, r7, r8, lx, ly, lz, d, inv);
             loc[3 * k] = lx; loc[3 * k + 1] = ly; loc[3 * k + 2] = lz;
             dir[3 * k] = lx * inv; dir[3 * k + 1] = ly * inv; dir[3 * k + 2] = lz * inv;
             dist[k] = d;
@@ -894,9 +900,66 @@ constexpr int BI2 = 32, NPW2 = 4, RPW2 = BI2 / NPW2, NTH2 = 512, HPW = 6;
 #else
 #define C32_L2(x, r) __builtin_fmaf((x), kScale2, mterm_[r])
 #endif
+// FUSE (round 4): the block's tail -- out_transform, mask, residual, LayerNorm, mlp_transition, LayerNorm (ga.py:174-177) -- runs as the
+// EPILOGUE of this kernel on the 32 rows the workgroup owns; `feat` (7.3 KB per row: 60 MB written here and read back by the tail kernel
+// at the bench shape) never leaves the chip and the block is two launches instead of three.  After the key loop:
+//   C waves   normalise their accumulators; node features -> bf16-term planes of staging buffers 0 / 1 (chunks 4 / 5 of the 1824 feature
+//             columns), aggregated points -> LDS.  From then on A and C waves are the four CONSUMERS (one per SIMD): wave 4 + cb owns the
+//             32 output columns 32 cb .. 32 cb + 31 of u = feat . W_out^T for all 32 rows and every k-step -- the eight accumulator chains
+//             (K group, term pair) the stand-alone tail kernel spreads over four waves, in the same order (tail_common.h: ot_chunk_at,
+//             ot_kstep6); W_out streams from L2 as fp32 and is split in registers between the MFMAs, as there.
+//   pair waves are the PRODUCERS: they split their 32 x 768 normalised pair features once (192 registers of packed terms) and, one
+//             192-column chunk per interval, write them -- then what the point epilogue derives from the aggregated points (local
+//             coordinates, distances, directions: chunks 6..9) -- into the staging buffer the consumers read next.  One barrier per chunk.
+//   all waves the stand-alone kernel's phase 2 (tail_common.h: tail_p2_run) on 8 waves.
+// Same arithmetic in the same order as ipa_core32_kernel<false> followed by out_ln_mlp_kernel: bit-identical
+// (tests/test_hip_parity.py::test_fused_block_is_bit_identical).
+#ifndef C32F_ABL
+#define C32F_ABL 0       // developer ablations of the fused epilogue (timing only, results wrong): 1 no W_out refills | 2 no MFMAs | 4 producers write nothing | 8 / 16 C waves: no node-feature staging / no point writes
+#endif
+#ifdef C32F_TIMING   // developer build: clock stamps of every wave of workgroup 17 through the fused epilogue, printed by the launcher
+__device__ long long g_c32f_timing[8][16];
+#define C32F_STAMP(k) if (blockIdx.x == 17 && lane == 0) g_c32f_timing[wave][k] = clock64() - t32f_begin;
+#else
+#define C32F_STAMP(k)
+#endif
+struct TailArgs {
+    const float *wot, *wmf, *x, *ubias, *g1, *be1, *b0, *b1, *b2, *g2, *be2;
+    float* out;
+};
+constexpr int C32_LOOP_LDS_FLOATS = 3 * 32 * SROW + 2 * 32 * SCLD + 32 * SCLD + 32 * 32;      // sp | scl | lsum | mlr (then the key mask)
+constexpr int C32F_PTS_OFF = ((C32_LOOP_LDS_FLOATS * 4 + 2048 + 255) / 256) * 256;               // aggregated points [32][12][24] fp32, behind the key mask of L <= 2048
+constexpr int C32F_PTSLD = H * P * 3 + 4;                                                          // row stride of the aggregated points (292 floats: rows 36 banks apart)
+constexpr int C32F_LDS_BYTES = C32F_PTS_OFF + 32 * C32F_PTSLD * 4;
+constexpr int C32F_U_OFF = 0, C32F_YS_OFF = MR * XLD * 4, C32F_APA_OFF = 2 * MR * XLD * 4;
+constexpr int C32F_BIAS_OFF = 2 * OT_STAGE;                                                     // the three MLP biases: free LDS behind the staging buffers, filled during the dump
+static_assert(2 * OT_STAGE <= 3 * 32 * SROW * 4, "staging buffers must fit into the S/P tile");
+static_assert(C32F_BIAS_OFF + 3 * F * 4 <= 3 * 32 * SROW * 4 && C32F_APA_OFF + 3 * AP_PLANE <= 2 * OT_STAGE && 3 * AP_PLANE <= 32 * C32F_PTSLD * 4, "phase-2 buffers of the fused tail");
+static_assert(C32F_LDS_BYTES <= 160 * 1024, "LDS of the fused block kernel");
+
+// a product rounded to fp32 HERE: the values below go straight into split_pair's `e - h`, which the compiler would otherwise contract
+// with the multiplication into one fma (an exact product minus h) -- the two-launch form rounds the product when it stores feat
+__device__ __forceinline__ float mul_rn(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// four consecutive feature columns of one row -> their three bf16 planes of a staging buffer
+__device__ __forceinline__ void stage_put4(char* buf, int row, int col, float v0, float v1, float v2, float v3) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair(v0, v1, h0, m0, l0);
+    split_pair(v2, v3, h1, m1, l1);
+    char* d = buf + row * OT_SROW + col * 2;
+    *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(d + OT_PLANE) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(d + 2 * OT_PLANE) = make_uint2(l0, l1);
+}
+
+template <bool FUSE>
 __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restrict__ qfrag, const float* __restrict__ kvfrag, const float* __restrict__ z,
                                                           const uint8_t* __restrict__ mask, const float* __restrict__ R, const float* __restrict__ t,
-                                                          float* __restrict__ feat, const float* __restrict__ pbc, int L, int nib2, int xcd_remap, int z_shared) {
+                                                          float* __restrict__ feat, const float* __restrict__ pbc, int L, int nib2, int xcd_remap, int z_shared,
+                                                          TailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sp = reinterpret_cast<float*>(smem_raw);                     // [3][BI2][SROW]
     float* scl = sp + 3 * BI2 * SROW;                                   // [2][BI2][SCLD]
@@ -912,6 +975,9 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunk = (L + JC - 1) / JC, nib16 = (L + BI - 1) / BI;
+#ifdef C32F_TIMING
+    const long long t32f_begin = clock64();
+#endif
 #ifdef C32_TIMING   // developer build: per-role clocks of workgroup 17: total | barrier waits in the chunk loop | wall clock (100 MHz ticks)
     const long long t_begin = clock64(), w_begin = wall_clock64();
     long long t_wait = 0;
@@ -927,6 +993,103 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
     const int64_t rowbase = (int64_t)n * L;
     const int64_t zbase = z_shared ? 0 : rowbase;
     auto fill_mask = [&]() { for (int e = tid; e < nchunk * JC; e += NTH2) mk[e] = (e < L) ? mask[rowbase + e] : 0; };
+    // ---- fused tail (FUSE): LDS views valid after barrier F1, and the consumer role (A and C waves after their loops)
+    char* const stage = smem_raw;                                               // [2][3][32][OT_SROW]: aliases the S/P tile
+    float* const ptsf = reinterpret_cast<float*>(smem_raw + C32F_PTS_OFF);      // [32][H][24]
+    const int64_t row0f = rowbase + i0, row_endf = rowbase + L;               // the 32 rows of this block in the flattened [N L] order
+    TailP2Pre<NTH2 / 64> pre;                                                   // what phase 2 needs from global memory: requested while phase 1 finishes
+    constexpr int RD = 8;                                                       // W_out k-steps in flight per consumer wave: 8 x 3 KB of terms, 96 KB per CU
+    // W_out arrives PRE-SPLIT here (ta.wot: the bf16 terms out_ln_mlp_kernel forms in registers, made once per weight version by
+    // out_frag_terms_kernel with the same split): one consumer wave per SIMD has nobody to hide 44 VALU operations per k-step behind --
+    // with the split in registers the phase was bound by that wave's instruction issue (466 cycles per k-step, 64k cycles in all).
+    struct WT { u32x4 h, m, l; };
+    auto consumer = [&](int cb, WT (&wt)[RD]) {
+        // k-step number i of the sequence = position i / 12, (K group, slot) i % 12  ->  k-step 12 chunk(position) + i % 12 of W_out
+        const u32x4* wfr = reinterpret_cast<const u32x4*>(ta.wot) + (int64_t)cb * OT_ST * 192 + lane;
+        auto kstep = [&](int i) { return min(ot_chunk_at(min(i / OT_SPC, OT_NCH - 1)) * OT_SPC + (i % OT_SPC), OT_ST - 1); };
+        f32x16 acc[4];                                                          // one chain per K group (ot_kstep6)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc_zero(acc[g]);
+        C32F_STAMP(1)
+        __syncthreads();                                                        // E0: staging buffers 0 / 1 and the aggregated points are in LDS
+        C32F_STAMP(2)
+        const char* xrd = stage + (lane & 31) * OT_SROW + (lane >> 5) * 16;
+        // One k-step: the six products of ot_kstep6 on operands already in registers; the feat terms of the next k-step are requested from
+        // LDS before the first product (this wave is alone on its SIMD's matrix pipe: nobody else hides an LDS round trip) and the ring
+        // slot is refilled with the W terms of k-step i + RD.  Straight-line code per position (a branch per k-step makes the compiler
+        // wait for ALL outstanding requests at every block entry).
+#define C32F_KSTEP(P_, KK, NK)                                                                                           \
+        {                                                                                                                \
+            const int i_ = (P_) * OT_SPC + (KK);                                                                         \
+            const u32x4 wH = wt[(KK) % RD].h, wM = wt[(KK) % RD].m, wL = wt[(KK) % RD].l;                                \
+            const u32x4 xh = xnh, xm = xnm, xl = xnl;                                                                    \
+            if ((KK) + 1 < (NK)) {                                                                                       \
+                xnh = *reinterpret_cast<const u32x4*>(xb + ((KK) % OT_SPC + 1) * 32); xnm = *reinterpret_cast<const u32x4*>(xb + ((KK) % OT_SPC + 1) * 32 + OT_PLANE); \
+                xnl = *reinterpret_cast<const u32x4*>(xb + ((KK) % OT_SPC + 1) * 32 + 2 * OT_PLANE);                     \
+            }                                                                                                            \
+            if (C32F_ABL & 2) acc[((KK) % OT_SPC) / OT_SPW][0] += __uint_as_float((wH[0] ^ xh[0]) + (wM[1] ^ xm[1]) + (wL[2] ^ xl[2]));  \
+            else ot_kstep6(wH, wM, wL, xh, xm, xl, acc[((KK) % OT_SPC) / OT_SPW]);                                      \
+            if (!(C32F_ABL & 1) && i_ + RD < OT_ST) { const u32x4* nf_ = wfr + (int64_t)kstep(i_ + RD) * 192; wt[(KK) % RD].h = nf_[0]; wt[(KK) % RD].m = nf_[64]; wt[(KK) % RD].l = nf_[128]; } \
+        }
+#define C32F_XFIRST() { xnh = *reinterpret_cast<const u32x4*>(xb); xnm = *reinterpret_cast<const u32x4*>(xb + OT_PLANE); xnl = *reinterpret_cast<const u32x4*>(xb + 2 * OT_PLANE); }
+        u32x4 xnh, xnm, xnl;
+        static_assert(OT_SPC == 12 && OT_ST - (OT_NCH - 1) * OT_SPC == 6 && ot_chunk_at(OT_NCH - 1) == OT_NCH - 1, "positions 0..8 are full chunks, the last one holds six k-steps");
+        static_assert((2 * OT_SPC) % RD == 0, "ring slots must repeat every two positions");
+        for (int p = 0; p < OT_NCH - 2; p += 2) {                               // two positions per trip: the ring slot of a k-step is a compile-time constant
+            {
+                const char* xb = xrd;
+                C32F_XFIRST()
+                C32F_KSTEP(p, 0, 12) C32F_KSTEP(p, 1, 12) C32F_KSTEP(p, 2, 12) C32F_KSTEP(p, 3, 12) C32F_KSTEP(p, 4, 12) C32F_KSTEP(p, 5, 12)
+                C32F_KSTEP(p, 6, 12) C32F_KSTEP(p, 7, 12) C32F_KSTEP(p, 8, 12) C32F_KSTEP(p, 9, 12) C32F_KSTEP(p, 10, 12) C32F_KSTEP(p, 11, 12)
+                C32F_STAMP(3 + p)
+                __syncthreads();                                                // E(p + 1)
+            }
+            {
+                const char* xb = xrd + OT_STAGE;
+                C32F_XFIRST()
+                C32F_KSTEP(p, 12, 24) C32F_KSTEP(p, 13, 24) C32F_KSTEP(p, 14, 24) C32F_KSTEP(p, 15, 24) C32F_KSTEP(p, 16, 24) C32F_KSTEP(p, 17, 24)
+                C32F_KSTEP(p, 18, 24) C32F_KSTEP(p, 19, 24) C32F_KSTEP(p, 20, 24) C32F_KSTEP(p, 21, 24) C32F_KSTEP(p, 22, 24) C32F_KSTEP(p, 23, 24)
+                C32F_STAMP(4 + p)
+                __syncthreads();                                                // E(p + 2)
+            }
+        }
+        {
+            const char* xb = xrd;                                               // position 8
+            C32F_XFIRST()
+            C32F_KSTEP(8, 0, 12) C32F_KSTEP(8, 1, 12) C32F_KSTEP(8, 2, 12) C32F_KSTEP(8, 3, 12) C32F_KSTEP(8, 4, 12) C32F_KSTEP(8, 5, 12)
+            C32F_KSTEP(8, 6, 12) C32F_KSTEP(8, 7, 12) C32F_KSTEP(8, 8, 12) C32F_KSTEP(8, 9, 12) C32F_KSTEP(8, 10, 12) C32F_KSTEP(8, 11, 12)
+            C32F_STAMP(3 + 8)
+            __syncthreads();                                                    // E9
+        }
+        {
+            const char* xb = xrd + OT_STAGE;                                    // position 9: six k-steps
+            C32F_XFIRST()
+
+            C32F_KSTEP(8, 12, 18) C32F_KSTEP(8, 13, 18) C32F_KSTEP(8, 14, 18) C32F_KSTEP(8, 15, 18) C32F_KSTEP(8, 16, 18) C32F_KSTEP(8, 17, 18)
+            C32F_STAMP(3 + 9)
+            __syncthreads();                                                    // E10
+        }
+#undef C32F_KSTEP
+#undef C32F_XFIRST
+        C32F_STAMP(13)
+        // u (without the bias) = ((p0 + p1) + (p2 + p3)): what out_ln_mlp_kernel forms from its four K-group slabs
+        float (*us)[XLD] = reinterpret_cast<float (*)[XLD]>(smem_raw + C32F_U_OFF);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = 4 * g + e;
+                v[e] = (acc[0][q] + acc[1][q]) + (acc[2][q] + acc[3][q]);
+            }
+            *reinterpret_cast<f32x4*>(&us[lane & 31][cb * 32 + g * 8 + (lane >> 5) * 4]) = v;
+        }
+    };
+    auto consumer_prefetch = [&](int cb, WT (&wt)[RD]) {
+        const u32x4* wfr = reinterpret_cast<const u32x4*>(ta.wot) + (int64_t)cb * OT_ST * 192 + lane;
+#pragma unroll
+        for (int j = 0; j < RD; ++j) { const u32x4* f = wfr + (int64_t)(ot_chunk_at(0) * OT_SPC + j) * 192; wt[j].h = f[0]; wt[j].m = f[64]; wt[j].l = f[128]; }
+    };
 
     if (wave < NPW2) {
         // =========================================================================================== pair waves: 8 rows each
@@ -1114,6 +1277,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
 #undef P2_KOFF
 #undef P2_BOFF
         // alpha = P / l, zero for masked queries (ga.py:24-25); pair features out
+        if constexpr (!FUSE) {
 #pragma unroll
         for (int ii = 0; ii < RPW2; ++ii) {
             const int il = il0 + ii, i = i0 + il;
@@ -1131,6 +1295,91 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         C32_REPORT(0)
         __syncthreads();                                                    // F1: lsum visible, C waves done with the last chunk
         __syncthreads();                                                    // F2: aggregated points in LDS
+        } else {
+        // ---- fused tail, producer role.  Lane (head fm, key group kq) holds, for row ii and r = 0..3, the four consecutive feature columns
+        // 64 fm + 16 kq + 4 r .. + 3 (accP[ii][0..3][r]): chunk r of the tail's column order (tail_common.h: ot_feat_col) takes exactly that
+        // entry from every lane.  Normalisation and the split into bf16 terms happen chunk by chunk, in the interval before the consumers
+        // need it (splitting everything up front put 800 VALU operations of this wave next to the C waves' dump on the same SIMD).
+#pragma unroll
+        for (int ii = 0; ii < RPW2; ++ii)
+            if (kq == 0) lsum[(il0 + ii) * SCLD + fm] = mlw[ii * 32 + 1];
+        C32_REPORT(0)
+        C32F_STAMP(0)
+        __syncthreads();                                                    // F1: lsum visible, every wave is done with the S/P tile (mlr and the key mask are not aliased)
+        float rinv[RPW2];
+#pragma unroll
+        for (int ii = 0; ii < RPW2; ++ii) {
+            const int i = i0 + il0 + ii;
+            const bool mi = (i < L) && mk[min(i, L - 1)] != 0;
+            rinv[ii] = mi ? 1.f / mlw[ii * 32 + 1] : 0.f;
+        }
+        // this thread's share of the point chunks: row prow, eighth psub of the columns
+        const int ptid = wave * 64 + lane, prow = ptid >> 3, psub = ptid & 7;
+        float rr_[9], tt_[3];
+        {
+            const int64_t grow = rowbase + min(i0 + prow, L - 1);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) rr_[q] = R[grow * 9 + q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tt_[q] = t[grow * 3 + q];
+        }
+        C32F_STAMP(1)
+        __syncthreads();                                                    // E0
+        C32F_STAMP(2)
+        // local coordinates / distance / direction of aggregated point number pt of row prow (point_local: the arithmetic of the unfused epilogues)
+        auto local_of = [&](int pt, float& lx, float& ly, float& lz, float& d, float& inv) {
+            const float* a = ptsf + prow * C32F_PTSLD + pt * 3;
+            point_local(a[0] - tt_[0], a[1] - tt_[1], a[2] - tt_[2], rr_[0], rr_[1], rr_[2], rr_[3], rr_[4], rr_[5], rr_[6], rr_[7], rr_[8], lx, ly, lz, d, inv);
+        };
+        // npt consecutive points starting at pt0 -> 3 npt consecutive columns starting at col0 of staging buffer b: coordinates (DIR = false) or directions
+        auto put_points = [&](char* buf, int col0, int pt0, int npt, bool dir) {
+            float v[24];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < npt) {
+                    float lx, ly, lz, d, inv;
+                    local_of(pt0 + k, lx, ly, lz, d, inv);
+                    v[3 * k] = dir ? mul_rn(lx, inv) : lx; v[3 * k + 1] = dir ? mul_rn(ly, inv) : ly; v[3 * k + 2] = dir ? mul_rn(lz, inv) : lz;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (4 * q < 3 * npt) stage_put4(buf, prow, col0 + 4 * q, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        };
+#pragma unroll
+        for (int p = 0; p < OT_NCH; ++p) {
+            // interval p: the consumers read buffer p & 1 (position p); this role fills buffer (p + 1) & 1 with position p + 1
+            // (positions 0 and 1 -- the node features -- were written by the C waves before E0)
+            if (p >= 1 && p + 1 < OT_NCH && !(C32F_ABL & 4)) {
+                char* buf = stage + ((p + 1) & 1) * OT_STAGE;
+                const int c = ot_chunk_at(p + 1);
+                if (c < 4) {                                                // pair features, channels 16 kq + 4 c + 0..3 of every head (ot_feat_col)
+                    if (fm < H) {
+#pragma unroll
+                        for (int ii = 0; ii < RPW2; ++ii)
+                            stage_put4(buf, il0 + ii, fm * 16 + kq * 4, mul_rn(accP[ii][0][c], rinv[ii]), mul_rn(accP[ii][1][c], rinv[ii]),
+                                       mul_rn(accP[ii][2][c], rinv[ii]), mul_rn(accP[ii][3][c], rinv[ii]));
+                    }
+                } else if (c == 6) {                                        // columns 1152..1343: coordinates of points 0..63
+                    put_points(buf, psub * 24, psub * 8, 8, false);
+                } else if (c == 7) {                                        // 1344..1439: coordinates of points 64..95 | 1440..1535: the 96 distances
+                    put_points(buf, psub * 12, 64 + psub * 4, 4, false);
+                    float dd[12];
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) { float lx, ly, lz, inv; local_of(psub * 12 + k, lx, ly, lz, dd[k], inv); }
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) stage_put4(buf, prow, 96 + psub * 12 + 4 * q, dd[4 * q], dd[4 * q + 1], dd[4 * q + 2], dd[4 * q + 3]);
+                } else if (c == 8) {                                        // 1536..1727: directions of points 0..63
+                    put_points(buf, psub * 24, psub * 8, 8, true);
+                } else {                                                    // 1728..1823: directions of points 64..95
+                    put_points(buf, psub * 12, 64 + psub * 4, 4, true);
+                }
+            }
+            C32F_STAMP(3 + p)
+            __syncthreads();                                                // E(p + 1)
+        }
+        C32F_STAMP(13)
+        }
     } else if (wave < NPW2 + 2) {
         // =========================================================================================== A waves: S(t + 1), 6 heads x 2 row tiles
         const int h0 = (wave - NPW2) * HPW;
@@ -1183,8 +1432,17 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         }
         C32_SYNC()                                                          // barrier #nchunk
         C32_REPORT(1)
+        if constexpr (!FUSE) {
         __syncthreads();                                                    // F1
         __syncthreads();                                                    // F2
+        } else {
+        WT raw[RD];
+        consumer_prefetch(wave - NPW2, raw);                                // the first W_out fragments travel while the other roles finish
+        C32F_STAMP(0)
+        __syncthreads();                                                    // F1
+        tail_p2_stage_bias(reinterpret_cast<float (*)[F]>(smem_raw + C32F_BIAS_OFF), ta.b0, ta.b1, ta.b2, tid - NPW2 * 64);   // these two waves idle until E0
+        consumer(wave - NPW2, raw);                                         // E0 .. E10 inside
+        }
 #undef A2_ISSUE
     } else {
         // =========================================================================================== C waves: aggregation of chunk t - 1, 6 heads x 2 row tiles
@@ -1238,8 +1496,11 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         }
         consume(nchunk - 1, buf);
         C32_REPORT(2)
+        WT raw[RD];
+        C32F_STAMP(0)
         __syncthreads();                                                    // F1
-        float* pts = sp;                                                    // [BI2][H][24] aggregated global-frame points; the S/P tile is free now
+        float* pts = FUSE ? ptsf : sp;                                      // [BI2][H][24] aggregated global-frame points; the S/P tile is free now
+        char* nbuf = stage + (wave - NPW2 - 2) * OT_STAGE;                  // FUSE: heads 0..5 are chunk 4 = position 0, heads 6..11 chunk 5 = position 1
 #pragma unroll
         for (int hh = 0; hh < HPW; ++hh) {
             const int h = h0 + hh;
@@ -1248,21 +1509,47 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                 const int il = rt * 16 + fm, i = i0 + il;
                 const bool mi = (i < L) && mk[min(i, L - 1)] != 0;
                 const float inv = mi ? 1.f / lsum[il * SCLD + h] : 0.f;
-                if (i < L) {
+                if constexpr (FUSE) {
+                    const f32x4 a0 = accV[hh][rt][0], a1 = accV[hh][rt][1];
+                    if (!(C32F_ABL & 8)) {
+                    stage_put4(nbuf, il, hh * D + kq * 4, mul_rn(a0[0], inv), mul_rn(a0[1], inv), mul_rn(a0[2], inv), mul_rn(a0[3], inv));
+                    stage_put4(nbuf, il, hh * D + 16 + kq * 4, mul_rn(a1[0], inv), mul_rn(a1[1], inv), mul_rn(a1[2], inv), mul_rn(a1[3], inv));
+                    }
+                } else if (i < L) {
                     float* fo = feat + (rowbase + i) * FEAT + H * C + h * D + kq * 4;
                     *reinterpret_cast<f32x4*>(fo) = accV[hh][rt][0] * inv;
                     *reinterpret_cast<f32x4*>(fo + 16) = accV[hh][rt][1] * inv;
                 }
-                float* po = pts + (il * H + h) * (P * 3) + kq * 3;
+                float* po = pts + il * (FUSE ? C32F_PTSLD : H * P * 3) + h * (P * 3) + kq * 3;
+                if (!(FUSE && (C32F_ABL & 16))) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) { po[r] = accT[hh][rt][0][r] * inv; po[12 + r] = accT[hh][rt][1][r] * inv; }
+                }
             }
         }
-        __syncthreads();                                                    // F2
+        if constexpr (FUSE) {
+            consumer_prefetch(wave - NPW2, raw);                            // (only now: 192 accumulators + 96 fragment registers do not fit)
+            consumer(wave - NPW2, raw);                                     // E0 .. E10 inside
+        }
+        else __syncthreads();                                               // F2
 #undef C2_ISSUE
     }
-    // ---------------------------------------------------------------- all waves: local frame, norm, direction of the aggregated points (ga.py:136-139)
-    persist_point_epilogue(sp, R, t, feat, rowbase, i0, L, tid, NTH2, BI2);
+    if constexpr (!FUSE) {
+        // ---------------------------------------------------------------- all waves: local frame, norm, direction of the aggregated points (ga.py:136-139)
+        persist_point_epilogue(sp, R, t, feat, rowbase, i0, L, tid, NTH2, BI2);
+    } else {
+        // ---------------------------------------------------------------- all waves: LayerNorm1, mlp_transition, LayerNorm2 of the 32 rows (tail_common.h)
+        const int64_t row0 = row0f, row_end = row_endf;
+        pre = tail_p2_prefetch<NTH2 / 64>(ta.x, ta.ubias, mask, ta.g1, ta.be1, ta.wmf, row0, row_end, wave, lane);
+        float (*bias)[F] = reinterpret_cast<float (*)[F]>(smem_raw + C32F_BIAS_OFF);
+        C32F_STAMP(14)
+        __syncthreads();                                                    // U: u and the biases are in LDS
+        const float (*us)[XLD] = reinterpret_cast<const float (*)[XLD]>(smem_raw + C32F_U_OFF);
+        auto get_u = [&](int rl) { return *reinterpret_cast<const float2*>(&us[rl][2 * lane]); };
+        tail_p2_run<NTH2 / 64, false>(pre, get_u, reinterpret_cast<float (*)[XLD]>(smem_raw + C32F_YS_OFF), bias, smem_raw + C32F_APA_OFF,
+                                      smem_raw + C32F_PTS_OFF, ta.wmf, ta.g2, ta.be2, ta.out, nullptr, 0, row0, row_end, wave, lane);
+        C32F_STAMP(15)
+    }
 }
 
 // Pair-bias cache: lp[l][n,i,j,h] = z[n,i,j,:] . Wb_l[h,:] for every layer l in ONE pass over z (ga.py:88-90).  z and the weights do
@@ -1349,11 +1636,8 @@ __global__ __launch_bounds__(256) void ipa_split_merge_kernel(const float* __res
         const float* Rr = R + row * 9;
         const float* tr = t + row * 3;
         const float dx = pts[3 * tid] - tr[0], dy = pts[3 * tid + 1] - tr[1], dz = pts[3 * tid + 2] - tr[2];
-        const float lx = Rr[0] * dx + Rr[3] * dy + Rr[6] * dz;            // R^T (a - t), geometry.py:94-117
-        const float ly = Rr[1] * dx + Rr[4] * dy + Rr[7] * dz;
-        const float lz = Rr[2] * dx + Rr[5] * dy + Rr[8] * dz;
-        const float d = sqrtf(lx * lx + ly * ly + lz * lz);
-        const float inv = 1.f / (d + 1e-4f);                              // ga.py:138-139
+        float lx, ly, lz, d, inv;
+        point_local(dx, dy, dz, Rr[0], Rr[1], Rr[2], Rr[3], Rr[4], Rr[5], Rr[6], Rr[7], Rr[8], lx, ly, lz, d, inv);
         float* fp = fo + H * C + H * D;
         fp[3 * tid] = lx; fp[3 * tid + 1] = ly; fp[3 * tid + 2] = lz;
         fp[H * P * 3 + tid] = d;
@@ -1414,6 +1698,46 @@ static bool use_core32(int N, int L, int cus) {
     return total * 100 >= rounds * cus * 95;
 }
 
+// The whole block behind the projections in ONE launch (ipa_core32_kernel<true>: core + tail) where the 32-row kernel is the core of
+// choice; *fused = 0 and nothing launched otherwise (the caller then runs core and tail separately -- same results bit for bit).
+// ABOPT_FUSE_TAIL=0 keeps the two-launch form (A/B, tests).
+int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
+                           const float* pair_bias_cache, int N, int L, hipStream_t st, int z_shared, const float* wot, const float* wmf, const float* x,
+                           const float* ubias, const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2,
+                           const float* be2, float* out, int* fused) {
+    *fused = 0;
+    const char* e = getenv("ABOPT_FUSE_TAIL");
+    if (!pair_bias_cache || !wot || !wmf || (e && e[0] == '0') || CORE_ABL || C32_ABL) return ABOPT_OK;
+    int cus = 0;
+    if (int rc = device_cu_count(&cus)) return rc;
+    if (!use_core32(N, L, cus)) return ABOPT_OK;
+    const int nib2 = (L + BI2 - 1) / BI2;
+    static LdsConfig lds_cfg;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel<true>), C32F_LDS_BYTES, lds_cfg)) return rc;
+    TailArgs ta{wot, wmf, x, ubias, g1, be1, b0, b1, b2, g2, be2, out};
+    prof::begin(st);
+    hipLaunchKernelGGL(ipa_core32_kernel<true>, dim3((unsigned)(N * nib2)), dim3(NTH2), C32F_LDS_BYTES, st, qfrag, kvfrag, z, mask, R, t, (float*)nullptr,
+                       pair_bias_cache, L, nib2, (N % 8 == 0) ? 1 : 0, z_shared, ta);
+    prof::end(st);
+    ABOPT_LAUNCH_CHECK();
+#ifdef C32F_TIMING
+    {
+        long long h[8][16];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_c32f_timing), sizeof(h));
+        static int calls = 0;
+        if (++calls == 8)
+            for (int w = 0; w < 8; ++w) {
+                fprintf(stderr, "[c32f timing WG 17 wave %d] cycles since kernel start: at F1 %lld | at E0 %lld, past %lld | arrival at E1..E10:", w, h[w][0], h[w][1], h[w][2]);
+                for (int k = 3; k < 13; ++k) fprintf(stderr, " %lld", h[w][k]);
+                fprintf(stderr, " | past E10 %lld | at U %lld | end %lld\n", h[w][13], h[w][14], h[w][15]);
+            }
+    }
+#endif
+    *fused = 1;
+    return ABOPT_OK;
+}
+
 int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                            const float* w_pair_bias, float* feat, float* dump, float* dump_stats, const float* pair_bias_cache, int N, int L, hipStream_t st,
                            int z_shared, float* split_ws, size_t split_ws_floats) {
@@ -1426,10 +1750,10 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
         const size_t lds = sizeof(float) * (3 * BI2 * SROW + 2 * BI2 * SCLD + BI2 * SCLD + BI2 * 32) + (size_t)nchunk * JC;
         ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core: L=%d needs %zu bytes of LDS for the key mask (max 163840)", L, lds);
         static LdsConfig lds_cfg;
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel), lds, lds_cfg)) return rc;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel<false>), lds, lds_cfg)) return rc;
         prof::begin(st);
-        hipLaunchKernelGGL(ipa_core32_kernel, dim3((unsigned)(N * nib2)), dim3(NTH2), lds, st, qfrag, kvfrag, z, mask, R, t, feat, pair_bias_cache, L, nib2,
-                           (N % 8 == 0) ? 1 : 0, z_shared);
+        hipLaunchKernelGGL(ipa_core32_kernel<false>, dim3((unsigned)(N * nib2)), dim3(NTH2), lds, st, qfrag, kvfrag, z, mask, R, t, feat, pair_bias_cache, L, nib2,
+                           (N % 8 == 0) ? 1 : 0, z_shared, TailArgs{});
         prof::end(st);
         ABOPT_LAUNCH_CHECK();
 #ifdef C32_TIMING

@@ -30,6 +30,12 @@ int launch_ipa_core(const float* qfrag, const float* kvfrag, const float* z, con
                     int N, int L, hipStream_t st, int z_shared = 0 /* 1: z and the pair-bias cache hold ONE sample that every batch entry shares */,
                     float* split_ws = nullptr, size_t split_ws_floats = 0 /* scratch of the key-split form (small batches), ipa_split_ws_floats(N, L) */);
 
+// ipa_core.hip: core + tail of a block in one launch where the 32-row core applies (sets *fused; otherwise launches nothing)
+int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
+                           const float* pair_bias_cache, int N, int L, hipStream_t st, int z_shared, const float* wot /* W_out as bf16 terms */, const float* wmf, const float* x,
+                           const float* ubias, const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2,
+                           const float* be2, float* out, int* fused);
+
 // node_frags.hip: x [N*L,128] -> qfrag / kvfrag directly (projection GEMM + frame transform + fragment layout in one kernel)
 size_t node_wfrag_floats();
 int launch_node_frags(const float* x, const float* wfrag, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag,
@@ -56,6 +62,8 @@ int launch_heads_mlp(const float* xe, const float* beta, const float* wfrag, con
                      const float* b2r, const float* b2s, const float* b3c, const float* b3r, const float* b3s, float* out3, int64_t rows, int L,
                      hipStream_t st);
 size_t out_wfrag_floats();
+size_t out_wterms_floats();
+int launch_out_frag_terms(const float* wof, float* wot, hipStream_t st);
 size_t mlp_wfrag_floats();
 int launch_pack_tail_weights(const float* w_out, const float* w0, const float* w1, const float* w2, float* wof, float* wmf, float* wmt, hipStream_t st);
 int launch_tail_backward(const float* dout, const float* saved, const float* wmt, const uint8_t* mask, const float* g1, const float* g2,

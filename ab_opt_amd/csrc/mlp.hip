@@ -6,16 +6,13 @@
 // work per row block is latency/launch bound, so a 256-thread workgroup keeps its 32 rows on chip (LDS) through all three
 // layers and stages each 64 KB weight matrix into LDS once (register-prefetched behind the previous phase).
 // fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32.
-#include "ipa_common.h"
+#include "tail_common.h"
 #include "kernels.h"
 
 namespace abopt {
 
-constexpr int F = 128, XLD = F + 4;
-
 __device__ __forceinline__ f32x4 mfma4m(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-constexpr int MR = 32;                     // rows per workgroup
 constexpr int WPT = F * F / 4 / 256;       // float4 weight loads per thread per layer (16)
 
 // the 64 KB weight matrix of one layer travels global -> registers (issued early, hidden behind the previous phase) -> LDS
@@ -218,120 +215,6 @@ int launch_fused_ln_mlp(const float* x, const float* u, int nslab, int64_t slab_
 __device__ long long g_ot_timing[16][8];
 namespace abopt {
 #endif
-namespace {
-constexpr int OT_K = ABOPT_IPA_FEAT;          // 1824
-constexpr int OT_KC = 192, OT_NCH = (OT_K + OT_KC - 1) / OT_KC;           // 10 chunks of 192 columns = 12 k-steps of 16 (the last one half full)
-constexpr int OT_ST = OT_K / 16;              // 114 k-steps
-constexpr int OT_SPC = OT_KC / 16, OT_SPW = OT_SPC / 4;                   // 12 k-steps per chunk, 3 per wave
-constexpr int OT_TH = 1024, OT_NW = OT_TH / 64;
-constexpr int OT_SROW = OT_KC * 2 + 16;       // bytes per row of one bf16 plane of a chunk: 400, rows 36 banks apart (conflict-free b128 reads)
-constexpr int OT_PLANE = MR * OT_SROW, OT_STAGE = 3 * OT_PLANE;           // 12800, 38400 bytes
-constexpr int AP_ROW = F * 2 + 16, AP_PLANE = MR * AP_ROW;                // activation planes: 272 bytes per row (rows 4 banks apart)
-constexpr int OT_MS = F / 16;                 // 8 k-steps per MLP layer
-static_assert(OT_K % 16 == 0 && OT_KC % 64 == 0 && MR == 32 && F == 128, "out_transform tiling");
-
-struct OtSmem {
-    float ys[MR][XLD];                        // y = LayerNorm1(...) in fp32 (residual of the MLP)
-    float bias[3][F];                         // b_mlp0..2
-    char ap[3 * AP_PLANE];                    // input of the current layer as [term][row][128 bf16 + pad]
-    union {
-        char stage[2][OT_STAGE];              // phase 1: feat chunks as [term][row][192 bf16 + pad]
-        float part[4][MR][XLD];               // partial sums of the four K groups
-    };
-};
-
-__device__ __forceinline__ void acc_zero(f32x16& a) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = 0.f;
-}
-// accumulator register 4 g + i = output column 32 cb + 8 g + 4 (lane >> 5) + i, lane & 31 = residue
-__device__ __forceinline__ void store_partial(float (*dst)[XLD], const f32x16& a0, const f32x16& a1, int cb, int lane) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(&dst[lane & 31][cb * 32 + g * 8 + (lane >> 5) * 4]) =
-            (f32x4){a0[4 * g] + a1[4 * g], a0[4 * g + 1] + a1[4 * g + 1], a0[4 * g + 2] + a1[4 * g + 2], a0[4 * g + 3] + a1[4 * g + 3]};
-}
-// two adjacent values -> one 4-byte entry in each of the three planes
-__device__ __forceinline__ void store_terms2(char* ap, int byte_off, float e0, float e1) {
-    const unsigned h = pk_bf16(e0, e1);
-    const float r0 = e0 - __uint_as_float(h << 16), r1 = e1 - __uint_as_float(h & 0xffff0000u);
-    const unsigned m = pk_bf16(r0, r1);
-    const unsigned l = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
-    *reinterpret_cast<unsigned*>(ap + byte_off) = h;
-    *reinterpret_cast<unsigned*>(ap + AP_PLANE + byte_off) = m;
-    *reinterpret_cast<unsigned*>(ap + 2 * AP_PLANE + byte_off) = l;
-}
-struct MlpW { u32x4 v[2][3]; };               // a wave's two k-steps of one layer: [step][term]
-__device__ __forceinline__ MlpW load_mlp_w(const float* __restrict__ wm, int layer, int cb, int kg, int lane) {
-    const u32x4* p = reinterpret_cast<const u32x4*>(wm) + ((int64_t)(layer * 4 + cb) * OT_MS + kg * 2) * 192 + lane;
-    MlpW w;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) w.v[j][sp] = p[j * 192 + sp * 64];
-    return w;
-}
-// partial [32 rows x 32 columns] of one layer for the wave's two k-steps
-__device__ __forceinline__ void mlp_partial(const char* ap, const MlpW& w, float (*dst)[XLD], int cb, int kg, int lane) {
-    f32x16 a0, a1;
-    acc_zero(a0); acc_zero(a1);
-    const char* xp = ap + (lane & 31) * AP_ROW + kg * 64 + (lane >> 5) * 16;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const u32x4 xh = *reinterpret_cast<const u32x4*>(xp + j * 32), xm = *reinterpret_cast<const u32x4*>(xp + j * 32 + AP_PLANE),
-                    xl = *reinterpret_cast<const u32x4*>(xp + j * 32 + 2 * AP_PLANE);
-        a0 = mfma_bf32(w.v[j][0], xl, a0); a1 = mfma_bf32(w.v[j][2], xh, a1);
-        a0 = mfma_bf32(w.v[j][1], xm, a0); a1 = mfma_bf32(w.v[j][0], xm, a1);
-        a0 = mfma_bf32(w.v[j][1], xh, a0); a1 = mfma_bf32(w.v[j][0], xh, a1);
-    }
-    store_partial(dst, a0, a1, cb, lane);
-}
-}  // namespace
-
-// ---- phase-2 layer weights for the 16x16x32 form: wmf [layer][ct 8][k-step 4][lane 64] x 8 fp32, lane (m = lane & 15, kq = lane >> 4)
-// holds W[16 ct + m][32 s + 8 kq + i].  fp32 (4 bytes per weight instead of the 6 of three bf16 terms): the phase is bound by how fast a
-// CU can pull the three layers from L2, and the split costs 176 VALU operations per wave and layer.  Eight waves compute (wave = column
-// tile ct, both row tiles with the same weight registers); a layer's fragment is 32 registers, requested one layer ahead.
-namespace {
-struct MlpRaw { f32x4 v[4][2]; };
-__device__ __forceinline__ MlpRaw load_mlp_raw(const float* __restrict__ wm, int layer, int ct, int lane) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(wm) + ((int64_t)((layer * 8 + ct) * 4) * 64 + lane) * 2;
-    MlpRaw w;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { w.v[s][0] = p[s * 128]; w.v[s][1] = p[s * 128 + 1]; }
-    return w;
-}
-// [16 output columns of tile ct] x [32 rows] of one layer, K = 128, no K split: o[rt] register r of lane (n, kq) = output column
-// 16 ct + 4 kq + r of row 16 rt + n.  (Splitting the whole layer before the barrier that publishes its input, with the LDS reads one
-// k-step ahead, was measured: 128 VGPRs + 52 bytes of scratch per lane, no faster.)
-__device__ __forceinline__ void mlp16_layer(const char* ap, const MlpRaw& w, int lane, f32x4 (&o)[2]) {
-    f32x4 a[2][2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) { a[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; a[rt][1] = a[rt][0]; }
-    const char* xp = ap + (lane & 15) * AP_ROW + (lane >> 4) * 16;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const Split3 w3 = split3(w.v[s][0], w.v[s][1]);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {   // smallest terms first; two accumulators per row tile so consecutive MFMAs never depend on each other
-            const char* xr = xp + rt * 16 * AP_ROW + s * 64;
-            const u32x4 xh = *reinterpret_cast<const u32x4*>(xr), xm = *reinterpret_cast<const u32x4*>(xr + AP_PLANE),
-                        xl = *reinterpret_cast<const u32x4*>(xr + 2 * AP_PLANE);
-            a[rt][0] = mfma_bf(w3.h, xl, a[rt][0]); a[rt][1] = mfma_bf(w3.l, xh, a[rt][1]);
-            a[rt][0] = mfma_bf(w3.m, xm, a[rt][0]); a[rt][1] = mfma_bf(w3.h, xm, a[rt][1]);
-            a[rt][0] = mfma_bf(w3.m, xh, a[rt][0]); a[rt][1] = mfma_bf(w3.h, xh, a[rt][1]);
-        }
-    }
-    o[0] = a[0][0] + a[0][1]; o[1] = a[1][0] + a[1][1];
-}
-// one pair of adjacent fp32 values -> its three packed bf16 term words
-__device__ __forceinline__ void split_pair(float e0, float e1, unsigned& h, unsigned& m, unsigned& l) {
-    h = pk_bf16(e0, e1);
-    const float r0 = e0 - __uint_as_float(h << 16), r1 = e1 - __uint_as_float(h & 0xffff0000u);
-    m = pk_bf16(r0, r1);
-    l = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
-}
-}  // namespace
 
 // DUMP (training): also writes what the backward needs, five [rows,128] slabs: pre-LayerNorm1 sum | y | h0 | h1 | pre-LayerNorm2 sum
 //
@@ -362,12 +245,17 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
     const long long tc0 = clock64();
 #endif
     // ---------------------------------------------------------------- phase 1: u = feat . W_out^T
+    // The ten 192-column chunks are taken in the order ot_chunk_at(0..9) = 4 5 0 1 2 3 6 7 8 9 (tail_common.h: the order in which the
+    // fused core + tail kernel can produce them); position p lives in staging buffer p & 1.
     // feat chunk loader: 32 rows x 24 octets of 8 floats: thread e < 768 -> (row e / 24, octet e % 24); split, then three 16-byte stores
     const int lr = min(tid / (OT_KC / 8), MR - 1), lo = tid % (OT_KC / 8);
     const bool ldr = tid < MR * (OT_KC / 8);
-    const float* fsrc = feat + min(row0 + lr, rows - 1) * OT_K + lo * 8;
+    const float* frow = feat + min(row0 + lr, rows - 1) * OT_K;                                           // staging columns 8 lo .. 8 lo + 7 of a chunk = two quads of feature columns (ot_feat_col)
+    auto fload = [&](int c, f32x4& v0, f32x4& v1) {
+        v0 = *reinterpret_cast<const f32x4*>(frow + ot_feat_col(c, lo * 8)); v1 = *reinterpret_cast<const f32x4*>(frow + ot_feat_col(c, lo * 8 + 4));
+    };
     char* fdst0 = &sm.stage[0][0] + lr * OT_SROW + lo * 16;
-    auto chunk_ok = [&](int c) { return ldr && c < OT_NCH && c * OT_KC + lo * 8 < OT_K; };          // the last chunk is half full
+    auto chunk_ok = [&](int p) { return ldr && p < OT_NCH && ot_chunk_at(p) * OT_KC + lo * 8 < OT_K; };   // the last chunk is half full
     auto stage_store = [&](int b, const f32x4& v0, const f32x4& v1) {
         const Split3 sp = split3(v0, v1);
         char* d = fdst0 + b * OT_STAGE;
@@ -375,18 +263,18 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
     };
     const int cb = wave & 3, kg = wave >> 2;
     // this wave's W_out stream: fp32 in operand order, [cb][k-step][lane][8 floats], lane (column lane & 31, k half lane >> 5).
-    // Its k-steps, in order: chunk c, slot j -> k-step 12 c + 3 kg + j (c < 10, j < 3; past 113: nothing to do -- a clamped reload keeps the code uniform)
+    // Its k-steps, in order: position p, slot j -> k-step 12 chunk(p) + 3 kg + j (p < 10, j < 3; past 113: nothing to do -- a clamped reload keeps the code uniform)
     const f32x4* wfr = reinterpret_cast<const f32x4*>(wof) + ((int64_t)cb * OT_ST * 64 + lane) * 2;
-    auto kstep = [&](int i) { return min((i / OT_SPW) * OT_SPC + kg * OT_SPW + (i % OT_SPW), OT_ST - 1); };
+    auto kstep = [&](int i) { return min(ot_chunk_at(min(i / OT_SPW, OT_NCH - 1)) * OT_SPC + kg * OT_SPW + (i % OT_SPW), OT_ST - 1); };
     f32x4 raw[OT_SPW][2];                                                                                 // ring: k-step i lives in slot i % 3
 #pragma unroll
     for (int j = 0; j < OT_SPW; ++j) { raw[j][0] = wfr[kstep(j) * 128]; raw[j][1] = wfr[kstep(j) * 128 + 1]; }
     f32x4 fv0 = (f32x4){0.f, 0.f, 0.f, 0.f}, fv1 = fv0;
     if (chunk_ok(0)) {
-        fv0 = *reinterpret_cast<const f32x4*>(fsrc); fv1 = *reinterpret_cast<const f32x4*>(fsrc + 4);
+        fload(ot_chunk_at(0), fv0, fv1);
         stage_store(0, fv0, fv1);
     }
-    if (chunk_ok(1)) { fv0 = *reinterpret_cast<const f32x4*>(fsrc + OT_KC); fv1 = *reinterpret_cast<const f32x4*>(fsrc + OT_KC + 4); }
+    if (chunk_ok(1)) fload(ot_chunk_at(1), fv0, fv1);
     u32x4 nH, nM, nL;                                                                                     // terms of the NEXT k-step
     { const Split3 w3 = split3(raw[0][0], raw[0][1]); nH = w3.h; nM = w3.m; nL = w3.l; }
     raw[0][0] = wfr[kstep(OT_SPW) * 128]; raw[0][1] = wfr[kstep(OT_SPW) * 128 + 1];
@@ -394,13 +282,13 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
 #ifdef OT_TIMING
     const long long tc1 = clock64();
 #endif
-    f32x16 acc0, acc1;
-    acc_zero(acc0); acc_zero(acc1);
+    f32x16 acc0;                                                                                          // ONE chain per (column block, K group): see ot_kstep6
+    acc_zero(acc0);
     const char* xrd = &sm.stage[0][0] + (lane & 31) * OT_SROW + (kg * OT_SPW) * 32 + (lane >> 5) * 16;
     for (int c = 0; c < OT_NCH; ++c) {
         const int b = c & 1;
-        // the last chunk has work for K groups 0 and 1 only (and nothing left to stage): the others go straight to the barrier
-        if (c * OT_SPC + kg * OT_SPW < OT_ST) {
+        // the last position (chunk 9) has work for K groups 0 and 1 only (and nothing left to stage): the others go straight to the barrier
+        if (ot_chunk_at(c) * OT_SPC + kg * OT_SPW < OT_ST) {
 #pragma unroll
         for (int j = 0; j < OT_SPW; ++j) {
             const int i = c * OT_SPW + j;
@@ -409,20 +297,21 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
             const u32x4 xh = *reinterpret_cast<const u32x4*>(xp), xm = *reinterpret_cast<const u32x4*>(xp + OT_PLANE),
                         xl = *reinterpret_cast<const u32x4*>(xp + 2 * OT_PLANE);
             // the fragment of k-step i + 1 (slot (j + 1) % 3, requested three k-steps ago) is split pair by pair between the MFMAs of k-step i
+            // (same products in the same order as ot_kstep6)
             const f32x4 r0 = raw[(j + 1) % OT_SPW][0], r1 = raw[(j + 1) % OT_SPW][1];
-            acc0 = mfma_bf32(wH, xl, acc0); acc1 = mfma_bf32(wL, xh, acc1);
+            acc0 = mfma_bf32(wH, xl, acc0); acc0 = mfma_bf32(wL, xh, acc0);
             { unsigned h_, m_, l_; split_pair(r0[0], r0[1], h_, m_, l_); nH[0] = h_; nM[0] = m_; nL[0] = l_; }
             acc0 = mfma_bf32(wM, xm, acc0);
             { unsigned h_, m_, l_; split_pair(r0[2], r0[3], h_, m_, l_); nH[1] = h_; nM[1] = m_; nL[1] = l_; }
-            acc1 = mfma_bf32(wH, xm, acc1);
+            acc0 = mfma_bf32(wH, xm, acc0);
             { unsigned h_, m_, l_; split_pair(r1[0], r1[1], h_, m_, l_); nH[2] = h_; nM[2] = m_; nL[2] = l_; }
             acc0 = mfma_bf32(wM, xh, acc0);
             { unsigned h_, m_, l_; split_pair(r1[2], r1[3], h_, m_, l_); nH[3] = h_; nM[3] = m_; nL[3] = l_; }
-            acc1 = mfma_bf32(wH, xh, acc1);
+            acc0 = mfma_bf32(wH, xh, acc0);
             { const int64_t nst = kstep(i + 1 + OT_SPW); raw[(j + 1) % OT_SPW][0] = wfr[nst * 128]; raw[(j + 1) % OT_SPW][1] = wfr[nst * 128 + 1]; }
             if (j == 0) {                                                                               // feat staging in the shadow of this chunk's MFMAs
-                if (chunk_ok(c + 1)) stage_store(b ^ 1, fv0, fv1);                                      // chunk c + 1 -> the other buffer
-                if (chunk_ok(c + 2)) { fv0 = *reinterpret_cast<const f32x4*>(fsrc + (c + 2) * OT_KC); fv1 = *reinterpret_cast<const f32x4*>(fsrc + (c + 2) * OT_KC + 4); }
+                if (chunk_ok(c + 1)) stage_store(b ^ 1, fv0, fv1);                                      // position c + 1 -> the other buffer
+                if (chunk_ok(c + 2)) fload(ot_chunk_at(c + 2), fv0, fv1);
             }
         }
         }
@@ -430,132 +319,46 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
     }
 #ifdef OT_TIMING
     const long long tc2 = clock64();
-    long long tp2 = 0;
 #endif
-    // ---------------------------------------------------------------- phase 2: LayerNorm1 (each wave 2 rows), MLP, LayerNorm2
-    constexpr int RW = MR / OT_NW;
-    const int fm = lane & 15, kq = lane >> 4;
-    const bool mlpw = wave < 8;                                                                          // waves 0..7 own the eight 16-column tiles
-    const int ct = wave & 7;
-    // what LayerNorm1 needs from global memory goes out FIRST: loads return in order, and the layer weights behind them are a 64 KB burst
-    float2 xv_[RW];
-    bool keep_[RW];
-#pragma unroll
-    for (int rr = 0; rr < RW; ++rr) {
-        const int64_t row = min(row0 + wave * RW + rr, rows - 1);
-        keep_[rr] = mask ? (mask[row] != 0) : true;
-        xv_[rr] = reinterpret_cast<const float2*>(x + row * F)[lane];
-    }
-    const float2 bb = ubias ? reinterpret_cast<const float2*>(ubias)[lane] : make_float2(0.f, 0.f);
-    const float2 g1v = reinterpret_cast<const float2*>(g1)[lane], be1v = reinterpret_cast<const float2*>(be1)[lane];
-    MlpRaw mw;
-    if (mlpw) mw = load_mlp_raw(wmf, 0, ct, lane);
-    store_partial(sm.part[kg], acc0, acc1, cb, lane);                                                   // the staging planes are dead: the loop ended on a barrier
-    if (tid < 3 * F / 4) {                                                                               // the three bias vectors -> LDS (read per layer by the compute waves)
-        const float* bsrc = tid < F / 4 ? b0 : (tid < F / 2 ? b1 : b2);
-        *reinterpret_cast<f32x4*>(&sm.bias[tid >> 5][(tid & 31) * 4]) = *reinterpret_cast<const f32x4*>(bsrc + (tid & 31) * 4);
-    }
-    const int ocol = ct * 16 + kq * 4;                                                                   // this lane's four output columns in every layer
+    // ---------------------------------------------------------------- phase 2: LayerNorm1 (each wave 2 rows), MLP, LayerNorm2 (tail_common.h)
+    TailP2Pre<OT_NW> pre = tail_p2_prefetch<OT_NW>(x, ubias, mask, g1, be1, wmf, row0, rows, wave, lane);
+    store_partial1(sm.part[kg], acc0, cb, lane);                                                         // the staging planes are dead: the loop ended on a barrier
+    tail_p2_stage_bias(sm.bias, b0, b1, b2, tid);
     __syncthreads();
     char* apA = sm.ap;                                                                                   // planes: LayerNorm1 output, later layer-1 output
     char* apB = reinterpret_cast<char*>(&sm.part[2][0][0]);                                              // second set (layer-0 output): part[2..3] are free after LayerNorm1
     static_assert(3 * AP_PLANE <= (int)(2 * MR * XLD * sizeof(float)), "second activation plane set must fit into two K-group slabs");
-    {
-        const float2 g = g1v, bt = be1v;
-        float a_[RW], b_[RW], mean[RW], var[RW];
-#pragma unroll
-        for (int rr = 0; rr < RW; ++rr) {
-            const int rl = wave * RW + rr;
-            const float2 u0 = *reinterpret_cast<const float2*>(&sm.part[0][rl][2 * lane]), u1 = *reinterpret_cast<const float2*>(&sm.part[1][rl][2 * lane]);
-            const float2 u2 = *reinterpret_cast<const float2*>(&sm.part[2][rl][2 * lane]), u3 = *reinterpret_cast<const float2*>(&sm.part[3][rl][2 * lane]);
-            float2 us = make_float2(((u0.x + u1.x) + (u2.x + u3.x)) + bb.x, ((u0.y + u1.y) + (u2.y + u3.y)) + bb.y);
-            if (!keep_[rr]) us = make_float2(0.f, 0.f);
-            a_[rr] = xv_[rr].x + us.x; b_[rr] = xv_[rr].y + us.y;
-            if (DUMP && row0 + rl < rows) reinterpret_cast<float2*>(dump + (row0 + rl) * F)[lane] = make_float2(a_[rr], b_[rr]);
-        }
-#pragma unroll
-        for (int rr = 0; rr < RW; ++rr) mean[rr] = wave_sum(a_[rr] + b_[rr]) * (1.f / F);
-#pragma unroll
-        for (int rr = 0; rr < RW; ++rr) { a_[rr] -= mean[rr]; b_[rr] -= mean[rr]; var[rr] = wave_sum(a_[rr] * a_[rr] + b_[rr] * b_[rr]) * (1.f / F); }
-#pragma unroll
-        for (int rr = 0; rr < RW; ++rr) {
-            const int rl = wave * RW + rr;
-            const float sd = sqrtf(var[rr] + 1e-10f);
-            const float y0 = a_[rr] / sd * g.x + bt.x, y1 = b_[rr] / sd * g.y + bt.y;
-            *reinterpret_cast<float2*>(&sm.ys[rl][2 * lane]) = make_float2(y0, y1);
-            store_terms2(apA, rl * AP_ROW + lane * 4, y0, y1);
-            if (DUMP && row0 + rl < rows) reinterpret_cast<float2*>(dump + slab + (row0 + rl) * F)[lane] = make_float2(y0, y1);
-        }
-    }
-    __syncthreads();                                                                                     // y planes complete; every read of part[] is done
+    auto get_u = [&](int rl) {
+        const float2 u0 = *reinterpret_cast<const float2*>(&sm.part[0][rl][2 * lane]), u1 = *reinterpret_cast<const float2*>(&sm.part[1][rl][2 * lane]);
+        const float2 u2 = *reinterpret_cast<const float2*>(&sm.part[2][rl][2 * lane]), u3 = *reinterpret_cast<const float2*>(&sm.part[3][rl][2 * lane]);
+        return make_float2((u0.x + u1.x) + (u2.x + u3.x), (u0.y + u1.y) + (u2.y + u3.y));
+    };
+    tail_p2_run<OT_NW, DUMP>(pre, get_u, sm.ys, sm.bias, apA, apB, wmf, g2, be2, out, dump, slab, row0, rows, wave, lane);
 #ifdef OT_TIMING
-    const long long tp1 = clock64();
-#endif
-    // ---- layer 0: relu(W0 y + b0) -> planes B ; layer 1: relu(W1 h + b1) -> planes A (their last readers passed the barrier in between)
-#pragma unroll
-    for (int layer = 0; layer < 2; ++layer) {
-        if (mlpw) {
-            const char* src = layer == 0 ? apA : apB;
-            char* dst = layer == 0 ? apB : apA;
-            const MlpRaw nxt = load_mlp_raw(wmf, layer + 1, ct, lane);                                  // the next layer's fragment travels while this one computes
-            f32x4 o[2];
-            mlp16_layer(src, mw, lane, o);
-            mw = nxt;
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(&sm.bias[layer][ocol]);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const int orow = rt * 16 + fm;
-                const f32x4 v = o[rt] + bias;
-                const f32x4 hv = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-                store_terms2(dst, orow * AP_ROW + ocol * 2, hv[0], hv[1]);
-                store_terms2(dst, orow * AP_ROW + ocol * 2 + 4, hv[2], hv[3]);
-                if (DUMP && row0 + orow < rows) *reinterpret_cast<f32x4*>(dump + (2 + layer) * slab + (row0 + orow) * F + ocol) = hv;
-            }
-        }
-        __syncthreads();
-#ifdef OT_TIMING
-        if (layer == 0) tp2 = clock64();
-#endif
-    }
-    // ---- layer 2 + residual (in place in ys: every element has exactly one owner), then LayerNorm2
-    if (mlpw) {
-        f32x4 o[2];
-        mlp16_layer(apA, mw, lane, o);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(&sm.bias[2][ocol]);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const int orow = rt * 16 + fm;
-            f32x4 yv = *reinterpret_cast<const f32x4*>(&sm.ys[orow][ocol]);
-            yv += o[rt] + bias;
-            *reinterpret_cast<f32x4*>(&sm.ys[orow][ocol]) = yv;
-            if (DUMP && row0 + orow < rows) *reinterpret_cast<f32x4*>(dump + 4 * slab + (row0 + orow) * F + ocol) = yv;
-        }
-    }
-    __syncthreads();
-#ifdef OT_TIMING
-    const long long tp3 = clock64();
-#endif
-    {
-        const float2 g = reinterpret_cast<const float2*>(g2)[lane], bt = reinterpret_cast<const float2*>(be2)[lane];
-        float2 v[RW];
-        float mean[RW], var[RW];
-#pragma unroll
-        for (int rr = 0; rr < RW; ++rr) { v[rr] = *reinterpret_cast<const float2*>(&sm.ys[wave * RW + rr][2 * lane]); mean[rr] = wave_sum(v[rr].x + v[rr].y) * (1.f / F); }
-#pragma unroll
-        for (int rr = 0; rr < RW; ++rr) { v[rr].x -= mean[rr]; v[rr].y -= mean[rr]; var[rr] = wave_sum(v[rr].x * v[rr].x + v[rr].y * v[rr].y) * (1.f / F); }
-#pragma unroll
-        for (int rr = 0; rr < RW; ++rr) {
-            const int64_t row = row0 + wave * RW + rr;
-            const float sd = sqrtf(var[rr] + 1e-10f);
-            if (row < rows) reinterpret_cast<float2*>(out + row * F)[lane] = make_float2(v[rr].x / sd * g.x + bt.x, v[rr].y / sd * g.y + bt.y);
-        }
-    }
-#ifdef OT_TIMING
-    if (blockIdx.x == 17 && lane == 0) { long long* o = g_ot_timing[wave]; o[0] = tc1 - tc0; o[1] = tc2 - tc1; o[2] = clock64() - tc2; o[3] = tp1 - tc2; o[4] = tp2 - tp1; o[5] = tp3 - tp2; }
+    if (blockIdx.x == 17 && lane == 0) { long long* o = g_ot_timing[wave]; o[0] = tc1 - tc0; o[1] = tc2 - tc1; o[2] = clock64() - tc2; o[3] = 0; o[4] = 0; o[5] = 0; }
 #endif
 }
 
+
 size_t out_wfrag_floats() { return (size_t)F * OT_K; }
+size_t out_wterms_floats() { return (size_t)F * OT_K * 3 / 2; }
+
+// w_out_frag (fp32, operand order [cb][k-step][lane][8]) -> w_out_terms [cb][k-step][term h | m | l][lane] x 8 bf16: the split the tail kernel
+// performs in registers (split3 = three round-to-nearest bf16 terms, h + m + l == w exactly), done once per weight version for the fused
+// core + tail kernel, whose consumer waves have no VALU time to spare.
+__global__ __launch_bounds__(256) void out_frag_terms_kernel(const float* __restrict__ wof, float* __restrict__ wot) {
+    const int id = blockIdx.x * 256 + threadIdx.x;                           // (cb, k-step, lane)
+    if (id >= 4 * OT_ST * 64) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(wof) + (int64_t)id * 2;
+    const Split3 sp = split3(src[0], src[1]);
+    u32x4* dst = reinterpret_cast<u32x4*>(wot) + (int64_t)(id >> 6) * 192 + (id & 63);
+    dst[0] = sp.h; dst[64] = sp.m; dst[128] = sp.l;
+}
+int launch_out_frag_terms(const float* wof, float* wot, hipStream_t st) {
+    hipLaunchKernelGGL(out_frag_terms_kernel, dim3((4 * OT_ST * 64 + 255) / 256), dim3(256), 0, st, wof, wot);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
 size_t mlp_wfrag_floats() { return (size_t)3 * F * F * 3 / 2; }
 
 template <bool DUMP>
@@ -602,9 +405,10 @@ __global__ __launch_bounds__(256) void pack_tail_weights_kernel(const float* __r
     int id = blockIdx.x * 256 + threadIdx.x;
     if (id < NOUT) {                                                     // W_out stays fp32
         const int lane = id & 63, st = (id >> 6) % OT_ST, cb = (id >> 6) / OT_ST;
-        const float* p = w_out + (int64_t)(cb * 32 + (lane & 31)) * OT_K + st * 16 + (lane >> 5) * 8;
+        const float* p = w_out + (int64_t)(cb * 32 + (lane & 31)) * OT_K;
+        const int kk = st * 16 + (lane >> 5) * 8, c = kk / OT_KC, j = kk % OT_KC;      // K index in staging order -> feature columns (two quads)
         f32x4* d32 = reinterpret_cast<f32x4*>(wof) + ((int64_t)(cb * OT_ST + st) * 64 + lane) * 2;
-        d32[0] = *reinterpret_cast<const f32x4*>(p); d32[1] = *reinterpret_cast<const f32x4*>(p + 4);
+        d32[0] = *reinterpret_cast<const f32x4*>(p + ot_feat_col(c, j)); d32[1] = *reinterpret_cast<const f32x4*>(p + ot_feat_col(c, j + 4));
         return;
     }
     id -= NOUT;

@@ -1,0 +1,290 @@
+// Shared pieces of the GABlock tail (out_transform + LayerNorm + mlp_transition + LayerNorm, ga.py:174-177) used by the stand-alone
+// tail kernel (mlp.hip: out_ln_mlp_kernel) and by the fused IPA-core + tail kernel (ipa_core.hip: ipa_core32_kernel<true>).  Both run
+// the SAME arithmetic in the SAME order per output element -- k-steps of a (column block, K group) chain in the chunk order
+// ot_chunk_at(), partial sums ((p0 + p1) + (p2 + p3)) + bias, phase 2 row-local -- so their results are bit-identical
+// (tests/test_hip_parity.py::test_fused_block_is_bit_identical).
+#pragma once
+#include "ipa_common.h"
+
+namespace abopt {
+
+constexpr int F = 128, XLD = F + 4;
+constexpr int MR = 32;                     // rows per workgroup
+
+namespace {
+constexpr int OT_K = ABOPT_IPA_FEAT;          // 1824
+constexpr int OT_KC = 192, OT_NCH = (OT_K + OT_KC - 1) / OT_KC;           // 10 chunks of 192 columns = 12 k-steps of 16 (the last one half full)
+constexpr int OT_ST = OT_K / 16;              // 114 k-steps
+constexpr int OT_SPC = OT_KC / 16, OT_SPW = OT_SPC / 4;                   // 12 k-steps per chunk, 3 per wave
+constexpr int OT_TH = 1024, OT_NW = OT_TH / 64;
+constexpr int OT_SROW = OT_KC * 2 + 16;       // bytes per row of one bf16 plane of a chunk: 400, rows 36 banks apart (conflict-free b128 reads)
+constexpr int OT_PLANE = MR * OT_SROW, OT_STAGE = 3 * OT_PLANE;           // 12800, 38400 bytes
+constexpr int AP_ROW = F * 2 + 16, AP_PLANE = MR * AP_ROW;                // activation planes: 272 bytes per row (rows 4 banks apart)
+constexpr int OT_MS = F / 16;                 // 8 k-steps per MLP layer
+static_assert(OT_K % 16 == 0 && OT_KC % 64 == 0 && MR == 32 && F == 128, "out_transform tiling");
+
+struct OtSmem {
+    float ys[MR][XLD];                        // y = LayerNorm1(...) in fp32 (residual of the MLP)
+    float bias[3][F];                         // b_mlp0..2
+    char ap[3 * AP_PLANE];                    // input of the current layer as [term][row][128 bf16 + pad]
+    union {
+        char stage[2][OT_STAGE];              // phase 1: feat chunks as [term][row][192 bf16 + pad]
+        float part[4][MR][XLD];               // partial sums of the four K groups
+    };
+};
+
+__device__ __forceinline__ void acc_zero(f32x16& a) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = 0.f;
+}
+// accumulator register 4 g + i = output column 32 cb + 8 g + 4 (lane >> 5) + i, lane & 31 = residue
+__device__ __forceinline__ void store_partial1(float (*dst)[XLD], const f32x16& a0, int cb, int lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(&dst[lane & 31][cb * 32 + g * 8 + (lane >> 5) * 4]) = (f32x4){a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]};
+}
+__device__ __forceinline__ void store_partial(float (*dst)[XLD], const f32x16& a0, const f32x16& a1, int cb, int lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(&dst[lane & 31][cb * 32 + g * 8 + (lane >> 5) * 4]) =
+            (f32x4){a0[4 * g] + a1[4 * g], a0[4 * g + 1] + a1[4 * g + 1], a0[4 * g + 2] + a1[4 * g + 2], a0[4 * g + 3] + a1[4 * g + 3]};
+}
+// two adjacent values -> one 4-byte entry in each of the three planes
+__device__ __forceinline__ void store_terms2(char* ap, int byte_off, float e0, float e1) {
+    const unsigned h = pk_bf16(e0, e1);
+    const float r0 = e0 - __uint_as_float(h << 16), r1 = e1 - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = pk_bf16(r0, r1);
+    const unsigned l = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+    *reinterpret_cast<unsigned*>(ap + byte_off) = h;
+    *reinterpret_cast<unsigned*>(ap + AP_PLANE + byte_off) = m;
+    *reinterpret_cast<unsigned*>(ap + 2 * AP_PLANE + byte_off) = l;
+}
+struct MlpW { u32x4 v[2][3]; };               // a wave's two k-steps of one layer: [step][term]
+__device__ __forceinline__ MlpW load_mlp_w(const float* __restrict__ wm, int layer, int cb, int kg, int lane) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(wm) + ((int64_t)(layer * 4 + cb) * OT_MS + kg * 2) * 192 + lane;
+    MlpW w;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) w.v[j][sp] = p[j * 192 + sp * 64];
+    return w;
+}
+// partial [32 rows x 32 columns] of one layer for the wave's two k-steps
+__device__ __forceinline__ void mlp_partial(const char* ap, const MlpW& w, float (*dst)[XLD], int cb, int kg, int lane) {
+    f32x16 a0, a1;
+    acc_zero(a0); acc_zero(a1);
+    const char* xp = ap + (lane & 31) * AP_ROW + kg * 64 + (lane >> 5) * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const u32x4 xh = *reinterpret_cast<const u32x4*>(xp + j * 32), xm = *reinterpret_cast<const u32x4*>(xp + j * 32 + AP_PLANE),
+                    xl = *reinterpret_cast<const u32x4*>(xp + j * 32 + 2 * AP_PLANE);
+        a0 = mfma_bf32(w.v[j][0], xl, a0); a1 = mfma_bf32(w.v[j][2], xh, a1);
+        a0 = mfma_bf32(w.v[j][1], xm, a0); a1 = mfma_bf32(w.v[j][0], xm, a1);
+        a0 = mfma_bf32(w.v[j][1], xh, a0); a1 = mfma_bf32(w.v[j][0], xh, a1);
+    }
+    store_partial(dst, a0, a1, cb, lane);
+}
+}  // namespace
+
+// ---- phase-2 layer weights for the 16x16x32 form: wmf [layer][ct 8][k-step 4][lane 64] x 8 fp32, lane (m = lane & 15, kq = lane >> 4)
+// holds W[16 ct + m][32 s + 8 kq + i].  fp32 (4 bytes per weight instead of the 6 of three bf16 terms): the phase is bound by how fast a
+// CU can pull the three layers from L2, and the split costs 176 VALU operations per wave and layer.  Eight waves compute (wave = column
+// tile ct, both row tiles with the same weight registers); a layer's fragment is 32 registers, requested one layer ahead.
+namespace {
+struct MlpRaw { f32x4 v[4][2]; };
+__device__ __forceinline__ MlpRaw load_mlp_raw(const float* __restrict__ wm, int layer, int ct, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(wm) + ((int64_t)((layer * 8 + ct) * 4) * 64 + lane) * 2;
+    MlpRaw w;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { w.v[s][0] = p[s * 128]; w.v[s][1] = p[s * 128 + 1]; }
+    return w;
+}
+// [16 output columns of tile ct] x [32 rows] of one layer, K = 128, no K split: o[rt] register r of lane (n, kq) = output column
+// 16 ct + 4 kq + r of row 16 rt + n.  (Splitting the whole layer before the barrier that publishes its input, with the LDS reads one
+// k-step ahead, was measured: 128 VGPRs + 52 bytes of scratch per lane, no faster.)
+__device__ __forceinline__ void mlp16_layer(const char* ap, const MlpRaw& w, int lane, f32x4 (&o)[2]) {
+    f32x4 a[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) { a[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; a[rt][1] = a[rt][0]; }
+    const char* xp = ap + (lane & 15) * AP_ROW + (lane >> 4) * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const Split3 w3 = split3(w.v[s][0], w.v[s][1]);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {   // smallest terms first; two accumulators per row tile so consecutive MFMAs never depend on each other
+            const char* xr = xp + rt * 16 * AP_ROW + s * 64;
+            const u32x4 xh = *reinterpret_cast<const u32x4*>(xr), xm = *reinterpret_cast<const u32x4*>(xr + AP_PLANE),
+                        xl = *reinterpret_cast<const u32x4*>(xr + 2 * AP_PLANE);
+            a[rt][0] = mfma_bf(w3.h, xl, a[rt][0]); a[rt][1] = mfma_bf(w3.l, xh, a[rt][1]);
+            a[rt][0] = mfma_bf(w3.m, xm, a[rt][0]); a[rt][1] = mfma_bf(w3.h, xm, a[rt][1]);
+            a[rt][0] = mfma_bf(w3.m, xh, a[rt][0]); a[rt][1] = mfma_bf(w3.h, xh, a[rt][1]);
+        }
+    }
+    o[0] = a[0][0] + a[0][1]; o[1] = a[1][0] + a[1][1];
+}
+// one pair of adjacent fp32 values -> its three packed bf16 term words
+__device__ __forceinline__ void split_pair(float e0, float e1, unsigned& h, unsigned& m, unsigned& l) {
+    h = pk_bf16(e0, e1);
+    const float r0 = e0 - __uint_as_float(h << 16), r1 = e1 - __uint_as_float(h & 0xffff0000u);
+    m = pk_bf16(r0, r1);
+    l = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
+}  // namespace
+
+namespace {
+// Order in which the ten 192-column chunks of feat enter the out_transform sums.  The fused kernel gets the node features (chunks 4, 5:
+// the C waves' accumulators, which must leave their registers before those waves can take part in the products) first, then the pair
+// features (0..3, the pair waves' accumulators), then what the point epilogue derives (6..9; the last one half full).
+__device__ __forceinline__ constexpr int ot_chunk_at(int p) { return p < 2 ? 4 + p : (p < 6 ? p - 2 : p); }
+// Which feature column sits at staging column j (0..191) of chunk c.  The 768 pair-feature columns (h, channel) are dealt to chunks 0..3
+// by (channel % 16) / 4, not by head: chunk c, j = 16 h + 4 (channel / 16) + channel % 4.  In the fused kernel a pair wave's lane
+// (head, key group kq) holds the channels 16 kq + 4 r + 0..3 of its head: chunk r takes ONE 8-byte entry per row from EVERY lane (24
+// stores per wave and chunk instead of 96 from 12 of its 64 lanes, which cost the consumers 2..3k cycles per interval).  W_out is packed
+// in the same column order (pack_tail_weights_kernel), so the products are unchanged, only the order of the sum.  Chunks 4..9: identity.
+__device__ __forceinline__ constexpr int ot_feat_col(int c, int j) {
+    return c < 4 ? (j >> 4) * 64 + ((j >> 2) & 3) * 16 + 4 * c + (j & 3) : c * OT_KC + j;
+}
+
+// the six bf16-term products of one k-step (smallest terms first), two independent accumulator chains
+// into ONE accumulator chain per (column block, K group).  (Two chains per K group -- round 3 -- cost the fused kernel's consumer waves,
+// which run all four K groups, 128 accumulator registers; with 64 they keep twelve W_out fragments in flight instead of four, which is
+// what the epilogue needs while other workgroups still stream z: L2 round trips of ~2000 cycles.)
+__device__ __forceinline__ void ot_kstep6(const u32x4& wH, const u32x4& wM, const u32x4& wL, const u32x4& xh, const u32x4& xm, const u32x4& xl, f32x16& acc) {
+    acc = mfma_bf32(wH, xl, acc); acc = mfma_bf32(wL, xh, acc);
+    acc = mfma_bf32(wM, xm, acc); acc = mfma_bf32(wH, xm, acc);
+    acc = mfma_bf32(wM, xh, acc); acc = mfma_bf32(wH, xh, acc);
+}
+
+// ---- phase 2 of the tail: LayerNorm1, three 128 x 128 layers, LayerNorm2 on the 32 rows of a workgroup of NW waves (16 or 8).
+// What it needs from global memory is requested by tail_p2_prefetch BEFORE the caller publishes u (loads return in order, and the layer
+// weights behind them are a 64 KB burst).
+template <int NW>
+struct TailP2Pre {
+    float2 xv[MR / NW];
+    bool keep[MR / NW];
+    float2 bb, g1v, be1v;
+    MlpRaw mw;
+};
+template <int NW>
+__device__ __forceinline__ TailP2Pre<NW> tail_p2_prefetch(const float* __restrict__ x, const float* __restrict__ ubias, const uint8_t* __restrict__ mask,
+                                                         const float* __restrict__ g1, const float* __restrict__ be1, const float* __restrict__ wmf,
+                                                         int64_t row0, int64_t row_end, int wave, int lane) {
+    constexpr int RW = MR / NW;
+    TailP2Pre<NW> p;
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int64_t row = min(row0 + wave * RW + rr, row_end - 1);
+        p.keep[rr] = mask ? (mask[row] != 0) : true;
+        p.xv[rr] = reinterpret_cast<const float2*>(x + row * F)[lane];
+    }
+    p.bb = ubias ? reinterpret_cast<const float2*>(ubias)[lane] : make_float2(0.f, 0.f);
+    p.g1v = reinterpret_cast<const float2*>(g1)[lane];
+    p.be1v = reinterpret_cast<const float2*>(be1)[lane];
+    if (wave < 8) p.mw = load_mlp_raw(wmf, 0, wave & 7, lane);
+    return p;
+}
+// the three bias vectors -> LDS (read per layer by the compute waves); call before the barrier that publishes u
+__device__ __forceinline__ void tail_p2_stage_bias(float (*bias)[F], const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2, int tid) {
+    if (tid < 3 * F / 4) {
+        const float* bsrc = tid < F / 4 ? b0 : (tid < F / 2 ? b1 : b2);
+        *reinterpret_cast<f32x4*>(&bias[tid >> 5][(tid & 31) * 4]) = *reinterpret_cast<const f32x4*>(bsrc + (tid & 31) * 4);
+    }
+}
+// GetU(rl) -> this lane's two columns (2 lane, 2 lane + 1) of u = feat . W_out^T for local row rl, WITHOUT the bias.  The caller has
+// passed the barrier that publishes u and the staged biases.  ys [MR][XLD] fp32, apA / apB two sets of three bf16 planes (AP_PLANE each);
+// none of them may alias what GetU reads.  DUMP (training): five [rows, 128] slabs, see out_ln_mlp_kernel.
+template <int NW, bool DUMP, class GetU>
+__device__ __forceinline__ void tail_p2_run(TailP2Pre<NW>& pre, GetU&& get_u, float (*ys)[XLD], float (*bias)[F], char* apA, char* apB,
+                                            const float* __restrict__ wmf, const float* __restrict__ g2, const float* __restrict__ be2,
+                                            float* __restrict__ out, float* __restrict__ dump, int64_t slab, int64_t row0, int64_t row_end,
+                                            int wave, int lane) {
+    constexpr int RW = MR / NW;
+    const int fm = lane & 15, kq = lane >> 4;
+    const bool mlpw = wave < 8;                                                                          // waves 0..7 own the eight 16-column tiles
+    const int ct = wave & 7;
+    const int ocol = ct * 16 + kq * 4;                                                                   // this lane's four output columns in every layer
+    MlpRaw mw = pre.mw;
+    {
+        const float2 g = pre.g1v, bt = pre.be1v;
+        float a_[RW], b_[RW], mean[RW], var[RW];
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int rl = wave * RW + rr;
+            const float2 u = get_u(rl);
+            float2 us = make_float2(u.x + pre.bb.x, u.y + pre.bb.y);
+            if (!pre.keep[rr]) us = make_float2(0.f, 0.f);
+            a_[rr] = pre.xv[rr].x + us.x; b_[rr] = pre.xv[rr].y + us.y;
+            if (DUMP && row0 + rl < row_end) reinterpret_cast<float2*>(dump + (row0 + rl) * F)[lane] = make_float2(a_[rr], b_[rr]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) mean[rr] = wave_sum(a_[rr] + b_[rr]) * (1.f / F);
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) { a_[rr] -= mean[rr]; b_[rr] -= mean[rr]; var[rr] = wave_sum(a_[rr] * a_[rr] + b_[rr] * b_[rr]) * (1.f / F); }
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int rl = wave * RW + rr;
+            const float sd = sqrtf(var[rr] + 1e-10f);
+            const float y0 = a_[rr] / sd * g.x + bt.x, y1 = b_[rr] / sd * g.y + bt.y;
+            *reinterpret_cast<float2*>(&ys[rl][2 * lane]) = make_float2(y0, y1);
+            store_terms2(apA, rl * AP_ROW + lane * 4, y0, y1);
+            if (DUMP && row0 + rl < row_end) reinterpret_cast<float2*>(dump + slab + (row0 + rl) * F)[lane] = make_float2(y0, y1);
+        }
+    }
+    __syncthreads();                                                                                     // y planes complete; every read of u is done
+    // ---- layer 0: relu(W0 y + b0) -> planes B ; layer 1: relu(W1 h + b1) -> planes A (their last readers passed the barrier in between)
+#pragma unroll
+    for (int layer = 0; layer < 2; ++layer) {
+        if (mlpw) {
+            const char* src = layer == 0 ? apA : apB;
+            char* dst = layer == 0 ? apB : apA;
+            const MlpRaw nxt = load_mlp_raw(wmf, layer + 1, ct, lane);                                  // the next layer's fragment travels while this one computes
+            f32x4 o[2];
+            mlp16_layer(src, mw, lane, o);
+            mw = nxt;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[layer][ocol]);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int orow = rt * 16 + fm;
+                const f32x4 v = o[rt] + bv;
+                const f32x4 hv = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                store_terms2(dst, orow * AP_ROW + ocol * 2, hv[0], hv[1]);
+                store_terms2(dst, orow * AP_ROW + ocol * 2 + 4, hv[2], hv[3]);
+                if (DUMP && row0 + orow < row_end) *reinterpret_cast<f32x4*>(dump + (2 + layer) * slab + (row0 + orow) * F + ocol) = hv;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- layer 2 + residual (in place in ys: every element has exactly one owner), then LayerNorm2
+    if (mlpw) {
+        f32x4 o[2];
+        mlp16_layer(apA, mw, lane, o);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[2][ocol]);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int orow = rt * 16 + fm;
+            f32x4 yv = *reinterpret_cast<const f32x4*>(&ys[orow][ocol]);
+            yv += o[rt] + bv;
+            *reinterpret_cast<f32x4*>(&ys[orow][ocol]) = yv;
+            if (DUMP && row0 + orow < row_end) *reinterpret_cast<f32x4*>(dump + 4 * slab + (row0 + orow) * F + ocol) = yv;
+        }
+    }
+    __syncthreads();
+    {
+        const float2 g = reinterpret_cast<const float2*>(g2)[lane], bt = reinterpret_cast<const float2*>(be2)[lane];
+        float2 v[RW];
+        float mean[RW], var[RW];
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) { v[rr] = *reinterpret_cast<const float2*>(&ys[wave * RW + rr][2 * lane]); mean[rr] = wave_sum(v[rr].x + v[rr].y) * (1.f / F); }
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) { v[rr].x -= mean[rr]; v[rr].y -= mean[rr]; var[rr] = wave_sum(v[rr].x * v[rr].x + v[rr].y * v[rr].y) * (1.f / F); }
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int64_t row = row0 + wave * RW + rr;
+            const float sd = sqrtf(var[rr] + 1e-10f);
+            if (row < row_end) reinterpret_cast<float2*>(out + row * F)[lane] = make_float2(v[rr].x / sd * g.x + bt.x, v[rr].y / sd * g.y + bt.y);
+        }
+    }
+}
+}  // namespace
+
+}  // namespace abopt

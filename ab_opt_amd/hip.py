@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -22,7 +22,7 @@ c_u8 = C.c_void_p       # device uint8*
 class GaWeights(C.Structure):
     _fields_ = [(n, c_f) for n in (
         'w_node', 'w_pair_bias', 'spatial_coef', 'w_out', 'b_out', 'ln1_gamma', 'ln1_beta',
-        'w_mlp0', 'b_mlp0', 'w_mlp1', 'b_mlp1', 'w_mlp2', 'b_mlp2', 'ln2_gamma', 'ln2_beta', 'w_node_frag', 'w_out_frag', 'w_mlp_frag')]
+        'w_mlp0', 'b_mlp0', 'w_mlp1', 'b_mlp1', 'w_mlp2', 'b_mlp2', 'ln2_gamma', 'ln2_beta', 'w_node_frag', 'w_out_frag', 'w_mlp_frag', 'w_out_terms')]
 
 
 class GaDebug(C.Structure):
@@ -77,7 +77,7 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
-           'abopt_out_frag_floats', 'abopt_heads_frag_floats', 'abopt_mixer_frag_floats', 'abopt_mlp_frag_floats', 'abopt_pack_tail_weights', 'abopt_block_tail_forward', 'abopt_block_tail_backward']
+           'abopt_out_frag_floats', 'abopt_out_terms_floats', 'abopt_out_frag_terms', 'abopt_heads_frag_floats', 'abopt_mixer_frag_floats', 'abopt_mlp_frag_floats', 'abopt_pack_tail_weights', 'abopt_block_tail_forward', 'abopt_block_tail_backward']
 
 _lib = None
 _lock = threading.Lock()
@@ -158,6 +158,8 @@ def lib():
         L.abopt_dockq_workspace_bytes.argtypes = [C.c_int]
         L.abopt_dockq_lite.argtypes = [c_f, c_u8, C.c_int, c_f, c_u8, C.c_void_p, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_out_frag_floats.restype = C.c_size_t
+        L.abopt_out_terms_floats.restype = C.c_size_t
+        L.abopt_out_frag_terms.argtypes = [c_f, c_f, C.c_void_p]
         L.abopt_heads_frag_floats.restype = C.c_size_t
         L.abopt_mixer_frag_floats.restype = C.c_size_t
         L.abopt_mlp_frag_floats.restype = C.c_size_t
@@ -250,7 +252,7 @@ def ga_weights_struct(t):
     """t: dict name -> contiguous device tensor with the field names of GaWeights (w_node_frag optional)."""
     s = GaWeights()
     for name, _ in GaWeights._fields_:
-        setattr(s, name, ptr(t.get(name), torch.float32, optional=name in ('w_node_frag', 'w_out_frag', 'w_mlp_frag')))
+        setattr(s, name, ptr(t.get(name), torch.float32, optional=name in ('w_node_frag', 'w_out_frag', 'w_mlp_frag', 'w_out_terms')))
     return s
 
 
@@ -271,9 +273,19 @@ def pack_heads_weights(w_head1, w_crd2, w_rot2, w_seq2, w_crd3, w_rot3, w_seq3):
     return pack_mfma_operand(rows.contiguous())
 
 
+def out_feat_order():
+    """The order in which the 1824 feature columns enter the tail's K index (csrc/tail_common.h: ot_feat_col): the 768 pair-feature columns
+    (head h, channel ch) sit at K index 192 * ((ch % 16) // 4) + 16 h + 4 (ch // 16) + ch % 4, the other columns keep their place."""
+    k = torch.arange(1824)
+    c, j = k // 192, k % 192
+    perm = (j >> 4) * 64 + ((j >> 2) & 3) * 16 + 4 * c + (j & 3)
+    return torch.where(k < 768, perm, k)
+
+
 def pack_out_weights(w_out):
     """w_out [128, 1824] -> w_out_frag [4, 114, 64, 8] fp32 in operand order (include/abopt.h: abopt_ga_weights.w_out_frag)."""
-    return w_out.float().reshape(4, 32, 114, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+    w = w_out.float()[:, out_feat_order().to(w_out.device)]
+    return w.reshape(4, 32, 114, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
 def pack_mlp_weights(w0, w1, w2):
@@ -654,6 +666,13 @@ def pack_tail_weights(w_out, w0, w1, w2, transposed=False):
     _check(lib().abopt_pack_tail_weights(ptr(w_out, torch.float32), ptr(w0, torch.float32), ptr(w1, torch.float32), ptr(w2, torch.float32),
                                          ptr(wof), ptr(wmf), ptr(wmt, torch.float32, optional=True), stream()))
     return (wof, wmf, wmt) if transposed else (wof, wmf)
+
+
+def out_frag_terms(wof):
+    """w_out_frag -> its three bf16 terms in operand order (abopt_out_frag_terms): what the fused core + tail kernel streams."""
+    wot = torch.empty(lib().abopt_out_terms_floats(), dtype=torch.float32, device=wof.device)
+    _check(lib().abopt_out_frag_terms(ptr(wof, torch.float32), ptr(wot), stream()))
+    return wot
 
 
 def block_tail_forward(feat, wof, wmf, x, b_out, mask, g1, be1, b0, b1, b2, g2, be2, save=False):

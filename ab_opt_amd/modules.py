@@ -99,6 +99,7 @@ class GABlock(nn.Module):
         if t['w_node'].is_cuda:
             t['w_node_frag'] = hip.pack_node_weights(t['w_node'])
             t['w_out_frag'], t['w_mlp_frag'] = hip.pack_tail_weights(t['w_out'], t['w_mlp0'], t['w_mlp1'], t['w_mlp2'])
+            t['w_out_terms'] = hip.out_frag_terms(t['w_out_frag'])
         s = hip.ga_weights_struct(t)
         self._pack = (snap, t, s)
         return t, s

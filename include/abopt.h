@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 33
+#define ABOPT_ABI_VERSION 34
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -59,12 +59,18 @@ typedef struct {
     const float* w_node_frag;   /* optional [12, 12, 4, 3, 64, 4]: w_node re-laid out per head in MFMA operand order, every weight as its three
                                    bf16 terms (layout below); when given, the fused projection kernel replaces the GEMM + fragment pass
                                    (same results up to fp32 summation order) */
-    const float* w_out_frag;    /* optional [4, 114, 64, 8]: w_out as fp32 in MFMA operand order: [cb][s][lane = 32 kh + c][i] = w_out[32 cb + c][16 s + 8 kh + i]
-                                   (the kernel splits it into bf16 terms in registers);
+    const float* w_out_frag;    /* optional [4, 114, 64, 8]: w_out as fp32 in MFMA operand order: [cb][s][lane = 32 kh + c][i] = w_out[32 cb + c][col(16 s + 8 kh + i)]
+                                   (the kernel splits it into bf16 terms in registers).  col(k) = k for k >= 768; the 768 pair-feature columns
+                                   (head h, channel ch) enter the K index at k = 192 ((ch % 16) / 4) + 16 h + 4 (ch / 16) + ch % 4 -- the order in
+                                   which the fused core + tail kernel's lanes hold them (csrc/tail_common.h: ot_feat_col; abopt_pack_tail_weights
+                                   produces this layout);
                                    when given together with w_mlp_frag, out_transform runs inside the LayerNorm/MLP kernel (no split-K partial slabs) */
     const float* w_mlp_frag;    /* optional, abopt_mlp_frag_floats() floats: w_mlp0, w_mlp1, w_mlp2 as fp32 in 16x16x32 MFMA operand order,
                                    [layer][ct][s][lane = 16 kq + m][i] = w[16 ct + m][32 s + 8 kq + i] (3 * 8 * 4 * 64 * 8 floats, the rest of
                                    the buffer is zero); the fused tail kernel reads its weights from here and splits them into bf16 terms */
+    const float* w_out_terms;   /* optional, abopt_out_terms_floats() floats: w_out_frag split into its three bf16 terms by abopt_out_frag_terms,
+                                   [cb][s][term][lane] -> 8 bf16.  When given (with w_mlp_frag and a pair-bias cache), the IPA core and the tail of the
+                                   block run as ONE kernel wherever the 32-row core applies: feat never leaves the chip (bit-identical results) */
 } abopt_ga_weights;
 
 /* Host-side description of the w_node_frag layout (used by the binding to pack weights once): for head h, tile T (0,1 q | 2,3 k |
@@ -91,6 +97,10 @@ size_t abopt_out_frag_floats(void);
 size_t abopt_heads_frag_floats(void);
 size_t abopt_mixer_frag_floats(void);
 size_t abopt_mlp_frag_floats(void);
+size_t abopt_out_terms_floats(void);
+/* w_out_frag (abopt_pack_tail_weights) -> w_out_terms: the three round-to-nearest bf16 terms of every weight (h + m + l == w exactly), the
+ * same split the tail kernel performs in registers. */
+int abopt_out_frag_terms(const float* w_out_frag, float* w_out_terms, abopt_stream stream);
 int abopt_pack_tail_weights(const float* w_out, const float* w_mlp0, const float* w_mlp1, const float* w_mlp2, float* w_out_frag,
                             float* w_mlp_frag, float* w_mlpT_frag, abopt_stream stream);
 int abopt_block_tail_forward(const float* feat, const float* w_out_frag, const float* w_mlp_frag, const float* x, const float* b_out,

@@ -1225,6 +1225,7 @@ def test_core32_is_bit_identical(N, L, lengths, monkeypatch):
     lengths that leave the second row tile of the last block empty or partial, chunk counts not divisible by 3, ragged masks."""
     from ab_opt_amd import hip
     monkeypatch.setenv('ABOPT_CORE_NO_SPLIT', '1')
+    monkeypatch.setenv('ABOPT_FUSE_TAIL', '0')                  # the 32-row core on its own (its fused form: test_fused_block_is_bit_identical)
     d = standalone_abdesign_dpm(100, 2).to(DEV)
     lens = [L] * N if lengths is None else [L - (7 * i) % min(60, L // 2) for i in range(N)]
     v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lens, 6100 + N, [(5, 14), (22, 30)])
@@ -1240,6 +1241,39 @@ def test_core32_is_bit_identical(N, L, lengths, monkeypatch):
     monkeypatch.delenv('ABOPT_CORE32')                          # the library's own choice (the 32-row kernel at the bench shape): same bits either way
     auto = hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc)
     assert all(torch.equal(auto[k], ref[k]) for k in ('R_next', 'eps_pos', 'c'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,L,lengths', [(32, 256, None), (32, 256, 'ragged'), (3, 100, None), (5, 250, 'ragged'), (8, 48, 'ragged'), (4, 40, None), (2, 33, None), (9, 130, None),
+                                         (24, 256, 'ragged')])
+def test_fused_block_is_bit_identical(N, L, lengths, monkeypatch):
+    """Round 4: core + tail of a GABlock as ONE kernel (csrc/ipa_core.hip: ipa_core32_kernel<true> -- out_transform, LayerNorm,
+    mlp_transition, LayerNorm of ga.py:174-177 as the epilogue of the 32-row core, `feat` never written).  Its sums run in the order of
+    the stand-alone tail kernel (tail_common.h), so the whole EpsilonNet output is bit-identical to the two-launch form and to the 16-row
+    kernels: lengths that leave the last block's second row tile empty or partial, ragged masks (masked query rows: u = 0), the
+    library's own choice at the bench shape."""
+    from ab_opt_amd import hip
+    monkeypatch.setenv('ABOPT_CORE_NO_SPLIT', '1')
+    d = standalone_abdesign_dpm(100, 2).to(DEV)
+    lens = [L] * N if lengths is None else [L - (7 * i) % min(60, L // 2) for i in range(N)]
+    v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lens, 7100 + N, [(5, 14), (22, 30)])
+    beta = d.trans_pos.var_sched.betas[37].expand([N]).contiguous()
+    arr, ew = d.eps_net.encoder.packed_array(), d.eps_net.packed()
+    pbc = hip.pair_bias_cache(arr, 6, pf)
+    run = lambda: hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc)
+    monkeypatch.setenv('ABOPT_CORE32', '0')
+    ref16 = run()
+    monkeypatch.setenv('ABOPT_CORE32', '1')
+    monkeypatch.setenv('ABOPT_FUSE_TAIL', '0')
+    ref32 = run()
+    monkeypatch.setenv('ABOPT_FUSE_TAIL', '1')
+    got = run()
+    for k in ('R_next', 'eps_pos', 'c'):
+        assert torch.isfinite(got[k]).all() and torch.equal(got[k], ref32[k]) and torch.equal(got[k], ref16[k]), k
+    monkeypatch.delenv('ABOPT_CORE32')
+    monkeypatch.delenv('ABOPT_FUSE_TAIL')
+    auto = run()
+    assert all(torch.equal(auto[k], ref16[k]) for k in ('R_next', 'eps_pos', 'c'))
 
 
 def test_residue_features_native_vs_torch_statement():
