@@ -359,7 +359,7 @@ static int ga_encoder(const abopt_ga_weights* blocks, int num_layers, const floa
     for (int i = 0; i < num_layers; ++i) {
         float* dst = ((num_layers - 1 - i) % 2 == 0) ? x_out : pong;
         int rc = ga_block(&blocks[i], R, t, cur, z, mask, dst, N, L, nullptr, s, st,
-                          pair_bias_cache ? pair_bias_cache + (size_t)i * pair_bias_layer_floats(z_shared ? 1 : N, L) : nullptr, z_shared);
+                          pair_bias_cache ? pair_bias_cache + (size_t)i * pair_bias_layer_floats(z_shared ? N / z_shared : N, L) : nullptr, z_shared);
         if (rc) return rc;
         cur = dst;
     }
@@ -450,6 +450,10 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
     hipStream_t st = (hipStream_t)stream;
     const int64_t M = (int64_t)N * L;
     if (M == 0) return ABOPT_OK;
+    // pair_feat_shared: 0 distinct | 1 one entry for the whole batch | g > 1 consecutive groups of g samples share an entry
+    ABOPT_CHECK_ARG(pair_feat_shared >= 0 && (pair_feat_shared <= 1 || N % pair_feat_shared == 0), "eps_net_forward: pair_feat_shared=%d does not divide N=%d", pair_feat_shared, N);
+    ABOPT_CHECK_ARG(!pair_feat_shared || pair_bias_cache, "eps_net_forward: a shared pair_feat comes with its pair-bias cache");
+    const int zg = pair_feat_shared == 1 ? N : pair_feat_shared;
     Carver cv(ws, ws_bytes);
     EpsScratch e = carve_eps(cv, M, N, L, 64);
     if (!cv.ok) { set_error("eps_net_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, abopt_eps_workspace_bytes(N, L, Fd, Cd)); return ABOPT_EWORKSPACE; }
@@ -464,7 +468,7 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
         if ((rc = launch_linear(e.x0, F, w->w_mix1, F, w->b_mix1, e.cat, F, (int)M, F, F, false, st))) return rc;   // reuse cat[:, :F] as x (ld = F)
     }
     // dpm_full.py:90  encoder
-    if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st, pair_bias_cache, pair_feat_shared ? 1 : 0))) return rc;
+    if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st, pair_bias_cache, zg))) return rc;
     if (w->w_heads_frag) {
         // dpm_full.py:92-101: time features + the three heads in one launch (heads.hip)
         if (has_prmsd && (rc = launch_build_infeat(e.xe, beta, e.infeat, w->prmsd_ln_gamma, w->prmsd_ln_beta, e.infeat_ln, N, L, st))) return rc;

@@ -207,5 +207,10 @@ static int prof_sum(int* launches, double* total_ms, bool reset) {
     return ABOPT_OK;
 }
 extern "C" int abopt_prof_collect(int* launches, double* total_ms) { return prof_sum(launches, total_ms, true); }
+extern "C" int abopt_prof_clock(long long* cycles, long long* wall_ticks_100mhz) {
+    ABOPT_CHECK_ARG(cycles && wall_ticks_100mhz, "prof_clock: NULL argument");
+    ABOPT_HIP(hipDeviceSynchronize());
+    return abopt::read_clock_probe(cycles, wall_ticks_100mhz);
+}
 // the same without forgetting the pairs: event records captured into a hipGraph are re-recorded by every replay
 extern "C" int abopt_prof_peek(int* launches, double* total_ms) { return prof_sum(launches, total_ms, false); }

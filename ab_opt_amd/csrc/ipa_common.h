@@ -74,6 +74,7 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
                            const float* w_pair_bias, float* feat, float* dump, float* dump_stats, const float* pair_bias_cache, int N, int L,
                            hipStream_t st, int z_shared, float* split_ws = nullptr, size_t split_ws_floats = 0);
 size_t ipa_split_ws_floats(int N, int L);
+int read_clock_probe(long long* cycles, long long* wall_ticks);
 int launch_pair_bias_cache(const float* z, const float* const* wb, int num_layers, float* cache, int N, int L, hipStream_t st);
 
 }  // namespace abopt

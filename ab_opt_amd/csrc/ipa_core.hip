@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
     const int nchunk = (L + JC - 1) / JC;
     const int i0 = ib * BI;
     const int64_t rowbase = (int64_t)n * L;
-    const int64_t zbase = z_shared ? 0 : rowbase;                      // z_shared: one pair_feat (and bias cache) for the whole batch
+    const int64_t zbase = z_shared ? (int64_t)(n / z_shared) * L : rowbase;   // z_shared = g > 0: consecutive groups of g samples share one pair_feat (and bias cache) entry
     // Key chunks are visited in natural order by every query block of a sample: the 16 blocks then read the same 96 KB of key/value
     // fragments at about the same time and all but the first hit in the XCD's L2.  (A per-block rotated order was measured: L2 hit
     // rate of the fragments fell from ~90 % to ~25 %, FETCH_SIZE 0.75 -> 1.16 GB per launch, kernel 185 -> 199 us.)
@@ -483,7 +483,7 @@ __device__ __forceinline__ PBlk pblk_of(int b, int nib, int L, int xcd_remap, in
     if (xcd_remap) { const int xcd = b & 7, k = b >> 3; n = xcd + 8 * (k / nib); ib = k % nib; }
     else { n = b / nib; ib = b % nib; }
     PBlk r;
-    r.n = n; r.i0 = ib * BI; r.rowbase = (int64_t)n * L; r.zbase = z_shared ? 0 : r.rowbase;
+    r.n = n; r.i0 = ib * BI; r.rowbase = (int64_t)n * L; r.zbase = z_shared ? (int64_t)(n / z_shared) * L : r.rowbase;
     return r;
 }
 
@@ -914,6 +914,10 @@ constexpr int BI2 = 32, NPW2 = 4, RPW2 = BI2 / NPW2, NTH2 = 512, HPW = 6;
 //   all waves the stand-alone kernel's phase 2 (tail_common.h: tail_p2_run) on 8 waves.
 // Same arithmetic in the same order as ipa_core32_kernel<false> followed by out_ln_mlp_kernel: bit-identical
 // (tests/test_hip_parity.py::test_fused_block_is_bit_identical).
+// Clock probe (abopt_prof_clock): wave 0 of workgroup 0 of the last 32-row launch leaves {shader cycles, 100 MHz wall ticks} from its first to
+// its last instruction -- the clock the chip sustained under THAT kernel (DVFS moves it between 1.7 and 2.2 GHz), so a
+// reader of the bench line can tell a slow box from a slow kernel.  Two scalar timer reads and one store per launch.
+__device__ long long g_clock_probe[2];
 #ifndef C32F_ABL
 #define C32F_ABL 0       // developer ablations of the fused epilogue (timing only, results wrong): 1 no W_out refills | 2 no MFMAs | 4 producers write nothing | 8 / 16 C waves: no node-feature staging / no point writes
 #endif
@@ -969,12 +973,19 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
     int n, ib;
     {
         const int b = blockIdx.x;
-        if (xcd_remap) { const int xcd = b & 7, k = b >> 3; n = xcd + 8 * (k / nib2); ib = k % nib2; }
+        if (xcd_remap == 2) {
+            // groups of g samples share a complex (config 4: 8 complexes x 16 samples in one launch): a complex stays on ONE XCD, and the
+            // workgroups that are resident there together work on the same query block of its g samples -- the 2 MB of z (and the bias
+            // cache rows) of that block are fetched from HBM once and served to the other g - 1 samples by the XCD's L2
+            const int xcd = b & 7, k = b >> 3, per = nib2 * z_shared, r = k % per;
+            ib = r / z_shared; n = (xcd + 8 * (k / per)) * z_shared + r % z_shared;
+        } else if (xcd_remap) { const int xcd = b & 7, k = b >> 3; n = xcd + 8 * (k / nib2); ib = k % nib2; }
         else { n = b / nib2; ib = b % nib2; }
     }
     const int tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunk = (L + JC - 1) / JC, nib16 = (L + BI - 1) / BI;
+    const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
 #ifdef C32F_TIMING
     const long long t32f_begin = clock64();
 #endif
@@ -991,7 +1002,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
 #endif
     const int i0 = ib * BI2;
     const int64_t rowbase = (int64_t)n * L;
-    const int64_t zbase = z_shared ? 0 : rowbase;
+    const int64_t zbase = z_shared ? (int64_t)(n / z_shared) * L : rowbase;
     auto fill_mask = [&]() { for (int e = tid; e < nchunk * JC; e += NTH2) mk[e] = (e < L) ? mask[rowbase + e] : 0; };
     // ---- fused tail (FUSE): LDS views valid after barrier F1, and the consumer role (A and C waves after their loops)
     char* const stage = smem_raw;                                               // [2][3][32][OT_SROW]: aliases the S/P tile
@@ -1550,6 +1561,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                                       smem_raw + C32F_PTS_OFF, ta.wmf, ta.g2, ta.be2, ta.out, nullptr, 0, row0, row_end, wave, lane);
         C32F_STAMP(15)
     }
+    if (blockIdx.x == 0 && tid == 0) { g_clock_probe[0] = clock64() - probe_c0; g_clock_probe[1] = wall_clock64() - probe_w0; }
 }
 
 // Pair-bias cache: lp[l][n,i,j,h] = z[n,i,j,:] . Wb_l[h,:] for every layer l in ONE pass over z (ga.py:88-90).  z and the weights do
@@ -1687,6 +1699,12 @@ static int launch_core_variant(const float* qfrag, const float* kvfrag, const fl
 //   259; N = 20, L = 400: 385 against 258).
 //   short lengths gain nothing (L = 128: equal; L = 64: 134 against 128).
 // ABOPT_CORE32=0 / 1 overrides (1: whenever 16 < L <= 2048).
+// block -> (sample, query block) mapping of the 32-row kernels: 2 = by complex (groups of z_shared samples, a multiple of 8 complexes),
+// 1 = all query blocks of a sample on one XCD (N % 8 == 0), 0 = plain
+static int core32_remap(int N, int z_shared) {
+    if (z_shared > 1 && z_shared < N && N % z_shared == 0 && (N / z_shared) % 8 == 0) return 2;
+    return (N % 8 == 0) ? 1 : 0;
+}
 static bool use_core32(int N, int L, int cus) {
     const char* e = getenv("ABOPT_CORE32");
     if (L > 2048) return false;                                 // its buffer descriptors address a sample's z slab (L^2 * 256 bytes) with 32-bit offsets
@@ -1717,7 +1735,7 @@ int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float*
     TailArgs ta{wot, wmf, x, ubias, g1, be1, b0, b1, b2, g2, be2, out};
     prof::begin(st);
     hipLaunchKernelGGL(ipa_core32_kernel<true>, dim3((unsigned)(N * nib2)), dim3(NTH2), C32F_LDS_BYTES, st, qfrag, kvfrag, z, mask, R, t, (float*)nullptr,
-                       pair_bias_cache, L, nib2, (N % 8 == 0) ? 1 : 0, z_shared, ta);
+                       pair_bias_cache, L, nib2, core32_remap(N, z_shared), z_shared, ta);
     prof::end(st);
     ABOPT_LAUNCH_CHECK();
 #ifdef C32F_TIMING
@@ -1738,6 +1756,13 @@ int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float*
     return ABOPT_OK;
 }
 
+int read_clock_probe(long long* cycles, long long* wall_ticks) {
+    long long h[2] = {0, 0};
+    ABOPT_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clock_probe), sizeof(h)));
+    *cycles = h[0]; *wall_ticks = h[1];
+    return ABOPT_OK;
+}
+
 int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                            const float* w_pair_bias, float* feat, float* dump, float* dump_stats, const float* pair_bias_cache, int N, int L, hipStream_t st,
                            int z_shared, float* split_ws, size_t split_ws_floats) {
@@ -1753,7 +1778,7 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel<false>), lds, lds_cfg)) return rc;
         prof::begin(st);
         hipLaunchKernelGGL(ipa_core32_kernel<false>, dim3((unsigned)(N * nib2)), dim3(NTH2), lds, st, qfrag, kvfrag, z, mask, R, t, feat, pair_bias_cache, L, nib2,
-                           (N % 8 == 0) ? 1 : 0, z_shared, TailArgs{});
+                           core32_remap(N, z_shared), z_shared, TailArgs{});
         prof::end(st);
         ABOPT_LAUNCH_CHECK();
 #ifdef C32_TIMING

@@ -117,7 +117,7 @@ class FullDPM(nn.Module):
             return self._run_eager(state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
                                    ppl_masked, noise, seed, rng_offset, pbar, stop_after, optimize_mode, use_bias_cache)
         N, L = mask_res.shape
-        shared = pair_feat.shape[0] == 1 and N > 1
+        shared = pair_feat.shape[0] != N
         if use_bias_cache is None:
             use_bias_cache = shared or self._bias_cache_fits(pair_feat.shape[0], L, res_feat.device, graph=True)
         self.eps_net.packed()
@@ -171,13 +171,21 @@ class FullDPM(nn.Module):
         # Replicated-complex batches (one crop, N samples: design_for_pdb.py:141-147) may pass the context ONCE: res_feat
         # (1,L,F) / pair_feat (1,L,L,C) are then shared by all N samples -- the kernels index pair_feat and its bias cache
         # with batch stride 0, so the 100 x 6 passes over it are served from L2/MALL instead of HBM.
-        shared = pair_feat.shape[0] == 1 and N > 1
+        # ... and a test set of complexes x S samples may pass G complexes once each: pair_feat (G,L,L,C), samples S c .. S c + S - 1 share
+        # entry c (design_for_testset.py:556-589 runs them one structure at a time; BASELINE config 4).
+        Nc = pair_feat.shape[0]
+        if Nc < 1 or N % Nc:
+            raise ValueError(f'pair_feat holds {Nc} complexes for a batch of {N} samples: the batch must be a whole number of samples per complex')
+        group = N // Nc
+        shared = group > 1
         if use_bias_cache is None:
-            use_bias_cache = shared or self._bias_cache_fits(pair_feat.shape[0], L, dev)
+            use_bias_cache = shared or self._bias_cache_fits(Nc, L, dev)
         if shared and not use_bias_cache:
             raise ValueError('a shared pair_feat requires the pair-bias cache')
-        if res_feat.shape[0] == 1 and N > 1:
-            res_feat = res_feat.expand(N, -1, -1)
+        if res_feat.shape[0] != N:
+            if res_feat.shape[0] != Nc:
+                raise ValueError('res_feat must hold one entry per sample or one per complex')
+            res_feat = res_feat.repeat_interleave(group, dim=0)
         res_feat, pair_feat = res_feat.contiguous().float(), pair_feat.contiguous().float()
         mask_generate, mask_res = mask_generate.contiguous(), mask_res.contiguous()
         ew = self.eps_net.packed()
@@ -203,7 +211,7 @@ class FullDPM(nn.Module):
                 break
             beta = beta_rows[t]
             hip.eps_net_forward(ew, tv[t], p_norm, ts[t], res_feat, pair_feat, beta, mask_generate, mask_res,
-                                self.abdock, self.num_bins, False, out=net, pair_bias_cache=pbc, pair_feat_shared=shared)
+                                self.abdock, self.num_bins, False, out=net, pair_bias_cache=pbc, pair_feat_shared=(group if shared else 0))
             sp = self._step_params(t, sample_structure, sample_sequence, ppl_masked, optimize_mode)
             out = dict(v=tv[t - 1], p=tp[t - 1], s=ts[t - 1], p_norm=p_norm)
             if self.abdock:
@@ -308,7 +316,7 @@ class _LoopGraph:
     def replay(self, state, res_feat, pair_feat, mask_generate, mask_res, seed, rng_offset):
         for dst, src in zip(self.state, state):
             dst.copy_(src)
-        self.res_feat.copy_(res_feat.expand_as(self.res_feat))
+        self.res_feat.copy_(res_feat if res_feat.shape == self.res_feat.shape else res_feat.expand_as(self.res_feat))
         # pair_feat is the one large input (537 MB at N=32, L=256): when the caller hands over the very tensor object of the last replay,
         # unmodified (same _version), the static copy is still current.  Identity of the live OBJECT, not of the address: a freed tensor's
         # address can come back from the allocator with other contents.

@@ -126,41 +126,124 @@ def sample_replicated(model, complex_batch, num_samples, sample_opt=None, optimi
 
 
 def complexes_of_rank(n_complexes, world_size, rank):
-    """By-complex partition of a test set (BASELINE config 4): complex c runs on rank c % world, so every
-    sample of a complex -- and therefore its whole commonness ranking -- stays on one GPU and nothing is exchanged per complex."""
-    return list(range(rank, n_complexes, world_size))
+    """By-complex partition of a test set (BASELINE config 4): contiguous, balanced blocks of complexes per rank
+    (64 complexes over 8 ranks: rank r owns 8 r .. 8 r + 7), so every sample of a complex -- and therefore its whole commonness ranking --
+    stays on one GPU, nothing is exchanged per complex, and the global sample indices of a rank's launch are contiguous (one Philox
+    offset per launch keeps the draws independent of the number of ranks)."""
+    a, b = shard_range(n_complexes, world_size, rank)
+    return list(range(a, b))
+
+
+def pad_complex(one, L):
+    """A batch dict with batch dim 1 padded to L residues the way the reference's PaddingCollate does (AbDock/src/utils/data.py:60-76:
+    zeros, `aa` with the padding token 21, masks False)."""
+    L0 = one['aa'].shape[1]
+    if L0 == L:
+        return one
+    out = {}
+    for k, v in one.items():
+        if torch.is_tensor(v) and v.dim() >= 2 and v.shape[1] == L0:
+            pad = v.new_full((v.shape[0], L - L0) + tuple(v.shape[2:]), 21 if k == 'aa' else 0)
+            out[k] = torch.cat([v, pad], 1)
+        else:
+            out[k] = v
+    return out
 
 
 @torch.no_grad()
-def design_testset_sharded(model, complexes, samples_per_complex, sample_opt=None, k=1, group=None, seed=0, optimize_step=None):
+def sample_grouped(model, complexes, num_samples, sample_opt=None, optimize_step=None):
+    """`num_samples` samples of EACH of G complexes in one launch (BASELINE config 4: a rank's leg of a test set).
+
+    The reference designs a test set one structure at a time (AbDock/src/tools/runner/design_for_testset.py:556-589), each with its
+    crop replicated `num_samples` times on the host.  Here the G complexes (a list of batch dicts with batch dim 1; padded to a common
+    length like PaddingCollate does) are encoded ONCE each as a batch of G, and the sampler runs G x num_samples samples as one batch
+    whose samples share the pair features of their complex (`abopt_eps_net_forward(pair_feat_shared = num_samples)`): the kernels see
+    full-size launches instead of G small ones, and z is read from HBM once per complex and query block, not once per sample.
+    Sample g * num_samples + s is sample s of complex g.  Returns the trajectory dict of `model.sample` (batch dim G * num_samples)."""
+    from . import hip
+    sample_opt = dict(sample_opt or {'sample_structure': True, 'sample_sequence': True})
+    sample_opt.pop('contig', None)
+    L = max(int(c['aa'].shape[1]) for c in complexes)
+    padded = [pad_complex(c, L) for c in complexes]
+    batch = {k: (torch.cat([c[k][:1] for c in padded], 0) if torch.is_tensor(v) else v) for k, v in padded[0].items()}
+    res_feat, pair_feat, R_0, p_0 = model.encode(batch, remove_structure=sample_opt.get('sample_structure', True),
+                                                remove_sequence=sample_opt.get('sample_sequence', True))
+    rep = lambda a: a.repeat_interleave(num_samples, dim=0).contiguous()
+    v_0 = rep(hip.so3_log(R_0, grad_mode=False))
+    args = (v_0, rep(p_0), rep(batch['aa']))
+    masks = (rep(batch['generate_flag']), rep(batch['mask']))
+    if optimize_step is None:
+        return model.diffusion.sample(*args, res_feat, pair_feat, *masks, **sample_opt)
+    return model.diffusion.optimize(*args, optimize_step, res_feat, pair_feat, *masks, **sample_opt)
+
+
+@torch.no_grad()
+def design_testset_sharded(model, complexes, samples_per_complex, sample_opt=None, k=1, group=None, seed=0, optimize_step=None,
+                           complexes_per_launch=8, native=None):
     """BASELINE config 4: a test set of complexes x `samples_per_complex` samples over the ranks of `group`, partitioned BY COMPLEX.
 
     The reference fans this out as one subprocess per structure through Ray and collects files
     (AbDock/optimize_ab.py:21-31,66-72; AbDock/src/tools/runner/design_for_testset.py:556-589 ranks each structure's samples).
-    Here every rank designs its own complexes with the shared-context sampler (`sample_replicated`: the complex is encoded once,
-    N samples share its pair features), ranks each complex's candidates locally with the commonness score, and the per-complex
-    summaries (a few hundred bytes each) are exchanged once at the end with all_gather_object.
+    Here every rank designs its own block of complexes, `complexes_per_launch` of them at a time as ONE batch (`sample_grouped`:
+    every complex encoded once, its samples share its pair features inside the kernels), ranks each complex's candidates locally with
+    the commonness score, optionally scores them against the native structure (DockQ on the device), and the per-complex summaries
+    (a few hundred bytes each) are exchanged once at the end with all_gather_object.
 
-    complexes: list of batch dicts with batch dim 1.  Seeds depend on the complex index only, so results do not depend on the
-    number of ranks.  -> list (one entry per complex, in input order, identical on every rank) of
-    dict(complex=index, rank=owner, top=LongTensor(k), score=Tensor(S), ca=final CA positions of the generated residues (S, n_gen, 3))."""
+    complexes: list of batch dicts with batch dim 1.  The Philox stream position of a sample depends on its global index
+    (complex index x samples_per_complex + sample) and on the padded length of its launch only, so results do not depend on the number of
+    ranks as long as the launches group the same complexes (complexes_per_launch divides the per-rank count, or is 1).
+    native (optional): dict(pos (L,A,3), mask (L,A)) per complex, or True to score against the complex's own input coordinates.
+    -> list (one entry per complex, in input order, identical on every rank) of
+    dict(complex=index, rank=owner, top=LongTensor(k), score=Tensor(S), ca=final CA positions of the generated residues (S, n_gen, 3)
+    [, dockq=dict of (S,) tensors])."""
     world, rank = (dist.get_world_size(group), dist.get_rank(group)) if dist.is_initialized() else (1, 0)
     sample_opt = dict(sample_opt or {'sample_structure': True, 'sample_sequence': True})
+    S = int(samples_per_complex)
     mine = []
-    for c in complexes_of_rank(len(complexes), world, rank):
-        one = complexes[c]
-        opt = dict(sample_opt, seed=int(seed) + 1000003 * c, rng_offset=0)
-        traj = sample_replicated(model, one, samples_per_complex, opt, optimize_step=optimize_step)
-        gen = one['generate_flag'][:1].expand(samples_per_complex, -1)
-        cand = candidates_from_positions(traj[0][1], gen)
-        score = commonness_score(cand)
-        top = torch.topk(score, k=min(k, samples_per_complex), largest=False)[1]
-        mine.append(dict(complex=c, rank=rank, top=top.cpu(), score=score.cpu(), ca=cand.cpu()))
+    own = complexes_of_rank(len(complexes), world, rank)
+    G = max(1, int(complexes_per_launch))
+    for lo in range(0, len(own), G):
+        ids = own[lo:lo + G]
+        chunk = [complexes[c] for c in ids]
+        L = max(int(c['aa'].shape[1]) for c in chunk)
+        opt = dict(sample_opt, seed=int(seed), rng_offset=ids[0] * S * L)
+        traj = sample_grouped(model, chunk, S, opt, optimize_step=optimize_step)
+        p_fin = traj[0][1]
+        for g, c in enumerate(ids):
+            one = pad_complex(complexes[c], L)
+            gen = one['generate_flag'][:1].expand(S, -1)
+            pc = p_fin[g * S:(g + 1) * S]
+            cand = candidates_from_positions(pc, gen)
+            score = commonness_score(cand)
+            top = torch.topk(score, k=min(k, S), largest=False)[1]
+            rec = dict(complex=c, rank=rank, top=top.cpu(), score=score.cpu(), ca=cand.cpu())
+            if native is not None:
+                rec['dockq'] = {kk: v.cpu() for kk, v in _dockq_of_samples(model, one, traj, g * S, S, native if native is not True else None, c).items()}
+            mine.append(rec)
     if world > 1:
         everyone = [None] * world
         dist.all_gather_object(everyone, mine, group=group)
         mine = [e for part in everyone for e in part]
     return sorted(mine, key=lambda e: e['complex'])
+
+
+def _dockq_of_samples(model, one, traj, lo, S, native, c):
+    """DockQ (CA-only flavour the runner uses, design_for_pdb.py:316-321) of samples lo .. lo + S - 1 of a finished trajectory against the
+    native complex: the generated residues' backbone is rebuilt from the final frames (reconstruct_backbone_partially), everything on
+    the device."""
+    from . import geometry, hip
+    v, p, s = traj[0][0][lo:lo + S], traj[0][1][lo:lo + S], traj[0][2][lo:lo + S]
+    rep = lambda a: a[:1].expand(S, *a.shape[1:]).contiguous()
+    R = hip.so3_exp(v)
+    gen = rep(one['generate_flag'])
+    pos, mask = geometry.reconstruct_backbone_partially(rep(one['pos_heavyatom']), R, p, torch.where(gen, s, rep(one['aa'])), rep(one['chain_nb']),
+                                                        rep(one['res_nb']), rep(one['mask_heavyatom']), gen)
+    if native is None:
+        npos, nmask = one['pos_heavyatom'][0], one['mask_heavyatom'][0]
+    else:
+        nat = native[c] if isinstance(native, (list, tuple)) else native
+        npos, nmask = nat['pos'].to(pos.device), nat['mask'].to(pos.device)
+    return dockq_scores(pos, mask, npos, nmask, fragment_type=one['fragment_type'][0])
 
 
 def wrap_ddp(model, device=None, **kw):

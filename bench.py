@@ -14,10 +14,13 @@ Samples are independent, so ranks share nothing during the loop (weak scaling, 3
 exchange is the candidate all_gather of the batched-sampling reduction after the last step, which is inside the
 timed region at N>1.
 
-Roofline accounting: the dominant kernel is the IPA core; its ALGORITHMIC bytes
-per launch are N*(256*L^2 + 1076*L) (pair features once + node features in/out + frames/mask), its duration is measured
-live with HIP events recorded on the launch stream around every launch (DESIGN.md section 5 says where they sit when the loop is
-replayed from a hipGraph).  The timed region is run `--repeats` times and the median is reported (min / max alongside).
+Roofline accounting: the dominant kernel is the IPA core -- since round 4 with the block's
+tail (out_transform + LayerNorm + MLP + LayerNorm) fused into it; its ALGORITHMIC bytes per launch are N*(256*L^2 + 1076*L) (pair
+features once + node features in/out + frames/mask: the survey's figure for the whole block), its duration is measured live with HIP
+events recorded on the launch stream around every launch (DESIGN.md section 5 says where they sit when the loop is replayed from a
+hipGraph).  `roofline.two_launch_form` times the core alone (ABOPT_FUSE_TAIL=0) in one extra pass; `box` carries the device-to-device
+copy rate and the clock the dominant kernel sustained, so a reader can tell a slow box from a slow kernel.  The timed region is run
+`--repeats` times and the median is reported (min / max alongside).
 """
 import argparse
 import json
@@ -179,7 +182,7 @@ def secondary_measurements(dev, L):
     res['sample_e2e_eager_vs_graph_ms'] = e2e
     res['sample_e2e_config'] = (f'model.sample, AbDesign flavour, N=32, L={L}, T=100: encode + pair-bias cache + 100 steps + D2H of the trajectory '
                                 '(graph: the loop replayed from a hipGraph captured by an earlier call, inputs copied into its static buffers)')
-    model.diffusion._graphs.clear()
+    model.diffusion.clear_graphs()
     torch.cuda.empty_cache()
     # ---- config 5 training step: eager launches and the whole step replayed from one hipGraph (training.GraphedTrainStep)
     from ab_opt_amd import training
@@ -226,8 +229,9 @@ def secondary_measurements(dev, L):
     res['train_roofline'] = {'algorithmic_bytes': tb_bytes, 'flops': tb_flops, 'ms': round(best, 2),
                              'hbm_frac': round(tb_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              'tflops': round(tb_flops / (best * 1e-3) / 1e12, 2), 'flop_frac': round(tb_flops / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
-                             'bound': 'fp32 matrix / vector pipes (0.57 ms of HBM time against 2.9 ms of fp32 FLOPs at peak)',
-                             'kernel_share': 'profiles/r03_*_train_full_step_kernel_stats.txt: share of GPU time in abopt:: kernels'}
+                             'bound': ('fp32 matrix / vector pipes' if tb_flops / (FP32_PEAK_TFLOPS * 1e12) > tb_bytes / (HBM_PEAK_GBS * 1e9) else 'hbm') +
+                                      ' (%.2f ms of HBM time against %.2f ms of fp32 FLOPs at peak)' % (tb_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, tb_flops / (FP32_PEAK_TFLOPS * 1e12) * 1e3),
+                             'kernel_share': 'profiles/r04_*_train_full_step_kernel_stats.txt: share of GPU time in abopt:: kernels'}
     model.zero_grad(set_to_none=True)
     model.eval()
     del adam, tb
@@ -244,6 +248,31 @@ def secondary_measurements(dev, L):
     res['config3_config'] = f'AbDock dock_single model block (prmsd head, pred_x0), structure-only sampling, N={N3} poses, L={L}, {K3} timed steps'
     del dpm, state, res_feat, pair_feat
     torch.cuda.empty_cache()
+    # ---- config 4, ONE rank's leg at its own size: 8 complexes x 16 samples, L = 256, T = 100, through the test-set driver (encode of
+    # the 8 complexes, ONE grouped launch per step for the 128 samples, per-complex commonness ranking and DockQ on the device)
+    try:
+        from ab_opt_amd import sampler
+        m4 = build_model(100, 7, flavour='abdesign', device=dev).eval()
+        cx = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(1, layout, seed=500 + c).items()} for c in range(8)]
+        leg = {}
+        for name, per in (('grouped', 8), ('per_complex', 1)):
+            sampler.design_testset_sharded(m4, cx, 16, k=3, seed=3, native=True, complexes_per_launch=per)        # warm (and, for the sampler's graph mode, the eager first call)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            out4 = sampler.design_testset_sharded(m4, cx, 16, k=3, seed=3, native=True, complexes_per_launch=per)
+            torch.cuda.synchronize()
+            leg[name] = time.perf_counter() - t0
+            assert len(out4) == 8 and all(torch.isfinite(r['ca']).all() for r in out4)
+        res['config4_rank_leg_sample_steps_per_s'] = round(8 * 16 * 100 / leg['grouped'], 1)
+        res['config4_rank_leg_s'] = {k: round(v, 4) for k, v in leg.items()}
+        res['config4_config'] = (f'sampler.design_testset_sharded on one rank: 8 complexes x 16 samples, L={L}, T=100, AbDesign flavour; wall time of the WHOLE leg '
+                                 '(encode, 100 steps, trajectory hand-over, per-complex commonness ranking, backbone reconstruction + DockQ of all 128 designs); '
+                                 'grouped = one launch of 128 samples sharing pair features per complex (pair_feat_shared=16), per_complex = eight launches of 16 '
+                                 '(the round-3 path); value = 8*16*100 / grouped wall time')
+        m4.diffusion.clear_graphs()
+        del m4, cx, out4
+        torch.cuda.empty_cache()
+    except Exception as e:
+        res['config4_error'] = repr(e)
     # ---- the reference's own headline invocation (AbDock/README.md:61: dock_pdb.py -n 1000 -b 1000 with configs/test/dock_cdr.yml): 1000 poses of
     # ONE complex cropped to the CDR-H3 + 20 antigen residues (dock_single.yml:12-14 antigen_size 20, initial_patch_size 0) -> L ~ 30..48
     res.update(poses_measurement(dev, 1000, 48, 'poses1000'))
@@ -275,7 +304,7 @@ def poses_measurement(dev, N, L, key, abdesign=False, K=20):
     Nz = pair_feat.shape[0]
     alg = NUM_LAYERS * (Nz * 256 * L * L + N * 1076 * L) + 13.0e6          # SURVEY 8(d) with z counted once per DISTINCT complex
     return {f'{key}_sample_steps_per_s': best[0], f'{key}_ms_per_step': best[1], f'{key}_eager_vs_graph': out,
-            f'{key}_step_hbm_frac': round(alg / (best[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            f'{key}_step_hbm_frac': (round(alg / (best[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if Nz == N else None),   # (one shared complex: z lives in L2 / MALL, HBM is not the bound)
             f'{key}_step_tflops': round(step_flops(N, L) / (best[1] * 1e-3) / 1e12, 2),
             f'{key}_config': (f'{"AbDesign codesign" if abdesign else "AbDock dock_single (prmsd head, pred_x0), structure-only"} sampling loop, '
                               f'N={N}, L={L}, {"one complex shared by all poses" if Nz == 1 else "distinct complexes"}, {K} timed steps; '
@@ -405,6 +434,44 @@ def main():
         hip.prof_enable(False)
         instrumented = round(dt_i / K * 1e3, 4)
         log('instrumented eager pass: %.4f ms per step' % instrumented)
+    clock = hip.prof_clock()                                    # the clock wave 0 / workgroup 0 of the last dominant-kernel launch ran at
+    # the two-launch form of a block (32-row core, then the tail kernel) in one more eager pass: the IPA core ALONE, for continuity with
+    # the rounds before the tail was fused into it (bit-identical results; not part of the timed region)
+    two_launch = None
+    if rank == 0 and world == 1 and not args.no_prof and os.environ.get('ABOPT_FUSE_TAIL') is None:
+        os.environ['ABOPT_FUSE_TAIL'] = '0'
+        try:
+            run(2)
+            dt_u = timed_pass(False, events=True)
+            n_u, ms_u = hip.prof_collect()
+            hip.prof_enable(False)
+            two_launch = dict(ms_per_step_eager=round(dt_u / K * 1e3, 4), ipa_core_avg_launch_ms=round(ms_u / max(n_u, 1), 4), launches=n_u)
+        finally:
+            del os.environ['ABOPT_FUSE_TAIL']
+    # what this box gives: device-to-device copy rate (read + write bytes) and the one-off cost of a sample() call that the K steps share
+    box = None
+    if rank == 0:
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev)           # 1 GiB
+        b = torch.empty_like(a)
+        b.copy_(a); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * a.numel() * 4 / (time.perf_counter() - t0) / 1e9
+        del a, b
+        arr = dpm.eps_net.encoder.packed_array()
+        hip.pair_bias_cache(arr, NUM_LAYERS, pair_feat); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hip.pair_bias_cache(arr, NUM_LAYERS, pair_feat); torch.cuda.synchronize()
+        cache_ms = (time.perf_counter() - t0) * 1e3
+        box = dict(copy_GBs=round(copy_gbs, 1), copy_note='1 GiB device-to-device copy, read + write bytes / time',
+                   dominant_kernel_clock_GHz=round(clock[2], 3) if clock else None,
+                   dominant_kernel_wave_us=round(clock[1] * 1e6, 1) if clock else None,
+                   clock_note='shader cycles / 100 MHz wall ticks of wave 0, workgroup 0 of the last dominant-kernel launch (abopt_prof_clock)',
+                   one_off_ms={'pair_bias_cache': round(cache_ms, 3),
+                               'note': 'built once per sample() call (pair_feat and the weights are constant over the T steps); it IS inside every '
+                                       'timed K-step region here (conservative: a 100-step call amortises it over 100 steps, this run over K)'})
 
     if rank == 0:
         ts_sorted = sorted(times)
@@ -418,6 +485,9 @@ def main():
             'HIP event records captured into the replayed graph around every ipa_core launch' if graph_events else
             'HIP events on the launch stream around every ipa_core launch in one eager pass of the same K steps run right after the '
             'timed graph replays (host-recorded events cannot be placed inside a replayed graph); that pass took instrumented_ms_per_step')
+        fused = bool(two_launch) and per_launch_ms > 1.08 * two_launch['ipa_core_avg_launch_ms']
+        kernel_name = ('ipa_core32_kernel<true>: IPA core + block tail (out_transform, LayerNorm, MLP, LayerNorm) as ONE kernel -- the survey\'s per-layer bytes are '
+                       'those of the whole block, so they apply unchanged' if fused else 'ipa_core')
         line = {
             'metric': 'denoising steps/sec (256-res complex, 100-step sampler)', 'value': round(world * N * K / dt, 2),
             'unit': 'sample-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(step_s * 1e3, 4),
@@ -431,7 +501,7 @@ def main():
                        'launch': ('hipGraph replay of the K-step loop (captured once, before the timed region; Philox position from device memory)'
                                   if use_graph else 'eager launches'),
                        'backend': backend, 'ranks_per_device': (world + ndev - 1) // ndev if world > 1 else 1},
-            'roofline': {'bound': 'hbm', 'kernel': 'ipa_core', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': {'bound': 'hbm', 'kernel': kernel_name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src, 'launches': launches,
                          'avg_launch_ms': round(per_launch_ms, 4), 'timing': timing, 'instrumented_ms_per_step': instrumented,
                          'algorithmic_bytes_per_launch': alg,
@@ -441,16 +511,24 @@ def main():
                          'step': {'algorithmic_bytes': step_algorithmic_bytes(N, L), 'hbm_frac': round(step_algorithmic_bytes(N, L) / step_s / 1e9 / HBM_PEAK_GBS, 4),
                                   'flops': step_flops(N, L), 'tflops': round(step_flops(N, L) / step_s / 1e12, 2),
                                   'fp32_peak_tflops': FP32_PEAK_TFLOPS, 'flop_frac': round(step_flops(N, L) / step_s / 1e12 / FP32_PEAK_TFLOPS, 4),
-                                  'ipa_core_share_of_step': round(per_launch_ms * NUM_LAYERS / (step_s * 1e3), 4) if launches else None}},
+                                  'dominant_kernel_share_of_step': (round(per_launch_ms * NUM_LAYERS / instrumented, 4) if (launches and instrumented) else
+                                                                    (round(per_launch_ms * NUM_LAYERS / (step_s * 1e3), 4) if launches else None)),
+                                  'share_note': 'kernel time and step time of the SAME (instrumented, eager) pass'}},
+            'box': box,
         }
+        if two_launch:
+            u = two_launch['ipa_core_avg_launch_ms']
+            two_launch.update(ipa_core_frac=round(alg / (u * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              note='ABOPT_FUSE_TAIL=0: the 32-row IPA core as its own kernel (HIP events, one eager pass of the same K steps); '
+                                   'same arithmetic, bit-identical results -- the timed region above runs the fused form')
+            line['roofline']['two_launch_form'] = two_launch
         if world == 1 and not args.no_cpu_baseline:
             log('cpu baseline on', os.cpu_count(), 'cores ...')
             check = (dpm, T, state, res_feat, pair_feat, gen, mres, first, [0, N // 2 + 1] if N > 2 else [0]) if first is not None else None
             line['cpu_baseline'] = cpu_baseline(L, T, check=check)
         if world == 1 and not args.no_secondary:
             log('secondary configs ...')
-            del dpm._graphs
-            dpm._graphs = {}
+            dpm.clear_graphs()
             torch.cuda.empty_cache()
             try:
                 line['secondary'] = secondary_measurements(dev, L)

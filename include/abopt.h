@@ -171,9 +171,11 @@ int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_t, const fl
                           float* v_next, float* R_next, float* eps_pos, float* c_denoised, float* prmsd_logits,
                           int N, int L, int F, int C, int grad_mode,
                           const float* pair_bias_cache /* NULL: compute the pair bias inside the step */,
-                          int pair_feat_shared /* 1: pair_feat is [1,L,L,C] (and the cache was built with N = 1) and is shared by
-                                                  all N samples -- the replicated-complex batches of the reference's runners,
-                                                  D/tools/runner/design_for_pdb.py:141-147 */,
+                          int pair_feat_shared /* 0: pair_feat is [N,L,L,C].  1: pair_feat is [1,L,L,C] (and the cache was built with N = 1) and is
+                                                  shared by all N samples -- the replicated-complex batches of the reference's runners,
+                                                  D/tools/runner/design_for_pdb.py:141-147.  g > 1 (g divides N): pair_feat is [N/g,L,L,C] and
+                                                  samples g c .. g c + g - 1 share entry c -- a test set of complexes x g samples in ONE launch
+                                                  (D/tools/runner/design_for_testset.py:556-589; BASELINE config 4) */,
                           void* ws, size_t ws_bytes, abopt_stream stream);
 
 /* ---- Per-step transitions: D/modules/diffusion/transition.py:42-50,80-101 (position), :146-160
@@ -453,6 +455,10 @@ int abopt_commonness_score(const float* structs, float* score, int B, int n, abo
  * use from several host threads (the only global state in the library). */
 int abopt_prof_enable(int on);   /* 1: on (forgets earlier pairs), 0: off (forgets), 2: off but keep the recorded pairs */
 int abopt_prof_collect(int* launches, double* total_ms);
+/* Clock probe: shader cycles and 100 MHz wall-clock ticks that wave 0 of workgroup 0 of the most recent 32-row IPA launch (core or fused
+ * core + tail) spent from its first to its last instruction: cycles / (10 ns * ticks) = the clock the chip sustained under that kernel.
+ * Synchronises the device.  Zeros when no such launch has run. */
+int abopt_prof_clock(long long* cycles, long long* wall_ticks_100mhz);
 /* The same sum without forgetting the event pairs: records captured into a hipGraph are re-recorded by every replay. */
 int abopt_prof_peek(int* launches, double* total_ms);
 

@@ -31,7 +31,7 @@ def sharded_worker(rank, world, port, outdir):
         torch.save(dict(a=a, e=e, top=top.cpu(), cand=cand.cpu(), p0=traj[0][1].cpu(), s0=traj[0][2].cpu()), os.path.join(outdir, f'sharded_{rank}.pt'))
         # by-complex partition (config 4): 3 complexes x 4 samples
         cx = [{k: v.to(dev) for k, v in synth.make_batch(1, synth.LAYOUT_128, seed=100 + c).items()} for c in range(3)]
-        res = sampler.design_testset_sharded(m, cx, 4, k=2, seed=7)
+        res = sampler.design_testset_sharded(m, cx, 4, k=2, seed=7, complexes_per_launch=1)
         torch.save(res, os.path.join(outdir, f'testset_{rank}.pt'))
     finally:
         dist.destroy_process_group()

@@ -65,7 +65,8 @@ def test_shard_helpers():
 
 
 def test_by_complex_partition():
-    """BASELINE config 4 layout: 64 complexes over 8 ranks = 8 per rank, every complex on exactly one rank, round-robin."""
+    """BASELINE config 4 layout: 64 complexes over 8 ranks = 8 per rank, every complex on exactly one rank, contiguous blocks (the global
+    sample indices of a rank's grouped launch are then contiguous: one Philox offset per launch)."""
     owners = {}
     for r in range(8):
         mine = sampler.complexes_of_rank(64, 8, r)
@@ -73,8 +74,24 @@ def test_by_complex_partition():
         for c in mine:
             assert c not in owners
             owners[c] = r
-    assert sorted(owners) == list(range(64)) and owners[9] == 1
-    assert sampler.complexes_of_rank(3, 2, 1) == [1] and sampler.complexes_of_rank(1, 4, 2) == []
+    assert sorted(owners) == list(range(64)) and owners[9] == 1 and sampler.complexes_of_rank(64, 8, 3) == list(range(24, 32))
+    assert sampler.complexes_of_rank(3, 2, 0) == [0, 1] and sampler.complexes_of_rank(3, 2, 1) == [2] and sampler.complexes_of_rank(1, 4, 2) == []
+
+
+def test_pad_complex_matches_padding_collate():
+    """sampler.pad_complex: the reference's PaddingCollate (AbDock/src/utils/data.py:60-76) pads every per-residue tensor with zeros, `aa`
+    with 21 and the masks with False."""
+    from ab_opt_amd.utils import synth
+    one = synth.make_batch(1, synth.LAYOUT_128, seed=3)
+    L0 = one['aa'].shape[1]
+    p = sampler.pad_complex(one, L0 + 9)
+    assert sampler.pad_complex(one, L0) is one
+    for k, v in one.items():
+        if torch.is_tensor(v) and v.dim() >= 2 and v.shape[1] == L0:
+            assert p[k].shape[1] == L0 + 9 and torch.equal(p[k][:, :L0], v)
+            tail = p[k][:, L0:]
+            assert bool((tail == (21 if k == 'aa' else 0)).all()), k
+    assert not p['mask'][:, L0:].any() and not p['generate_flag'][:, L0:].any()
 
 
 def _object_worker(rank, world, port, out):
@@ -100,4 +117,4 @@ def test_testset_summary_exchange_world2():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_object_worker, args=(2, port, out), nprocs=2, join=True)
-    assert out[0] == out[1] == [(0, 0, [0, 1]), (1, 1, [1, 2]), (2, 0, [2, 3]), (3, 1, [3, 4]), (4, 0, [4, 5])]
+    assert out[0] == out[1] == [(0, 0, [0, 1]), (1, 0, [1, 2]), (2, 0, [2, 3]), (3, 1, [3, 4]), (4, 1, [4, 5])]      # contiguous blocks: rank 0 owns 0..2

@@ -1019,7 +1019,7 @@ def test_two_rank_sharded_sampling_is_bit_identical_to_one_rank(tmp_path):
     b = {k: dev(v) for k, v in synth.make_batch(5, synth.LAYOUT_128, seed=11, replicate=True).items()}
     traj, (a, e), top, cand = sampler.sample_sharded(m, b, dict(sample_structure=True, sample_sequence=True, contig=''), k=2, seed=42)
     cx = [{k: dev(v) for k, v in synth.make_batch(1, synth.LAYOUT_128, seed=100 + c).items()} for c in range(3)]
-    ref = sampler.design_testset_sharded(m, cx, 4, k=2, seed=7)
+    ref = sampler.design_testset_sharded(m, cx, 4, k=2, seed=7, complexes_per_launch=1)
     assert [r['complex'] for r in ref] == [0, 1, 2] and ref[0]['ca'].shape[0] == 4
     _spawn2(mp_workers.sharded_worker, tmp_path)
     parts = [torch.load(tmp_path / f'sharded_{r}.pt') for r in range(2)]
@@ -1030,9 +1030,73 @@ def test_two_rank_sharded_sampling_is_bit_identical_to_one_rank(tmp_path):
     assert torch.equal(torch.cat([parts[0]['s0'], parts[1]['s0']]), traj[0][2].cpu())
     for r in range(2):
         got = torch.load(tmp_path / f'testset_{r}.pt', weights_only=False)
-        assert [g_['complex'] for g_ in got] == [0, 1, 2] and [g_['rank'] for g_ in got] == [0, 1, 0]
+        assert [g_['complex'] for g_ in got] == [0, 1, 2] and [g_['rank'] for g_ in got] == [0, 0, 1]
         for g_, r_ in zip(got, ref):
             assert torch.equal(g_['ca'], r_['ca']) and torch.equal(g_['top'], r_['top']) and torch.equal(g_['score'], r_['score'])
+
+
+@pytest.mark.gpu
+def test_config4_rank_leg_grouped_launch(monkeypatch):
+    """BASELINE config 4, one rank's leg at its own size: 8 complexes x 16 samples, L = 256, as ONE batch of 128 samples whose samples
+    share the pair features of their complex (abopt_eps_net_forward(pair_feat_shared = 16): a complex stays on one XCD, z is read once
+    per complex and query block).  (i) EpsilonNet of the grouped batch against the oracle on a subset of samples (different complexes,
+    first / last sample of a group); (ii) the grouped launch is bit-identical to the same samples run with their pair features
+    replicated per sample, and to eight per-complex launches of 16 (the path design_testset_sharded took before); (iii) the test-set
+    driver: per-complex commonness ranking and DockQ from the grouped launch equal the per-complex path's, bit for bit."""
+    from ab_opt_amd import hip, sampler
+    from oracle import dpm as odpm
+    monkeypatch.setenv('ABOPT_CORE_NO_SPLIT', '1')
+    G, S, L = 8, 16, 256
+    m = build_model(10, 3, device=DEV)
+    d = m.diffusion
+    lens = [L - 3 * g for g in range(G)]
+    rf = dev(synth.hash_tensor((G, L, 128), 811, scale=2.0))
+    pf = dev(synth.hash_tensor((G, L, L, 64), 812, scale=2.0))
+    mres_c = synth.mask_from_lengths(lens, L)
+    N = G * S
+    v = dev(synth.hash_tensor((N, L, 3), 813, scale=4.0)); p = dev(synth.hash_tensor((N, L, 3), 814, scale=3.0))
+    s = dev((synth.hash_tensor((N, L), 815) + 0.5).mul(21).long().clamp(0, 20))
+    mres = dev(mres_c.repeat_interleave(S, 0))
+    gen = dev(synth.gen_from_ranges(N, L, [(25, 33), (94, 106)])) & mres
+    beta = d.trans_pos.var_sched.betas[7].expand([N]).contiguous()
+    arr, ew = d.eps_net.encoder.packed_array(), d.eps_net.packed()
+    grouped = hip.eps_net_forward(ew, v, p, s, rf.repeat_interleave(S, 0), pf, beta, gen, mres, d.abdock, d.num_bins, False,
+                                  pair_bias_cache=hip.pair_bias_cache(arr, 6, pf), pair_feat_shared=S)
+    grouped = {k: (a.clone() if a is not None else None) for k, a in grouped.items()}
+    # (i) oracle on a subset
+    sd = {k: a.detach().cpu() for k, a in m.state_dict().items()}
+    for n in (0, S - 1, 5 * S + 3, N - 1):
+        c = n // S
+        sl = slice(n, n + 1)
+        ref = odpm.eps_net(sd, 'diffusion.eps_net.', v[sl].cpu(), p[sl].cpu(), s[sl].cpu(), rf[c:c + 1].cpu(), pf[c:c + 1].cpu(), beta[sl].cpu(), gen[sl].cpu(),
+                           mres[sl].cpu(), num_layers=6, prmsd_head=True, mode='mm')
+        for name, kk in (('R_next', 1), ('eps_pos', 2), ('c', 3)):
+            assert (grouped[name][sl].cpu() - ref[kk]).abs().max().item() < 5e-5, (n, name)
+    # (ii) replicated pair features, and per-complex launches
+    rep = hip.eps_net_forward(ew, v[:4 * S], p[:4 * S], s[:4 * S], rf[:4].repeat_interleave(S, 0), pf[:4].repeat_interleave(S, 0).contiguous(), beta[:4 * S],
+                              gen[:4 * S], mres[:4 * S], d.abdock, d.num_bins, False, pair_bias_cache=hip.pair_bias_cache(arr, 6, pf[:4].repeat_interleave(S, 0).contiguous()))
+    for k in ('R_next', 'eps_pos', 'c'):
+        assert torch.equal(rep[k], grouped[k][:4 * S]), k
+    for c in (0, 3, 7):
+        sl = slice(c * S, (c + 1) * S)
+        one = hip.eps_net_forward(ew, v[sl], p[sl], s[sl], rf[c:c + 1].expand(S, -1, -1).contiguous(), pf[c:c + 1], beta[sl], gen[sl], mres[sl], d.abdock, d.num_bins, False,
+                                  pair_bias_cache=hip.pair_bias_cache(arr, 6, pf[c:c + 1]), pair_feat_shared=True)
+        for k in ('R_next', 'eps_pos', 'c', 'prmsd_logits'):
+            assert torch.equal(one[k], grouped[k][sl]), (c, k)
+    # (iii) the driver: eight different complexes, 16 samples each
+    cx = [{k: dev(a) for k, a in synth.make_batch(1, synth.LAYOUT_256, seed=300 + c).items()} for c in range(G)]
+    a = sampler.design_testset_sharded(m, cx, S, k=3, seed=11, native=True)
+    b = sampler.design_testset_sharded(m, cx, S, k=3, seed=11, native=True, complexes_per_launch=1)
+    assert [r['complex'] for r in a] == list(range(G))
+    for ra, rb in zip(a, b):
+        assert torch.isfinite(ra['ca']).all() and torch.equal(ra['ca'], rb['ca']) and torch.equal(ra['score'], rb['score']) and torch.equal(ra['top'], rb['top'])
+        for kk in ('DockQ', 'fnat', 'irms', 'Lrms'):
+            assert torch.equal(ra['dockq'][kk], rb['dockq'][kk]) and torch.isfinite(ra['dockq'][kk]).all()
+        assert ra['dockq']['DockQ'].shape == (S,) and float(ra['dockq']['DockQ'].min()) >= 0 and float(ra['dockq']['DockQ'].max()) <= 1
+    # complexes of different lengths in one launch: padded like PaddingCollate pads a batch; the padding never reaches a real residue
+    rag = [{k: dev(a) for k, a in synth.make_batch(1, synth.LAYOUT_256, seed=400 + c, lengths=[L - 9 * c]).items()} for c in range(3)]
+    r3 = sampler.design_testset_sharded(m, rag, 4, k=2, seed=5)
+    assert [int(r['ca'].shape[0]) for r in r3] == [4, 4, 4] and all(torch.isfinite(r['ca']).all() for r in r3)
 
 
 def test_two_rank_ddp_gradients_equal_the_mean(tmp_path):
