@@ -8,6 +8,7 @@ Tolerances (fp32, stated per SURVEY.md section 8c / BASELINE.md section 4):
     scales with 1/sin(theta) and the clamp zone is excluded.
 """
 import math
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -1787,45 +1788,75 @@ def test_eps_net_reference_headline_shape_vs_oracle():
             assert torch.equal(net[k][sl], small[k]), (k, lo)
 
 
-def test_training_step_config5_native_vs_plain_statement():
-    """BASELINE config 5 at full size (AbDesign flavour, N = 16, L = 256): one training forward + backward through the native path
-    (HIP noising, IPA core forward / backward, block tail, pair embedding, every GEMM on abopt_gemm, shared d pair_feat buffer) against
-    the plain torch statement of the same network (training.NATIVE_IPA = False) with the same step indices and noise: finite losses,
-    equal to 2e-5 relative, parameter gradients from block 1 on within 3e-5 of their own maximum in the median, 2e-4 at the 90th percentile
-    and 2e-3 at worst (ReLU kinks), 5e-3 upstream of block 1 (see below)."""
-    from ab_opt_amd import training
-    m = build_model(100, 7, flavour='abdesign', device=DEV).train()
-    batch = {k: dev(v) for k, v in synth.make_batch(16, synth.LAYOUT_256, seed=21).items()}
-    out = {}
-    try:
-        for native in (True, False):
-            training.NATIVE_IPA = native
-            m.zero_grad(set_to_none=True)
-            torch.manual_seed(1234); torch.cuda.manual_seed(1234)
-            loss = m(dict(batch))
-            total = sum(loss.values())
-            total.backward()
-            out[native] = ({k: v.item() for k, v in loss.items()}, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
-    finally:
-        training.NATIVE_IPA = True
-        m.zero_grad(set_to_none=True); m.eval()
-    (la, ga), (lb, gb) = out[True], out[False]
-    assert set(la) == {'rot', 'pos', 'seq'} and all(math.isfinite(v) for v in la.values())
-    for k in la:
-        assert abs(la[k] - lb[k]) <= 2e-5 * max(abs(lb[k]), 1e-3), (k, la[k], lb[k])
-    assert set(ga) == set(gb) and len(ga) > 150
-    rel = sorted((((ga[n] - gb[n]).abs().max() / gb[n].abs().max().clamp_min(1e-12)).item(), n) for n in ga)
-    rl2 = sorted((((ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-12)).item(), n) for n in ga)
-    # Everything from block 1 to the heads agrees to ~1e-5 (asserted at 2e-4).  Block 0 -- the only block whose input is not layer-normalised
-    # (the raw mixer output: with the synthetic weights its point / distance logits are two orders of magnitude larger and their gradients
-    # are differences of nearly equal sums) -- and what lies upstream of it (mixer, embeddings) differ by ~2e-3 between the two fp32
-    # evaluations; the same code matches the REFERENCE's recorded gradients at 3e-4 on the small fixtures (test_training_*_vs_reference).
-    down = [a for a, n in rel if any(f'blocks.{b}.' in n for b in range(1, 6)) or 'eps_crd_net' in n or 'eps_rot_net' in n or 'eps_seq_net' in n]
-    # ... except where a ReLU of a block's transition MLP sits on its kink for some residue: one flipped unit of the 4096 rows moves that
-    # layer's bias / weight gradient by ~1/4096 of its maximum (2e-4 .. 1e-3 observed on single layers after an ulp-level change upstream)
-    assert len(down) > 100 and sorted(down)[len(down) // 2] < 3e-5 and sorted(down)[(9 * len(down)) // 10] < 2e-4 and max(down) < 2e-3, \
-        ' | '.join('%.1e %s' % (a, n.replace('diffusion.eps_net.', '')) for a, n in rel if a >= 1e-4)
-    assert rel[-1][0] < 5e-3, rel[-3:]
+def test_training_step_config5_vs_oracle_at_full_size():
+    """BASELINE config 5 at its own size (AbDesign flavour FullDPM.forward, N = 16, L = 256): losses and the gradient of EVERY parameter
+    of the denoiser, res_feat and pair_feat from the native path (HIP noising, IPA core forward / backward, block tail, abopt_gemm
+    everywhere, shared d pair_feat buffer) against the ORACLE under CPU autograd with the same step indices and injected noise -- not
+    against another evaluation by this package.  The oracle runs in float64 (the yardstick) and in float32 (what the reference's own
+    arithmetic leaves of it): losses within 2e-5, every gradient within 3e-4 of its maximum of the float64 value, block 0 and the mixer
+    included -- or no further from it than twice the float32 oracle is (single layers whose transition-MLP ReLUs sit on a kink)."""
+    from oracle import dpm as odpm
+    N, L = 16, 256
+    d = standalone_abdesign_dpm(100, 2).to(DEV).train()
+    d.zero_grad(set_to_none=True)
+    lens = [L - (5 * i) % 40 for i in range(N)]
+    v, p, s, res_feat, pair_feat, _, gen, mres = synth.eps_inputs(N, L, lens, [(25, 33), (51, 57), (94, 106), (133, 144), (159, 166), (198, 207)], salt=900)
+    s = s.clamp(max=19)
+    g = torch.Generator().manual_seed(77)
+    t = torch.randint(1, 100, (N,), generator=g)
+    noise = dict(axis=torch.randn(N, L, 3, generator=g), bin=torch.randint(0, 8191, (N, L), generator=g), ubin=torch.rand(N, L, generator=g),
+                 gauss=torch.randn(N, L, generator=g), pos=torch.randn(N, L, 3, generator=g), s_noisy=torch.randint(0, 20, (N, L), generator=g))
+    rf = dev(res_feat).clone().requires_grad_(True)
+    pf = dev(pair_feat).clone().requires_grad_(True)
+    loss = d(dev(v), dev(p) * 10, dev(s), rf, pf, dev(gen), dev(mres), True, True, t=dev(t), noise={k: dev(a) for k, a in noise.items()})
+    sum(loss.values()).backward()
+    got = {n: q.grad.detach().cpu() for n, q in d.named_parameters() if q.grad is not None}
+    got['res_feat'], got['pair_feat'] = rf.grad.cpu(), pf.grad.cpu()
+    got_loss = {k: a.item() for k, a in loss.items()}
+    d.zero_grad(set_to_none=True)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    f = d.trans_rot.angular_distrib_fwd
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        cv = lambda a: (a.detach().cpu().to(dt) if a.is_floating_point() else a.detach().cpu())
+        sd = {k: cv(a).requires_grad_(a.is_floating_point() and 'eps_net' in k) for k, a in d.state_dict().items()}
+        den = odpm.Denoiser(sd, num_steps=100, variant='abdesign', pre='', tables=(None, None), mode='mm')
+        den.sch = {k: cv(a) for k, a in den.sch.items()}
+        den.tab_fwd = dict(stddevs=cv(f.stddevs), approx_flag=f.approx_flag.cpu(), X=cv(f.X), Y=cv(f.Y))
+        r_, p_ = cv(res_feat).requires_grad_(True), cv(pair_feat).requires_grad_(True)
+        nz = dict(rot=dict(axis=cv(noise['axis']), bin=noise['bin'], ubin=cv(noise['ubin']), gauss=cv(noise['gauss'])), pos=cv(noise['pos']), s_noisy=noise['s_noisy'])
+        with torch.enable_grad():
+            lo = den.loss(cv(v), cv(p) * 10, s, r_, p_, gen, mres, t, nz)
+            sum(lo.values()).backward()
+        gr = {k: a.grad for k, a in sd.items() if a.grad is not None}
+        gr['res_feat'], gr['pair_feat'] = r_.grad, p_.grad
+        ref[dt] = ({k: a.item() for k, a in lo.items()}, gr)
+    (l64, g64), (l32, g32) = ref[torch.float64], ref[torch.float32]
+    assert set(got_loss) == {'rot', 'pos', 'seq'}
+    for k in got_loss:
+        assert abs(got_loss[k] - l64[k]) <= 2e-5 * max(1.0, abs(l64[k])), (k, got_loss[k], l64[k])
+    assert set(g64) == set(got) and len(got) > 140
+    # Error of a tensor = max over its rows (output units of a weight / residues of an activation gradient) of |got - fp64| / max |fp64|.
+    # ONE ReLU of the 3 x 6 transition / head layers sitting within an ulp of its kink for ONE of the 4096 residues flips between two fp32
+    # evaluations and moves exactly one row (measured: eps_seq_net.0 unit 29 at 2.3e-3, every other unit of that layer <= 5e-6; the oracle's
+    # own fp32 evaluation happens to land on the fp64 side): the two worst rows of a tensor are held to 5e-3, all the others to 3e-4.
+    rows, exempt = [], []
+    for n in sorted(got):
+        mx = g64[n].abs().max().item() + 1e-30
+        e = ((got[n].double() - g64[n]).abs() / mx)
+        e = e.reshape(-1, e.shape[-1]).max(1).values if e.dim() > 1 else e
+        srt = torch.sort(e.flatten(), descending=True).values
+        e_all, e_rest = srt[0].item(), (srt[2].item() if srt.numel() > 2 else 0.0)
+        e_o32 = (g32[n].double() - g64[n]).abs().max().item() / mx
+        rows.append((e_rest, e_all, e_o32, n))
+        if e_all > 3e-4:
+            exempt.append((n, e_all, e_rest))
+    print('config 5 at full size vs the float64 oracle -- tensors with a row above 3e-4 (name, worst row, third-worst row):', exempt)
+    print('worst tensors (all rows but the two worst | worst row | oracle fp32 | name):', ' ; '.join('%.1e | %.1e | %.1e | %s' % w for w in sorted(rows)[-4:]))
+    assert all(a <= 3e-4 and b <= 5e-3 for a, b, c, n in rows), [w for w in rows if w[0] > 3e-4 or w[1] > 5e-3][:6]
+    assert len(exempt) <= 6, exempt
+    block0 = [w for w in rows if 'blocks.0.' in w[3] or 'mixer' in w[3]]
+    assert len(block0) > 20 and max(w[1] for w in block0) <= 3e-4, sorted(block0)[-3:]
 
 
 @pytest.mark.parametrize('N,L,lengths', [(8, 256, 'ragged'), (3, 256, None), (2, 100, 'ragged'), (5, 128, None)])
