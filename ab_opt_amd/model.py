@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from . import hip
 from .dpm import FullDPM
-from .embed import ResidueEmbedding, PairEmbedding, construct_3d_basis, ATOM_CA, ATOM_C, ATOM_N
+from .embed import ResidueEmbedding, PairEmbedding, ATOM_CA
 
 _MODEL_DICT = {}
 max_num_heavyatoms = 15
@@ -75,21 +75,20 @@ class _DiffabBase(nn.Module):
         sm = ctx if remove_structure else None
         qm = ctx if remove_sequence else None
         extra = {} if self.ABDOCK else dict(hotspot=batch.get('hotspot'))
-        if not torch.is_grad_enabled():          # sample / optimize: HIP kernels (csrc/embed.hip); training keeps the autograd statement
+        if not torch.is_grad_enabled():          # sample / optimize / validation: the inference kernels (csrc/embed.hip), nothing saved for a backward
             inp, keep = hip.encode_inputs(batch['aa'], batch['res_nb'], batch['chain_nb'], batch['pos_heavyatom'], batch['mask_heavyatom'],
                                           self.residue_embed.max_num_atoms, fragment_type=batch['fragment_type'], hotspot=extra.get('hotspot'),
                                           structure_mask=sm, sequence_mask=qm)
             res_feat, R, p = self.residue_embed.forward_hip(inp)
             return res_feat, self.pair_embed.forward_hip(inp), R, p
-        res_feat = self.residue_embed(aa=batch['aa'], res_nb=batch['res_nb'], chain_nb=batch['chain_nb'],
-                                      pos_atoms=batch['pos_heavyatom'], mask_atoms=batch['mask_heavyatom'],
-                                      fragment_type=batch['fragment_type'], structure_mask=sm, sequence_mask=qm, **extra)
+        # training: the same kernels under custom autograd functions (embed.py); the frames come out of the residue-feature kernel
+        res_feat, R, p = self.residue_embed.forward_with_frames(aa=batch['aa'], res_nb=batch['res_nb'], chain_nb=batch['chain_nb'],
+                                                                pos_atoms=batch['pos_heavyatom'], mask_atoms=batch['mask_heavyatom'],
+                                                                fragment_type=batch['fragment_type'], structure_mask=sm, sequence_mask=qm, **extra)
         pair_feat = self.pair_embed(aa=batch['aa'], res_nb=batch['res_nb'], chain_nb=batch['chain_nb'],
                                     pos_atoms=batch['pos_heavyatom'], mask_atoms=batch['mask_heavyatom'],
                                     structure_mask=sm, sequence_mask=qm)
-        pos = batch['pos_heavyatom']
-        R = construct_3d_basis(pos[:, :, ATOM_CA], pos[:, :, ATOM_C], pos[:, :, ATOM_N])
-        return res_feat, pair_feat, R, pos[:, :, ATOM_CA]
+        return res_feat, pair_feat, R, p
 
     def forward(self, batch):
         """diffab.py:85-112 -> loss dict (AbDock: prmsd, dist, rot, pos, seq; AbDesign: rot, pos, seq)."""

@@ -1,72 +1,24 @@
-"""Training loss of the denoiser (FullDPM.forward) with gradients.
+"""Training loss of the denoiser (FullDPM.forward) with gradients, on libabopt_hip.so.
 
-Status: the forward noising runs in the HIP kernel `abopt_add_noise`; inside every GABlock the
-IPA core -- the part that streams pair_feat -- is a custom autograd function on two HIP entry points
-(`abopt_ipa_core_train_forward`, `abopt_ipa_pair_backward`, csrc/ipa_train.hip): forward keeps alpha (N,L,L,12) instead of
-the reference's (N,L,L,12,64) broadcast products, backward reads z once and writes dz once; the remaining (N,L,L,12)-sized
-gradient contractions, the dense projections, LayerNorm/MLP, heads and losses are torch ops (library GEMMs) in the
-autograd graph.  `ga_block(..., native=False)` is the plain torch statement of the same block: it is what the native path is
-verified against (and what the reference's recorded gradients pin).  Nothing here is used by sample()/optimize(), and it
-is not a CPU fallback: noising and the IPA core require the HIP library and device tensors.
+The forward noising runs in the HIP kernel `abopt_add_noise`; every GABlock is three custom autograd functions over HIP entry points --
+NativeLinear (the six projections as one product), IpaCore (`abopt_ipa_core_train_forward` / `abopt_ipa_pair_backward`: forward keeps
+alpha (N,L,L,12) instead of the reference's (N,L,L,12,64) broadcast products, backward reads z once and writes dz once) and BlockTail
+(the fused tail kernel with its activation dump, one row-local backward launch + library GEMMs) --, the heads' geometric epilogue and
+the three losses with their gradients are one launch each (HeadsEpilogue, DpmLosses), and every dense product is `abopt_gemm`.  What is
+still an ATen op: the AbDock flavour's prmsd / dist losses and the prmsd head's LayerNorm.
+There is ONE implementation here: no torch restatement of the network and no CPU path (a CPU tensor reaches hip.ptr()'s error).  The
+plain torch statements the native functions are checked against live in tests/plain_statement.py.
 
 Maths follows the reference line by line (D/ = AbDock/src/):
-  GABlock.forward               D/modules/encoders/ga.py:149-178   (contractions as einsum instead of 5-D broadcast products)
+  GABlock.forward               D/modules/encoders/ga.py:149-178
   EpsilonNet.forward            D/modules/diffusion/dpm_full.py:70-112
   FullDPM.forward               D/modules/diffusion/dpm_full.py:156-234 (AbDesign: A/modules/diffusion/dpm_full.py:138-191)
   rotation_matrix_cosine_loss   dpm_full.py:15-32;  calc_dist_loss :369-378;  pRMSDCa loss  D/modules/common/prmsd.py:49-70
 """
-import math
 import torch
 import torch.nn.functional as F
 
 H, D, P, K_AA = 12, 32, 8, 20
-
-
-# ------------------------------------------------------------------ differentiable geometry (so3.py, geometry.py)
-def _hat(w):
-    x, y, z = w.unbind(-1)
-    o = torch.zeros_like(x)
-    return torch.stack([o, z, -y, -z, o, x, y, -x, o], dim=-1).reshape(w.shape[:-1] + (3, 3))
-
-
-def so3_exp(w):
-    S = _hat(w)
-    th = torch.linalg.norm(w, dim=-1)
-    b = (torch.sin(th) + 1e-8) / (th + 1e-8)
-    c = (1 - torch.cos(th) + 1e-8) / (th ** 2 + 2e-8)
-    eye = torch.eye(3, dtype=w.dtype, device=w.device).expand(S.shape)
-    return eye + b[..., None, None] * S + c[..., None, None] * (S @ S)
-
-
-def so3_log(R, min_cos=None):
-    """rotation_to_so3vec: the reference clamps the cosine at -0.999 when grad is enabled, at -1.0 under no_grad, e.g. in its
-    validation passes (so3.py:12-16)."""
-    if min_cos is None:
-        min_cos = -0.999 if torch.is_grad_enabled() else -1.0
-    tr = R[..., 0, 0] + R[..., 1, 1] + R[..., 2, 2]
-    ct = ((tr - 1) / 2).clamp_min(min_cos)
-    st = torch.sqrt(1 - ct ** 2)
-    th = torch.acos(ct)
-    A = ((th + 1e-8) / (2 * st + 2e-8))[..., None, None] * (R - R.transpose(-1, -2))
-    return torch.stack([A[..., 1, 2], A[..., 2, 0], A[..., 0, 1]], dim=-1)
-
-
-def quat1ijk_to_rot(e):
-    b, c, d = e.unbind(-1)
-    s = torch.sqrt(1 + b ** 2 + c ** 2 + d ** 2)
-    a, b, c, d = 1 / s, b / s, c / s, d / s
-    m = [a ** 2 + b ** 2 - c ** 2 - d ** 2, 2 * b * c - 2 * a * d, 2 * b * d + 2 * a * c,
-         2 * b * c + 2 * a * d, a ** 2 - b ** 2 + c ** 2 - d ** 2, 2 * c * d - 2 * a * b,
-         2 * b * d - 2 * a * c, 2 * c * d + 2 * a * b, a ** 2 - b ** 2 - c ** 2 + d ** 2]
-    return torch.stack(m, -1).reshape(e.shape[:-1] + (3, 3))
-
-
-def _to_global(R, t, p):        # p: (N, L, K, 3)
-    return torch.einsum('nlab,nlkb->nlka', R, p) + t.unsqueeze(2)
-
-
-def _to_local(R, t, q):
-    return torch.einsum('nlba,nlkb->nlka', R, q - t.unsqueeze(2))
 
 
 def _ln(x, mod):
@@ -104,12 +56,8 @@ class NativeLinear(torch.autograd.Function):
 
 
 def _linear(mod, x, relu=False):
-    """nn.Linear `mod` (followed by a ReLU if asked) through NativeLinear on the device (plain F.linear for CPU tensors: the float64 /
-    CPU checkers)."""
-    if x.is_cuda and x.dtype == torch.float32:
-        return NativeLinear.apply(x, mod.weight, mod.bias, relu)
-    y = F.linear(x, mod.weight, mod.bias)
-    return y.relu() if relu else y
+    """nn.Linear `mod` (followed by a ReLU if asked) through NativeLinear (a CPU tensor raises in the binding: there is no other path)."""
+    return NativeLinear.apply(x, mod.weight, mod.bias, relu)
 
 
 def _mlp(seq, x):
@@ -183,9 +131,6 @@ class IpaCore(torch.autograd.Function):
         return dproj, dz, None, None, None, dWb, dgamma, None, None
 
 
-NATIVE_IPA = True      # tests flip this to compare the native path with the plain torch statement
-
-
 class BlockTail(torch.autograd.Function):
     """out_transform -> mask -> +x -> LayerNorm -> mlp_transition -> +y -> LayerNorm (ga.py:174-177) as ONE forward launch
     (csrc/mlp.hip: out_ln_mlp_kernel with its activation dump) and, backward, one launch for everything row-local
@@ -214,51 +159,20 @@ class BlockTail(torch.autograd.Function):
         return da1.view(dout.shape), dfeat, None, dw_out, cs[7], cs[6], cs[5], dw0, cs[4], dw1, cs[3], dw2, cs[2], cs[1], cs[0]
 
 
-def _block_tail(blk, x, feat, mask, native=True):
-    if native and x.is_cuda:
-        m = blk.mlp_transition
-        return BlockTail.apply(x, feat, mask, blk.out_transform.weight, blk.out_transform.bias, blk.layer_norm_1.gamma, blk.layer_norm_1.beta,
-                               m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias, blk.layer_norm_2.gamma, blk.layer_norm_2.beta)
-    u = blk.out_transform(feat)
-    u = torch.where(mask.unsqueeze(-1), u, torch.zeros_like(u))
-    y = _ln(x + u, blk.layer_norm_1)
-    return _ln(y + blk.mlp_transition(y), blk.layer_norm_2)
+def _block_tail(blk, x, feat, mask):
+    m = blk.mlp_transition
+    return BlockTail.apply(x, feat, mask, blk.out_transform.weight, blk.out_transform.bias, blk.layer_norm_1.gamma, blk.layer_norm_1.beta,
+                           m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias, blk.layer_norm_2.gamma, blk.layer_norm_2.beta)
 
 
 # ------------------------------------------------------------------ network
-def ga_block(blk, R, t, x, z, mask, native=None, pbc=None, zsink=None):
-    """pbc: this block's slice of hip.pair_bias_cache_layers (forward-only shortcut: the core reads proj_pair_bias(z) instead of
-    recomputing it; gradients of z and the weight still come from the backward kernel)."""
-    N, L, _ = x.shape
-    if NATIVE_IPA if native is None else native:
-        w_node = torch.cat([blk.proj_query.weight, blk.proj_key.weight, blk.proj_value.weight,
-                            blk.proj_query_point.weight, blk.proj_key_point.weight, blk.proj_value_point.weight], dim=0)
-        feat = IpaCore.apply(NativeLinear.apply(x, w_node), z, R.detach(), t.detach(), mask, blk.proj_pair_bias.weight, blk.spatial_coef, pbc, zsink)
-        return _block_tail(blk, x, feat, mask)
-    q = blk.proj_query(x).view(N, L, H, D)
-    k = blk.proj_key(x).view(N, L, H, D)
-    v = blk.proj_value(x).view(N, L, H, D)
-    qp = _to_global(R, t, blk.proj_query_point(x).view(N, L, H * P, 3)).reshape(N, L, H, P * 3)
-    kp = _to_global(R, t, blk.proj_key_point(x).view(N, L, H * P, 3)).reshape(N, L, H, P * 3)
-    vp = _to_global(R, t, blk.proj_value_point(x).view(N, L, H * P, 3)).reshape(N, L, H, P, 3)
-    l_node = torch.einsum('nihd,njhd->nijh', q, k) * (1 / math.sqrt(D))
-    l_pair = blk.proj_pair_bias(z)
-    d2 = (qp ** 2).sum(-1).unsqueeze(2) + (kp ** 2).sum(-1).unsqueeze(1) - 2 * torch.einsum('nihe,njhe->nijh', qp, kp)
-    gamma = F.softplus(blk.spatial_coef)
-    l_spat = d2 * ((-1 * gamma * math.sqrt(2 / (9 * P))) / 2)
-    logits = (l_node + l_pair + l_spat) * math.sqrt(1 / 3)
-    mrow = mask.view(N, L, 1, 1)
-    mpair = mrow & mask.view(N, 1, L, 1)
-    alpha = torch.softmax(torch.where(mpair, logits, logits - 1e5), dim=2)
-    alpha = torch.where(mrow, alpha, torch.zeros_like(alpha))
-    f_pair = torch.einsum('nijh,nijc->nihc', alpha, z).reshape(N, L, -1)
-    f_node = torch.einsum('nijh,njhd->nihd', alpha, v).reshape(N, L, -1)
-    agg = torch.einsum('nijh,njhpa->nihpa', alpha, vp).reshape(N, L, H * P, 3)
-    loc = _to_local(R, t, agg)
-    dist = loc.norm(dim=-1)
-    direc = loc / (dist.unsqueeze(-1) + 1e-4)
-    feat = torch.cat([f_pair, f_node, loc.reshape(N, L, -1), dist, direc.reshape(N, L, -1)], dim=-1)
-    return _block_tail(blk, x, feat, mask, native=False)
+def ga_block(blk, R, t, x, z, mask, pbc=None, zsink=None):
+    """GABlock.forward under autograd (ga.py:149-178).  pbc: this block's slice of hip.pair_bias_cache_layers (forward-only shortcut: the
+    core reads proj_pair_bias(z) instead of recomputing it; gradients of z and the weight still come from the backward kernel)."""
+    w_node = torch.cat([blk.proj_query.weight, blk.proj_key.weight, blk.proj_value.weight,
+                        blk.proj_query_point.weight, blk.proj_key_point.weight, blk.proj_value_point.weight], dim=0)
+    feat = IpaCore.apply(NativeLinear.apply(x, w_node), z, R.detach(), t.detach(), mask, blk.proj_pair_bias.weight, blk.spatial_coef, pbc, zsink)
+    return _block_tail(blk, x, feat, mask)
 
 
 class HeadsEpilogue(torch.autograd.Function):
@@ -282,34 +196,27 @@ class HeadsEpilogue(torch.autograd.Function):
 
 
 def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res, want_v=True):
-    """EpsilonNet.forward under autograd.  want_v=False skips v_next = log(R_next) (the training losses use R_next only)."""
-    N, L = mask_res.shape
-    native = NATIVE_IPA and v_t.is_cuda and not v_t.requires_grad
-    if native:
-        from . import hip
-        R = hip.so3_exp(v_t.detach().float())
-    else:
-        R = so3_exp(v_t)
+    """EpsilonNet.forward under autograd (dpm_full.py:70-112).  The noised state (v_t, p_t, s_t) carries no gradient, as in the reference's
+    training loop.  want_v=False skips v_next = log(R_next) (the training losses use R_next only); when asked for, it is returned detached."""
+    from . import hip
     from .embed import embed_rows
+    if v_t.requires_grad:
+        raise NotImplementedError('eps_net: gradients with respect to the noised orientations are not part of the training path (dpm_full.py:162-178 noises without grad)')
+    N, L = mask_res.shape
+    R = hip.so3_exp(v_t.detach().float())
     x = _mlp(net.res_feat_mixer, torch.cat([res_feat, embed_rows(net.current_sequence_embedding, s_t)], dim=-1))
-    caches = [None] * len(net.encoder.blocks)
-    if NATIVE_IPA and pair_feat.is_cuda:
-        # proj_pair_bias(pair_feat) of all blocks in one pass over pair_feat (the sampler's per-call cache, rebuilt every training step)
-        from . import hip
-        caches = hip.pair_bias_cache_layers([blk.proj_pair_bias.weight for blk in net.encoder.blocks], pair_feat.detach())
-    zsink = dict(buf=None, users=0) if (NATIVE_IPA and pair_feat.is_cuda and pair_feat.requires_grad) else None
+    # proj_pair_bias(pair_feat) of all blocks in one pass over pair_feat (the sampler's per-call cache, rebuilt every training step)
+    caches = hip.pair_bias_cache_layers([blk.proj_pair_bias.weight for blk in net.encoder.blocks], pair_feat.detach())
+    zsink = dict(buf=None, users=0) if pair_feat.requires_grad else None
     for blk, pbc in zip(net.encoder.blocks, caches):
         x = ga_block(blk, R, p_t, x, pair_feat, mask_res, pbc=pbc, zsink=zsink)
     temb = torch.stack([beta, torch.sin(beta), torch.cos(beta)], dim=-1)[:, None, :].expand(N, L, 3)
     feat = torch.cat([x, temb], dim=-1)
-    gen3 = mask_generate[:, :, None].expand(N, L, 3)
-    eps_crd = _mlp(net.eps_crd_net, feat)
-    if native:
-        R_next, eps_pos = HeadsEpilogue.apply(R, eps_crd, _mlp(net.eps_rot_net, feat), mask_generate)
-    else:
-        eps_pos = torch.where(gen3, torch.einsum('nlab,nlb->nla', R, eps_crd), torch.zeros_like(eps_crd))
-        R_next = R @ quat1ijk_to_rot(_mlp(net.eps_rot_net, feat))
-    v_next = torch.where(gen3, so3_log(R_next), v_t) if want_v else None
+    R_next, eps_pos = HeadsEpilogue.apply(R, _mlp(net.eps_crd_net, feat), _mlp(net.eps_rot_net, feat), mask_generate)
+    v_next = None
+    if want_v:
+        gen3 = mask_generate[:, :, None].expand(N, L, 3)
+        v_next = torch.where(gen3, hip.so3_log(R_next.detach(), grad_mode=torch.is_grad_enabled()), v_t)
     c = _mlp(net.eps_seq_net, feat)
     if net.no_bins is None:
         return v_next, R_next, eps_pos, c
@@ -319,19 +226,6 @@ def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_r
 
 
 # ------------------------------------------------------------------ losses
-def _one_hot20(x):
-    ok = (x >= 0) & (x < K_AA)
-    return (F.one_hot(x.clamp(0, K_AA - 1), K_AA) * ok[..., None]).float()
-
-
-def _posterior(alpha_bars, x_t, x_0, t):
-    c_t = x_t if x_t.dim() == 3 else _one_hot20(x_t)
-    c_0 = x_0 if x_0.dim() == 3 else _one_hot20(x_0)
-    a = alpha_bars[t][:, None, None]
-    th = ((a * c_t) + (1 - a) / K_AA) * ((a * c_0) + (1 - a) / K_AA)       # transition.py:223-224: alpha_bar_t in both factors
-    return th / (th.sum(dim=-1, keepdim=True) + 1e-8)
-
-
 class DpmLosses(torch.autograd.Function):
     """(rot, pos, seq) sums over the generated residues (dpm_full.py:199-231) and their gradients in ONE launch (csrc/rows.hip:
     dpm_losses_kernel) instead of the ~50 forward and ~70 backward elementwise kernels of the statement in fulldpm_loss below."""
@@ -373,10 +267,7 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
                                                  seed_dev=seed_dev if noise is None else None)
     p0n = dpm._normalize_position(p_0)
     p_n = dpm._normalize_position(p_n_ang)
-    if NATIVE_IPA and v_0.is_cuda and not v_0.requires_grad:
-        R_0 = hip.so3_exp(v_0.detach().float())
-    else:
-        R_0 = so3_exp(v_0)
+    R_0 = hip.so3_exp(v_0.detach().float())          # frames of the input structure: no gradient (dpm_full.py:160-161 builds them from the batch)
     beta = vs.betas[t]
     out = eps_net(dpm.eps_net, v_n, p_n, s_n, res_feat, pair_feat, beta, mask_generate, mask_res, want_v=False)
     v_pred, R_pred, p_pred, c_den = out[:4]
@@ -407,20 +298,10 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
         pos_target = p_true
     else:
         pos_target = eps_p
-    if NATIVE_IPA and R_pred.is_cuda and R_pred.dtype == torch.float32 and not (R_0.requires_grad or pos_target.requires_grad):
-        sums = DpmLosses.apply(R_pred, R_0, p_pred, pos_target, c_den, s_n, s_0, vs.alpha_bars[t], mask_generate) / denom
-        loss['rot'], loss['pos'], loss['seq'] = sums[0], sums[1], sums[2]
-        return loss
-    cp = R_pred.transpose(-2, -1).reshape(-1, 3)
-    ct = R_0.transpose(-2, -1).reshape(-1, 3)
-    lr = F.cosine_embedding_loss(cp, ct, torch.ones(cp.shape[0], dtype=torch.long, device=dev), reduction='none')
-    lr = lr.reshape(list(R_pred.shape[:-2]) + [3]).sum(-1)
-    loss['rot'] = (lr * genf).sum() / denom
-    loss['pos'] = (F.mse_loss(p_pred, pos_target, reduction='none').sum(-1) * genf).sum() / denom
-    post_true = _posterior(vs.alpha_bars, s_n, s_0, t)
-    log_pred = torch.log(_posterior(vs.alpha_bars, s_n, c_den, t) + 1e-8)
-    kl = F.kl_div(input=log_pred, target=post_true, reduction='none', log_target=False).sum(-1)
-    loss['seq'] = (kl * genf).sum() / denom
+    # rot (cosine-embedding loss on the matrix columns, dpm_full.py:15-32,199-204), pos (MSE, :206-208) and seq (KL of the posteriors,
+    # :210-231) summed over the generated residues, with their gradients, in one launch
+    sums = DpmLosses.apply(R_pred, R_0, p_pred, pos_target.detach(), c_den, s_n, s_0, vs.alpha_bars[t], mask_generate) / denom
+    loss['rot'], loss['pos'], loss['seq'] = sums[0], sums[1], sums[2]
     return loss
 
 

@@ -54,6 +54,19 @@ def test_no_cpu_fallback():
         m.sample(batch)
     with pytest.raises(RuntimeError, match='HIP device only'):
         hip.so3_exp(torch.zeros(4, 3))
+    # the training entry point too: model(batch) on CPU tensors raises in the binding, there is no torch restatement behind it
+    m.train()
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        m(dict(batch))
+    with pytest.raises(RuntimeError, match='HIP device only'), torch.no_grad():
+        m(dict(batch))                                  # (a validation pass)
+    from ab_opt_amd import training, embed
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        training._linear(torch.nn.Linear(8, 4), torch.zeros(3, 8))
+    assert not hasattr(training, 'NATIVE_IPA') and not hasattr(embed, 'NATIVE_FEATURES')
+    import inspect
+    src = inspect.getsource(training) + inspect.getsource(embed)
+    assert 'F.linear' not in src and 'einsum(\'nijh' not in src          # no second implementation of the network in the package
 
 
 def test_contig_mask_and_registry():

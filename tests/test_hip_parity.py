@@ -269,8 +269,9 @@ def test_encode_training_gradients_vs_reference():
     ('abdock', 'full', 128, (True, True)), ('abdock', 'full', 128, (False, True)), ('abdock', 'full', 128, (False, False)),
     ('abdock', 'backbone+CB', 128, (True, True)), ('abdesign', 'full', 128, (True, False)), ('abdesign', 'full', 256, (True, True))])
 def test_encode_hip_vs_autograd_statement(flavour, resolution, L, flags):
-    """HIP inference encode against the differentiable torch statement of the same module on the device (which is pinned to
-    the reference by the golden fixtures): both resolutions, hotspot embedding, every mask mode, ragged and full lengths."""
+    """HIP encode (inference kernels and the training path's autograd functions) against the plain torch statement of the same modules
+    on the device (tests/plain_statement.py, float32 and float64): both resolutions, hotspot embedding, every mask mode, ragged and
+    full lengths."""
     from ab_opt_amd import get_model
     cfg = cases.cfg_abdock(10)
     cfg['resolution'] = resolution
@@ -293,8 +294,9 @@ def test_encode_hip_vs_autograd_statement(flavour, resolution, L, flags):
     batch['mask_heavyatom'] &= batch['mask'][:, :, None]
     if flavour == 'abdesign':
         batch['hotspot'] = (dev(synth.hash_tensor((3, L), 31, scale=1.0)) > 0.7).long() * batch['mask'].long()
-    with torch.enable_grad():
-        ref = [t.detach() for t in m.encode(dict(batch), *flags)]
+    import plain_statement
+    with torch.no_grad():
+        ref = [t.detach() for t in plain_statement.encode(m, dict(batch), *flags)]
     # the same statement in float64: the yardstick.  The hash-filled tables give O(1e3) features with heavy cancellation
     # (and acos near its clamp on the i == j diagonal), so fp32 results differ from the exact value by ~1e-4 relative
     # whatever the summation order; the HIP path must be as close to the fp64 value as the fp32 torch statement is.
@@ -302,10 +304,13 @@ def test_encode_hip_vs_autograd_statement(flavour, resolution, L, flags):
     m64.load_state_dict(m.state_dict())
     m64 = m64.to(DEV).double()
     b64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
-    with torch.enable_grad():
-        ref64 = [t.detach() for t in m64.encode(dict(b64), *flags)]
     with torch.no_grad():
+        ref64 = [t.detach() for t in plain_statement.encode(m64, dict(b64), *flags)]
         out = m.encode(dict(batch), *flags)
+    with torch.enable_grad():
+        out_train = [t.detach() for t in m.encode(dict(batch), *flags)]           # the training path (custom autograd functions on the same kernels)
+    for a, b in zip(out, out_train):
+        assert max_abs(a, b) <= 2e-5 * max(1.0, b.abs().max().item())
     for name, a, b, c in zip(('res_feat', 'pair_feat', 'R', 'p'), out, ref, ref64):
         assert a.shape == b.shape, name
         e_hip, e_t32 = (a.double() - c).abs(), (b.double() - c).abs()
@@ -647,8 +652,9 @@ def test_training_loss_and_grads_vs_reference():
 @pytest.mark.parametrize('N,L,lengths', [(2, 24, [24, 19]), (3, 70, [70, 33, 1]), (2, 256, [256, 250])])
 def test_ipa_core_autograd_function_vs_torch_statement(N, L, lengths):
     """Native training block (HIP forward with alpha kept, HIP z-streaming backward + (N,L,L,12) GEMMs) against the plain
-    torch statement of the same GABlock (which the reference's recorded gradients pin): output and every gradient."""
+    torch statement of the same GABlock (tests/plain_statement.py; the reference's recorded gradients pin both): output and every gradient."""
     from ab_opt_amd import training
+    import plain_statement
     blk = _block_on_device(seed=9)
     with torch.no_grad():
         blk.spatial_coef.copy_(dev(synth.hash_tensor((1, 1, 1, 12), 77, scale=1.0)))
@@ -658,7 +664,7 @@ def test_ipa_core_autograd_function_vs_torch_statement(N, L, lengths):
     for native in (False, True):
         blk.zero_grad()
         xx, zz = x.clone().requires_grad_(True), z.clone().requires_grad_(True)
-        out = training.ga_block(blk, R, t, xx, zz, mask, native=native)
+        out = training.ga_block(blk, R, t, xx, zz, mask) if native else plain_statement.ga_block(blk, R, t, xx, zz, mask)
         (out * wout).sum().backward()
         res[native] = dict(out=out.detach(), dx=xx.grad, dz=zz.grad, **{'d_' + n: p.grad.clone() for n, p in blk.named_parameters()})
     for k, ref in res[False].items():
@@ -1185,6 +1191,7 @@ def test_block_tail_autograd_function_vs_torch_statement(N, L, lengths):
     torch statement of ga.py:174-177: output, d x, d feat and the gradient of every parameter of the tail; row counts that are not a
     multiple of the 32-row tile and masked rows included."""
     from ab_opt_amd import training
+    import plain_statement
     blk = _block_on_device(seed=13)
     with torch.no_grad():
         for ln in (blk.layer_norm_1, blk.layer_norm_2):          # non-trivial LayerNorm parameters
@@ -1198,7 +1205,7 @@ def test_block_tail_autograd_function_vs_torch_statement(N, L, lengths):
     for native in (False, True):
         blk.zero_grad()
         xx, ff = x.clone().requires_grad_(True), feat.clone().requires_grad_(True)
-        out = training._block_tail(blk, xx, ff, mask, native=native)
+        out = training._block_tail(blk, xx, ff, mask) if native else plain_statement.block_tail(blk, xx, ff, mask)
         (out * wout).sum().backward()
         res[native] = dict(out=out.detach(), dx=xx.grad, dfeat=ff.grad,
                            **{'d_' + n: p.grad.clone() for n, p in blk.named_parameters() if n.split('.')[0] in names})
@@ -1237,12 +1244,13 @@ def test_ga_block_and_cache_above_2048_residues():
     """L = 2085 (> 2048, not a multiple of the 16-key chunk; round 1 fell back to a superseded kernel there): the sampler's block (fused
     projections, core with and without the pair-bias cache, fused tail) against the plain torch statement of the block evaluated on the
     same GPU -- which the reference's recorded gradients pin (test_ipa_core_autograd_function_vs_torch_statement)."""
-    from ab_opt_amd import hip, training
+    from ab_opt_amd import hip
+    import plain_statement
     N, L = 1, 2085
     blk = _block_on_device(seed=17)
     R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(N, L, [2003], salt=4100)]
     with torch.no_grad():
-        ref = training.ga_block(blk, R, t, x, z, mask, native=False)
+        ref = plain_statement.ga_block(blk, R, t, x, z, mask)
     _, s_full = blk.packed()
     out = hip.ga_block_forward(s_full, R, t, x, z, mask)
     tol = 2e-5 * max(1.0, ref.abs().max().item())
@@ -1345,7 +1353,7 @@ def test_residue_features_native_vs_torch_statement():
     """ResidueEmbedding on the training path: features from abopt_residue_features (+ bucketed row sums for the embedding tables) against
     the torch statement of residue.py:33-88 in the same module -- output and every parameter gradient, both flavours (hotspot table),
     ragged lengths, two chains, structure / sequence masks."""
-    from ab_opt_amd import embed
+    import plain_statement
     for flavour in ('abdock', 'abdesign'):
         m = build_model(10, 3, flavour=flavour, device=DEV).train()
         re_ = m.residue_embed
@@ -1358,17 +1366,13 @@ def test_residue_features_native_vs_torch_statement():
             kw['hotspot'] = (b['fragment_type'] == 3).long()
         w = dev(synth.hash_tensor((3, 128, 128), 9, scale=1.0))
         out = {}
-        try:
-            for native in (True, False):
-                embed.NATIVE_FEATURES = native
-                re_.zero_grad(set_to_none=True)
-                with torch.enable_grad():
-                    y = re_(*args, **kw)
-                    (y * w).sum().backward()
-                out[native] = (y.detach(), {n: p.grad.clone() for n, p in re_.named_parameters() if p.grad is not None})
-        finally:
-            embed.NATIVE_FEATURES = True
+        for native in (True, False):
             re_.zero_grad(set_to_none=True)
+            with torch.enable_grad():
+                y = re_(*args, **kw) if native else plain_statement.residue_embedding(re_, *args, **kw)
+                (y * w).sum().backward()
+            out[native] = (y.detach(), {n: p.grad.clone() for n, p in re_.named_parameters() if p.grad is not None})
+        re_.zero_grad(set_to_none=True)
         (ya, ga), (yb, gb) = out[True], out[False]
         assert (ya - yb).abs().max().item() <= 2e-5 * max(1.0, yb.abs().max().item())
         assert set(ga) == set(gb)
@@ -1381,6 +1385,7 @@ def test_dpm_losses_autograd_function_vs_torch_statement():
     gradients in one launch) against the torch statement of the same lines (cosine_embedding_loss, mse_loss, kl_div on the posteriors):
     sums and the three input gradients; sequence states outside 0..19 and masked rows included."""
     from ab_opt_amd import training, hip
+    import plain_statement
     g = torch.Generator().manual_seed(11)
     N, L = 4, 100
     R0 = hip.so3_exp(dev(torch.randn(N, L, 3, generator=g)))
@@ -1400,8 +1405,8 @@ def test_dpm_losses_autograd_function_vs_torch_statement():
     cp, ct = Rp.transpose(-2, -1).reshape(-1, 3), R0.transpose(-2, -1).reshape(-1, 3)
     lr = F.cosine_embedding_loss(cp, ct, torch.ones(cp.shape[0], dtype=torch.long, device=DEV), reduction='none').reshape(N, L, 3).sum(-1)
     t_idx = torch.arange(N, device=DEV)
-    post_true = training._posterior(ab, st, s0, t_idx)
-    log_pred = torch.log(training._posterior(ab, st, cd, t_idx) + 1e-8)
+    post_true = plain_statement.posterior(ab, st, s0, t_idx)
+    log_pred = torch.log(plain_statement.posterior(ab, st, cd, t_idx) + 1e-8)
     kl = F.kl_div(input=log_pred, target=post_true, reduction='none', log_target=False).sum(-1)
     ref = torch.stack([(lr * genf).sum(), (F.mse_loss(pp, pt, reduction='none').sum(-1) * genf).sum(), (kl * genf).sum()])
     (ref * w).sum().backward()
@@ -1414,6 +1419,7 @@ def test_heads_epilogue_autograd_function_vs_torch_statement():
     dpm_full.py:95-101 under autograd) against the torch statement of the same lines: values and both input gradients, small and
     large quaternion vectors, masked rows."""
     from ab_opt_amd import training, hip
+    import plain_statement
     g = torch.Generator().manual_seed(3)
     N, L = 5, 77
     R = hip.so3_exp(dev(torch.randn(N, L, 3, generator=g) * 1.5))
@@ -1427,7 +1433,7 @@ def test_heads_epilogue_autograd_function_vs_torch_statement():
     crd.grad = rot.grad = None
     gen3 = gen[:, :, None].expand(N, L, 3)
     ep2 = torch.where(gen3, torch.einsum('nlab,nlb->nla', R, crd), torch.zeros_like(crd))
-    Rn2 = R @ training.quat1ijk_to_rot(rot)
+    Rn2 = R @ plain_statement.quat1ijk_to_rot(rot)
     ((Rn2 * wR).sum() + (ep2 * wp).sum()).backward()
     for a, b, name in zip(got, (Rn2.detach(), ep2.detach(), crd.grad, rot.grad), ('R_next', 'eps_pos', 'd eps_crd', 'd eps_rot')):
         assert (a - b).abs().max().item() <= 3e-6 * max(1.0, b.abs().max().item()), name

@@ -1,12 +1,11 @@
 """Training step timing (BASELINE config 5: AbDesign forward+backward, batch 16 x 256 residues):
-    python tools/bench_train.py [N] [L] [iters]     -> ms per step for the native IPA path and the plain torch statement."""
+    python tools/bench_train.py [N] [L] [iters]     -> ms per training step."""
 import sys, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 from ab_opt_amd.utils.synth import build_model
-from ab_opt_amd import training
 from ab_opt_amd.utils.synth import make_batch, LAYOUT_256, LAYOUT_128
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
@@ -26,8 +25,7 @@ def step():
     return loss
 
 
-for native in (True, False):
-    training.NATIVE_IPA = native
+for native in (True,):
     torch.cuda.reset_peak_memory_stats()
     try:
         for _ in range(2):
