@@ -404,11 +404,26 @@ class GraphedTrainStep:
 
     def __init__(self, model, optimizer, batch, loss_weights=None, max_grad_norm=None, warmup=3):
         from . import hip
+        ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)
+        if ddp:
+            # DDP's gradient all-reduce runs inside backward, i.e. inside the capture: only RCCL collectives on device buffers can be
+            # captured (gloo stages through host memory), and DDP's unused-parameter search walks the autograd graph on the host every
+            # iteration.  PyTorch's recipe for DDP under graph capture (static graph, no unused-parameter search, >= 11 warm-up
+            # iterations) has NOT been validated for this model on MI355X nodes: refuse what cannot work and say what is untested.
+            import torch.distributed as dist
+            if dist.get_backend(model.process_group) != 'nccl':
+                raise NotImplementedError('GraphedTrainStep: a DistributedDataParallel model needs the nccl (RCCL) backend, one GPU per rank -- its gradient '
+                                          'all-reduce is part of the captured step; run eager steps (FusedAdam is capture-free as well) on other backends')
+            if model.find_unused_parameters:
+                raise NotImplementedError('GraphedTrainStep: build the DDP wrapper with find_unused_parameters=False (sampler.wrap_ddp(..., '
+                                          'find_unused_parameters=False, static_graph=True)): the search runs on the host every iteration and cannot be captured')
+            warmup = max(warmup, 11)
         self.model, self.opt = model, optimizer
         self.weights, self.max_grad_norm = loss_weights, max_grad_norm
         dev = next(model.parameters()).device
         self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
-        dpm = model.diffusion
+        dpm = (model.module if ddp else model).diffusion
+        self._dpm = dpm
         self.seed_dev = torch.zeros(2, dtype=torch.int64, device=dev)
         self._set_seed(dpm)
         side = torch.cuda.Stream(device=dev)
@@ -430,7 +445,7 @@ class GraphedTrainStep:
 
     def _one_step(self):
         self.opt.zero_grad(set_to_none=True)
-        dpm = self.model.diffusion
+        dpm = self._dpm
         dpm._train_seed_dev = self.seed_dev                            # for this step only (fulldpm_loss)
         try:
             losses = self.model(dict(self.static))
@@ -450,7 +465,7 @@ class GraphedTrainStep:
         for k, v in batch.items():
             if torch.is_tensor(v) and k in self.static:
                 self.static[k].copy_(v)
-        self._set_seed(self.model.diffusion)
+        self._set_seed(self._dpm)
         if isinstance(self.opt, FusedAdam):
             self.opt.refresh_hyper(self.max_grad_norm)                 # a scheduler may have moved lr since the last replay
             self.graph.replay()
@@ -471,4 +486,4 @@ class GraphedTrainStep:
                                'device memory at replay), a tensor lr, or build a new GraphedTrainStep')
 
     def close(self):
-        self.model.diffusion._train_seed_dev = None
+        self._dpm._train_seed_dev = None

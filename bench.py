@@ -343,10 +343,14 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
     dist, backend = None, None
-    if world > 1:
+    # ABOPT_BENCH_FORCE_DIST=1: initialise the process group (and run the gather / max-over-ranks code) even with ONE rank, so the RCCL
+    # branch executes on a 1-GPU box (tests/test_hip_parity.py::test_bench_nccl_branch_single_rank)
+    if world > 1 or os.environ.get('ABOPT_BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
         # RCCL needs one device per rank; with fewer devices than ranks the (tiny) exchange goes through gloo and host memory
         backend = os.environ.get('ABOPT_BENCH_BACKEND', 'nccl' if ndev >= world else 'gloo')
+        if world == 1 and 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', '29533'), RANK='0', WORLD_SIZE='1')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:

@@ -56,3 +56,36 @@ def ddp_worker(rank, world, port, outdir):
         m.zero_grad(); m.eval()
     finally:
         dist.destroy_process_group()
+
+
+def ddp_fused_adam_worker(rank, world, port, outdir):
+    """Two ranks on cuda:0 (gloo): eager DDP steps with training.FusedAdam keep the replicas in lock step; GraphedTrainStep refuses a DDP
+    model on a backend whose all-reduce cannot be captured."""
+    torch, dist = _init(rank, world, port)
+    try:
+        from conftest import build_model
+        from ab_opt_amd import sampler, training
+        from ab_opt_amd.utils import synth
+        dev = torch.device('cuda:0')
+        m = build_model(10, 3, device=dev).train()
+        ddp = sampler.wrap_ddp(m, dev)
+        opt = training.FusedAdam(ddp.parameters(), lr=1e-3)
+        full = synth.make_batch(2, synth.LAYOUT_128, seed=5, lengths=[64, 57])
+        mine = {k: v[rank:rank + 1].to(dev) for k, v in full.items()}
+        refused = None
+        try:
+            training.GraphedTrainStep(ddp, opt, mine, max_grad_norm=100.0)
+        except NotImplementedError as e:
+            refused = str(e)
+        losses = []
+        for it in range(3):
+            torch.manual_seed(100 + it)
+            opt.zero_grad(set_to_none=True)
+            loss = sum(ddp(dict(mine)).values())
+            loss.backward()
+            opt.step(max_grad_norm=100.0)
+            losses.append(loss.item())
+        sd = {n: p.detach().cpu() for n, p in m.named_parameters()}
+        torch.save(dict(losses=losses, params=sd, refused=refused), os.path.join(outdir, f'ddpadam_{rank}.pt'))
+    finally:
+        dist.destroy_process_group()

@@ -1709,6 +1709,46 @@ def test_bench_two_ranks_on_one_gpu():
     assert 0.3 * l1['value'] < l2['value'] < 1.6 * l1['value'], (l1['value'], l2['value'])
 
 
+@pytest.mark.gpu
+def test_bench_nccl_branch_single_rank():
+    """bench.py's RCCL branch (init_process_group('nccl', device_id=...), candidate all_gather on device buffers, MAX all-reduce of the
+    step time, barriers) executed with ONE rank on the one GPU of the box (ABOPT_BENCH_FORCE_DIST=1): no 8-GPU node exists for the builder,
+    but the code the driver's N > 1 runs take is no longer unexecuted."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', ABOPT_BENCH_FORCE_DIST='1', ABOPT_BENCH_BACKEND='nccl', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '1', '--repeats', '2', '--batch', '8',
+                        '--no-cpu-baseline', '--no-secondary'], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith('{')][-1])
+    assert line['config']['backend'] == 'nccl' and line['n_gpus'] == 1 and line['value'] > 0
+
+
+@pytest.mark.gpu
+def test_two_rank_ddp_with_fused_adam_and_graph_guard(tmp_path):
+    """Data-parallel training with the native optimizer: two DDP ranks on cuda:0 (gloo) take three FusedAdam steps on different samples and
+    end with bit-identical parameters (the all-reduced gradients are the same on both, and so is the clipping norm); GraphedTrainStep
+    refuses the DDP model there (a gloo all-reduce inside backward cannot be captured; with find_unused_parameters=True neither could an
+    RCCL one) instead of capturing a step that would silently skip the gradient exchange."""
+    import mp_workers
+    _spawn2(mp_workers.ddp_fused_adam_worker, tmp_path)
+    a, b = [torch.load(tmp_path / f'ddpadam_{r}.pt') for r in range(2)]
+    assert a['refused'] and 'nccl' in a['refused'] and b['refused']
+    assert all(math.isfinite(x) for x in a['losses'] + b['losses'])
+    ref = build_model(10, 3).state_dict()
+    moved = 0
+    for n in a['params']:
+        assert torch.equal(a['params'][n], b['params'][n]), n
+        moved += int(not torch.equal(a['params'][n], ref[n]))
+    assert moved > 150
+
+
 def test_add_noise_probs_without_sequence_noise_and_dockq_empty_selection():
     """abopt_add_noise(c_noisy) with noise_sequence=0 returns c_0 = onehot(s_0) (it used to leave the buffer unwritten);
     abopt_dockq_lite marks a candidate without common CA atoms in a chain with -1 and the binding raises like calc_DockQ's asserts."""
