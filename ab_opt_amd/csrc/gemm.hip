@@ -388,7 +388,9 @@ int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const floa
     // back to back) -- a C that is a column slice of a wider matrix (ldc > N) or has gaps between batches takes the unsplit kernel
     const bool dense_c = ldc == N && (batch == 1 || sc == (int64_t)M * ldc);
     if (tiles < 128 && K >= 1024 && ws && !bias && !relu && dense_c) {      // (an epilogue with bias / ReLU needs the whole sum in one workgroup)
-        ksplit = min(min(512 / max(tiles, 1), K / 512), 256);
+        // (up to 1024 slabs: the tall products of the pair embedding -- K = N L^2 rows, one or four output tiles -- are HBM streams, and
+        // 256 workgroups of four waves keep too few bytes in flight: 143 us for 2 x 268 MB at 256 slabs)
+        ksplit = min(min(1024 / max(tiles, 1), K / 512), 1024);
         while (ksplit > 1 && (size_t)ksplit * batch * M * ldc > ws_floats) --ksplit;
         ksplit = max(ksplit, 1);
     }
