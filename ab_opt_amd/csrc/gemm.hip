@@ -6,6 +6,7 @@
 // (reference ga.py:54-66), out_transform + mlp_transition (ga.py:69-79), res_feat_mixer and the
 // eps_* / prmsd heads (dpm_full.py:39-65).
 #include "abopt_common.h"
+#include <cstdlib>
 #include "kernels.h"
 
 namespace abopt {
@@ -390,7 +391,8 @@ int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const floa
     if (tiles < 128 && K >= 1024 && ws && !bias && !relu && dense_c) {      // (an epilogue with bias / ReLU needs the whole sum in one workgroup)
         // (up to 1024 slabs: the tall products of the pair embedding -- K = N L^2 rows, one or four output tiles -- are HBM streams, and
         // 256 workgroups of four waves keep too few bytes in flight: 143 us for 2 x 268 MB at 256 slabs)
-        ksplit = min(min(1024 / max(tiles, 1), K / 512), 1024);
+        static const int kdiv = getenv("ABOPT_GEMM_KDIV") ? atoi(getenv("ABOPT_GEMM_KDIV")) : 256;     // shortest K range of a slab (developer knob; 512 -> 256: 10.8 -> 10.3 ms per training step, more workgroups per weight-gradient product)
+        ksplit = min(min(1024 / max(tiles, 1), K / kdiv), 1024);
         while (ksplit > 1 && (size_t)ksplit * batch * M * ldc > ws_floats) --ksplit;
         ksplit = max(ksplit, 1);
     }
