@@ -331,10 +331,18 @@ extern "C" int abopt_ipa_pair_backward(const float* pair_feat, const float* alph
     int rc;
     if ((rc = check_dims(N, L, F, Cd))) return rc;
     if ((int64_t)N * L == 0) return ABOPT_OK;
-    ABOPT_CHECK_ARG(pair_feat && alpha && dalpha_node && delta && dfeat && w_pair_bias && g && dpair_feat && dw_pair_bias_rows && ld_dfeat >= ABOPT_HEADS * 64 && (ld_dfeat % 4) == 0,
-                    "ipa_pair_backward: bad argument");
+    ABOPT_CHECK_ARG(pair_feat && alpha && dalpha_node && delta && dfeat && w_pair_bias && g && dw_pair_bias_rows && ld_dfeat >= ABOPT_HEADS * 64 && (ld_dfeat % 4) == 0,
+                    "ipa_pair_backward: bad argument");          // dpair_feat may be NULL: d pair_feat is then left to abopt_ipa_dz_assemble
     return launch_ipa_pair_backward(pair_feat, alpha, dalpha_node, delta, dfeat, ld_dfeat, w_pair_bias, g, dpair_feat, dw_pair_bias_rows, N, L, (hipStream_t)stream,
                                     dpair_feat_accumulate ? 1 : 0);
+}
+
+extern "C" int abopt_ipa_dz_assemble(int num_blocks, const float* const* alpha, const float* const* g, const float* const* dfeat, int ld_dfeat,
+                                     const float* const* w_pair_bias, float* dpair_feat, int N, int L, int Cd, abopt_stream stream) {
+    int rc;
+    if ((rc = check_dims(N, L, F, Cd))) return rc;
+    ABOPT_CHECK_ARG(alpha && g && dfeat && w_pair_bias && dpair_feat && ld_dfeat >= ABOPT_HEADS * 64 && (ld_dfeat % 4) == 0, "ipa_dz_assemble: bad argument");
+    return launch_ipa_dz_assemble(num_blocks, alpha, g, dfeat, ld_dfeat, w_pair_bias, dpair_feat, N, L, (hipStream_t)stream);
 }
 
 extern "C" int abopt_ga_block_forward(const abopt_ga_weights* w, const float* R, const float* t, const float* x, const float* z,

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
     __syncthreads();
     const float del = (fm < H) ? delta[row * H + fm] : 0.f;
     const float* zrow = z + row * (int64_t)L * C;
-    float* dzrow = dz + row * (int64_t)L * C;
+    float* dzrow = dz ? dz + row * (int64_t)L * C : nullptr;
     const int64_t hm = ((n * H + fm) * (int64_t)L + i) * L;                // (n, h = fm, i, j = 0) of the head-major arrays
     const int nchunk = (L + JC - 1) / JC;
     f32x4 zr[4], zc[4], accW[4];                                          // accW: this wave's share of sum_j g[h,j] z[j,c] (d proj_pair_bias.weight)
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) accW[mt] = mfma4(zc[r][mt], g4[r], accW[mt]);
+        if (!dz) continue;                                                 // (wave-uniform) dz is assembled for all blocks at once: ipa_dz_assemble_kernel
         // ---- [alpha ; g] -> LDS transposed ([key][head]) for the dz product
 #pragma unroll
         for (int r = 0; r < 4; ++r) { sm.ag[wave][kq * 4 + r][fm] = a4[r]; sm.ag[wave][kq * 4 + r][16 + fm] = g4[r]; }
@@ -140,6 +141,108 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
         const int h = e / C, c = e % C;
         dwb_part[row * (H * C) + e] = (red[0][h][c] + red[1][h][c]) + (red[2][h][c] + red[3][h][c]);
     }
+}
+
+// d pair_feat of ALL blocks of an encoder in one pass (round 4):
+//     dz_ijc = sum over blocks l, heads h of  alpha_l,ijh dfp_l,ihc + g_l,ijh Wb_l,hc
+// Each block's ipa_pair_backward_kernel used to add its term into the shared d pair_feat buffer: a read-modify-write of N L^2 C floats
+// per block (2.95 GB per step at config 5).  The terms need no z, only what the blocks' backward passes leave behind anyway (alpha, g,
+// d feat, the weights), so they are summed here with ONE write of dz: a K = 32 nl contraction per (row, key chunk), same tiling as above.
+struct DzLayers { const float* alpha[8]; const float* g[8]; const float* dfeat[8]; const float* wb[8]; int nl; int ld_dfeat; };
+struct DzSmem {
+    float at[6][C][36];              // per block: [c][0:16] = dfp^T of this row, [16:32] = Wb^T
+    float ag[4][JC][36];             // per wave: [key][0:16] = alpha over heads, [16:32] = g over heads (one block at a time)
+};
+__global__ __launch_bounds__(256) void ipa_dz_assemble_kernel(DzLayers a, float* __restrict__ dz, int L) {
+    extern __shared__ __attribute__((aligned(16))) char dz_raw[];
+    DzSmem& sm = *reinterpret_cast<DzSmem*>(dz_raw);
+    const int64_t row = blockIdx.x;
+    const int64_t n = row / L;
+    const int i = (int)(row % L);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
+    for (int l = 0; l < a.nl; ++l) {
+        const float* dfp = a.dfeat[l] + row * a.ld_dfeat;
+        for (int e = tid; e < 16 * C; e += 256) {
+            const int h = e / C, c = e % C;
+            sm.at[l][c][h] = (h < H) ? dfp[h * C + c] : 0.f;
+            sm.at[l][c][16 + h] = (h < H) ? a.wb[l][h * C + c] : 0.f;
+        }
+    }
+    __syncthreads();
+    float* dzrow = dz + row * (int64_t)L * C;
+    const int64_t hm = ((n * H + fm) * (int64_t)L + i) * L;
+    const int nchunk = (L + JC - 1) / JC;
+    // the (alpha, g) quads of ALL blocks for a chunk are requested together, one chunk ahead of their use (requested block by block next
+    // to the LDS transposes the kernel ran at 1.9 TB/s: every block's round trip was exposed)
+    f32x4 an[6], gn[6];
+    auto fetch = [&](int ch, f32x4 (&av)[6], f32x4 (&gv)[6]) {
+        const int jq = ch * JC + kq * 4;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {
+            av[l] = (f32x4){0.f, 0.f, 0.f, 0.f}; gv[l] = av[l];
+            if (l < a.nl && fm < H && ch < nchunk) {
+                if (jq + 3 < L && (L % 4) == 0) {
+                    av[l] = *reinterpret_cast<const f32x4*>(a.alpha[l] + hm + jq);
+                    gv[l] = *reinterpret_cast<const f32x4*>(a.g[l] + hm + jq);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (jq + r < L) { av[l][r] = a.alpha[l][hm + jq + r]; gv[l][r] = a.g[l][hm + jq + r]; }
+                }
+            }
+        }
+    };
+    fetch(wave, an, gn);
+    for (int ch = wave; ch < nchunk; ch += 4) {
+        const int j0 = ch * JC;
+        f32x4 ac[6], gc[6];
+#pragma unroll
+        for (int l = 0; l < 6; ++l) { ac[l] = an[l]; gc[l] = gn[l]; }
+        fetch(ch + 4, an, gn);
+        f32x4 o[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {
+            if (l >= a.nl) break;
+            wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sm.ag[wave][kq * 4 + r][fm] = ac[l][r]; sm.ag[wave][kq * 4 + r][16 + fm] = gc[l][r]; }
+            wave_lds_sync();
+            f32x4 bq[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) bq[blk] = *reinterpret_cast<const f32x4*>(&sm.ag[wave][fm][blk * 16 + kq * 4]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const f32x4 aq = *reinterpret_cast<const f32x4*>(&sm.at[l][ct * 16 + fm][blk * 16 + kq * 4]);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) o[ct] = mfma4(aq[s_], bq[blk][s_], o[ct]);
+                }
+        }
+        if (j0 + fm < L) {
+            float* dzj = dzrow + (int64_t)(j0 + fm) * C + kq * 4;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<f32x4*>(dzj + ct * 16) = o[ct];
+        }
+    }
+}
+
+int launch_ipa_dz_assemble(int nl, const float* const* alpha, const float* const* g, const float* const* dfeat, int ld_dfeat, const float* const* wb,
+                           float* dz, int N, int L, hipStream_t st) {
+    if ((int64_t)N * L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(nl >= 1 && nl <= 6, "ipa_dz_assemble: %d blocks (1..6)", nl);
+    DzLayers a;
+    a.nl = nl; a.ld_dfeat = ld_dfeat;
+    for (int l = 0; l < nl; ++l) {
+        ABOPT_CHECK_ARG(alpha[l] && g[l] && dfeat[l] && wb[l], "ipa_dz_assemble: NULL pointer for block %d", l);
+        a.alpha[l] = alpha[l]; a.g[l] = g[l]; a.dfeat[l] = dfeat[l]; a.wb[l] = wb[l];
+    }
+    static LdsConfig lds_cfg;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_dz_assemble_kernel), sizeof(DzSmem), lds_cfg)) return rc;
+    hipLaunchKernelGGL(ipa_dz_assemble_kernel, dim3((unsigned)((int64_t)N * L)), dim3(256), sizeof(DzSmem), st, a, dz, L);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
 }
 
 // alpha (ga.py:11-26,166) in place over the core's head-major dump x [N,12,L,L]: alpha = mask_i mask_j ? exp2(x - m_ih) / l_ih : 0

@@ -97,6 +97,9 @@ int launch_ipa_backward_assemble(const float* P1, const float* P2, const float* 
 int launch_ipa_pair_backward(const float* z, const float* alpha, const float* dalpha_node, const float* delta, const float* dfeat, int ld_dfeat,
                              const float* Wb, float* g_out, float* dz, float* dwb_part /* [N*L, 12*C] per-row partials of d proj_pair_bias.weight */,
                              int N, int L, hipStream_t st, int dz_accumulate = 0 /* 1: dz += (the blocks of an encoder share one buffer) */);
+// d pair_feat of all blocks in one pass from what their backward passes left (alpha, g, d feat, proj_pair_bias.weight), no z read
+int launch_ipa_dz_assemble(int nl, const float* const* alpha, const float* const* g, const float* const* dfeat, int ld_dfeat, const float* const* wb,
+                           float* dz, int N, int L, hipStream_t st);
 
 // embed.hip: encode() ----------------------------------------------------------------------------
 size_t residue_embed_ws_bytes(int N, int L, int A, int hotspot);

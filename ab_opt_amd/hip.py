@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -74,7 +74,7 @@ EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
            'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_dpm_losses', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek', 'abopt_prof_clock',
-           'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward',
+           'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward', 'abopt_ipa_dz_assemble',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
            'abopt_out_frag_floats', 'abopt_out_terms_floats', 'abopt_out_frag_terms', 'abopt_heads_frag_floats', 'abopt_mixer_frag_floats', 'abopt_mlp_frag_floats', 'abopt_pack_tail_weights', 'abopt_block_tail_forward', 'abopt_block_tail_backward']
@@ -522,18 +522,32 @@ def ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, spatial_coef):
     return dproj, e
 
 
-def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias, dz_into=None):
+def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias, dz_into=None, want_dz=True):
     """alpha, dalpha_node head-major (N,12,L,L) -> g (N,12,L,L), dz (N,L,L,C), dWb (12,C)  (include/abopt.h: abopt_ipa_pair_backward).
-    dz_into: an existing d pair_feat buffer this block's gradient is ADDED to (returned as dz)."""
+    dz_into: an existing d pair_feat buffer this block's gradient is ADDED to (returned as dz).  want_dz=False: dz is None -- the caller
+    assembles d pair_feat of all blocks at once (ipa_dz_assemble)."""
     N, L = z.shape[:2]
     g = torch.empty_like(alpha)
-    dz = torch.empty_like(z) if dz_into is None else dz_into
+    dz = None if not want_dz else (torch.empty_like(z) if dz_into is None else dz_into)
     dwb_rows = torch.empty(N * L, 12 * z.shape[-1], device=z.device)
     z, alpha, dalpha_node, delta, dfeat, w_pair_bias = _contig(z, alpha, dalpha_node, delta, dfeat, w_pair_bias)
     _check(lib().abopt_ipa_pair_backward(ptr(z, torch.float32), ptr(alpha, torch.float32), ptr(dalpha_node, torch.float32),
                                          ptr(delta, torch.float32), ptr(dfeat, torch.float32), dfeat.shape[-1],
-                                         ptr(w_pair_bias, torch.float32), ptr(g), ptr(dz), ptr(dwb_rows), int(dz_into is not None), N, L, z.shape[-1], stream()))
+                                         ptr(w_pair_bias, torch.float32), ptr(g), ptr(dz, torch.float32, optional=True), ptr(dwb_rows), int(dz_into is not None), N, L, z.shape[-1], stream()))
     return g, dz, colsum(dwb_rows).view(12, z.shape[-1])
+
+
+def ipa_dz_assemble(alphas, gs, dfeats, wbs, like):
+    """d pair_feat (shape of `like`) of all blocks of an encoder from their (alpha, g, d feat, proj_pair_bias.weight): abopt_ipa_dz_assemble."""
+    nl = len(alphas)
+    N, L, _, Cd = like.shape
+    keep = [_contig(*ts) for ts in (alphas, gs, dfeats, [w.detach().float() for w in wbs])]
+    ld = keep[2][0].shape[-1]
+    assert all(t.shape[-1] == ld for t in keep[2])
+    arr = lambda ts: (C.c_void_p * nl)(*[ptr(t, torch.float32).value for t in ts])
+    dz = torch.empty_like(like)
+    _check(lib().abopt_ipa_dz_assemble(nl, arr(keep[0]), arr(keep[1]), arr(keep[2]), ld, arr(keep[3]), ptr(dz), N, L, Cd, stream()))
+    return dz
 
 
 def encode_inputs(aa, res_nb, chain_nb, pos_atoms, mask_atoms, atoms, fragment_type=None, hotspot=None, structure_mask=None, sequence_mask=None):

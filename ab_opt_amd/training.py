@@ -77,6 +77,10 @@ def _mlp(seq, x):
 
 
 # ------------------------------------------------------------------ IPA core as an autograd function on the HIP kernels
+import os as _os
+DEFER_DZ = _os.environ.get('ABOPT_DZ_DEFER', '1') != '0'
+
+
 class IpaCore(torch.autograd.Function):
     """feat = IPA(proj, z): ga.py:81-147 between the six projections and out_transform.
 
@@ -112,14 +116,23 @@ class IpaCore(torch.autograd.Function):
         # backward adds into it in the kernel and only the last one to run hands it to autograd -- instead of six 268 MB tensors and five
         # elementwise additions
         sink = ctx.zsink if (ctx.zsink is not None and ctx.zsink['users'] > 0) else None       # (a second backward over a retained graph: no sharing)
-        g, dz, dWb = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb, dz_into=sink['buf'] if sink is not None else None)
-        if sink is not None:
+        if sink is not None and not DEFER_DZ:                      # developer A/B: the round-3 form (every block adds into one shared buffer)
+            g, dz, dWb = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb, dz_into=sink['buf'])
             sink['buf'] = dz
             sink['users'] -= 1
-            if sink['users'] > 0:
-                dz = None
-            else:
-                sink['buf'] = None
+            dz = None if sink['users'] > 0 else dz
+            sink = None
+        else:
+            g, dz, dWb = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb, want_dz=sink is None)
+        if sink is not None:
+            # the blocks of one encoder pass leave (alpha, g, d feat, W_b) behind; the LAST backward to run sums all their d pair_feat terms
+            # in one pass with one write (abopt_ipa_dz_assemble) -- each block adding into a shared buffer was a read-modify-write of
+            # N L^2 C floats per block
+            sink.setdefault('terms', []).append((alpha, g, dfeat, Wb))
+            sink['users'] -= 1
+            if sink['users'] == 0:
+                terms = sink.pop('terms')
+                dz = hip.ipa_dz_assemble([t_[0] for t_ in terms], [t_[1] for t_ in terms], [t_[2] for t_ in terms], [t_[3] for t_ in terms], z)
         del da_node
         # every (N,12,L,L) matrix is multiplied ONCE from each side (abopt_gemm reads the transposed views in place):
         P1 = mm(g, T(Ak))                                                           # sum_j g_ij [k_j | kg_j | 1]

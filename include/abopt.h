@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 34
+#define ABOPT_ABI_VERSION 35
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -298,11 +298,18 @@ int abopt_ipa_backward_operands(const float* proj_local, const float* R, const f
 int abopt_ipa_backward_assemble(const float* P1, const float* P2, const float* P3, const float* Aq, const float* Ak, const float* R,
                                 const float* spatial_coef, float* dproj, float* e, int N, int L, abopt_stream stream);
 int abopt_ipa_pair_backward(const float* pair_feat, const float* alpha, const float* dalpha_node, const float* delta,
-                            const float* dfeat, int ld_dfeat, const float* w_pair_bias, float* g, float* dpair_feat,
+                            const float* dfeat, int ld_dfeat, const float* w_pair_bias, float* g, float* dpair_feat /* may be NULL: see abopt_ipa_dz_assemble */,
                             float* dw_pair_bias_rows /* [N*L, 12*C]: per-query-row partials of d proj_pair_bias.weight (sum over rows) */,
                             int dpair_feat_accumulate /* 1: dpair_feat += this block's gradient (the six blocks of the encoder share one
                                                          buffer instead of six 268 MB tensors that autograd adds up); 0: overwrite */,
                             int N, int L, int C, abopt_stream stream);
+
+/* d pair_feat of ALL blocks of an encoder in one pass: dpair_feat[n,i,j,c] = sum over blocks l and heads h of
+ * alpha_l[n,h,i,j] dfeat_l[n,i,h*C+c] + g_l[n,h,i,j] w_pair_bias_l[h,c] (the pair-aggregation and proj_pair_bias terms of ga.py:88-90,114-118
+ * differentiated), from what abopt_ipa_pair_backward(..., dpair_feat = NULL, ...) of every block left behind.  No z read and ONE write of
+ * d pair_feat instead of a read-modify-write per block.  alpha / g / dfeat / w_pair_bias: HOST arrays of num_blocks (<= 6) device pointers. */
+int abopt_ipa_dz_assemble(int num_blocks, const float* const* alpha, const float* const* g, const float* const* dfeat, int ld_dfeat,
+                          const float* const* w_pair_bias, float* dpair_feat, int N, int L, int C, abopt_stream stream);
 
 /* ---- encode(): D/models/diffab.py:39-83.  ResidueEmbedding.forward (D/modules/encoders/residue.py:26-92; the AbDesign
  * variant adds hotspot_embed, A/modules/encoders/residue.py:19-21), PairEmbedding.forward (D/modules/encoders/pair.py:37-101),
