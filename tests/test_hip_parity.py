@@ -1834,6 +1834,39 @@ def test_eps_net_reference_headline_shape_vs_oracle():
             assert torch.equal(net[k][sl], small[k]), (k, lo)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,L,shared', [(64, 256, 1), (64, 256, 0), (128, 256, 16), (40, 200, 0)])
+def test_fused_block_repeats_bit_for_bit_over_several_rounds(N, L, shared):
+    """Race detector for the fused core + tail kernel: its epilogue re-uses the LDS of the S/P tile, the key mask region and the aggregated
+    points for staging buffers, u, the LayerNorm rows and the activation planes, separated only by workgroup barriers.  Shapes with
+    several rounds of workgroups per CU (N = 64: two, N = 128 grouped: four) and a partial last block (L = 200), twelve runs each: every
+    output equal to the first run's, bit for bit, and to the two-launch form's."""
+    import os
+    from ab_opt_amd import hip
+    d = standalone_abdesign_dpm(100, 2).to(DEV)
+    lens = [L - (3 * i) % 30 for i in range(N)]
+    v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lens, 9100 + N, [(5, 14), (22, 30)])
+    Nc = N if not shared else (1 if shared == 1 else N // shared)
+    pfc = pf[:Nc].contiguous()
+    beta = d.trans_pos.var_sched.betas[37].expand([N]).contiguous()
+    arr, ew = d.eps_net.encoder.packed_array(), d.eps_net.packed()
+    pbc = hip.pair_bias_cache(arr, 6, pfc)
+    run = lambda: {k: (a.clone() if a is not None else None) for k, a in
+                   hip.eps_net_forward(ew, v, p, s, rf, pfc, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc, pair_feat_shared=shared).items()}
+    first = run()
+    for rep in range(11):
+        again = run()
+        for k in ('R_next', 'eps_pos', 'c'):
+            assert torch.equal(again[k], first[k]), (rep, k)
+    os.environ['ABOPT_FUSE_TAIL'] = '0'
+    try:
+        two = run()
+    finally:
+        del os.environ['ABOPT_FUSE_TAIL']
+    for k in ('R_next', 'eps_pos', 'c'):
+        assert torch.isfinite(first[k]).all() and torch.equal(two[k], first[k]), k
+
+
 def test_training_step_config5_vs_oracle_at_full_size():
     """BASELINE config 5 at its own size (AbDesign flavour FullDPM.forward, N = 16, L = 256): losses and the gradient of EVERY parameter
     of the denoiser, res_feat and pair_feat from the native path (HIP noising, IPA core forward / backward, block tail, abopt_gemm
