@@ -238,6 +238,26 @@ extern "C" int abopt_dpm_losses(const float* R_pred, const float* R_0, const flo
                              (hipStream_t)stream);
 }
 
+extern "C" int abopt_abdock_losses(const float* prmsd_logits, const float* p_pred, const float* p0_norm, const float* coef_a, const float* coef_b,
+                                   const uint8_t* mask_generate, const uint8_t* mask_res, const float* bin_offsets, int num_bins, int N, int L, float position_scale,
+                                   int pred_x0, float* sample_parts, float* dprmsd_logits, float* dp_pred, abopt_stream stream) {
+    ABOPT_CHECK_ARG(N >= 0 && L >= 0 && prmsd_logits && p_pred && p0_norm && mask_generate && mask_res && bin_offsets && sample_parts && dprmsd_logits && dp_pred &&
+                    (pred_x0 || (coef_a && coef_b)), "abdock_losses: NULL argument");
+    return launch_abdock_losses(prmsd_logits, p_pred, p0_norm, coef_a, coef_b, mask_generate, mask_res, bin_offsets, num_bins, N, L, position_scale, pred_x0,
+                                sample_parts, dprmsd_logits, dp_pred, (hipStream_t)stream);
+}
+
+extern "C" int abopt_layer_norm_forward(const float* x, const float* gamma, const float* beta, int cols, float eps, int64_t rows, float* y, float* xhat, float* rstd,
+                                        abopt_stream stream) {
+    ABOPT_CHECK_ARG(rows >= 0 && x && gamma && beta && y && (!xhat == !rstd), "layer_norm_forward: NULL argument (xhat and rstd come together)");
+    return launch_row_layer_norm(x, gamma, beta, cols, eps, rows, y, xhat, rstd, (hipStream_t)stream);
+}
+extern "C" int abopt_layer_norm_backward(const float* dy, const float* xhat, const float* rstd, const float* gamma, int cols, int64_t rows, float* dx, float* dy_xhat,
+                                         abopt_stream stream) {
+    ABOPT_CHECK_ARG(rows >= 0 && dy && xhat && rstd && gamma && dx && dy_xhat, "layer_norm_backward: NULL argument");
+    return launch_row_layer_norm_backward(dy, xhat, rstd, gamma, cols, rows, dx, dy_xhat, (hipStream_t)stream);
+}
+
 extern "C" int abopt_heads_epilogue_forward(const float* R, const float* v_t, const float* eps_crd, const float* eps_rot, const uint8_t* mask_generate,
                                             float* v_next, float* R_next, float* eps_pos, int64_t rows, int grad_mode, abopt_stream stream) {
     ABOPT_CHECK_ARG(rows >= 0 && R && eps_crd && eps_rot && mask_generate && R_next && eps_pos && (!v_next || v_t), "heads_epilogue_forward: NULL argument");

@@ -79,6 +79,11 @@ int launch_heads_epilogue(const float* R, const float* v_t, const float* eps_crd
                           int64_t rows, int grad_mode, hipStream_t st);
 int launch_dpm_losses(const float* R_pred, const float* R_0, const float* p_pred, const float* p_target, const float* c_den, const int64_t* s_t, const int64_t* s_0,
                       const float* abar, const uint8_t* mask_generate, int N, int L, float* part, float* gR, float* gp, float* gc, hipStream_t st);
+int launch_abdock_losses(const float* prmsd_logits, const float* p_pred, const float* p0n, const float* coef_a, const float* coef_b, const uint8_t* gen,
+                         const uint8_t* mres, const float* offsets, int nb, int N, int L, float scale, int pred_x0, float* part, float* glogit, float* gp,
+                         hipStream_t st);
+int launch_row_layer_norm(const float* x, const float* gamma, const float* beta, int cols, float eps, int64_t rows, float* y, float* xhat, float* rstd, hipStream_t st);
+int launch_row_layer_norm_backward(const float* dy, const float* xhat, const float* rstd, const float* gamma, int cols, int64_t rows, float* dx, float* dyx, hipStream_t st);
 int launch_heads_epilogue_backward(const float* R, const float* eps_rot, int ld3, const uint8_t* mask_generate, const float* dR_next, const float* deps_pos,
                                    float* deps_crd, float* deps_rot, int64_t rows, hipStream_t st);
 // out[n, b] = mean_l in[n, l, b]

@@ -282,6 +282,168 @@ int launch_dpm_losses(const float* R_pred, const float* R_0, const float* p_pred
     return ABOPT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The two losses only the AbDock flavour has (D/modules/diffusion/dpm_full.py:180-198, D/modules/common/prmsd.py:49-70, dpm_full.py:369-378),
+// one workgroup per sample:
+//   prmsd: rmsd_n = sqrt(sum_gen |scale (pred_p0 - p0)|^2 / #gen)   (detached) -> bin = argmin_b |rmsd - offset_b|,
+//          err_n = -log_softmax(prmsd_logits_n)[bin];   loss = sum_n err_n m0_n / (sum_n m0_n + 1e-10),  m0_n = mask_generate[n, 0]
+//   dist (obj = pred_x0): smooth_l1(|p_pred_i - p_pred_j| - |p_true_i - p_true_j|) over the pairs gen_i & mres_i & mres_j (i == j included), mean.
+// part[n] = {err_n, m0_n, sum of the sample's smooth-l1 terms, their count}; glogit [N, nb] = softmax - onehot (to be scaled by
+// m0_n / (sum m0 + 1e-10)); gp [N, L, 3] = d(sum of smooth-l1 terms) / d p_pred (to be scaled by 1 / total count).  pred_x0 = 0: pred_p0 =
+// gen ? a_n p0 - b_n p_pred : p0 (transition.py:52-60) and there is no dist loss (gp is zeroed).
+__global__ __launch_bounds__(256) void abdock_losses_kernel(const float* __restrict__ prmsd_logits, const float* __restrict__ p_pred, const float* __restrict__ p0n,
+                                                            const float* __restrict__ coef_a, const float* __restrict__ coef_b, const uint8_t* __restrict__ gen,
+                                                            const uint8_t* __restrict__ mres, const float* __restrict__ offsets, int nb, int L, float scale,
+                                                            int pred_x0, float* __restrict__ part, float* __restrict__ glogit, float* __restrict__ gp) {
+    extern __shared__ __attribute__((aligned(16))) float al_s[];           // [L][4] p_pred (x, y, z, gen & mres flags) | [L][4] p_true
+    float* pp = al_s;
+    float* pt = al_s + 4 * L;
+    __shared__ float red[2][4];
+    __shared__ float s_rmsd;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int64_t base = (int64_t)n * L;
+    const float ca = pred_x0 ? 0.f : coef_a[n], cb = pred_x0 ? 0.f : coef_b[n];
+    float sq = 0.f, cnt = 0.f;
+    for (int l = tid; l < L; l += 256) {
+        const bool g = gen[base + l] != 0, m = mres[base + l] != 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a = p_pred[(base + l) * 3 + k], b = p0n[(base + l) * 3 + k];
+            pp[4 * l + k] = a; pt[4 * l + k] = b;
+            const float d = (pred_x0 ? a - b : (ca * b - cb * a) - b) * scale;
+            if (g) sq += d * d;
+        }
+        pp[4 * l + 3] = (g ? 1.f : 0.f) + (m ? 2.f : 0.f);
+        if (g) cnt += 1.f;
+    }
+    sq = wave_sum(sq); cnt = wave_sum(cnt);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = sq; red[1][tid >> 6] = cnt; }
+    __syncthreads();
+    if (tid == 0) s_rmsd = sqrtf(((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])));
+    __syncthreads();
+    // ---- prmsd cross entropy (wave 0): nb <= 64 bins, one lane per bin
+    if (tid < 64) {
+        const float rm = s_rmsd;
+        const float x = (tid < nb) ? prmsd_logits[(int64_t)n * nb + tid] : -INFINITY;
+        const float dist = (tid < nb) ? fabsf(rm - offsets[tid]) : INFINITY;
+        // argmin with the lowest index on ties (torch.argmin)
+        float best = dist; int bi = tid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        const float mx = wave_max(x);
+        const float e = (tid < nb) ? expf(x - mx) : 0.f;
+        const float se = wave_sum(e);
+        const float lse = mx + logf(se);
+        const float xb = __shfl(x, bi);
+        if (tid < nb) glogit[(int64_t)n * nb + tid] = e / se - (tid == bi ? 1.f : 0.f);
+        if (tid == 0) { part[n * 4 + 0] = -(xb - lse); part[n * 4 + 1] = gen[base] ? 1.f : 0.f; }      // (a NaN rmsd -- no generated residue -- selects bin 0, as argmin does)
+    }
+    // ---- dist loss: thread k owns residue k: its row terms (i = k) and its column terms (j = k)
+    float lsum = 0.f, lcnt = 0.f;
+    for (int k = tid; k < L; k += 256) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (pred_x0) {
+            const float kx = pp[4 * k], ky = pp[4 * k + 1], kz = pp[4 * k + 2], tx = pt[4 * k], ty = pt[4 * k + 1], tz = pt[4 * k + 2];
+            const int fk = (int)pp[4 * k + 3];
+            const bool row_k = (fk & 1) && (fk & 2);                          // gen_k & mres_k: k is a row of the selection
+            for (int j = 0; j < L; ++j) {
+                const int fj = (int)pp[4 * j + 3];
+                const bool as_row = row_k && (fj & 2), as_col = (fj & 1) && (fj & 2) && (fk & 2);      // (k, j) selected | (j, k) selected
+                if (!as_row && !as_col) continue;
+                const float dx = kx - pp[4 * j], dy = ky - pp[4 * j + 1], dz = kz - pp[4 * j + 2];
+                const float ex = tx - pt[4 * j], ey = ty - pt[4 * j + 1], ez = tz - pt[4 * j + 2];
+                const float dp = sqrtf(dx * dx + dy * dy + dz * dz), dt = sqrtf(ex * ex + ey * ey + ez * ez);
+                const float x = dp - dt, ax = fabsf(x);
+                const float sl = ax < 1.f ? 0.5f * x * x : ax - 0.5f, ds = ax < 1.f ? x : (x > 0.f ? 1.f : -1.f);
+                if (as_row) { lsum += sl; lcnt += 1.f; }
+                const float w = (dp > 0.f ? ds / dp : 0.f) * ((as_row ? 1.f : 0.f) + (as_col ? 1.f : 0.f));      // cdist backward: zero at zero distance
+                gx += w * dx; gy += w * dy; gz += w * dz;
+            }
+        }
+        gp[(base + k) * 3] = gx; gp[(base + k) * 3 + 1] = gy; gp[(base + k) * 3 + 2] = gz;
+    }
+    __syncthreads();
+    lsum = wave_sum(lsum); lcnt = wave_sum(lcnt);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = lsum; red[1][tid >> 6] = lcnt; }
+    __syncthreads();
+    if (tid == 0) { part[n * 4 + 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]); part[n * 4 + 3] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]); }
+}
+
+int launch_abdock_losses(const float* prmsd_logits, const float* p_pred, const float* p0n, const float* coef_a, const float* coef_b, const uint8_t* gen,
+                         const uint8_t* mres, const float* offsets, int nb, int N, int L, float scale, int pred_x0, float* part, float* glogit, float* gp,
+                         hipStream_t st) {
+    if (N == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(nb >= 1 && nb <= 64 && L >= 1 && (size_t)L * 32 <= 160 * 1024, "abdock_losses: num_bins=%d (1..64), L=%d (at most 5120)", nb, L);
+    static LdsConfig lds_cfg;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(abdock_losses_kernel), (size_t)L * 32, lds_cfg)) return rc;
+    hipLaunchKernelGGL(abdock_losses_kernel, dim3(N), dim3(256), (size_t)L * 32, st, prmsd_logits, p_pred, p0n, coef_a, coef_b, gen, mres, offsets, nb, L, scale, pred_x0,
+                       part, glogit, gp);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
+// LayerNorm of the reference's own definition over rows of `cols` (<= 256) values (D/modules/common/layers.py:146-155: biased variance,
+// sqrt(var + eps)); forward keeps xhat = (x - mean) / sd and 1 / sd for the backward:
+//   dx = (g dy - mean(g dy) - xhat mean(g dy xhat)) / sd;   d gamma = sum_rows dy xhat, d beta = sum_rows dy (left to abopt_colsum on dyx / dy).
+// One wave per row.
+__global__ __launch_bounds__(256) void row_layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, int cols,
+                                                             float eps, int64_t rows, float* __restrict__ y, float* __restrict__ xhat, float* __restrict__ rstd) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float v[4], s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int c = lane + 64 * q; v[q] = c < cols ? x[r * cols + c] : 0.f; s += v[q]; }
+    const float mean = wave_sum(s) / (float)cols;
+    float s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int c = lane + 64 * q; v[q] = c < cols ? v[q] - mean : 0.f; s2 += v[q] * v[q]; }
+    const float sd = sqrtf(wave_sum(s2) / (float)cols + eps);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        if (c < cols) { const float h = v[q] / sd; y[r * cols + c] = h * gamma[c] + beta[c]; if (xhat) xhat[r * cols + c] = h; }
+    }
+    if (rstd && lane == 0) rstd[r] = 1.f / sd;
+}
+__global__ __launch_bounds__(256) void row_layer_norm_backward_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                                      const float* __restrict__ gamma, int cols, int64_t rows, float* __restrict__ dx,
+                                                                      float* __restrict__ dyx) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float g[4], h[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        const float d = c < cols ? dy[r * cols + c] : 0.f;
+        h[q] = c < cols ? xhat[r * cols + c] : 0.f;
+        g[q] = c < cols ? d * gamma[c] : 0.f;
+        s1 += g[q]; s2 += g[q] * h[q];
+        if (c < cols) dyx[r * cols + c] = d * h[q];
+    }
+    const float m1 = wave_sum(s1) / (float)cols, m2 = wave_sum(s2) / (float)cols, rs = rstd[r];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int c = lane + 64 * q; if (c < cols) dx[r * cols + c] = (g[q] - m1 - h[q] * m2) * rs; }
+}
+int launch_row_layer_norm(const float* x, const float* gamma, const float* beta, int cols, float eps, int64_t rows, float* y, float* xhat, float* rstd, hipStream_t st) {
+    if (rows == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(cols >= 1 && cols <= 256, "layer_norm: %d columns (1..256)", cols);
+    hipLaunchKernelGGL(row_layer_norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, gamma, beta, cols, eps, rows, y, xhat, rstd);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+int launch_row_layer_norm_backward(const float* dy, const float* xhat, const float* rstd, const float* gamma, int cols, int64_t rows, float* dx, float* dyx, hipStream_t st) {
+    if (rows == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(cols >= 1 && cols <= 256, "layer_norm_backward: %d columns (1..256)", cols);
+    hipLaunchKernelGGL(row_layer_norm_backward_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, dy, xhat, rstd, gamma, cols, rows, dx, dyx);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
 // prmsd_logits.mean(dim=1) over ALL L rows incl. padding (dpm_full.py:110).  One workgroup per sample: thread (bin b, slice p of 16)
 // sums rows p, p + 16, ... with the loads of four rows in flight, the slices meet in LDS (fixed order: deterministic).
 __global__ __launch_bounds__(1024) void mean_over_L_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int B) {

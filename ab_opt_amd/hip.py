@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,7 +73,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_dpm_losses', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek', 'abopt_prof_clock',
+           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_dpm_losses', 'abopt_abdock_losses', 'abopt_layer_norm_forward', 'abopt_layer_norm_backward', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek', 'abopt_prof_clock',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward', 'abopt_ipa_dz_assemble',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
@@ -151,6 +151,9 @@ def lib():
         L.abopt_pair_embed_backward.argtypes = [C.POINTER(EncodeInputs), C.POINTER(PairEmbedWeights), c_f, c_f, c_f, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_node_frag_source_row.argtypes = [C.c_int] * 3
         L.abopt_node_frag_floats.restype = C.c_size_t
+        L.abopt_abdock_losses.argtypes = [c_f, c_f, c_f, c_f, c_f, c_u8, c_u8, c_f, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, c_f, c_f, c_f, C.c_void_p]
+        L.abopt_layer_norm_forward.argtypes = [c_f, c_f, c_f, C.c_int, C.c_float, C.c_int64, c_f, c_f, c_f, C.c_void_p]
+        L.abopt_layer_norm_backward.argtypes = [c_f, c_f, c_f, c_f, C.c_int, C.c_int64, c_f, c_f, C.c_void_p]
         L.abopt_adam_ws_floats.restype = C.c_size_t
         L.abopt_adam_ws_floats.argtypes = [C.c_int, C.c_void_p]
         L.abopt_adam_step.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 6 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -785,6 +788,47 @@ def dpm_losses(R_pred, R_0, p_pred, p_target, c_den, s_t, s_0, abar_t, mask_gene
                                   ptr(s_t, torch.int64), ptr(s_0, torch.int64), ptr(abar_t, torch.float32), ptr(mask_generate, torch.bool), N, L, ptr(part), ptr(gR), ptr(gp),
                                   ptr(gc), stream()))
     return colsum(part), gR, gp, gc
+
+
+def abdock_losses(prmsd_logits, p_pred, p0n, coef_a, coef_b, mask_generate, mask_res, offsets, scale, pred_x0):
+    """-> parts (N,4) = {CE_n, m0_n, smooth-l1 sum_n, count_n}, d prmsd_logits (N,nb) = softmax - onehot, d p_pred (N,L,3) of the smooth-l1 sum
+    (abopt_abdock_losses: the prmsd and dist losses of the AbDock flavour, dpm_full.py:180-198,369-378)."""
+    N, L = mask_generate.shape
+    nb = prmsd_logits.shape[-1]
+    prmsd_logits, p_pred, p0n, mask_generate, mask_res, offsets = _contig(prmsd_logits.float(), p_pred.float(), p0n.float(), mask_generate, mask_res, offsets.float())
+    ca = cb = None
+    if not pred_x0:
+        ca, cb = _contig(coef_a.float(), coef_b.float())
+    part = torch.empty(N, 4, dtype=torch.float32, device=p_pred.device)
+    gl, gp = torch.empty_like(prmsd_logits), torch.empty_like(p_pred)
+    _check(lib().abopt_abdock_losses(ptr(prmsd_logits, torch.float32), ptr(p_pred, torch.float32), ptr(p0n, torch.float32), ptr(ca, torch.float32, optional=True),
+                                     ptr(cb, torch.float32, optional=True), ptr(mask_generate, torch.bool), ptr(mask_res, torch.bool), ptr(offsets, torch.float32), nb, N, L,
+                                     C.c_float(float(scale)), int(bool(pred_x0)), ptr(part), ptr(gl), ptr(gp), stream()))
+    return part, gl, gp
+
+
+def layer_norm_forward(x, gamma, beta, eps, save=True):
+    """Rows of x (.., cols <= 256) through the reference's LayerNorm (layers.py:146-155) -> y [, xhat, rstd for the backward] (abopt_layer_norm_forward)."""
+    cols = x.shape[-1]
+    x2, gamma, beta = _contig(x.float().reshape(-1, cols), gamma.detach().float(), beta.detach().float())
+    rows = x2.shape[0]
+    y = torch.empty_like(x2)
+    xhat = torch.empty_like(x2) if save else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2.device) if save else None
+    _check(lib().abopt_layer_norm_forward(ptr(x2, torch.float32), ptr(gamma, torch.float32), ptr(beta, torch.float32), cols, C.c_float(float(eps)), C.c_int64(rows), ptr(y),
+                                          ptr(xhat, torch.float32, optional=True), ptr(rstd, torch.float32, optional=True), stream()))
+    return y.view(x.shape), xhat, rstd
+
+
+def layer_norm_backward(dy, xhat, rstd, gamma):
+    """-> dx (shape of dy), d gamma, d beta (abopt_layer_norm_backward + two column sums)."""
+    cols = dy.shape[-1]
+    dy2, gamma = _contig(dy.float().reshape(-1, cols), gamma.detach().float())
+    rows = dy2.shape[0]
+    dx, dyx = torch.empty_like(dy2), torch.empty_like(dy2)
+    _check(lib().abopt_layer_norm_backward(ptr(dy2, torch.float32), ptr(xhat, torch.float32), ptr(rstd, torch.float32), ptr(gamma, torch.float32), cols, C.c_int64(rows),
+                                           ptr(dx), ptr(dyx), stream()))
+    return dx.view(dy.shape), colsum(dyx), colsum(dy2)
 
 
 def heads_epilogue_forward(R, eps_crd, eps_rot, mask_generate):

@@ -21,10 +21,28 @@ import torch.nn.functional as F
 H, D, P, K_AA = 12, 32, 8, 20
 
 
+class NativeLayerNorm(torch.autograd.Function):
+    """layers.py:146-155 -- (x - mean) / sqrt(biased var + eps) * gamma + beta -- forward and backward as one launch each (csrc/rows.hip:
+    row_layer_norm_kernel / _backward_kernel) plus two column sums for d gamma / d beta: the prmsd head's layer_norm (nn.py:179-188)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        from . import hip
+        y, xhat, rstd = hip.layer_norm_forward(x, gamma, beta, eps)
+        ctx.save_for_backward(xhat, rstd, gamma)
+        return y
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, dy):
+        from . import hip
+        xhat, rstd, gamma = ctx.saved_tensors
+        dx, dg, db = hip.layer_norm_backward(dy.contiguous(), xhat, rstd, gamma)
+        return dx, dg, db, None
+
+
 def _ln(x, mod):
-    """layers.py:146-155: (x - mean) / sqrt(biased var + 1e-10) * gamma + beta -- exactly F.layer_norm's definition, which
-    runs as one fused kernel forward and one backward instead of ~30 elementwise launches."""
-    return F.layer_norm(x, (x.shape[-1],), mod.gamma, mod.beta, eps=mod.epsilon)
+    return NativeLayerNorm.apply(x, mod.gamma, mod.beta, float(mod.epsilon))
 
 
 # ------------------------------------------------------------------ dense layers on the library's own GEMM (csrc/gemm.hip: gemm_batched_kernel)
@@ -239,6 +257,29 @@ def eps_net(net, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_r
 
 
 # ------------------------------------------------------------------ losses
+class AbdockLosses(torch.autograd.Function):
+    """-> (prmsd, dist) of the AbDock flavour (dpm_full.py:180-198: pRMSDCa cross entropy on the binned, detached RMSD of the predicted
+    positions, and calc_dist_loss on the predicted positions when obj = pred_x0) with their gradients in ONE launch (csrc/rows.hip:
+    abdock_losses_kernel) plus the reductions over the N samples."""
+
+    @staticmethod
+    def forward(ctx, prmsd_logits, p_pred, p0n, coef_a, coef_b, mask_generate, mask_res, offsets, scale, pred_x0):
+        from . import hip
+        part, gl, gp = hip.abdock_losses(prmsd_logits, p_pred, p0n, coef_a, coef_b, mask_generate, mask_res, offsets, scale, pred_x0)
+        tot = part.sum(0)                                          # {sum err (unused), sum m0, sum sl1, count}
+        wn = part[:, 1] / (tot[1] + 1e-10)
+        prmsd = (part[:, 0] * wn).sum()
+        dist = tot[2] / tot[3] if pred_x0 else tot[2] * 0.0
+        ctx.save_for_backward(gl * wn[:, None], gp / tot[3] if pred_x0 else gp)
+        return prmsd, dist
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, dprmsd, ddist):
+        gl, gp = ctx.saved_tensors
+        return gl * dprmsd, gp * ddist, None, None, None, None, None, None, None, None
+
+
 class DpmLosses(torch.autograd.Function):
     """(rot, pos, seq) sums over the generated residues (dpm_full.py:199-231) and their gradients in ONE launch (csrc/rows.hip:
     dpm_losses_kernel) instead of the ~50 forward and ~70 backward elementwise kernels of the statement in fulldpm_loss below."""
@@ -288,26 +329,14 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
     denom = genf.sum() + 1e-8
     loss = {}
     if dpm.abdock:
-        if dpm.obj == 'pred_x0':
-            p_true, pred_p0 = p0n, p_pred
-        else:
-            p_true = p_n
-            a = vs.sqrt_recip_alphas_cumprod[t].view(-1, 1, 1)
-            b = vs.sqrt_recipm1_alphas_cumprod[t].view(-1, 1, 1)
-            pred_p0 = torch.where(mask_generate[..., None].expand_as(p0n), a * p0n - b * p_pred, p0n)
-        pa = dpm._unnormalize_position(pred_p0) * mask_generate.unsqueeze(-1)
-        pb = dpm._unnormalize_position(p0n) * mask_generate.unsqueeze(-1)
-        rmsd = torch.sqrt(((pa - pb) ** 2).sum(-1).sum(-1) / mask_generate.sum(-1)).detach()
-        off = dpm.prmsd.tobin.offset
-        diff = torch.abs(rmsd.unsqueeze(-1) - off)
-        onehot = torch.zeros_like(diff).scatter_(-1, torch.argmin(diff, -1, keepdim=True), 1.0)
-        err = -(onehot * F.log_softmax(out[4], dim=-1)).sum(-1)
-        m0 = mask_generate[:, 0]
-        loss['prmsd'] = (err * m0).sum() / (m0.sum() + 1e-10)
-        if dpm.obj == 'pred_x0':
-            dp, dt = torch.cdist(p_pred, p_pred), torch.cdist(p_true, p_true)
-            sel = mask_generate[:, :, None].expand_as(dp) & (mask_res[:, :, None] & mask_res[:, None, :])
-            loss['dist'] = F.smooth_l1_loss(torch.masked_select(dp, sel), torch.masked_select(dt, sel), reduction='none').mean()
+        x0 = dpm.obj == 'pred_x0'
+        p_true = p0n if x0 else p_n
+        # prmsd (pRMSDCa on the detached RMSD of the predicted positions, prmsd.py:49-70) and, for pred_x0, the dist loss (dpm_full.py:369-378)
+        ca = None if x0 else vs.sqrt_recip_alphas_cumprod[t]
+        cb = None if x0 else vs.sqrt_recipm1_alphas_cumprod[t]
+        loss['prmsd'], dist = AbdockLosses.apply(out[4], p_pred, p0n.detach(), ca, cb, mask_generate, mask_res, dpm.prmsd.tobin.offset.reshape(-1), h['scale'], x0)
+        if x0:
+            loss['dist'] = dist
         pos_target = p_true
     else:
         pos_target = eps_p

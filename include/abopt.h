@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 35
+#define ABOPT_ABI_VERSION 36
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -399,6 +399,23 @@ int abopt_pair_embed_backward(const abopt_encode_inputs* in, const abopt_pair_em
 int abopt_dpm_losses(const float* R_pred, const float* R_0, const float* p_pred, const float* p_target, const float* c_denoised, const int64_t* s_t,
                      const int64_t* s_0, const float* alpha_bar_t, const uint8_t* mask_generate, int N, int L, float* block_sums, float* dR_pred,
                      float* dp_pred, float* dc_denoised, abopt_stream stream);
+/* The two losses only the AbDock flavour has, with their gradients, one workgroup per sample (D/modules/diffusion/dpm_full.py:180-198,
+ * D/modules/common/prmsd.py:49-70 pRMSDCa, dpm_full.py:369-378 calc_dist_loss):
+ *   prmsd = sum_n CE(prmsd_logits[n], bin of rmsd_n) m0_n / (sum_n m0_n + 1e-10), rmsd_n over the generated residues of position_scale (pred_p0 - p0),
+ *           m0_n = mask_generate[n, 0]; pred_p0 = p_pred (pred_x0 = 1) or gen ? coef_a[n] p0 - coef_b[n] p_pred : p0 (pred_x0 = 0, transition.py:52-60);
+ *   dist  = mean smooth_l1(cdist(p_pred) - cdist(p0)) over the pairs mask_generate_i & mask_res_i & mask_res_j (pred_x0 = 1 only).
+ * sample_parts [N,4] = {CE_n, m0_n, sum of the sample's smooth-l1 terms, their count}; dprmsd_logits [N,num_bins] = softmax - onehot (scale by
+ * m0_n / (sum m0 + 1e-10)); dp_pred [N,L,3] = d(sum of smooth-l1 terms)/d p_pred (scale by 1 / total count; zeros when pred_x0 = 0). */
+int abopt_abdock_losses(const float* prmsd_logits, const float* p_pred, const float* p0_norm, const float* coef_a, const float* coef_b,
+                        const uint8_t* mask_generate, const uint8_t* mask_res, const float* bin_offsets, int num_bins, int N, int L, float position_scale,
+                        int pred_x0, float* sample_parts, float* dprmsd_logits, float* dp_pred, abopt_stream stream);
+/* LayerNorm with the reference's definition (D/modules/common/layers.py:146-155: biased variance, sqrt(var + eps)) over rows of cols <= 256 values --
+ * the prmsd head's layer_norm under autograd (D/modules/common/nn.py:179-188).  forward keeps xhat [rows,cols] and rstd [rows] (both or neither);
+ * backward writes dx and dy_xhat = dy * xhat (d gamma = column sums of dy_xhat, d beta = column sums of dy: abopt_colsum). */
+int abopt_layer_norm_forward(const float* x, const float* gamma, const float* beta, int cols, float eps, int64_t rows, float* y, float* xhat, float* rstd,
+                             abopt_stream stream);
+int abopt_layer_norm_backward(const float* dy, const float* xhat, const float* rstd, const float* gamma, int cols, int64_t rows, float* dx, float* dy_xhat,
+                              abopt_stream stream);
 int abopt_heads_epilogue_forward(const float* R, const float* v_t, const float* eps_crd, const float* eps_rot, const uint8_t* mask_generate,
                                  float* v_next, float* R_next, float* eps_pos, int64_t rows, int grad_mode, abopt_stream stream);
 int abopt_heads_epilogue_backward(const float* R, const float* eps_rot, const uint8_t* mask_generate, const float* dR_next, const float* deps_pos,

@@ -1414,6 +1414,61 @@ def test_dpm_losses_autograd_function_vs_torch_statement():
         assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item()), (name, (a - b).abs().max().item())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('pred_x0', [True, False])
+def test_abdock_losses_and_layer_norm_autograd_functions_vs_torch_statement(pred_x0):
+    """training.AbdockLosses (abopt_abdock_losses: the prmsd cross entropy on the binned, detached RMSD and the dist loss of
+    dpm_full.py:180-198,369-378, with their gradients in one launch) and training.NativeLayerNorm (the prmsd head's LayerNorm,
+    layers.py:146-155) against the torch statement of the same lines: values and input gradients; samples whose first residue is / is not
+    generated (the m0 mask), ragged residue masks, both objectives."""
+    from ab_opt_amd import training
+    g = torch.Generator().manual_seed(17)
+    N, L, nb, scale = 5, 70, 40, 10.0
+    logits = dev(torch.randn(N, nb, generator=g)).requires_grad_()
+    p_pred = dev(torch.randn(N, L, 3, generator=g)).requires_grad_()
+    p0n = dev(torch.randn(N, L, 3, generator=g))
+    gen = dev(torch.rand(N, L, generator=g) < 0.3)
+    gen[:, 0] = dev(torch.tensor([True, False, True, True, False]))
+    mres = dev(synth.mask_from_lengths([70, 66, 70, 41, 70], L))
+    gen &= mres
+    ca, cb = dev(torch.rand(N, generator=g) + 1.0), dev(torch.rand(N, generator=g))
+    off = dev(torch.linspace(0.5, 19.5, nb))
+    w = dev(torch.tensor([0.7, -1.3]))
+    prmsd, dist = training.AbdockLosses.apply(logits, p_pred, p0n, None if pred_x0 else ca, None if pred_x0 else cb, gen, mres, off, scale, pred_x0)
+    (prmsd * w[0] + dist * w[1]).backward()
+    got = (prmsd.detach(), dist.detach(), logits.grad.clone(), p_pred.grad.clone())
+    logits.grad = p_pred.grad = None
+    pred_p0 = p_pred if pred_x0 else torch.where(gen[..., None], ca.view(-1, 1, 1) * p0n - cb.view(-1, 1, 1) * p_pred, p0n)
+    pa, pb = pred_p0 * scale * gen.unsqueeze(-1), p0n * scale * gen.unsqueeze(-1)
+    rmsd = torch.sqrt(((pa - pb) ** 2).sum(-1).sum(-1) / gen.sum(-1)).detach()
+    diff = torch.abs(rmsd.unsqueeze(-1) - off)
+    onehot = torch.zeros_like(diff).scatter_(-1, torch.argmin(diff, -1, keepdim=True), 1.0)
+    err = -(onehot * F.log_softmax(logits, dim=-1)).sum(-1)
+    m0 = gen[:, 0]
+    ref_prmsd = (err * m0).sum() / (m0.sum() + 1e-10)
+    if pred_x0:
+        dp, dt = torch.cdist(p_pred, p_pred, compute_mode='donot_use_mm_for_euclid_dist'), torch.cdist(p0n, p0n, compute_mode='donot_use_mm_for_euclid_dist')
+        sel = gen[:, :, None].expand_as(dp) & (mres[:, :, None] & mres[:, None, :])
+        ref_dist = F.smooth_l1_loss(torch.masked_select(dp, sel), torch.masked_select(dt, sel), reduction='none').mean()
+    else:
+        ref_dist = p_pred.sum() * 0.0
+    (ref_prmsd * w[0] + ref_dist * w[1]).backward()
+    for a, b, name in zip(got, (ref_prmsd.detach(), ref_dist.detach(), logits.grad, p_pred.grad), ('prmsd', 'dist', 'd logits', 'd p_pred')):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), (name, (a - b).abs().max().item())
+    # LayerNorm of the prmsd head (131 columns)
+    x = dev(torch.randn(3, 37, 131, generator=g) * 3).requires_grad_()
+    gm, bt = dev(torch.randn(131, generator=g)).requires_grad_(), dev(torch.randn(131, generator=g)).requires_grad_()
+    wy = dev(torch.randn(3, 37, 131, generator=g))
+    y = training.NativeLayerNorm.apply(x, gm, bt, 1e-10)
+    (y * wy).sum().backward()
+    gotl = (y.detach(), x.grad.clone(), gm.grad.clone(), bt.grad.clone())
+    x.grad = gm.grad = bt.grad = None
+    yr = F.layer_norm(x, (131,), gm, bt, eps=1e-10)
+    (yr * wy).sum().backward()
+    for a, b, name in zip(gotl, (yr.detach(), x.grad, gm.grad, bt.grad), ('y', 'dx', 'd gamma', 'd beta')):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), (name, (a - b).abs().max().item())
+
+
 def test_heads_epilogue_autograd_function_vs_torch_statement():
     """training.HeadsEpilogue (abopt_heads_epilogue_forward / _backward: eps_pos = gen ? R eps_crd : 0, R_next = R U(eps_rot),
     dpm_full.py:95-101 under autograd) against the torch statement of the same lines: values and both input gradients, small and
