@@ -1575,29 +1575,54 @@ __global__ __launch_bounds__(256) void pair_bias_cache_kernel(const float* __res
                                                               int64_t rows, int L, int nchunk) {
     __shared__ __attribute__((aligned(16))) float zst[4][JC][ZSLD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fm = lane & 15, kq = lane >> 4;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + wave;                  // (query row, chunk)
-    if (unit >= rows * nchunk) return;
-    const int64_t row = unit / nchunk;
-    const int ch = (int)(unit % nchunk);
+    // a wave walks the chunks q, q + 4, q + 8, ... of one query row with the next chunk's z already requested (one chunk per wave and no
+    // prefetch ran at 2.7 TB/s: load -> transpose -> 96 MFMAs -> store, every round trip exposed)
+    const int64_t unit = (int64_t)blockIdx.x * 4 + wave;                  // (query row, chunk phase q)
+    if (unit >= rows * 4) return;
+    const int64_t row = unit >> 2;
+    const int q0 = (int)(unit & 3);
+    if (q0 >= nchunk) return;
     const float* zi = z + (row * (int64_t)L) * C;
+    f32x4 wv[6][4];                                                        // this lane's weights of (up to) six layers: head fm, channels 16 kq + 4 q ..
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<f32x4*>(&zst[wave][kq * 4 + r][fm * 4]) = *(reinterpret_cast<const f32x4*>(zi + (int64_t)min(ch * JC + kq * 4 + r, L - 1) * C) + fm);
-    wave_lds_sync();                                                      // cross-lane transpose through LDS
-    f32x4 za[4];
+    for (int l = 0; l < 6; ++l)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) za[q] = *reinterpret_cast<const f32x4*>(&zst[wave][fm][kq * 16 + q * 4]);
-    for (int l = 0; l < num_layers; ++l) {
-        f32x4 acc4[4];
+        for (int q = 0; q < 4; ++q) wv[l][q] = (l < num_layers && fm < H) ? reinterpret_cast<const f32x4*>(wl.w[l] + fm * C + kq * 16)[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 zn[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 wv = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (fm < H) wv = reinterpret_cast<const f32x4*>(wl.w[l] + fm * C + kq * 16)[q];
-            acc4[q] = mfma4(za[q][0], wv[0], (f32x4){0.f, 0.f, 0.f, 0.f});
-            acc4[q] = mfma4(za[q][1], wv[1], acc4[q]); acc4[q] = mfma4(za[q][2], wv[2], acc4[q]); acc4[q] = mfma4(za[q][3], wv[3], acc4[q]);
+    for (int r = 0; r < 4; ++r) zn[r] = *(reinterpret_cast<const f32x4*>(zi + (int64_t)min(q0 * JC + kq * 4 + r, L - 1) * C) + fm);
+    for (int ch = q0; ch < nchunk; ch += 4) {
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&zst[wave][kq * 4 + r][fm * 4]) = zn[r];
+        if (ch + 4 < nchunk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zn[r] = *(reinterpret_cast<const f32x4*>(zi + (int64_t)min((ch + 4) * JC + kq * 4 + r, L - 1) * C) + fm);
         }
-        const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);       // accumulator row 4 kq + r = key, column fm = head
-        if (fm < H) *reinterpret_cast<f32x4*>(cache + ((int64_t)l * rows * nchunk + unit) * (H * JC) + fm * JC + kq * 4) = acc;
+        wave_lds_sync();                                                  // cross-lane transpose through LDS
+        f32x4 za[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) za[q] = *reinterpret_cast<const f32x4*>(&zst[wave][fm][kq * 16 + q * 4]);
+        const int64_t u = row * nchunk + ch;
+        auto layer = [&](int l, const f32x4 (&w4)[4]) {
+            f32x4 acc4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc4[q] = mfma4(za[q][0], w4[q][0], (f32x4){0.f, 0.f, 0.f, 0.f});
+                acc4[q] = mfma4(za[q][1], w4[q][1], acc4[q]); acc4[q] = mfma4(za[q][2], w4[q][2], acc4[q]); acc4[q] = mfma4(za[q][3], w4[q][3], acc4[q]);
+            }
+            const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);   // accumulator row 4 kq + r = key, column fm = head
+            if (fm < H) *reinterpret_cast<f32x4*>(cache + ((int64_t)l * rows * nchunk + u) * (H * JC) + fm * JC + kq * 4) = acc;
+        };
+#pragma unroll
+        for (int l = 0; l < 6; ++l)
+            if (l < num_layers) layer(l, wv[l]);
+        for (int l = 6; l < num_layers; ++l) {                            // (more than six blocks: weights from L1 / L2 per chunk)
+            f32x4 w4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w4[q] = (fm < H) ? reinterpret_cast<const f32x4*>(wl.w[l] + fm * C + kq * 16)[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            layer(l, w4);
+        }
     }
 }
 
@@ -1610,7 +1635,8 @@ int launch_pair_bias_cache(const float* z, const float* const* wb, int num_layer
     const int nchunk = (L + JC - 1) / JC;
     const int64_t units = (int64_t)N * L * nchunk;
     if (units == 0) return ABOPT_OK;
-    hipLaunchKernelGGL(pair_bias_cache_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, z, wl, num_layers, cache, (int64_t)N * L, L, nchunk);
+    (void)units;
+    hipLaunchKernelGGL(pair_bias_cache_kernel, dim3((unsigned)((int64_t)N * L)), dim3(256), 0, st, z, wl, num_layers, cache, (int64_t)N * L, L, nchunk);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }
