@@ -5,13 +5,11 @@
 // Replaces every dense projection on the path: the six node projections of a GABlock
 // (reference ga.py:54-66), out_transform + mlp_transition (ga.py:69-79), res_feat_mixer and the
 // eps_* / prmsd heads (dpm_full.py:39-65).
-#include "abopt_common.h"
+#include "ipa_common.h"
 #include <cstdlib>
 #include "kernels.h"
 
 namespace abopt {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // 64x64 output tile per 256-thread workgroup (4 waves as 2x2, each wave 32x32 = 2x2 MFMA tiles).
 // K is consumed 32 at a time through LDS (one 128-byte line per row per tile).  K-permutation: in MFMA step kk lane group kq supplies
@@ -237,6 +235,11 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float* __restri
             else { for (int r = 0; r < 4; ++r) if (col + r < N) cp[r] = v[r]; }
         }
 }
+
+// (Round 4 measured this kernel's bf16-term twin -- operands split into three bf16 terms while a K tile is staged, six
+//  v_mfma_f32_16x16x32_bf16 per tile pair instead of 64 v_mfma_f32_16x16x4_f32 -- against it on the training step: 10.94 against 10.25 ms.
+//  These products are not matrix-pipe bound at 64 x 64 tiles with one wave per SIMD: the split costs every thread 88 VALU operations and,
+//  for a k-strided operand, twelve 4-byte LDS stores per K tile.  Not kept.)
 
 // out[e] = sum over slabs s of in[s * stride + e]  (fixed order)
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int slabs, int64_t stride) {
