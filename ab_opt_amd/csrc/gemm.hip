@@ -391,7 +391,8 @@ int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const floa
     // The partial slabs have C's own layout and the slab sum writes every element of it: only for a densely packed C (ldc == N, batches
     // back to back) -- a C that is a column slice of a wider matrix (ldc > N) or has gaps between batches takes the unsplit kernel
     const bool dense_c = ldc == N && (batch == 1 || sc == (int64_t)M * ldc);
-    if (tiles < 128 && K >= 1024 && ws && !bias && !relu && dense_c) {      // (an epilogue with bias / ReLU needs the whole sum in one workgroup)
+    static const int tmax = getenv("ABOPT_GEMM_TMAX") ? atoi(getenv("ABOPT_GEMM_TMAX")) : 256;      // split K below this many output tiles (developer knob; 128 -> 256: the 128-tile d x products of the projections fill the chip, 10.1 -> 9.9 ms per training step)
+    if (tiles < tmax && K >= 1024 && ws && !bias && !relu && dense_c) {      // (an epilogue with bias / ReLU needs the whole sum in one workgroup)
         // (up to 1024 slabs: the tall products of the pair embedding -- K = N L^2 rows, one or four output tiles -- are HBM streams, and
         // 256 workgroups of four waves keep too few bytes in flight: 143 us for 2 x 268 MB at 256 slabs)
         static const int kdiv = getenv("ABOPT_GEMM_KDIV") ? atoi(getenv("ABOPT_GEMM_KDIV")) : 256;     // shortest K range of a slab (developer knob; 512 -> 256: 10.8 -> 10.3 ms per training step, more workgroups per weight-gradient product)

@@ -755,7 +755,7 @@ def gemm(a, b, alpha=1.0, out=None, bias=None, relu=False):
         ldc, sc = o3.stride(1), (o3.stride(0) if nb > 1 else 0)
     tiles = ((M + 63) // 64) * ((N + 63) // 64) * nb
     ws = None
-    if tiles < 128 and K >= 1024 and bias is None and not relu:
+    if tiles < 1024 and K >= 1024 and bias is None and not relu:
         ws = Workspace.get(min(1024, max(K // 128, 1)) * nb * M * N * 4, a.device)
     if bias is not None:
         bias = bias.detach().float().contiguous()
