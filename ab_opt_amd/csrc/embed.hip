@@ -34,6 +34,14 @@ __device__ __forceinline__ V3 cross3(V3 a, V3 b) { return v3(a.y * b.z - a.z * b
 __device__ __forceinline__ float norm3(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 __device__ __forceinline__ V3 xyz(f32x4 a) { return v3(a[0], a[1], a[2]); }
 
+// The 225 Gaussian atom-pair features of a residue pair (pair.py:62-73: d = |x_a - x_b| / 10, g = exp(-softplus(coef) d^2)) are the
+// VALU hot spot of the pair embedding (PMC, round 4: 9 VALU instructions per MFMA, the two pipes together account for the run time).  The
+// squared scaled distance is formed without the square root and the IEEE division of the literal formula ((sqrt(s) / 10)^2 = s / 100 up
+// to 2 ulp), the exponential is one v_exp_f32 on the base-2 argument instead of libm's range-reduced expf (~1 ulp against ~0.5): the
+// forward and the backward's recomputation share these two functions, so T = dg / d softplus(coef) stays bit-identical between them.
+__device__ __forceinline__ float gauss_d2(float dx, float dy, float dz) { return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * 0.01f; }
+__device__ __forceinline__ float gauss_exp(float c, float dd) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * c * dd); }
+
 // geometry.py:336-362: signed dihedral of p0-p1-p2-p3, NaN -> 0
 __device__ __forceinline__ float dihedral_from_four_points(V3 p0, V3 p1, V3 p2, V3 p3) {
     const V3 v0 = p2 - p1, v1 = p0 - p1, v2 = p3 - p2;
@@ -327,10 +335,10 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float dx = pi[0] - pj[mt][q][0], dy = pi[1] - pj[mt][q][1], dz = pi[2] - pj[mt][q][2];
-                    const float d = sqrtf(dx * dx + dy * dy + dz * dz) / 10.f;                  // pair.py:64
-                    const float gv = expf(-1.f * c4[q] * (d * d));                              // pair.py:67
+                    const float dd = gauss_d2(dx, dy, dz);                                      // (|x_i - x_j| / 10)^2, pair.py:64
+                    const float gv = gauss_exp(c4[q], dd);                                      // exp(-c d^2), pair.py:67
                     g[mt][q] = (pi[3] != 0.f && pj[mt][q][3] != 0.f) ? gv : 0.f;               // pair.py:69-73
-                    tq[q] = -(d * d) * g[mt][q];
+                    tq[q] = -dd * g[mt][q];
                 }
                 if (a.gsave) {
                     const int j_ = j0 + mt * 16 + fm;
@@ -616,9 +624,9 @@ __global__ __launch_bounds__(256, 2) void pair_embed_backward_kernel(PairBwdArgs
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float dx = pi[0] - pj[mt][q][0], dy = pi[1] - pj[mt][q][1], dz = pi[2] - pj[mt][q][2];
-                        const float d = sqrtf(dx * dx + dy * dy + dz * dz) / 10.f;
-                        const float gv = expf(-1.f * c4[q] * (d * d));
-                        tq[q] = -(d * d) * ((pi[3] != 0.f && pj[mt][q][3] != 0.f) ? gv : 0.f);
+                        const float dd = gauss_d2(dx, dy, dz);
+                        const float gv = gauss_exp(c4[q], dd);
+                        tq[q] = -dd * ((pi[3] != 0.f && pj[mt][q][3] != 0.f) ? gv : 0.f);
                     }
                 }
                 *reinterpret_cast<f32x4*>(b.ds + o_) = acc[mt] * tq;
