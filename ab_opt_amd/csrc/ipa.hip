@@ -142,6 +142,9 @@ namespace prof {
 static bool g_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
 static size_t g_used = 0;
+static bool g_span_on = false;               // launch spans (abopt_prof_enable(3)): slot numbers handed to the 32-row launches
+static int g_span_next = 0;
+int next_span_slot() { return (g_span_on && g_span_next < 2048) ? g_span_next++ : -1; }
 void begin(hipStream_t st) {
     if (!g_on) return;
     if (g_used == g_pool.size()) {
@@ -189,8 +192,16 @@ int launch_ipa_core(const float* qfrag, const float* kvfrag, const float* z, con
 
 extern "C" int abopt_prof_enable(int on) {
     abopt::prof::g_on = on == 1;
-    if (on != 2) abopt::prof::g_used = 0;        // 2: stop bracketing new launches but keep the recorded pairs (see abopt_prof_peek)
+    if (on != 2 && on != 4) abopt::prof::g_used = 0;        // 2: stop bracketing new launches but keep the recorded pairs (see abopt_prof_peek)
+    if (on == 3) { abopt::prof::g_span_on = true; abopt::prof::g_span_next = 0; }      // 3: launch spans on, slots from 0 (use while capturing a graph)
+    else if (on != 4) abopt::prof::g_span_on = false;                                  // 4: stop handing out slots, keep the count
+    else abopt::prof::g_span_on = false;
     return ABOPT_OK;
+}
+extern "C" int abopt_prof_spans_reset(abopt_stream stream) { return abopt::prof_spans_reset((hipStream_t)stream); }
+extern "C" int abopt_prof_spans(int* launches, double* total_ms) {
+    ABOPT_CHECK_ARG(launches && total_ms, "prof_spans: NULL argument");
+    return abopt::prof_spans_read(abopt::prof::g_span_next, launches, total_ms);
 }
 
 static int prof_sum(int* launches, double* total_ms, bool reset) {

@@ -68,7 +68,9 @@ __device__ __forceinline__ f32x16 mfma_bf32(const u32x4& a, const u32x4& b, cons
 }
 __device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 
-namespace prof { void begin(hipStream_t st); void end(hipStream_t st); }
+namespace prof { void begin(hipStream_t st); void end(hipStream_t st); int next_span_slot(); }
+int prof_spans_reset(hipStream_t st);
+int prof_spans_read(int nslots, int* launches, double* total_ms);
 
 int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                            const float* w_pair_bias, float* feat, float* dump, float* dump_stats, const float* pair_bias_cache, int N, int L,

@@ -918,6 +918,16 @@ constexpr int BI2 = 32, NPW2 = 4, RPW2 = BI2 / NPW2, NTH2 = 512, HPW = 6;
 // its last instruction -- the clock the chip sustained under THAT kernel (DVFS moves it between 1.7 and 2.2 GHz), so a
 // reader of the bench line can tell a slow box from a slow kernel.  Two scalar timer reads and one store per launch.
 __device__ long long g_clock_probe[2];
+// Launch spans (abopt_prof_enable(3) / abopt_prof_spans): with a slot number in its arguments, every workgroup of a 32-row launch folds the
+// 100 MHz wall clock of its first and last instruction into {min start, max end} of that slot -- the launch's duration as rocprofv3 sees it,
+// but available INSIDE a replayed hipGraph, where host-recorded event pairs cannot be placed (the slot is baked into the captured node; the
+// host resets the slots before the replay it wants to read).  Two atomics per workgroup.
+constexpr int PROF_SLOTS = 2048;
+__device__ unsigned long long g_prof_span[PROF_SLOTS][2];
+__global__ void prof_span_reset_kernel() {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < PROF_SLOTS) { g_prof_span[i][0] = ~0ull; g_prof_span[i][1] = 0ull; }
+}
 #ifndef C32F_ABL
 #define C32F_ABL 0       // developer ablations of the fused epilogue (timing only, results wrong): 1 no W_out refills | 2 no MFMAs | 4 producers write nothing | 8 / 16 C waves: no node-feature staging / no point writes
 #endif
@@ -963,7 +973,7 @@ template <bool FUSE>
 __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restrict__ qfrag, const float* __restrict__ kvfrag, const float* __restrict__ z,
                                                           const uint8_t* __restrict__ mask, const float* __restrict__ R, const float* __restrict__ t,
                                                           float* __restrict__ feat, const float* __restrict__ pbc, int L, int nib2, int xcd_remap, int z_shared,
-                                                          TailArgs ta) {
+                                                          TailArgs ta, int prof_slot) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sp = reinterpret_cast<float*>(smem_raw);                     // [3][BI2][SROW]
     float* scl = sp + 3 * BI2 * SROW;                                   // [2][BI2][SCLD]
@@ -986,6 +996,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunk = (L + JC - 1) / JC, nib16 = (L + BI - 1) / BI;
     const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
+    if (prof_slot >= 0 && threadIdx.x == 0) atomicMin(&g_prof_span[prof_slot][0], (unsigned long long)probe_w0);
 #ifdef C32F_TIMING
     const long long t32f_begin = clock64();
 #endif
@@ -1562,6 +1573,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         C32F_STAMP(15)
     }
     if (blockIdx.x == 0 && tid == 0) { g_clock_probe[0] = clock64() - probe_c0; g_clock_probe[1] = wall_clock64() - probe_w0; }
+    if (prof_slot >= 0 && tid == 0) atomicMax(&g_prof_span[prof_slot][1], (unsigned long long)wall_clock64());
 }
 
 // Pair-bias cache: lp[l][n,i,j,h] = z[n,i,j,:] . Wb_l[h,:] for every layer l in ONE pass over z (ga.py:88-90).  z and the weights do
@@ -1761,7 +1773,7 @@ int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float*
     TailArgs ta{wot, wmf, x, ubias, g1, be1, b0, b1, b2, g2, be2, out};
     prof::begin(st);
     hipLaunchKernelGGL(ipa_core32_kernel<true>, dim3((unsigned)(N * nib2)), dim3(NTH2), C32F_LDS_BYTES, st, qfrag, kvfrag, z, mask, R, t, (float*)nullptr,
-                       pair_bias_cache, L, nib2, core32_remap(N, z_shared), z_shared, ta);
+                       pair_bias_cache, L, nib2, core32_remap(N, z_shared), z_shared, ta, prof::next_span_slot());
     prof::end(st);
     ABOPT_LAUNCH_CHECK();
 #ifdef C32F_TIMING
@@ -1782,6 +1794,22 @@ int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float*
     return ABOPT_OK;
 }
 
+int prof_spans_reset(hipStream_t st) {
+    hipLaunchKernelGGL(prof_span_reset_kernel, dim3(PROF_SLOTS / 256), dim3(256), 0, st);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+int prof_spans_read(int nslots, int* launches, double* total_ms) {
+    static unsigned long long h[PROF_SLOTS][2];
+    ABOPT_HIP(hipDeviceSynchronize());
+    ABOPT_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof_span), sizeof(h)));
+    int n = 0;
+    double tot = 0.0;
+    for (int i = 0; i < nslots && i < PROF_SLOTS; ++i)
+        if (h[i][1] > h[i][0]) { ++n; tot += (double)(h[i][1] - h[i][0]) * 1e-5; }      // 100 MHz ticks -> ms
+    *launches = n; *total_ms = tot;
+    return ABOPT_OK;
+}
 int read_clock_probe(long long* cycles, long long* wall_ticks) {
     long long h[2] = {0, 0};
     ABOPT_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clock_probe), sizeof(h)));
@@ -1804,7 +1832,7 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel<false>), lds, lds_cfg)) return rc;
         prof::begin(st);
         hipLaunchKernelGGL(ipa_core32_kernel<false>, dim3((unsigned)(N * nib2)), dim3(NTH2), lds, st, qfrag, kvfrag, z, mask, R, t, feat, pair_bias_cache, L, nib2,
-                           core32_remap(N, z_shared), z_shared, TailArgs{});
+                           core32_remap(N, z_shared), z_shared, TailArgs{}, prof::next_span_slot());
         prof::end(st);
         ABOPT_LAUNCH_CHECK();
 #ifdef C32_TIMING

@@ -302,12 +302,16 @@ class _LoopGraph:
         self.graph = torch.cuda.CUDAGraph()
         before = set(hip.Workspace._bufs)
         hip.prof_enable(hip.GRAPH_CAPTURE_EVENTS)                       # normally off: the measurement hook's event pairs stay out of the graph
+        if hip.GRAPH_CAPTURE_SPANS:
+            hip.lib().abopt_prof_enable(3)               # span slots for the dominant kernel's launches, baked into the captured nodes
         try:
             with torch.cuda.graph(self.graph):
                 self.out = dpm._run_eager(*args, stop_after=stop_after, **kw)
         finally:
             if hip.GRAPH_CAPTURE_EVENTS:
                 hip.lib().abopt_prof_enable(2)           # stop bracketing launches, keep the pairs the graph re-records
+            if hip.GRAPH_CAPTURE_SPANS:
+                hip.lib().abopt_prof_enable(4)
         # the scratch slab the capture allocated on the capturing stream lives in this graph's pool: it must not serve another stream user
         self.keep = [hip.Workspace._bufs.pop(k) for k in set(hip.Workspace._bufs) - before]
         self.info = dict(dpm.last_run_info)

@@ -383,7 +383,9 @@ def main():
         # capture (outside the timed region, like the warmup): K steps of the loop, the one-off pair-bias cache build included
         t_cap = time.perf_counter()
         hip.GRAPH_CAPTURE_EVENTS = bool(args.graph_events and not args.no_prof)
+        hip.GRAPH_CAPTURE_SPANS = not args.no_prof            # in-kernel launch spans: the dominant kernel timed inside the replayed graph
         run(K, graph=True)
+        hip.GRAPH_CAPTURE_SPANS = False
         torch.cuda.synchronize()
         graph_events = hip.GRAPH_CAPTURE_EVENTS
         log('graph captured + first replay: %.3f s' % (time.perf_counter() - t_cap))
@@ -431,13 +433,23 @@ def main():
             launches, ipa_ms = launches + n_, ipa_ms + ms_
     hip.prof_enable(False)
     log('timed region x%d: %s ms per step' % (R, ', '.join('%.4f' % (t / K * 1e3) for t in times)))
-    instrumented = None
+    instrumented, eager_events = None, None
     if use_graph and not graph_events and not args.no_prof:
-        dt_i = timed_pass(False, events=True)
-        launches, ipa_ms = hip.prof_collect()
-        hip.prof_enable(False)
+        # (i) one more replay of the SAME graph, its dominant-kernel launches timed by their in-kernel wall-clock spans (first workgroup in,
+        #     last workgroup out: what rocprofv3 reports) -- host-recorded events cannot sit in a replayed graph, and an eager pass is not the
+        #     same thing: its launch gaps let the chip clock up (kernels 5-10 % faster than in the back-to-back replay on a power-limited box)
+        hip.prof_spans_reset()
+        dt_i = timed_pass(True, events=False)
+        launches, ipa_ms = hip.prof_spans()
         instrumented = round(dt_i / K * 1e3, 4)
-        log('instrumented eager pass: %.4f ms per step' % instrumented)
+        log('instrumented graph replay: %.4f ms per step, %d launches, %.1f us per launch' % (instrumented, launches, ipa_ms / max(launches, 1) * 1e3))
+        # (ii) the eager pass with HIP events around every launch (round 3's method), kept next to it
+        dt_e = timed_pass(False, events=True)
+        n_e, ms_e = hip.prof_collect()
+        hip.prof_enable(False)
+        eager_events = dict(ms_per_step=round(dt_e / K * 1e3, 4), avg_launch_ms=round(ms_e / max(n_e, 1), 4), launches=n_e)
+        if launches == 0:                                   # (a shape that does not take the 32-row kernels: events are all there is)
+            launches, ipa_ms, instrumented = n_e, ms_e, eager_events['ms_per_step']
     clock = hip.prof_clock()                                    # the clock wave 0 / workgroup 0 of the last dominant-kernel launch ran at
     # the two-launch form of a block (32-row core, then the tail kernel) in one more eager pass: the IPA core ALONE, for continuity with
     # the rounds before the tail was fused into it (bit-identical results; not part of the timed region)
@@ -487,8 +499,9 @@ def main():
         traffic, traffic_src = MEASURED_TRAFFIC.get((N, L), (None, None))
         timing = ('HIP events on the launch stream around every ipa_core launch, all %d repeats of the timed region' % R) if not use_graph else (
             'HIP event records captured into the replayed graph around every ipa_core launch' if graph_events else
-            'HIP events on the launch stream around every ipa_core launch in one eager pass of the same K steps run right after the '
-            'timed graph replays (host-recorded events cannot be placed inside a replayed graph); that pass took instrumented_ms_per_step')
+            'in-kernel launch spans (abopt_prof_spans: 100 MHz wall clock of the first workgroup in / last workgroup out of every launch) of ONE more '
+            'replay of the timed graph, run right after the repeats (it took instrumented_ms_per_step); eager_events = the same K steps launched '
+            'eagerly with HIP events around every launch, for comparison')
         fused = bool(two_launch) and per_launch_ms > 1.08 * two_launch['ipa_core_avg_launch_ms']
         kernel_name = ('ipa_core32_kernel<true>: IPA core + block tail (out_transform, LayerNorm, MLP, LayerNorm) as ONE kernel -- the survey\'s per-layer bytes are '
                        'those of the whole block, so they apply unchanged' if fused else 'ipa_core')
@@ -507,7 +520,7 @@ def main():
                        'backend': backend, 'ranks_per_device': (world + ndev - 1) // ndev if world > 1 else 1},
             'roofline': {'bound': 'hbm', 'kernel': kernel_name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src, 'launches': launches,
-                         'avg_launch_ms': round(per_launch_ms, 4), 'timing': timing, 'instrumented_ms_per_step': instrumented,
+                         'avg_launch_ms': round(per_launch_ms, 4), 'timing': timing, 'instrumented_ms_per_step': instrumented, 'eager_events': eager_events,
                          'algorithmic_bytes_per_launch': alg,
                          'algorithmic_bytes_formula': 'N*(256*L^2 + 1076*L)  [SURVEY 8(d)]',
                          'kernel_io_bytes_per_launch': ipa_kernel_io_bytes(N, L),

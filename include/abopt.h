@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 36
+#define ABOPT_ABI_VERSION 37
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -477,7 +477,15 @@ int abopt_commonness_score(const float* structs, float* score, int B, int n, abo
  * by hipEvents on the stream it is launched on; abopt_prof_collect synchronises those events and returns the number
  * of launches and their summed duration since the last enable.  Process-global, off by default, not for concurrent
  * use from several host threads (the only global state in the library). */
-int abopt_prof_enable(int on);   /* 1: on (forgets earlier pairs), 0: off (forgets), 2: off but keep the recorded pairs */
+int abopt_prof_enable(int on);   /* 1: on (forgets earlier pairs), 0: off (forgets), 2: off but keep the recorded pairs;
+                                    3: launch spans on (below), 4: stop handing out span slots */
+/* Launch spans: the dominant kernel timed INSIDE a replayed hipGraph, where host-recorded event pairs cannot be placed.  While mode 3 is on
+ * (e.g. during the capture), every 32-row IPA launch (core, or fused core + tail) is given a slot number; each of its workgroups folds the
+ * 100 MHz wall clock of its first / last instruction into {min, max} of the slot.  abopt_prof_spans_reset (stream-ordered) clears the slots --
+ * call it before the replay to be read --, abopt_prof_spans synchronises the device and returns the number of launches that ran since and
+ * the sum of their (max end - min start) in milliseconds. */
+int abopt_prof_spans_reset(abopt_stream stream);
+int abopt_prof_spans(int* launches, double* total_ms);
 int abopt_prof_collect(int* launches, double* total_ms);
 /* Clock probe: shader cycles and 100 MHz wall-clock ticks that wave 0 of workgroup 0 of the most recent 32-row IPA launch (core or fused
  * core + tail) spent from its first to its last instruction: cycles / (10 ns * ticks) = the clock the chip sustained under that kernel.

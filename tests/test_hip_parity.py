@@ -1765,6 +1765,36 @@ def test_bench_two_ranks_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_launch_spans_time_the_dominant_kernel_inside_a_graph_replay():
+    """abopt_prof_spans: the 32-row launches of a captured loop carry span slots; after a reset, one replay yields exactly steps x layers
+    launches whose in-kernel wall-clock spans sum to a plausible duration (within a factor of the HIP-event timing of the same steps launched
+    eagerly), and a second reset + replay gives the same count again."""
+    from ab_opt_amd import hip
+    import bench
+    dpm, state, rf, pf, gen, mres = bench.build_workload(DEV, 32, 256, 100, seed=3)
+    run = lambda n, graph: dpm._run(state, 100, rf, pf, gen, mres, True, True, True, None, 7, 0, False, stop_after=n, graph=graph)
+    run(2, False)
+    hip.GRAPH_CAPTURE_SPANS = True
+    try:
+        run(3, True)
+    finally:
+        hip.GRAPH_CAPTURE_SPANS = False
+    for _ in range(2):
+        hip.prof_spans_reset()
+        run(3, True)
+        n, ms = hip.prof_spans()
+        assert n == 3 * 6, n
+    hip.prof_enable(True)
+    run(3, False)
+    torch.cuda.synchronize()
+    n_e, ms_e = hip.prof_collect()
+    hip.prof_enable(False)
+    assert n_e == 18 and 0.7 * ms_e < ms < 1.4 * ms_e, (ms, ms_e)
+    assert 0.05 < ms / n < 0.6                                # 50 .. 600 us per launch at this shape
+    dpm.clear_graphs()
+
+
+@pytest.mark.gpu
 def test_bench_nccl_branch_single_rank():
     """bench.py's RCCL branch (init_process_group('nccl', device_id=...), candidate all_gather on device buffers, MAX all-reduce of the
     step time, barriers) executed with ONE rank on the one GPU of the box (ABOPT_BENCH_FORCE_DIST=1): no 8-GPU node exists for the builder,
