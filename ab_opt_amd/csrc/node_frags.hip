@@ -80,9 +80,18 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
     for (int g = 0; g < NF_KS * NF_HT; ++g) {
         const int s = g / NF_HT, T = g % NF_HT;
         if (T == 0) {
+            // developer build -DNF_ABL=<mask>: 16 splits only at s == 0 (loads kept) | 32 loads only at s == 0 (splits kept) | 4 no epilogue | 8 no LDS reads after the first
+#if defined(NF_ABL) && (NF_ABL & 16)
+            for (int rt = 0; rt < 2; ++rt) { asm volatile("" ::"v"(xa[rt][0]), "v"(xa[rt][1])); }
+            if (s == 0)
+#endif
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) xs[rt] = split3(xa[rt][0], xa[rt][1]);
+#if defined(NF_ABL) && (NF_ABL & 32)
+            if (false) {
+#else
             if (s + 1 < NF_KS) {
+#endif
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     xa[rt][0] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + (s + 1) * 32 + kq * 8);
@@ -90,12 +99,20 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
                 }
             }
         }
+#if defined(NF_ABL) && (NF_ABL & 8)
+        if (g == 0) {
+#else
         if (g + 1 < NF_KS * NF_HT) {
+#endif
             const int sn = (g + 1) / NF_HT, Tn = (g + 1) % NF_HT;
 #pragma unroll
             for (int sp = 0; sp < NF_SPL; ++sp) wa[(g + 1) & 1][sp] = wh[((Tn * NF_KS + sn) * NF_SPL + sp) * 64];
         }
+#if defined(NF_ABL) && (NF_ABL & 8)
+        const u32x4 wH = wa[g ? 1 : 0][0], wM = wa[g ? 1 : 0][1], wL = wa[g ? 1 : 0][2];
+#else
         const u32x4 wH = wa[g & 1][0], wM = wa[g & 1][1], wL = wa[g & 1][2];
+#endif
         const bool swap = (HALF == 1) && (T >= 2);                               // value tiles: x is the A operand -> accumulator [residue 4 kq + r][channel fm]
         // smallest terms first; the two row tiles alternate so consecutive MFMAs never depend on each other
 #define NF_PROD(XT, WT)                                                                                                         \
@@ -106,6 +123,13 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
         __builtin_amdgcn_sched_barrier(0);
     }
     auto sq = [](const f32x4& g) { return fmaf(g[2], g[2], fmaf(g[1], g[1], g[0] * g[0])); };
+#if defined(NF_ABL) && (NF_ABL & 4)
+    {
+        float sum = 0.f;
+        for (int rt = 0; rt < 2; ++rt) for (int T = 0; T < NF_HT; ++T) for (int r = 0; r < 4; ++r) sum += acc[rt][T][r];
+        if (sum != 1.2345e-30f) return;
+    }
+#endif
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         if (tile0 + rt >= total_tiles) break;
@@ -186,15 +210,22 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
     // them round-robin, so both halves of a row-tile pair run on neighbouring waves and share the x rows in L1
     const int ntask = 2 * ((total_tiles + 1) / 2);
     const int t_lo = (int)((int64_t)ntask * blockIdx.x / gridDim.x), t_hi = (int)((int64_t)ntask * (blockIdx.x + 1) / gridDim.x);
+#ifdef NF_TIMING
+    long long te[3] = {0, 0, 0};
+    int ti = 0;
+#endif
     for (int task = t_lo + wave; task < t_hi; task += NF_WAVES) {
         const int tile0 = (task >> 1) * 2;
         if (task & 1) nf_task<1>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, lane, fm, kq);
         else          nf_task<0>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, lane, fm, kq);
+#ifdef NF_TIMING
+        if (ti < 3) te[ti++] = clock64() - c0;
+#endif
     }
 #ifdef NF_TIMING
-    if (blockIdx.x == 5 && blockIdx.y == 3 && lane == 0) {
+    if (blockIdx.x == NF_TIMING && blockIdx.y == 3 && lane == 0) {        // -DNF_TIMING=<row group>: 5 owns 25 tasks at the bench shape, 0 owns 24
         long long* o = g_nf_timing[wave];
-        o[0] = c1 - c0; o[1] = clock64() - c0; o[2] = wall_clock64() - w0; o[3] = 0; o[4] = 0; o[5] = (t_hi - t_lo);
+        o[0] = c1 - c0; o[1] = clock64() - c0; o[2] = wall_clock64() - w0; o[3] = te[0]; o[4] = te[1]; o[5] = (t_hi - t_lo); o[6] = te[2];
     }
 #endif
 }
@@ -222,8 +253,8 @@ int launch_node_frags(const float* x, const float* wfrag, const float* R, const 
         static int calls = 0;
         if (++calls == 8)
             for (int w = 0; w < NF_WAVES; ++w)
-                fprintf(stderr, "[nf timing WG(5,3) wave %d] W load %lld | total %lld shader clk = %lld x 10 ns wall | mfma loops %lld | epilogues %lld | tiles of WG %lld\n",
-                        w, hh[w][0], hh[w][1], hh[w][2], hh[w][3], hh[w][4], hh[w][5]);
+                fprintf(stderr, "[nf timing WG(%d,3) wave %d] W load %lld | total %lld shader clk = %lld x 10 ns wall | task ends %lld %lld %lld | tasks of WG %lld\n",
+                        (int)NF_TIMING, w, hh[w][0], hh[w][1], hh[w][2], hh[w][3], hh[w][4], hh[w][6], hh[w][5]);
     }
 #endif
     return ABOPT_OK;
