@@ -105,6 +105,42 @@ __device__ __forceinline__ Mat3 quat1ijk_to_rot(float qb, float qc, float qd) {
     return o;
 }
 
+// Geometric epilogue of the three denoiser heads for ONE residue i (dpm_full.py:95-107): eps_pos = gen ? R eps_crd : 0;
+// R_next = R * U(eps_rot); v_next = gen ? log(R_next) : v_t; c = softmax(seq logits).  crd / rot / seq point at the row's head outputs
+// (global memory: heads_epilogue_kernel; LDS: the tail of heads_mlp_kernel).  seq == nullptr: training path, the softmax stays in autograd.
+__device__ __forceinline__ void heads_epilogue_row(int64_t i, const float* __restrict__ R, const float* __restrict__ v_t, const float* crd, const float* rot,
+                                                   const float* seq, const uint8_t* __restrict__ mask_generate, float* __restrict__ v_next,
+                                                   float* __restrict__ R_next, float* __restrict__ eps_pos, float* __restrict__ c_den, int grad_mode) {
+    const bool gen = mask_generate[i] != 0;
+    Mat3 Rm;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rm.m[k] = R[i * 9 + k];
+    const float cx = crd[0], cy = crd[1], cz = crd[2];
+    // apply_rotation_to_vector = R p + 0 (geometry.py:116-117)
+    eps_pos[i * 3 + 0] = gen ? (Rm.m[0] * cx + Rm.m[1] * cy + Rm.m[2] * cz + 0.f) : 0.f;
+    eps_pos[i * 3 + 1] = gen ? (Rm.m[3] * cx + Rm.m[4] * cy + Rm.m[5] * cz + 0.f) : 0.f;
+    eps_pos[i * 3 + 2] = gen ? (Rm.m[6] * cx + Rm.m[7] * cy + Rm.m[8] * cz + 0.f) : 0.f;
+    const Mat3 U = quat1ijk_to_rot(rot[0], rot[1], rot[2]);
+    const Mat3 Rn = matmul3(Rm, U);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R_next[i * 9 + k] = Rn.m[k];
+    if (v_next) {
+        const Vec3 w = so3_log(Rn, grad_mode != 0);
+        v_next[i * 3 + 0] = gen ? w.x : v_t[i * 3 + 0];
+        v_next[i * 3 + 1] = gen ? w.y : v_t[i * 3 + 1];
+        v_next[i * 3 + 2] = gen ? w.z : v_t[i * 3 + 2];
+    }
+    if (!seq) return;
+    float lgt[ABOPT_AA], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < ABOPT_AA; ++k) { lgt[k] = seq[k]; mx = fmaxf(mx, lgt[k]); }
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < ABOPT_AA; ++k) { lgt[k] = expf(lgt[k] - mx); sm += lgt[k]; }
+#pragma unroll
+    for (int k = 0; k < ABOPT_AA; ++k) c_den[i * ABOPT_AA + k] = lgt[k] / sm;
+}
+
 // general quaternion (real first) -> R with normalisation, reference geometry.py:148-175.
 __device__ __forceinline__ Mat3 quat_to_rot(float r, float i, float j, float k) {
     float n = fmaxf(sqrtf(r * r + i * i + j * j + k * k), 1e-12f);

@@ -497,11 +497,16 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
     }
     // dpm_full.py:90  encoder
     if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st, pair_bias_cache, zg))) return rc;
+    bool heads_fused = false;
     if (w->w_heads_frag) {
         // dpm_full.py:92-101: time features + the three heads in one launch (heads.hip)
         if (has_prmsd && (rc = launch_build_infeat(e.xe, beta, e.infeat, w->prmsd_ln_gamma, w->prmsd_ln_beta, e.infeat_ln, N, L, st))) return rc;
+        // ... and, unless ABOPT_FUSE_HEADS=0 (A/B, tests), their geometric epilogue as the tail of the same kernel
+        const char* fh = getenv("ABOPT_FUSE_HEADS");
+        heads_fused = !(fh && fh[0] == '0');
+        const HeadsEpilogue hep{e.R, v_t, mask_generate, v_next, R_next, eps_pos, c_denoised, grad_mode};
         if ((rc = launch_heads_mlp(e.xe, beta, w->w_heads_frag, w->w_head1, FI, w->b_head1, w->b_crd2, w->b_rot2, w->b_seq2, w->b_crd3, w->b_rot3,
-                                   w->b_seq3, e.out3, M, L, st))) return rc;
+                                   w->b_seq3, e.out3, M, L, st, heads_fused ? &hep : nullptr))) return rc;
     } else {
     // dpm_full.py:92-93 time features
     if ((rc = launch_build_infeat(e.xe, beta, e.infeat, w->prmsd_ln_gamma, w->prmsd_ln_beta, has_prmsd ? e.infeat_ln : nullptr, N, L, st))) return rc;
@@ -515,8 +520,8 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
     if ((rc = launch_linear(e.hh2 + 1 * F, 3 * F, w->w_rot3, F, w->b_rot3, e.out3 + 4, 32, (int)M, 3, F, false, st))) return rc;
     if ((rc = launch_linear(e.hh2 + 2 * F, 3 * F, w->w_seq3, F, w->b_seq3, e.out3 + 8, 32, (int)M, ABOPT_AA, F, false, st))) return rc;
     }
-    if ((rc = launch_heads_epilogue(e.R, v_t, e.out3 + 0, e.out3 + 4, e.out3 + 8, 32, 32, mask_generate, v_next, R_next, eps_pos, c_denoised,
-                                    M, grad_mode, st))) return rc;
+    if (!heads_fused && (rc = launch_heads_epilogue(e.R, v_t, e.out3 + 0, e.out3 + 4, e.out3 + 8, 32, 32, mask_generate, v_next, R_next, eps_pos, c_denoised,
+                                                    M, grad_mode, st))) return rc;
     if (has_prmsd) {
         // PerResiduePredictor (nn.py:179-188) then mean over L (dpm_full.py:109-110)
         if ((rc = launch_linear(e.infeat_ln, FI, w->w_prmsd1, FI, w->b_prmsd1, e.pr1, F, (int)M, F, FI, true, st))) return rc;

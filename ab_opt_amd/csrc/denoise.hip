@@ -40,6 +40,16 @@ __global__ __launch_bounds__(256) void denoise_step_kernel(abopt_step_params sp,
     if (seed_dev) { seed = seed_dev[0]; offset = seed_dev[1]; }     // graph replays: the stream position comes from device memory
     const Philox rng(seed);
     float ppl_num = 0.f, ppl_den = 0.f;
+    // The histogram bin is the only long dependent chain of a residue (13 probes of the 8191-entry CDF row): the row is staged in LDS by
+    // coalesced loads first (same comparisons on the same values), and not searched at all where its result cannot reach the output
+    // (Gaussian branch of so3.py:129-138, t <= 1: e = 0, injected noise).
+    __shared__ float cdf_s[8192];
+    const bool need_bin = !injected && !sp.igso3_gaussian && sp.t > 1;
+    const bool cdf_lds = need_bin && bins - 1 <= 8192;
+    if (cdf_lds) {
+        for (int k = tid; k < bins - 1; k += 256) cdf_s[k] = igCdf[k];
+        __syncthreads();
+    }
 
     for (int l = tid; l < L; l += 256) {
         const int64_t i = (int64_t)n * L + l;
@@ -64,7 +74,8 @@ __global__ __launch_bounds__(256) void denoise_step_kernel(abopt_step_params sp,
             const float ub = u01(r2.z);
             // inverse CDF over bins-1 histogram cells == multinomial(Y[t, :-1]) (so3.py:122)
             int lo = 0, hi = bins - 2;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (igCdf[mid] > ub) hi = mid; else lo = mid + 1; }
+            if (cdf_lds) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf_s[mid] > ub) hi = mid; else lo = mid + 1; } }
+            else if (need_bin) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (igCdf[mid] > ub) hi = mid; else lo = mid + 1; } }
             bin = lo;
         }
         // ---- rotation (transition.py:146-160)

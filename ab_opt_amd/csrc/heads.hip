@@ -65,7 +65,7 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
                                                         const float* __restrict__ w1 /* [384, ld1]: columns 128..130 = the time features */, int ld1,
                                                         const float* __restrict__ b1, const float* __restrict__ b2c, const float* __restrict__ b2r,
                                                         const float* __restrict__ b2s, const float* __restrict__ b3c, const float* __restrict__ b3r,
-                                                        const float* __restrict__ b3s, float* __restrict__ out3, int64_t rows, int L) {
+                                                        const float* __restrict__ b3s, float* __restrict__ out3, int64_t rows, int L, HeadsEpilogue ep) {
     extern __shared__ __attribute__((aligned(16))) char hd_raw[];
     HeadsSmem& sm = *reinterpret_cast<HeadsSmem*>(hd_raw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
         block_gemm(sm.hp[wave], wf + (int64_t)(24 + wave) * HBLK, lane, a0, a1);
         const int nout = wave == 2 ? ABOPT_AA : 3, base = wave == 0 ? 0 : (wave == 1 ? 4 : 8);
         const float* b3 = wave == 0 ? b3c : (wave == 1 ? b3r : b3s);
+        float* os = reinterpret_cast<float*>(sm.xp) + mrow * 32 + base;       // the x planes are dead since layer 1: the row's 32 head outputs for the epilogue
         if (row0 + mrow < rows) {
             float* o = out3 + (row0 + mrow) * 32 + base;
 #pragma unroll
@@ -130,9 +131,17 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int c = g * 8 + csub + i;
-                    if (c < nout) o[c] = (a0[4 * g + i] + a1[4 * g + i]) + b3[c];
+                    if (c < nout) { const float v = (a0[4 * g + i] + a1[4 * g + i]) + b3[c]; o[c] = v; os[c] = v; }
                 }
         }
+    }
+    if (!ep.R_next) return;
+    // ---- geometric epilogue of the same rows (dpm_full.py:95-107; rows.hip: heads_epilogue_kernel is the stand-alone form of the same function):
+    // one launch and one dependent kernel boundary less per denoising step
+    __syncthreads();
+    if (wave == 3 && lane < HR && row0 + lane < rows) {
+        const float* os = reinterpret_cast<const float*>(sm.xp) + lane * 32;
+        heads_epilogue_row(row0 + lane, ep.R, ep.v_t, os, os + 4, os + 8, ep.mask_generate, ep.v_next, ep.R_next, ep.eps_pos, ep.c_den, ep.grad_mode);
     }
 }
 
@@ -209,12 +218,12 @@ size_t mixer_wfrag_floats() { return (size_t)8 * HBLK * 4; }
 
 int launch_heads_mlp(const float* xe, const float* beta, const float* wfrag, const float* w1, int ld1, const float* b1, const float* b2c,
                      const float* b2r, const float* b2s, const float* b3c, const float* b3r, const float* b3s, float* out3, int64_t rows, int L,
-                     hipStream_t st) {
+                     hipStream_t st, const HeadsEpilogue* ep) {
     if (rows == 0) return ABOPT_OK;
     static LdsConfig lds_cfg;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(heads_mlp_kernel), sizeof(HeadsSmem), lds_cfg)) return rc;
     hipLaunchKernelGGL(heads_mlp_kernel, dim3((unsigned)((rows + HR - 1) / HR)), dim3(HTH), sizeof(HeadsSmem), st, xe, beta, wfrag, w1, ld1, b1,
-                       b2c, b2r, b2s, b3c, b3r, b3s, out3, rows, L);
+                       b2c, b2r, b2s, b3c, b3r, b3s, out3, rows, L, ep ? *ep : HeadsEpilogue{});
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

@@ -115,34 +115,8 @@ __global__ __launch_bounds__(256) void heads_epilogue_kernel(const float* __rest
                                                              float* __restrict__ c_den, int64_t rows, int grad_mode) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
-    const bool gen = mask_generate[i] != 0;
-    Mat3 Rm;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Rm.m[k] = R[i * 9 + k];
-    const float cx = eps_crd[i * ld3], cy = eps_crd[i * ld3 + 1], cz = eps_crd[i * ld3 + 2];
-    // apply_rotation_to_vector = R p + 0 (geometry.py:116-117)
-    eps_pos[i * 3 + 0] = gen ? (Rm.m[0] * cx + Rm.m[1] * cy + Rm.m[2] * cz + 0.f) : 0.f;
-    eps_pos[i * 3 + 1] = gen ? (Rm.m[3] * cx + Rm.m[4] * cy + Rm.m[5] * cz + 0.f) : 0.f;
-    eps_pos[i * 3 + 2] = gen ? (Rm.m[6] * cx + Rm.m[7] * cy + Rm.m[8] * cz + 0.f) : 0.f;
-    const Mat3 U = quat1ijk_to_rot(eps_rot[i * ld3], eps_rot[i * ld3 + 1], eps_rot[i * ld3 + 2]);
-    const Mat3 Rn = matmul3(Rm, U);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) R_next[i * 9 + k] = Rn.m[k];
-    if (v_next) {
-        const Vec3 w = so3_log(Rn, grad_mode != 0);
-        v_next[i * 3 + 0] = gen ? w.x : v_t[i * 3 + 0];
-        v_next[i * 3 + 1] = gen ? w.y : v_t[i * 3 + 1];
-        v_next[i * 3 + 2] = gen ? w.z : v_t[i * 3 + 2];
-    }
-    if (!seq_logits) return;                                        // training path: the sequence head's softmax stays in the autograd graph
-    float lgt[ABOPT_AA], mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < ABOPT_AA; ++k) { lgt[k] = seq_logits[i * ldseq + k]; mx = fmaxf(mx, lgt[k]); }
-    float sm = 0.f;
-#pragma unroll
-    for (int k = 0; k < ABOPT_AA; ++k) { lgt[k] = expf(lgt[k] - mx); sm += lgt[k]; }
-#pragma unroll
-    for (int k = 0; k < ABOPT_AA; ++k) c_den[i * ABOPT_AA + k] = lgt[k] / sm;
+    heads_epilogue_row(i, R, v_t, eps_crd + i * ld3, eps_rot + i * ld3, seq_logits ? seq_logits + i * ldseq : nullptr, mask_generate, v_next, R_next, eps_pos, c_den,
+                       grad_mode);
 }
 
 int launch_heads_epilogue(const float* R, const float* v_t, const float* eps_crd, const float* eps_rot, const float* seq_logits,

@@ -1217,10 +1217,12 @@ def test_block_tail_autograd_function_vs_torch_statement(N, L, lengths):
 
 
 @pytest.mark.parametrize('flavour', ['abdesign', 'abdock'])
-def test_fused_heads_match_gemm_path(flavour):
+def test_fused_heads_match_gemm_path(flavour, monkeypatch):
     """heads.hip (the three denoiser heads as one kernel, time features as an affine term; the mixer as one kernel with the sequence
     embedding folded into a table) against the GEMM path through the C ABI:
-    same R_next / eps_pos / c up to fp32 summation order; per-sample beta, row count not a multiple of the 32-row tile."""
+    same R_next / eps_pos / c up to fp32 summation order; per-sample beta, row count not a multiple of the 32-row tile.
+    The heads' geometric epilogue (dpm_full.py:95-107) runs as the tail of the heads kernel; ABOPT_FUSE_HEADS=0 launches it on its own
+    (rows.hip: heads_epilogue_kernel, the same device function): bit-identical."""
     from ab_opt_amd import hip
     T, t, N, L = 100, 41, 3, 70
     d = (standalone_abdesign_dpm(T, 2) if flavour == 'abdesign' else build_model(T, 2).diffusion).to(DEV)
@@ -1234,6 +1236,11 @@ def test_fused_heads_match_gemm_path(flavour):
     plain.w_heads_frag = None
     plain.w_mix_frag = None
     a = hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False)
+    monkeypatch.setenv('ABOPT_FUSE_HEADS', '0')
+    a2 = hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False)
+    monkeypatch.delenv('ABOPT_FUSE_HEADS')
+    for k in ('R_next', 'v_next', 'eps_pos', 'c'):
+        assert torch.isfinite(a[k]).all() and torch.equal(a[k], a2[k]), k
     b = hip.eps_net_forward(plain, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False)
     for k in ('R_next', 'eps_pos', 'c'):          # v_next = log(R_next) amplifies near theta = pi; R_next pins it
         assert max_abs(a[k], b[k]) < 2e-5, (k, max_abs(a[k], b[k]))
