@@ -122,7 +122,8 @@ class _PairEmbedFn(torch.autograd.Function):
         same = chain_nb[:, :, None] == chain_nb[:, None, :]
         # rows summed by relative-position bucket (other-chain pairs skipped): abopt_bucket_colsum, no one-hot matrix
         s_rel = hip.bucket_colsum(do0, torch.where(same, rel, -1).reshape(M).to(torch.int32), 2 * ctx.max_relpos + 1)
-        dwo0 = torch.cat([s_aap.t() @ E_aap, s_rel.t() @ E_rel, _splitk_tn(do0, h1), _splitk_tn(do0, dih)], dim=1)
+        # [f_dist | f_dih] are adjacent columns of the saved activations: one product (one pass over do0) for both column groups
+        dwo0 = torch.cat([s_aap.t() @ E_aap, s_rel.t() @ E_rel, _splitk_tn(do0, a2[:, 64:154])], dim=1)
         dE_aap, dE_rel = s_aap @ wo0[:, :C], s_rel @ wo0[:, C:2 * C]
         unpad = lambda m: m.reshape(m.shape[0], A, 16)[:, :, :A].reshape(m.shape[0], A * A)          # [.., a, 16] -> [.., a*A + b]
         dwd0 = unpad(_splitk_tn(dh0, G.view(M, -1)))
