@@ -404,8 +404,12 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
             const int64_t jr = SEL4(jrow, mt);
             const float psm = SEL4(ps, mt);
             const V3 nj = xyz(a.atoms4[jr * 16 + 0]), caj = xyz(a.atoms4[jr * 16 + 1]), cj = xyz(a.atoms4[jr * 16 + 2]);
+#if defined(PE_ABL) && (PE_ABL & 1)      // developer build: no dihedral geometry
+            const float x0 = nj.x, x1 = caj.y;
+#else
             const float x0 = dihedral_from_four_points(ci, nj, caj, cj);
             const float x1 = dihedral_from_four_points(ni, cai, ci, nj);
+#endif
             f32x4 d0, d1;
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
@@ -415,7 +419,11 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
                     const int ang = k >= 13, m = k - 13 * ang;
                     const float x = ang ? x1 : x0;
                     float v = 0.f;
+#if defined(PE_ABL) && (PE_ABL & 2)      // developer build: no sin / cos
+                    if (k < 26) v = (m == 0) ? x : x * a.freq[m <= 6 ? m - 1 : m - 7];
+#else
                     if (k < 26) v = (m == 0) ? x : ((m <= 6) ? sinf(x * a.freq[m - 1]) : cosf(x * a.freq[m - 7]));
+#endif
                     if (blk == 0) d0[q] = v * psm; else d1[q] = v * psm;
                 }
             // register-array write with a loop-variant index would go to scratch: select per tile
