@@ -324,6 +324,22 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
 #pragma unroll 1
         for (int at = 0; at < A; ++at) {
             const f32x4 pi = a.atoms4[row_i * 16 + at];
+            // atom `at` of residue i absent (mask_heavyatom, pair.py:69-73): its 16 features are exact zeros for every pair of the strip and add
+            // nothing to the layer -- the whole K block is skipped (wave-uniform: a wave owns one i).  Backbone-only inputs skip 10 of 15 blocks.
+            if (__builtin_amdgcn_readfirstlane(__float_as_uint(pi[3])) == 0u) {
+                if (a.gsave) {
+#pragma unroll
+                    for (int mt = 0; mt < PMT; ++mt) {
+                        const int j_ = j0 + mt * 16 + fm;
+                        if (j_ < L) {
+                            const int64_t o_ = (((row_i * L) + j_) * A + at) * 16 + kq * 4;
+                            *reinterpret_cast<f32x4*>(a.gsave + o_) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (a.tsave) *reinterpret_cast<f32x4*>(a.tsave + o_) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+                }
+                continue;
+            }
             f32x4 w_[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) w_[nt] = a.wd0[(at * 4 + nt) * 64 + lane];
@@ -609,6 +625,13 @@ __global__ __launch_bounds__(256, 2) void pair_embed_backward_kernel(PairBwdArgs
     }
 #pragma unroll 1
     for (int at = 0; at < A; ++at) {
+        if (b.atoms4 && __builtin_amdgcn_readfirstlane(__float_as_uint(b.atoms4[row_i * 16 + at][3])) == 0u) {
+            // atom `at` of residue i absent: T = 0 for the whole strip, so ds = 0 whatever Wd0^T dY is (the forward skips the same K block)
+#pragma unroll
+            for (int mt = 0; mt < PMT; ++mt)
+                if (j0 + mt * 16 + fm < L) *reinterpret_cast<f32x4*>(b.ds + (((row_i * L) + jc[mt]) * A + at) * 16 + kq * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
         f32x4 acc[PMT];
 #pragma unroll
         for (int mt = 0; mt < PMT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
