@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void sample_init_kernel(const float* __restric
         box_muller(r1.z, r1.w, g[2], d0);
         const Philox rng2(seed ^ 0x5bd1e995ull);
         srand_ = (int64_t)(rng2(offset + (uint64_t)i, 0xFFFF02ull).x % 19u);     // randint_like(low=0, high=19): TYR never drawn
+        if (sr) srand_ = sr[i];      // sample_structure = False draws the sequence alone (dpm_full.py:262-267): it can be injected alone
     }
     // random_uniform_so3: F.normalize then quaternion_to_rotation_matrix (which normalises again), so3.py:66-68
     const float nq = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
@@ -238,14 +239,15 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const int64_t* __restric
     const float abar = alpha_bars[tt];
     const float c0 = sqrtf(abar), c1 = sqrtf(1.f - abar);
     const float mean[3] = {m0, m1, m2};
-    float ax, ay, az, ubin, gss, ex, ey, ez, useq;
-    int64_t bin;
+    float ax = 0.f, ay = 0.f, az = 0.f, ubin = 0.f, gss = 0.f, ex = 0.f, ey = 0.f, ez = 0.f, useq = 0.f;
+    int64_t bin = 0;
+    // injected draws: all of them, or -- when the structure is not noised (dpm_full.py:169-173 draws nothing for it) -- s_noisy alone
+    const bool injected = nz.axis != nullptr || (!noise_structure && nz.s_noisy != nullptr);
     if (nz.axis) {
         ax = nz.axis[i * 3]; ay = nz.axis[i * 3 + 1]; az = nz.axis[i * 3 + 2];
         bin = nz.bin[i]; ubin = nz.ubin[i]; gss = nz.gauss[i];
         ex = nz.pos[i * 3]; ey = nz.pos[i * 3 + 1]; ez = nz.pos[i * 3 + 2];
-        useq = 0.f;
-    } else {
+    } else if (!injected) {
         if (seed_dev) { seed = seed_dev[0]; offset = seed_dev[1]; }
         const Philox rng(seed);
         const uint4 r0 = rng(offset + (uint64_t)i, 0xA00000ull), r1 = rng(offset + (uint64_t)i, 0xA00001ull), r2 = rng(offset + (uint64_t)i, 0xA00002ull);
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const int64_t* __restric
             c[k] = ck + 1e-8f;                                                             // _sample adds 1e-8 (transition.py:179)
             tot += c[k];
         }
-        if (nz.axis) sn = nz.s_noisy[i];
+        if (injected) sn = nz.s_noisy[i];
         else {
             const float target = useq * tot;
             float cum = 0.f;
@@ -385,6 +387,8 @@ extern "C" int abopt_add_noise(const int64_t* t, const float* alpha_bars, const 
     if (noise && noise->axis) {
         ABOPT_CHECK_ARG(noise->bin && noise->ubin && noise->gauss && noise->pos && (noise->s_noisy || !noise_sequence), "add_noise: injected noise must provide every draw");
         nz = *noise;
+    } else if (noise && noise->s_noisy && !noise_structure) {
+        nz.s_noisy = noise->s_noisy;          // sequence-only noising (train_structure = False): the one draw this mode makes
     } else {
         ABOPT_CHECK_ARG(fwd_cdf, "add_noise: device RNG path needs the CDF table");
     }

@@ -324,11 +324,18 @@ class _LoopGraph:
         # pair_feat is the one large input (537 MB at N=32, L=256): when the caller hands over the very tensor object of the last replay,
         # unmodified (same _version), the static copy is still current.  Identity of the live OBJECT, not of the address: a freed tensor's
         # address can come back from the allocator with other contents.
+        # `_version` counts autograd-visible in-place writes only: a caller that refreshes the SAME tensor object through raw pointers
+        # (this library's kernels writing into it, `.data`) must pass a new tensor object or call clear_graphs(); inference-mode tensors
+        # have no version counter at all and are always copied.
         src = self._pf_src
-        same = src is not None and src[0]() is pair_feat and src[1] == pair_feat._version
+        try:
+            ver = pair_feat._version
+        except RuntimeError:
+            ver = None
+        same = ver is not None and src is not None and src[0]() is pair_feat and src[1] == ver
         if not same and pair_feat.data_ptr() != self.pair_feat.data_ptr():
             self.pair_feat.copy_(pair_feat)
-            self._pf_src = (weakref.ref(pair_feat), pair_feat._version)
+            self._pf_src = (weakref.ref(pair_feat), ver) if ver is not None else None
         self.mask_generate.copy_(mask_generate)
         self.mask_res.copy_(mask_res)
         self.seed_dev.copy_(torch.tensor([int(seed), int(rng_offset)], dtype=torch.int64))

@@ -440,8 +440,10 @@ def add_noise(t, alpha_bars, fwd, noise, seed, offset, v_0, p_0, s_0, mask_gener
     probs = torch.empty(N, L, 20, dtype=torch.float32, device=p_0.device) if want_probs else None
     nz = None
     if noise is not None:
-        nz = AddNoiseNoise(ptr(noise['axis'], torch.float32), ptr(noise['bin'], torch.int64), ptr(noise['ubin'], torch.float32),
-                           ptr(noise['gauss'], torch.float32), ptr(noise['pos'], torch.float32), ptr(noise.get('s_noisy'), torch.int64, optional=True))
+        o = not noise_structure                  # sequence-only noising draws s_noisy alone (dpm_full.py:163-178)
+        nz = AddNoiseNoise(ptr(noise.get('axis'), torch.float32, optional=o), ptr(noise.get('bin'), torch.int64, optional=o),
+                           ptr(noise.get('ubin'), torch.float32, optional=o), ptr(noise.get('gauss'), torch.float32, optional=o),
+                           ptr(noise.get('pos'), torch.float32, optional=o), ptr(noise.get('s_noisy'), torch.int64, optional=True))
     mean_arr = (C.c_float * 3)(*[float(m) for m in mean])
     cdf = fwd.cdf() if noise is None else None
     t, v_0, p_0, s_0, mask_generate = _contig(t, v_0, p_0, s_0, mask_generate)
@@ -755,8 +757,11 @@ def gemm(a, b, alpha=1.0, out=None, bias=None, relu=False):
         ldc, sc = o3.stride(1), (o3.stride(0) if nb > 1 else 0)
     tiles = ((M + 63) // 64) * ((N + 63) // 64) * nb
     ws = None
-    if tiles < 1024 and K >= 1024 and bias is None and not relu:
-        ws = Workspace.get(min(1024, max(K // 128, 1)) * nb * M * N * 4, a.device)
+    # split-K slabs: the C side (gemm.hip: launch_gemm_batched) splits below 256 output tiles, for a densely packed C only, into at most
+    # min(1024 / tiles, K / 256) slabs -- size the workspace for exactly that (an env-tuned ABOPT_GEMM_TMAX / _KDIV build clamps to what it gets)
+    dense_c = ldc == N and (nb == 1 or sc == M * N)
+    if tiles < 256 and K >= 1024 and bias is None and not relu and dense_c:
+        ws = Workspace.get(max(1, min(1024 // tiles, K // 256)) * nb * M * N * 4, a.device)
     if bias is not None:
         bias = bias.detach().float().contiguous()
         assert bias.numel() == N

@@ -177,6 +177,15 @@ def sample_grouped(model, complexes, num_samples, sample_opt=None, optimize_step
     return model.diffusion.optimize(*args, optimize_step, res_feat, pair_feat, *masks, **sample_opt)
 
 
+def launch_rng_offset(first_complex, samples_per_complex, L_max):
+    """Philox counter base of the launch whose first complex is `first_complex`.  A launch of G complexes x S samples padded to L <= L_max
+    reads counters base + n L + l (n < G S, l < L) in sample(), and up to base + 2 G S L in optimize() (the loop's draws sit G S L behind
+    add_noise's, dpm.py: FullDPM.optimize), so a stride of 2 S L_max per complex gives the launch [base, base + 2 G S L_max): the next
+    launch starts at or beyond its end whatever the two padded lengths are.  (A stride of S L with the launch's own L let a later,
+    shorter launch start inside an earlier, longer one: identical draws for samples of different complexes.)"""
+    return int(first_complex) * 2 * int(samples_per_complex) * int(L_max)
+
+
 @torch.no_grad()
 def design_testset_sharded(model, complexes, samples_per_complex, sample_opt=None, k=1, group=None, seed=0, optimize_step=None,
                            complexes_per_launch=8, native=None):
@@ -189,9 +198,10 @@ def design_testset_sharded(model, complexes, samples_per_complex, sample_opt=Non
     the commonness score, optionally scores them against the native structure (DockQ on the device), and the per-complex summaries
     (a few hundred bytes each) are exchanged once at the end with all_gather_object.
 
-    complexes: list of batch dicts with batch dim 1.  The Philox stream position of a sample depends on its global index
-    (complex index x samples_per_complex + sample) and on the padded length of its launch only, so results do not depend on the number of
-    ranks as long as the launches group the same complexes (complexes_per_launch divides the per-rank count, or is 1).
+    complexes: list of batch dicts with batch dim 1.  The Philox stream position of a sample depends on the index of its launch's first
+    complex, on the longest complex of the WHOLE test set (`launch_rng_offset`: every launch owns a counter range no other launch can
+    reach, whatever the padded lengths) and on its position in the launch, so results do not depend on the number of ranks as long as
+    the launches group the same complexes (complexes_per_launch divides the per-rank count, or is 1).
     native (optional): dict(pos (L,A,3), mask (L,A)) per complex, or True to score against the complex's own input coordinates.
     -> list (one entry per complex, in input order, identical on every rank) of
     dict(complex=index, rank=owner, top=LongTensor(k), score=Tensor(S), ca=final CA positions of the generated residues (S, n_gen, 3)
@@ -202,11 +212,12 @@ def design_testset_sharded(model, complexes, samples_per_complex, sample_opt=Non
     mine = []
     own = complexes_of_rank(len(complexes), world, rank)
     G = max(1, int(complexes_per_launch))
+    L_all = max(int(c['aa'].shape[1]) for c in complexes)            # the same on every rank: `complexes` is the whole test set
     for lo in range(0, len(own), G):
         ids = own[lo:lo + G]
         chunk = [complexes[c] for c in ids]
         L = max(int(c['aa'].shape[1]) for c in chunk)
-        opt = dict(sample_opt, seed=int(seed), rng_offset=ids[0] * S * L)
+        opt = dict(sample_opt, seed=int(seed), rng_offset=launch_rng_offset(ids[0], S, L_all))
         traj = sample_grouped(model, chunk, S, opt, optimize_step=optimize_step)
         p_fin = traj[0][1]
         for g, c in enumerate(ids):

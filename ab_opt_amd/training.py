@@ -134,7 +134,11 @@ class IpaCore(torch.autograd.Function):
         # backward adds into it in the kernel and only the last one to run hands it to autograd -- instead of six 268 MB tensors and five
         # elementwise additions
         sink = ctx.zsink if (ctx.zsink is not None and ctx.zsink['users'] > 0) else None       # (a second backward over a retained graph: no sharing)
-        if sink is not None and not DEFER_DZ:                      # developer A/B: the round-3 form (every block adds into one shared buffer)
+        if sink is not None:
+            sink.setdefault('total', sink['users'])                # blocks of this encoder pass (the first backward to run sees them all)
+        # abopt_ipa_dz_assemble sums the terms of at most 6 blocks (its LDS tile); deeper encoders (the library takes up to 8 layers) and
+        # the developer A/B ABOPT_DZ_DEFER=0 use the round-3 form: every block adds into one shared buffer
+        if sink is not None and (not DEFER_DZ or sink['total'] > 6):
             g, dz, dWb = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb, dz_into=sink['buf'])
             sink['buf'] = dz
             sink['users'] -= 1

@@ -241,6 +241,8 @@ int abopt_sample_init(const float* v, const float* p, const int64_t* s, const ui
  * training loss (dpm_full.py:162-178).  t [N] is per sample; alpha_bars/fwd_* are the schedule buffers ([T+1], [T+1,bins]);
  * fwd_cdf [T+1,bins-1] only for the device-RNG path.  p_0 / p_noisy in Angstrom.  noise: reference draw order
  * randn(N,L,3) axis, multinomial bin, rand ubin, randn gauss | randn(N,L,3) pos | multinomial s_noisy; all NULL => Philox.
+ * With noise_structure = 0 (train_structure / sample_structure = False: dpm_full.py:169-173 draws nothing for the structure)
+ * s_noisy alone may be injected.
  * c_noisy (optional, [N,L,20]): the categorical c_t the sequence sample is drawn from (transition.py:196-198), whether or not
  * the sample itself is injected; with noise_sequence = 0 it is onehot(s_0), the reference's c_0 (all-zero rows for s_0 outside 0..19). */
 typedef struct {

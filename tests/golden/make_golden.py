@@ -402,6 +402,162 @@ def case_training_abdesign():
     save('training_abdesign', **o)
 
 
+def _step_draws(tape, N, L, t, out, pre=''):
+    out[f'{pre}t{t}_axis'] = tape.pop('randn')
+    out[f'{pre}t{t}_bin'] = tape.pop('multinomial').reshape(N, L)
+    out[f'{pre}t{t}_ubin'] = tape.pop('rand_like').reshape(N, L)
+    out[f'{pre}t{t}_gauss'] = tape.pop('randn_like').reshape(N, L)
+    out[f'{pre}t{t}_z'] = tape.pop('randn_like')
+    out[f'{pre}t{t}_s_next'] = tape.pop('multinomial').reshape(N, L)
+
+
+def case_seqdesign():
+    """The sequence-design mode the reference ships (AbDock/configs/test/seq_design.yml:4-6, driven per pose by optimize_ab.py:14-36):
+    model.sample with sample_structure=False, sample_sequence=True and a contig.  dpm_full.py:255-267 (only the sequence is
+    initialised), :290-297 (every transition still draws; the structure keeps v_t, p_t).  Every step, every draw and the
+    categorical the reference sampled from are stored; the encode() of this mode (remove_structure=False) too."""
+    T = 10
+    m = abdock_model(T, seed=3)
+    batch = synth.make_batch(2, synth.LAYOUT_128, seed=2022, lengths=[128, 117])
+    b = {k: v.clone() for k, v in batch.items()}
+    torch.manual_seed(23)
+    tape = Tape()
+    with tape.recording():
+        traj = m.sample(b, sample_opt=dict(sample_structure=False, sample_sequence=True, contig='31-36'))
+    out = dict(gen=b['generate_flag'])                      # the contig-restricted flag model.sample left in the batch (diffab.py:125-129)
+    assert int(out['gen'].sum()) == 12 and bool(out['gen'][:, 30:36].all())
+    out['init_s'] = tape.pop('randint_like')
+    for t in range(T, 0, -1):
+        _step_draws(tape, 2, 128, t, out)
+    assert not tape.log and len(tape.cat_probs) == T
+    for t in range(T, -1, -1):
+        e = traj[t]
+        out[f'traj{t}_v'], out[f'traj{t}_p'], out[f'traj{t}_s'] = e[0], e[1], e[2]
+        if t < T:
+            out[f'traj{t}_prmsd'], out[f'traj{t}_ppl'] = e[3], e[4]
+            out[f't{t + 1}_probs'] = tape.cat_probs[T - t - 1].reshape(2, 128, 20)
+    with torch.no_grad():
+        rf, pf, R0, p0 = m.encode({k: v.clone() for k, v in b.items()}, False, True)
+    out.update(res_feat=rf, pair_feat_sub=pf[:, ::7, ::5], pair_feat_sum=pf.double().sum((1, 2)), R0=R0, p0=p0)
+    save('trajectory_abdock_T10_seqdesign', **out)
+
+    # AbDesign fixbb (AbDesign/configs/test/fixbb.yml:7) at FullDPM level
+    d = abdesign_fulldpm(T, seed=4)
+    N, L = 2, 40
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(N, L, [40, 33], [(5, 14), (22, 30)], num_steps=T, t=3)
+    torch.manual_seed(29)
+    tape = Tape()
+    with tape.recording():
+        traj = d.sample(v, p * 10, s, res_feat, pair_feat, gen, mres, sample_structure=False, sample_sequence=True)
+    out = dict(init_s=tape.pop('randint_like'))
+    for t in range(T, 0, -1):
+        _step_draws(tape, N, L, t, out)
+    assert not tape.log and len(tape.cat_probs) == T
+    for t in range(T, -1, -1):
+        out[f'traj{t}_v'], out[f'traj{t}_p'], out[f'traj{t}_s'] = traj[t]
+        if t < T:
+            out[f't{t + 1}_probs'] = tape.cat_probs[T - t - 1].reshape(N, L, 20)
+    save('trajectory_abdesign_T10_fixbb', **out)
+
+
+def case_training_seqonly():
+    """train_structure=False, train_sequence=True (AbDock/configs/train/seq_design.yml:11-12; dpm_full.py:163-178): the structure
+    enters un-noised, eps_p = 0, only the sequence is noised.  FullDPM.forward of both trees, fixed t, recorded draw, losses +
+    parameter / input gradients."""
+    T = 100
+    N, L = 2, 48
+    names = ['eps_net.encoder.blocks.0.proj_pair_bias.weight', 'eps_net.encoder.blocks.0.spatial_coef',
+             'eps_net.encoder.blocks.5.out_transform.weight', 'eps_net.encoder.blocks.3.proj_key_point.weight',
+             'eps_net.encoder.blocks.2.mlp_transition.2.weight', 'eps_net.encoder.blocks.4.layer_norm_1.gamma',
+             'eps_net.res_feat_mixer.0.weight', 'eps_net.eps_crd_net.4.weight', 'eps_net.eps_seq_net.0.weight',
+             'eps_net.eps_rot_net.4.weight', 'eps_net.current_sequence_embedding.weight']
+    for tag, dpm, seed in (('abdock', abdock_model(T, seed=2).train().diffusion, 31), ('abdesign', abdesign_fulldpm(T, seed=2).train(), 37)):
+        v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(N, L, [48, 41], [(6, 17), (30, 37)], salt=300)
+        s = s.clamp(max=19)
+        t = torch.tensor([37, 80])
+        res_feat = res_feat.clone().requires_grad_(True)
+        pair_feat = pair_feat.clone().requires_grad_(True)
+        dpm.zero_grad()
+        torch.manual_seed(seed)
+        tape = Tape()
+        with tape.recording():
+            loss = dpm(v, p * 10, s, res_feat, pair_feat, gen, mres, denoise_structure=False, denoise_sequence=True, t=t)
+        o = dict(s_noisy=tape.pop('multinomial').reshape(N, L))
+        assert not tape.log                                    # the structure draws nothing in this mode
+        o['addnoise_probs'] = tape.cat_probs[0].reshape(N, L, 20)
+        sum(loss.values()).backward()
+        for k, val in loss.items():
+            o['loss_' + k] = val
+        params = dict(dpm.named_parameters())
+        for n_ in names:
+            g_ = params[n_].grad
+            o['grad_' + n_] = g_[::3, ::5] if g_.numel() > 50000 else g_
+        o['grad_res_feat'] = res_feat.grad
+        o['grad_pair_feat_sub'] = pair_feat.grad[:, ::5, ::3]
+        save(f'training_seqonly_{tag}', **o)
+
+
+STEP_TS = (100, 64, 22, 21, 10, 2, 1)
+
+
+def case_steps_T100():
+    """T = 100 (the headline sampler's schedule), N = 2, L = 40, single denoising steps of the reference's own loops at t in STEP_TS:
+    state at t, all six draws of step t, the categorical sampled from, state at t - 1 (+ prmsd / perplexity).  t = 22 is the last
+    histogram row of the inverse IGSO(3) distribution, t = 2..21 take the Gaussian branch |2 sigma + sigma randn| mod pi
+    (so3.py:127-135), t = 1 adds no noise (transition.py:95,152).
+      AbDock:   FullDPM.sample run free from t = 100 to 0 (dpm_full.py:236-302); the steps of that one run are stored.
+      AbDesign: with hash-filled weights a free run's generated positions leave the fp32 range a 1e-4 A check means anything in
+                (3900 A at t = 64), so each step is the FIRST denoising step of FullDPM.optimize(opt_step = t)
+                (A/.../dpm_full.py:256-319: the same loop body as sample, entered from add_noise of a sane structure)."""
+    T = 100
+    N, L = 2, 40
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(N, L, [40, 33], [(5, 14), (22, 30)], num_steps=T, t=3)
+    s = torch.where(mres, s.clamp(max=19), s)
+
+    d = abdock_model(T, seed=2).diffusion
+    inv = d.trans_rot.angular_distrib_inv
+    flags = inv.approx_flag.tolist()
+    assert flags[22] is False and all(flags[2:22]) and abs(float(inv.stddevs[21]) - 0.1) > 1e-4
+    torch.manual_seed(41)
+    tape = Tape()
+    with tape.recording(), torch.no_grad():
+        traj = d.sample(v, p * 10, s, res_feat, pair_feat, gen, mres)
+    tape.pop('randn'); tape.pop('randn_like'); tape.pop('randint_like')
+    out = {}
+    for t in range(T, 0, -1):
+        tmp = {}
+        _step_draws(tape, N, L, t, tmp)
+        if t in STEP_TS:
+            out.update(tmp)
+            out[f't{t}_probs'] = tape.cat_probs[T - t].reshape(N, L, 20)
+            for tt in (t, t - 1):
+                e = traj[tt]
+                out[f'traj{tt}_v'], out[f'traj{tt}_p'], out[f'traj{tt}_s'] = e[0], e[1], e[2]
+                if tt < T:
+                    out[f'traj{tt}_prmsd'], out[f'traj{tt}_ppl'] = e[3], e[4]
+    assert not tape.log
+    for k, a in out.items():
+        assert torch.isfinite(a.float()).all() and (a.float().abs().max() < 100 or k.endswith('_bin')), k
+    save('steps_T100_abdock', **out)
+
+    d = abdesign_fulldpm(T, seed=2)
+    out = {}
+    for i, t in enumerate(STEP_TS):
+        torch.manual_seed(43 + i)
+        tape = Tape()
+        with tape.recording(), torch.no_grad():
+            traj = d.optimize(v, p * 10, s, t, res_feat, pair_feat, gen, mres)
+        for _ in range(6):
+            tape.log.pop(0)                                    # add_noise draws (rot: 4, pos: 1, seq: 1)
+        _step_draws(tape, N, L, t, out)
+        out[f't{t}_probs'] = tape.cat_probs[1].reshape(N, L, 20)
+        out[f'in{t}_v'], out[f'in{t}_p'], out[f'in{t}_s'] = traj[t]
+        out[f'out{t}_v'], out[f'out{t}_p'], out[f'out{t}_s'] = traj[t - 1]
+    for k, a in out.items():
+        assert torch.isfinite(a.float()).all() and (a.float().abs().max() < 100 or k.endswith('_bin')), k
+    save('steps_T100_abdesign', **out)
+
+
 def case_encode():
     m = abdock_model(10, seed=3)
     batch = synth.make_batch(2, synth.LAYOUT_128, seed=99, lengths=[24, 19])
@@ -555,7 +711,7 @@ if __name__ == '__main__':
     sys.path.insert(0, os.path.join(REF, 'AbDock'))
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['so3', 'ga_block', 'eps_net', 'schedule_tables', 'trajectory', 'structonly', 'abdesign_sample',
-                             'training', 'training_abdesign', 'encode', 'rank', 'reconstruct', 'posterior', 'dockq', 'dockq_edge']
+                             'training', 'training_abdesign', 'seqdesign', 'training_seqonly', 'steps_T100', 'encode', 'rank', 'reconstruct', 'posterior', 'dockq', 'dockq_edge']
     for w in which:
         print('==', w)
         globals()['case_' + w]()

@@ -118,3 +118,25 @@ def test_testset_summary_exchange_world2():
     out = mgr.dict()
     mp.spawn(_object_worker, args=(2, port, out), nprocs=2, join=True)
     assert out[0] == out[1] == [(0, 0, [0, 1]), (1, 0, [1, 2]), (2, 0, [2, 3]), (3, 1, [3, 4]), (4, 1, [4, 5])]      # contiguous blocks: rank 0 owns 0..2
+
+
+def test_launch_rng_ranges_never_overlap():
+    """launches of a test set with different padded lengths must own disjoint Philox counter ranges (sample and optimize)."""
+    from ab_opt_amd.sampler import launch_rng_offset, complexes_of_rank
+    import random
+    rnd = random.Random(5)
+    for trial in range(50):
+        n, S, G = rnd.randint(1, 40), rnd.randint(1, 16), rnd.choice([1, 2, 4, 8])
+        lens = [rnd.randint(20, 300) for _ in range(n)]
+        L_all = max(lens)
+        for world in (1, 2, 8):
+            ranges = []
+            for r in range(world):
+                own = complexes_of_rank(n, world, r)
+                for lo in range(0, len(own), G):
+                    ids = own[lo:lo + G]
+                    L = max(lens[c] for c in ids)
+                    base = launch_rng_offset(ids[0], S, L_all)
+                    ranges.append((base, base + 2 * len(ids) * S * L))          # optimize(): add_noise at base, the loop G S L behind it
+            ranges.sort()
+            assert all(a[1] <= b[0] for a, b in zip(ranges, ranges[1:])), (trial, world, ranges)

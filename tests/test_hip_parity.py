@@ -758,7 +758,7 @@ def test_commonness_score_vs_reference():
 
 
 # ------------------------------------------------------------------------------------------ categorical transition, pinned directly
-def _device_step_with_posterior(d, t, state, res_feat, pair_feat, gen, mres, noise_t, optimize_mode=False, sample_sequence=True):
+def _device_step_with_posterior(d, t, state, res_feat, pair_feat, gen, mres, noise_t, optimize_mode=False, sample_sequence=True, sample_structure=True):
     """eps_net + abopt_denoise_step(want_post) for step t from `state` (v, p_angstrom, s); returns (post, out dict)."""
     from ab_opt_amd import hip
     N, L = mres.shape
@@ -766,7 +766,7 @@ def _device_step_with_posterior(d, t, state, res_feat, pair_feat, gen, mres, noi
     p_norm = (state[1] - d.position_mean) / d.position_scale
     beta = d.trans_pos.var_sched.betas[t].expand([N]).contiguous()
     net = hip.eps_net_forward(d.eps_net.packed(), state[0], p_norm, state[2], res_feat, pair_feat, beta, gen, mres, d.abdock, d.num_bins, False)
-    sp = d._step_params(t, True, sample_sequence, not optimize_mode, optimize_mode)
+    sp = d._step_params(t, sample_structure, sample_sequence, not optimize_mode, optimize_mode)
     out = dict(v=torch.empty(N, L, 3, device=DEV), p=torch.empty(N, L, 3, device=DEV), s=torch.empty(N, L, dtype=torch.int64, device=DEV),
                prmsd=torch.empty(N, device=DEV), ppl=torch.empty(N, device=DEV))
     inv = d.trans_rot.angular_distrib_inv
@@ -948,15 +948,21 @@ def test_eps_net_bench_geometry_vs_oracle(flavour, N):
               ubin=torch.rand(N, L, device=DEV, generator=gtor), gauss=torch.randn(N, L, device=DEV, generator=gtor),
               z=torch.randn(N, L, 3, device=DEV, generator=gtor), s_next=torch.randint(0, 20, (N, L), device=DEV, generator=gtor))
     seq = flavour == 'abdesign'
-    tv, tp, ts, tpr, tpp = d._run((v.clone(), p * 10, s.clone()), t, rf, pf, gen, mres, True, seq, True, {t: nz}, 0, 0, False, stop_after=1)
-    v_n, p_n, s_n, ex = den.step(t, c(v), c(p * 10) / 10, c(s), c(rf), c(pf), c(gen), c(mres), {k: c(a) for k, a in nz.items()}, sample_sequence=seq)
-    assert max_abs(tp[t - 1][ix].cpu(), p_n * 10) < 1e-4
-    e = dpm.so3_noise(den.tab_inv, torch.full((len(ids), L), t), {k: c(a) for k, a in nz.items()})
-    n, worst = rot_close(tv[t - 1][ix].cpu(), v_n, G.so3_exp(e) @ G.so3_exp(ex['eps_out'][0]), R_upstream=ex['eps_out'][1])
-    assert n >= 0.9 * len(ids) * L and worst < 1.0, (n, worst)
-    assert torch.equal(ts[t - 1][ix].cpu(), s_n)
-    if d.abdock:
-        assert max_abs(tpr[t - 1][ix].cpu(), ex['prmsd']) < 1e-4 and max_abs(tpp[t - 1][ix].cpu(), ex['ppl']) < 1e-5
+    cn = {k: c(a) for k, a in nz.items()}
+    # t = 63 / 100: histogram rows of the inverse IGSO(3) table; t = 21 / 2: its Gaussian branch (so3.py:127-135), 20 of the sampler's 100 steps
+    for t in (63, 2, 21, 100):
+        tv, tp, ts, tpr, tpp = d._run((v.clone(), p * 10, s.clone()), t, rf, pf, gen, mres, True, seq, True, {t: nz}, 0, 0, False, stop_after=1)
+        v_n, p_n, s_n, ex = den.step(t, c(v), c(p * 10) / 10, c(s), c(rf), c(pf), c(gen), c(mres), cn, sample_sequence=seq)
+        assert max_abs(tp[t - 1][ix].cpu(), p_n * 10) < 1e-4, t
+        e = dpm.so3_noise(den.tab_inv, torch.full((len(ids), L), t), cn)
+        if t in (2, 21):
+            sd_t = inv.stddevs[t]
+            assert bool(inv.approx_flag[t]) and max_abs(e.norm(dim=-1), (2 * sd_t + cn['gauss'] * sd_t).abs() % math.pi) < 1e-6
+        n, worst = rot_close(tv[t - 1][ix].cpu(), v_n, G.so3_exp(e) @ G.so3_exp(ex['eps_out'][0]), R_upstream=ex['eps_out'][1])
+        assert n >= 0.9 * len(ids) * L and worst < 1.0, (t, n, worst)
+        assert torch.equal(ts[t - 1][ix].cpu(), s_n)
+        if d.abdock:
+            assert max_abs(tpr[t - 1][ix].cpu(), ex['prmsd']) < 1e-4 and max_abs(tpp[t - 1][ix].cpu(), ex['ppl']) < 1e-5, t
 
 
 def test_non_contiguous_inputs_keep_their_copies_alive():
@@ -2066,3 +2072,196 @@ def test_key_split_core_vs_unsplit_and_oracle(N, L, lengths, monkeypatch):
     assert max_abs(c(split['R_next']), ref[1]) < 3e-5
     assert max_abs(c(split['eps_pos']), ref[2]) < 3e-5
     assert max_abs(c(split['c']), ref[3]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ sequence-design mode (seq_design.yml / fixbb.yml)
+def _tables_inv(d_cpu):
+    inv = d_cpu.trans_rot.angular_distrib_inv
+    return (None, dict(stddevs=inv.stddevs, approx_flag=inv.approx_flag, X=inv.X, Y=None))
+
+
+def test_sequence_design_steps_teacher_forced_vs_reference():
+    """AbDock/configs/test/seq_design.yml:4-6 (sample_structure=False, sample_sequence=True, contig; per pose from optimize_ab.py:14-36):
+    every one of the 10 recorded reference steps.  The structure must be handed on untouched (dpm_full.py:294-295), the posterior is
+    the reference's at 2e-6, the sequence follows the injected draws; encode() of this mode and the init state as well; then the
+    whole model.sample() on the device RNG path."""
+    from ab_opt_amd import hip
+    from ab_opt_amd.model import generate_mask_from_str
+    g = load_golden('trajectory_abdock_T10_seqdesign')
+    _, m, batch = _traj_setup()
+    d = m.diffusion
+    b = {k: dev(v) for k, v in batch.items()}
+    gen = torch.logical_and(b['generate_flag'], generate_mask_from_str('31-36', b['generate_flag']))
+    assert torch.equal(gen.cpu(), g['gen'])
+    b['generate_flag'] = gen
+    with torch.no_grad():
+        rf, pf, R0, p0 = m.encode(dict(b), False, True)                      # remove_structure=False (diffab.py:132-136)
+    assert max_abs(rf.cpu(), g['res_feat']) < 2e-4 * g['res_feat'].abs().max().item()
+    assert max_abs(pf.cpu()[:, ::7, ::5], g['pair_feat_sub']) < 2e-4 * g['pair_feat_sub'].abs().max().item()
+    assert max_abs(R0.cpu(), g['R0']) < 1e-5 and max_abs(p0.cpu(), g['p0']) == 0
+    rf, mres = dev(g['res_feat']), b['mask']
+    v0 = hip.so3_log(dev(g['R0']), False)
+    v_i, p_i, s_i = hip.sample_init(v0, dev(g['p0']), b['aa'], gen, dict(s=dev(g['init_s'])), 0, 0, 10.0, [0.0, 0.0, 0.0], False, True)
+    assert torch.equal(v_i, v0) and max_abs(p_i.cpu(), g['traj10_p']) < 1e-5 and torch.equal(s_i.cpu(), g['traj10_s'])
+    for t in range(10, 0, -1):
+        state = (dev(g[f'traj{t}_v']), dev(g[f'traj{t}_p']), dev(g[f'traj{t}_s']))
+        noise_t = {k: dev(g[f't{t}_{k}']) for k in ('axis', 'bin', 'ubin', 'gauss', 'z', 's_next')}
+        tv, tp, ts, tpr, tpp = d._run(tuple(a.clone() for a in state), t, rf, pf, gen, mres, False, True, True, {t: noise_t}, 0, 0, False, stop_after=1)
+        assert torch.equal(tv[t - 1], state[0]) and torch.equal(tv[t - 1].cpu(), g[f'traj{t - 1}_v']), t     # bit for bit
+        assert max_abs(tp[t - 1].cpu(), g[f'traj{t - 1}_p']) < 2e-6 and max_abs(tp[t - 1], state[1]) < 2e-6, t
+        assert torch.equal(ts[t - 1].cpu(), g[f'traj{t - 1}_s']), t
+        assert max_abs(tpr[t - 1].cpu(), g[f'traj{t - 1}_prmsd']) < 1e-4 and max_abs(tpp[t - 1].cpu(), g[f'traj{t - 1}_ppl']) < 1e-5, t
+        post, out = _device_step_with_posterior(d, t, state, rf, pf, gen, mres, noise_t, sample_structure=False)
+        assert max_abs(post.cpu() + 1e-8, g[f't{t}_probs']) < 2e-6, t
+        assert torch.equal(out['v'], state[0])
+    # the whole call on the device's own RNG: structure untouched from t = 10 to 0, context sequence untouched, designed residues valid
+    bb = {k: dev(v) for k, v in batch.items()}
+    traj = m.sample(bb, sample_opt=dict(sample_structure=False, sample_sequence=True, contig='31-36'))
+    assert torch.equal(bb['generate_flag'], gen)
+    genc = gen.cpu()
+    for t in (10, 5, 0):
+        assert torch.equal(traj[t][0].cpu(), v0.cpu()), t
+        assert max_abs(traj[t][1].cpu(), g['p0']) < 1e-4, t
+        assert torch.equal(traj[t][2].cpu()[~genc], batch['aa'][~genc]), t
+        sg = traj[t][2].cpu()[genc]
+        assert bool(((sg >= 0) & (sg < 20)).all())
+
+
+def test_fixbb_abdesign_steps_teacher_forced_vs_reference():
+    """AbDesign/configs/test/fixbb.yml:7 mode at FullDPM level (A/.../dpm_full.py:193-254 with sample_structure=False): 10 recorded steps."""
+    g = load_golden('trajectory_abdesign_T10_fixbb')
+    d = standalone_abdesign_dpm(10, 4).to(DEV)
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(2, 40, [40, 33], [(5, 14), (22, 30)], num_steps=10, t=3)
+    rf, pf, gen, mres = dev(res_feat), dev(pair_feat), dev(gen), dev(mres)
+    for t in range(10, 0, -1):
+        state = (dev(g[f'traj{t}_v']), dev(g[f'traj{t}_p']), dev(g[f'traj{t}_s']))
+        noise_t = {k: dev(g[f't{t}_{k}']) for k in ('axis', 'bin', 'ubin', 'gauss', 'z', 's_next')}
+        tv, tp, ts, _, _ = d._run(tuple(a.clone() for a in state), t, rf, pf, gen, mres, False, True, True, {t: noise_t}, 0, 0, False, stop_after=1)
+        assert torch.equal(tv[t - 1].cpu(), g[f'traj{t - 1}_v']), t
+        assert max_abs(tp[t - 1].cpu(), g[f'traj{t - 1}_p']) < 2e-6, t
+        assert torch.equal(ts[t - 1].cpu(), g[f'traj{t - 1}_s']), t
+        post, _ = _device_step_with_posterior(d, t, state, rf, pf, gen, mres, noise_t, sample_structure=False)
+        assert max_abs(post.cpu() + 1e-8, g[f't{t}_probs']) < 2e-6, t
+    traj = d.sample(dev(v), dev(p) * 10, dev(s), rf, pf, gen, mres, sample_structure=False, sample_sequence=True, seed=3)
+    assert torch.equal(traj[0][0].cpu(), v) and max_abs(traj[0][1].cpu(), p * 10) < 1e-4
+    assert torch.equal(traj[0][2].cpu()[~gen.cpu()], s[~gen.cpu()])
+
+
+@pytest.mark.parametrize('flavour', ['abdock', 'abdesign'])
+def test_training_sequence_only_vs_reference(flavour):
+    """train_structure=False, train_sequence=True (AbDock/configs/train/seq_design.yml:11-12; dpm_full.py:163-178): the structure enters
+    un-noised, eps_p = 0, the one draw of the mode (s_noisy) injected; losses (2e-5 rel) and gradients (3e-4 of max) against the
+    reference's recorded values, both trees; add_noise's categorical against the recorded multinomial input."""
+    from ab_opt_amd import hip
+    from test_oracle_golden import _sub
+    g = load_golden(f'training_seqonly_{flavour}')
+    d = (build_model(100, 2, device=DEV).diffusion if flavour == 'abdock' else standalone_abdesign_dpm(100, 2).to(DEV)).train()
+    d.zero_grad()
+    N, L = 2, 48
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(N, L, [48, 41], [(6, 17), (30, 37)], salt=300)
+    s = s.clamp(max=19)
+    res_feat = dev(res_feat).clone().requires_grad_(True)
+    pair_feat = dev(pair_feat).clone().requires_grad_(True)
+    tt = torch.tensor([37, 80], device=DEV)
+    vs, h = d.trans_pos.var_sched, d._sched_host()
+    v_n, p_n, s_n, eps, probs = hip.add_noise(tt, vs.alpha_bars, d.trans_rot.angular_distrib_fwd, dict(s_noisy=dev(g['s_noisy'])), 0, 0, dev(v), dev(p) * 10,
+                                              dev(s), dev(gen), h['scale'], h['mean'], noise_structure=False, noise_sequence=True, grad_mode=True,
+                                              want_eps=True, want_probs=True)
+    assert torch.equal(v_n.cpu(), v) and max_abs(p_n.cpu(), p * 10) < 2e-6 and not eps.any() and torch.equal(s_n.cpu(), g['s_noisy'])
+    assert max_abs(probs.cpu() + 1e-8, g['addnoise_probs']) < 1e-7
+    loss = d(dev(v), dev(p) * 10, dev(s), res_feat, pair_feat, dev(gen), dev(mres), False, True, t=tt, noise=dict(s_noisy=dev(g['s_noisy'])))
+    assert set(loss) == ({'prmsd', 'dist', 'rot', 'pos', 'seq'} if flavour == 'abdock' else {'rot', 'pos', 'seq'})
+    for k, val in loss.items():
+        ref = g['loss_' + k].item()
+        assert abs(val.item() - ref) <= 2e-5 * max(1.0, abs(ref)), (k, val.item(), ref)
+    sum(loss.values()).backward()
+    params = dict(d.named_parameters())
+    n = 0
+    for k in g:
+        if k.startswith('grad_eps_net'):
+            got = _sub(params[k[len('grad_'):]].grad.cpu(), g[k])
+            assert max_abs(got, g[k]) <= 3e-4 * g[k].abs().max().item() + 1e-7, k
+            n += 1
+    assert n == 11
+    assert max_abs(res_feat.grad.cpu(), g['grad_res_feat']) <= 3e-4 * g['grad_res_feat'].abs().max().item()
+    assert max_abs(pair_feat.grad.cpu()[:, ::5, ::3], g['grad_pair_feat_sub']) <= 3e-4 * g['grad_pair_feat_sub'].abs().max().item()
+    d.zero_grad()
+
+
+# ------------------------------------------------------------------------------------------ the headline schedule, T = 100
+@pytest.mark.parametrize('flavour', ['abdock', 'abdesign'])
+def test_single_steps_T100_vs_reference(flavour):
+    """Recorded reference steps of the T = 100 sampler at t = 100, 64, 22 (last histogram row of the inverse IGSO(3) distribution), 21, 10, 2
+    (its Gaussian branch |2 sigma + sigma randn| mod pi, so3.py:127-135: t = 2..21, 20 of the 100 steps) and 1 (no noise), both trees,
+    draws injected into abopt_denoise_step: positions 1e-4 A, orientations under rot_close, posterior 2e-6."""
+    from oracle import dpm, geometry as G
+    from test_oracle_golden import STEP_TS, step_noise
+    g = load_golden(f'steps_T100_{flavour}')
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(2, 40, [40, 33], [(5, 14), (22, 30)], num_steps=100, t=3)
+    if flavour == 'abdock':
+        full = build_model(100, 2)
+        d_cpu, d = full.diffusion, build_model(100, 2, device=DEV).diffusion
+        den = dpm.Denoiser(full.state_dict(), num_steps=100, variant='abdock', obj='pred_x0', mode='mm', tables=_tables_inv(d_cpu))
+        a, b = 'traj{}', 'traj{}'
+    else:
+        d_cpu, d = standalone_abdesign_dpm(100, 2), standalone_abdesign_dpm(100, 2).to(DEV)
+        den = dpm.Denoiser(d_cpu.state_dict(), num_steps=100, variant='abdesign', pre='', mode='mm', tables=_tables_inv(d_cpu))
+        a, b = 'in{}', 'out{}'
+    rf, pf, gend, mresd = dev(res_feat), dev(pair_feat), dev(gen), dev(mres)
+    worst_p = 0.0
+    for t in STEP_TS:
+        i, o = a.format(t), b.format(t - 1 if flavour == 'abdock' else t)
+        nz = step_noise(g, t)
+        state = (dev(g[i + '_v']), dev(g[i + '_p']), dev(g[i + '_s']))
+        noise_t = {k: dev(x) for k, x in nz.items()}
+        tv, tp, ts, tpr, tpp = d._run(tuple(x.clone() for x in state), t, rf, pf, gend, mresd, True, True, True, {t: noise_t}, 0, 0, False, stop_after=1)
+        e = dpm.so3_noise(den.tab_inv, torch.full((2, 40), t), nz)
+        if t <= 1:
+            e = torch.zeros_like(e)
+        ref = den._eps(g[i + '_v'], den.norm(g[i + '_p']), g[i + '_s'], res_feat, pair_feat, den.sch['betas'][t].expand([2]), gen, mres, False)
+        n, worst = rot_close(tv[t - 1].cpu(), g[o + '_v'], G.so3_exp(e) @ G.so3_exp(ref[0]), R_upstream=ref[1])
+        assert n >= 70 and worst < 1.0, (t, n, worst)
+        dp = max_abs(tp[t - 1].cpu(), g[o + '_p'])
+        worst_p = max(worst_p, dp)
+        assert dp < 1e-4, (t, dp)
+        assert torch.equal(ts[t - 1].cpu(), g[o + '_s']), t
+        if flavour == 'abdock':
+            assert max_abs(tpr[t - 1].cpu(), g[o + '_prmsd']) < 1e-4 and max_abs(tpp[t - 1].cpu(), g[o + '_ppl']) < 1e-5, t
+        post, _ = _device_step_with_posterior(d, t, state, rf, pf, gend, mresd, noise_t)
+        assert max_abs(post.cpu() + 1e-8, g[f't{t}_probs']) < 2e-6, t
+    print('worst T=100 step position error (Angstrom):', worst_p)
+
+
+@pytest.mark.parametrize('t', [10, 21, 2])
+def test_inverse_igso3_gaussian_branch_on_device_rng(t):
+    """The device's OWN draws where the inverse IGSO(3) distribution takes its Gaussian branch (sigma_t <= 0.1: t = 2..21 at T = 100):
+    theta = |2 sigma + sigma N(0,1)| mod pi (so3.py:127-135), chi-square against the folded normal; no histogram bin is involved."""
+    from ab_opt_amd import hip
+    d = build_model(100, 2, device=DEV).diffusion
+    N, L = 64, 256
+    sp = d._step_params(t, True, True, True)
+    inv = d.trans_rot.angular_distrib_inv
+    sig = float(inv.stddevs[t])
+    assert sp.igso3_gaussian == 1 and 0 < sig <= 0.1
+    z3 = torch.zeros(N, L, 3, device=DEV)
+    c_net = torch.full((N, L, 20), 0.05, device=DEV)
+    s_t = torch.zeros(N, L, dtype=torch.int64, device=DEV)
+    gen = torch.ones(N, L, dtype=torch.bool, device=DEV)
+    out = dict(v=torch.empty(N, L, 3, device=DEV), p=torch.empty(N, L, 3, device=DEV), s=torch.empty(N, L, dtype=torch.int64, device=DEV),
+               prmsd=torch.empty(N, device=DEV), ppl=torch.empty(N, device=DEV))
+    # a CDF row of NaNs: the branch must not read it
+    hip.denoise_step(sp, None, 4321, 0, z3, z3, s_t, z3, z3, c_net, torch.zeros(N, 40, device=DEV), gen, inv.X[t], torch.full((8191,), float('nan'), device=DEV), 40, out)
+    theta = out['v'].norm(dim=-1).flatten().cpu().double()              # v_next = log(exp(e) exp(0)) = e
+    assert bool(torch.isfinite(theta).all())
+    Phi = lambda x: 0.5 * (1 + torch.erf(x / math.sqrt(2)))
+    edges = torch.linspace(0, 6 * sig, 33, dtype=torch.float64)
+    lo, hi = edges[:-1], edges[1:]
+    probs = Phi((hi - 2 * sig) / sig) - Phi((lo - 2 * sig) / sig) + Phi((-lo - 2 * sig) / sig) - Phi((-hi - 2 * sig) / sig)
+    hist = torch.histc(theta, bins=32, min=0.0, max=6 * sig)
+    expected = probs * theta.numel()
+    keep = expected > 20
+    chi2 = (((hist - expected) ** 2 / expected)[keep]).sum().item()
+    assert chi2 < 3 * int(keep.sum()), (t, chi2)
+    assert abs(theta.mean().item() - 2 * sig) < 0.02 * sig + 0.05 * sig            # folded tail moves the mean by 0.0085 sigma
+    axis = (out['v'] / out['v'].norm(dim=-1, keepdim=True)).reshape(-1, 3).cpu()
+    assert axis.mean(0).abs().max() < 0.02

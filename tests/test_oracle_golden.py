@@ -229,6 +229,162 @@ def test_trajectory_abdesign_T10():
     _traj_check(traj, g, 10, False, tol_R=1e-6, tol_p=1e-6)
 
 
+STEP_KEYS = ('axis', 'bin', 'ubin', 'gauss', 'z', 's_next')
+STEP_TS = (100, 64, 22, 21, 10, 2, 1)
+
+
+def step_noise(g, t, pre=''):
+    return {k: g[f'{pre}t{t}_{k}'] for k in STEP_KEYS}
+
+
+def ref_tables(dpm_module):
+    """(fwd, inv) IGSO(3) tables of a product FullDPM as the oracle's dicts (the 1024-term series takes 9 s per table to rebuild;
+    the product's init-time buffers are themselves pinned to the reference by test_model_buffers_match_reference)."""
+    r = dpm_module.trans_rot
+    return tuple(dict(stddevs=a.stddevs, approx_flag=a.approx_flag, X=a.X, Y=a.Y) for a in (r.angular_distrib_fwd, r.angular_distrib_inv))
+
+
+def test_state_dict_abdock_matches_reference_key_list():
+    """identical state_dict keys, shapes and ORDER (207 entries for AbDock), and a reference-shaped checkpoint loads
+    strictly."""
+    import json, os
+    from conftest import GOLDEN
+    ref = json.load(open(os.path.join(GOLDEN, 'state_dict_abdock.json')))
+    m = build_model(100, 2)
+    sd = m.state_dict()
+    assert len(ref) == 207 and list(ref) == list(sd)
+    assert all(list(sd[k].shape) == shp for k, shp in ref.items())
+    ckpt = {k: torch.zeros(shp, dtype=sd[k].dtype) for k, shp in ref.items()}
+    from ab_opt_amd import get_model
+    m2 = get_model(synth.AttrDict(synth.cfg_abdock(100)))
+    res = m2.load_state_dict(ckpt, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict({k: v for k, v in ckpt.items() if 'proj_pair_bias' not in k}, strict=True)
+
+
+def test_trajectory_seqdesign_abdock_T10():
+    """seq_design.yml mode (sample_structure=False, sample_sequence=True, contig): every recorded step of the reference's run."""
+    g = load_golden('trajectory_abdock_T10_seqdesign')
+    m = build_model(10, 3)
+    batch = synth.make_batch(2, synth.LAYOUT_128, seed=2022, lengths=[128, 117])
+    from ab_opt_amd.model import generate_mask_from_str
+    gen = torch.logical_and(batch['generate_flag'], generate_mask_from_str('31-36', batch['generate_flag']))      # diffab.py:125-129
+    assert torch.equal(gen, g['gen'])
+    batch['generate_flag'] = gen
+    sd = m.state_dict()
+    rf, pf, R0, p0 = embed.encode(sd, batch, False, True)                 # the structure stays in the features in this mode
+    assert max_abs(rf, g['res_feat']) < 2e-5 and max_abs(pf[:, ::7, ::5], g['pair_feat_sub']) < 2e-5
+    assert max_abs(R0, g['R0']) < 1e-6 and max_abs(p0, g['p0']) == 0
+    den = dpm.Denoiser(sd, num_steps=10, variant='abdock', obj='pred_x0', mode='ref', tables=ref_tables(m.diffusion))
+    nz = {t: step_noise(g, t) for t in range(10, 0, -1)}
+    nz['init'] = dict(q4=None, p=None, s=g['init_s'])
+    v0 = G.so3_log(R0)
+    traj = den.sample(v0, p0, batch['aa'], rf, pf, gen, batch['mask'], nz, sample_structure=False, sample_sequence=True)
+    assert torch.equal(traj[10][2][gen], g['init_s'][gen]) and torch.equal(traj[10][2][~gen], batch['aa'][~gen])
+    for t in range(10, -1, -1):
+        assert torch.equal(traj[t][0], v0), t                             # dpm_full.py:294-295: the structure is handed on untouched
+        assert max_abs(G.so3_exp(traj[t][0]), G.so3_exp(g[f'traj{t}_v'])) < 1e-6, t
+        assert max_abs(traj[t][1], g[f'traj{t}_p']) < 1e-6 and max_abs(traj[t][1], p0) < 1e-5, t
+        assert torch.equal(traj[t][2], g[f'traj{t}_s']), t
+        if t < 10:
+            assert max_abs(traj[t][3], g[f'traj{t}_prmsd']) < 1e-4 and max_abs(traj[t][4], g[f'traj{t}_ppl']) < 1e-5, t
+    for t in range(10, 0, -1):                                            # the categorical the reference sampled from, every step
+        _, _, _, ex = den.step(t, g[f'traj{t}_v'], den.norm(g[f'traj{t}_p']), g[f'traj{t}_s'], rf, pf, gen, batch['mask'], nz[t],
+                               sample_structure=False)
+        assert max_abs(ex['post'] + 1e-8, g[f't{t}_probs']) < 1e-7, t
+
+
+def test_trajectory_fixbb_abdesign_T10():
+    """AbDesign fixbb.yml mode at FullDPM level (A/.../dpm_full.py:193-254 with sample_structure=False)."""
+    g = load_golden('trajectory_abdesign_T10_fixbb')
+    m = standalone_abdesign_dpm(10, 4)
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(2, 40, [40, 33], [(5, 14), (22, 30)], num_steps=10, t=3)
+    den = dpm.Denoiser(m.state_dict(), num_steps=10, variant='abdesign', pre='', tables=ref_tables(m))
+    nz = {t: step_noise(g, t) for t in range(10, 0, -1)}
+    nz['init'] = dict(q4=None, p=None, s=g['init_s'])
+    traj = den.sample(v, p * 10, s, res_feat, pair_feat, gen, mres, nz, sample_structure=False, sample_sequence=True)
+    for t in range(10, -1, -1):
+        assert torch.equal(traj[t][0], v) and torch.equal(traj[t][0], g[f'traj{t}_v']), t
+        assert max_abs(traj[t][1], g[f'traj{t}_p']) < 1e-6, t
+        assert torch.equal(traj[t][2], g[f'traj{t}_s']), t
+    for t in range(10, 0, -1):
+        _, _, _, ex = den.step(t, g[f'traj{t}_v'], den.norm(g[f'traj{t}_p']), g[f'traj{t}_s'], res_feat, pair_feat, gen, mres, nz[t],
+                               sample_structure=False)
+        assert max_abs(ex['post'] + 1e-8, g[f't{t}_probs']) < 1e-7, t
+
+
+@pytest.mark.parametrize('flavour', ['abdock', 'abdesign'])
+def test_training_sequence_only_loss_and_grads(flavour):
+    """train_structure=False, train_sequence=True (configs/train/seq_design.yml:11-12; dpm_full.py:163-178): losses + gradients."""
+    g = load_golden(f'training_seqonly_{flavour}')
+    if flavour == 'abdock':
+        full = build_model(100, 2)
+        m, pre = full.diffusion, 'diffusion.'
+        sd0 = full.state_dict()
+    else:
+        m, pre = standalone_abdesign_dpm(100, 2), ''
+        sd0 = m.state_dict()
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and 'eps_net' in k) for k, v in sd0.items()}
+    N, L = 2, 48
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(N, L, [48, 41], [(6, 17), (30, 37)], salt=300)
+    s = s.clamp(max=19)
+    res_feat = res_feat.clone().requires_grad_(True)
+    pair_feat = pair_feat.clone().requires_grad_(True)
+    den = dpm.Denoiser(sd, num_steps=100, variant=flavour, obj='pred_x0', pre=pre, tables=ref_tables(m))
+    t = torch.tensor([37, 80])
+    assert max_abs(dpm.seq_add_noise_probs(den.sch, s, gen, t) + 1e-8, g['addnoise_probs']) < 1e-7
+    with torch.enable_grad():
+        loss = den.loss(v, p * 10, s, res_feat, pair_feat, gen, mres, t, dict(rot=None, pos=None, s_noisy=g['s_noisy']),
+                        denoise_structure=False, denoise_sequence=True)
+        sum(loss.values()).backward()
+    assert set(loss) == ({'prmsd', 'dist', 'rot', 'pos', 'seq'} if flavour == 'abdock' else {'rot', 'pos', 'seq'})
+    for k in loss:
+        ref = g['loss_' + k].item()
+        assert abs(loss[k].item() - ref) <= 1e-5 * max(1.0, abs(ref)), (k, loss[k].item(), ref)
+    n = 0
+    for k in g:
+        if k.startswith('grad_eps_net'):
+            got = _sub(sd[pre + k[len('grad_'):]].grad, g[k])
+            assert max_abs(got, g[k]) <= 2e-4 * g[k].abs().max().item() + 1e-7, k
+            n += 1
+    assert n == 11
+    assert max_abs(res_feat.grad, g['grad_res_feat']) <= 2e-4 * g['grad_res_feat'].abs().max().item()
+    assert max_abs(pair_feat.grad[:, ::5, ::3], g['grad_pair_feat_sub']) <= 2e-4 * g['grad_pair_feat_sub'].abs().max().item()
+
+
+@pytest.mark.parametrize('flavour', ['abdock', 'abdesign'])
+def test_single_steps_T100_vs_reference(flavour):
+    """The headline schedule (T = 100): recorded reference steps at t = 100, 64, 22 (last histogram row of the inverse IGSO(3)
+    distribution), 21, 10, 2 (Gaussian branch, so3.py:127-135) and 1 (no noise), both trees, 1e-6."""
+    g = load_golden(f'steps_T100_{flavour}')
+    v, p, s, res_feat, pair_feat, _, gen, mres = cases.eps_inputs(2, 40, [40, 33], [(5, 14), (22, 30)], num_steps=100, t=3)
+    if flavour == 'abdock':
+        full = build_model(100, 2)
+        den = dpm.Denoiser(full.state_dict(), num_steps=100, variant='abdock', obj='pred_x0', mode='ref', tables=ref_tables(full.diffusion))
+        a, b = 'traj{}', 'traj{}'
+    else:
+        m = standalone_abdesign_dpm(100, 2)
+        den = dpm.Denoiser(m.state_dict(), num_steps=100, variant='abdesign', pre='', mode='ref', tables=ref_tables(m))
+        a, b = 'in{}', 'out{}'
+    assert [bool(x) for x in den.tab_inv['approx_flag'][[100, 64, 22, 21, 10, 2, 1]]] == [False, False, False, True, True, True, True]      # sigma_1 = 0: flagged, but t = 1 adds no noise
+    for t in STEP_TS:
+        i, o = a.format(t), b.format(t - 1 if flavour == 'abdock' else t)
+        nz = step_noise(g, t)
+        v_n, p_n, s_n, ex = den.step(t, g[i + '_v'], den.norm(g[i + '_p']), g[i + '_s'], res_feat, pair_feat, gen, mres, nz)
+        assert max_abs(G.so3_exp(v_n), G.so3_exp(g[o + '_v'])) < 1e-6, t
+        assert max_abs(den.unnorm(p_n), g[o + '_p']) < 1e-6, t
+        assert torch.equal(s_n, g[o + '_s']), t
+        assert max_abs(ex['post'] + 1e-8, g[f't{t}_probs']) < 1e-7, t
+        if flavour == 'abdock':
+            assert max_abs(ex['prmsd'], g[o + '_prmsd']) < 1e-4 and max_abs(ex['ppl'], g[o + '_ppl']) < 1e-5, t
+        if t in (21, 10, 2):                           # the branch under test really decides the angle here
+            sd_t = den.tab_inv['stddevs'][t]
+            th = (2 * sd_t + nz['gauss'] * sd_t).abs() % math.pi
+            e = dpm.so3_noise(den.tab_inv, torch.full((2, 40), t), nz)
+            assert max_abs(e.norm(dim=-1), th) < 1e-6
+
+
 def test_training_loss_and_grads():
     g = load_golden('training_abdock')
     m = build_model(100, 2)
