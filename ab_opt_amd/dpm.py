@@ -273,7 +273,7 @@ class FullDPM(nn.Module):
         # dpm_full.py:351-358: the loop feeds the net's third output to the position update as noise whatever `obj` is,
         # and averages the perplexity over all residues (calc_perplexity(logits) without a mask)
         out = self._run(state, opt_step, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, False,
-                        noise, seed, rng_offset + N * v.shape[1], pbar, optimize_mode=True, use_bias_cache=use_bias_cache, graph=graph)
+                        noise, seed, rng_offset, pbar, optimize_mode=True, use_bias_cache=use_bias_cache, graph=graph)     # same counters as add_noise, other sub-sequence tags (csrc/denoise.hip): a sample's stream position does not depend on the batch it sits in
         traj = self._to_traj(opt_step, *out, first_extra=lambda s_: (torch.zeros_like(s_), torch.ones_like(s_)))
         return {k: tuple(e) for k, e in traj.items()}
 

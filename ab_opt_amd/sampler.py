@@ -151,7 +151,7 @@ def pad_complex(one, L):
 
 
 @torch.no_grad()
-def sample_grouped(model, complexes, num_samples, sample_opt=None, optimize_step=None):
+def sample_grouped(model, complexes, num_samples, sample_opt=None, optimize_step=None, pad_to=None):
     """`num_samples` samples of EACH of G complexes in one launch (BASELINE config 4: a rank's leg of a test set).
 
     The reference designs a test set one structure at a time (AbDock/src/tools/runner/design_for_testset.py:556-589), each with its
@@ -159,11 +159,13 @@ def sample_grouped(model, complexes, num_samples, sample_opt=None, optimize_step
     length like PaddingCollate does) are encoded ONCE each as a batch of G, and the sampler runs G x num_samples samples as one batch
     whose samples share the pair features of their complex (`abopt_eps_net_forward(pair_feat_shared = num_samples)`): the kernels see
     full-size launches instead of G small ones, and z is read from HBM once per complex and query block, not once per sample.
-    Sample g * num_samples + s is sample s of complex g.  Returns the trajectory dict of `model.sample` (batch dim G * num_samples)."""
+    Sample g * num_samples + s is sample s of complex g.  pad_to: pad to this length instead of the longest complex of the launch (the
+    test-set driver passes the longest complex of the whole set, see `launch_rng_offset`).  Returns the trajectory dict of `model.sample`
+    (batch dim G * num_samples)."""
     from . import hip
     sample_opt = dict(sample_opt or {'sample_structure': True, 'sample_sequence': True})
     sample_opt.pop('contig', None)
-    L = max(int(c['aa'].shape[1]) for c in complexes)
+    L = max(max(int(c['aa'].shape[1]) for c in complexes), int(pad_to or 0))
     padded = [pad_complex(c, L) for c in complexes]
     batch = {k: (torch.cat([c[k][:1] for c in padded], 0) if torch.is_tensor(v) else v) for k, v in padded[0].items()}
     res_feat, pair_feat, R_0, p_0 = model.encode(batch, remove_structure=sample_opt.get('sample_structure', True),
@@ -177,13 +179,14 @@ def sample_grouped(model, complexes, num_samples, sample_opt=None, optimize_step
     return model.diffusion.optimize(*args, optimize_step, res_feat, pair_feat, *masks, **sample_opt)
 
 
-def launch_rng_offset(first_complex, samples_per_complex, L_max):
-    """Philox counter base of the launch whose first complex is `first_complex`.  A launch of G complexes x S samples padded to L <= L_max
-    reads counters base + n L + l (n < G S, l < L) in sample(), and up to base + 2 G S L in optimize() (the loop's draws sit G S L behind
-    add_noise's, dpm.py: FullDPM.optimize), so a stride of 2 S L_max per complex gives the launch [base, base + 2 G S L_max): the next
-    launch starts at or beyond its end whatever the two padded lengths are.  (A stride of S L with the launch's own L let a later,
-    shorter launch start inside an earlier, longer one: identical draws for samples of different complexes.)"""
-    return int(first_complex) * 2 * int(samples_per_complex) * int(L_max)
+def launch_rng_offset(first_complex, samples_per_complex, L_pad):
+    """Philox counter base of the launch whose first complex is `first_complex`.  The kernels read counter base + n L + l for sample n,
+    residue l of a launch padded to L (distinct sub-sequence tags for sample_init / add_noise / the loop's steps, csrc/denoise.hip), so
+    when EVERY launch of a test set is padded to the same L_pad (the longest complex of the whole set) the launches' ranges
+    [c0 S L_pad, (c0 + G) S L_pad) tile the counter space: no two samples share a draw, and sample s of complex c reads
+    (c S + s) L_pad + l however the complexes are grouped into launches or spread over ranks.  (With each launch padded to its OWN longest
+    complex a later, shorter launch started inside an earlier, longer one's range: identical draws for samples of different complexes.)"""
+    return int(first_complex) * int(samples_per_complex) * int(L_pad)
 
 
 @torch.no_grad()
@@ -198,10 +201,10 @@ def design_testset_sharded(model, complexes, samples_per_complex, sample_opt=Non
     the commonness score, optionally scores them against the native structure (DockQ on the device), and the per-complex summaries
     (a few hundred bytes each) are exchanged once at the end with all_gather_object.
 
-    complexes: list of batch dicts with batch dim 1.  The Philox stream position of a sample depends on the index of its launch's first
-    complex, on the longest complex of the WHOLE test set (`launch_rng_offset`: every launch owns a counter range no other launch can
-    reach, whatever the padded lengths) and on its position in the launch, so results do not depend on the number of ranks as long as
-    the launches group the same complexes (complexes_per_launch divides the per-rank count, or is 1).
+    complexes: list of batch dicts with batch dim 1.  Every launch is padded to the longest complex of the WHOLE test set, so the Philox
+    stream position of a sample depends on its global index (complex x samples_per_complex + sample) alone (`launch_rng_offset`): no two
+    samples share a draw, and positions / sequences do not depend on the number of ranks or on `complexes_per_launch` (padding never
+    reaches a real residue; AbDock's prmsd score averages over the padded length like a PaddingCollate batch does, dpm_full.py:110).
     native (optional): dict(pos (L,A,3), mask (L,A)) per complex, or True to score against the complex's own input coordinates.
     -> list (one entry per complex, in input order, identical on every rank) of
     dict(complex=index, rank=owner, top=LongTensor(k), score=Tensor(S), ca=final CA positions of the generated residues (S, n_gen, 3)
@@ -216,9 +219,9 @@ def design_testset_sharded(model, complexes, samples_per_complex, sample_opt=Non
     for lo in range(0, len(own), G):
         ids = own[lo:lo + G]
         chunk = [complexes[c] for c in ids]
-        L = max(int(c['aa'].shape[1]) for c in chunk)
+        L = L_all
         opt = dict(sample_opt, seed=int(seed), rng_offset=launch_rng_offset(ids[0], S, L_all))
-        traj = sample_grouped(model, chunk, S, opt, optimize_step=optimize_step)
+        traj = sample_grouped(model, chunk, S, opt, optimize_step=optimize_step, pad_to=L_all)
         p_fin = traj[0][1]
         for g, c in enumerate(ids):
             one = pad_complex(complexes[c], L)

@@ -186,22 +186,38 @@ class AttrDict(dict):
 
 
 _MODELS = {}
+_MODEL_FP = {}            # fingerprint of every cached model as built (tests/conftest.py checks after each test that nobody changed or moved it)
+
+
+def model_fingerprint(m, device):
+    import torch
+    with torch.no_grad():
+        ts = list(m.parameters()) + list(m.buffers())
+        assert all(t.device.type == torch.device(device).type for t in ts), 'a cached model was moved to another device (module.to() works in place)'
+        return float(sum(t.double().abs().sum() for t in ts if t.is_floating_point()).item())
+
+
+def fresh_model(num_steps, seed, flavour='abdock', device='cpu'):
+    """A NEW get_model(cfg) of the dock_single / codesign_single model block with hash-filled weights (the same fill the reference got when
+    the golden vectors were made): for callers that change weights or move the module."""
+    from .. import get_model
+    cfg = cfg_abdock(num_steps)
+    if flavour == 'abdesign':
+        for k in ('num_bins', 'dist_min', 'dist_max'):
+            cfg.pop(k)
+        cfg['diffusion'].pop('obj')
+    m = get_model(AttrDict(cfg)).eval()
+    fill_module_(m, seed=seed)
+    return m.to(device)
 
 
 def build_model(num_steps, seed, flavour='abdock', device='cpu'):
-    """get_model(cfg) of the dock_single / codesign_single model block with hash-filled weights (the same fill the reference got
-    when the golden vectors were made); cached per (num_steps, seed, flavour, device)."""
-    from .. import get_model
+    """fresh_model, cached per (num_steps, seed, flavour, device): every caller of a session shares ONE module -- do not write to its
+    weights and do not call .to() on it (tests/conftest.py checks the fingerprint after every test)."""
     key = (num_steps, seed, flavour, str(device))
     if key not in _MODELS:
-        cfg = cfg_abdock(num_steps)
-        if flavour == 'abdesign':
-            for k in ('num_bins', 'dist_min', 'dist_max'):
-                cfg.pop(k)
-            cfg['diffusion'].pop('obj')
-        m = get_model(AttrDict(cfg)).eval()
-        fill_module_(m, seed=seed)
-        _MODELS[key] = m.to(device)
+        _MODELS[key] = fresh_model(num_steps, seed, flavour, device)
+        _MODEL_FP[key] = model_fingerprint(_MODELS[key], device)
     return _MODELS[key]
 
 

@@ -413,6 +413,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         assert torch.isfinite(tp[T - K]).all()
+        local_times.append(dt)                 # this rank's own clock (the reported time is the MAX over ranks)
         if dist is not None:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -422,7 +423,7 @@ def main():
     # ---- the timed region, R times.  Eager mode: HIP events around every IPA-core launch inside it.  Graph mode: host-recorded
     # event pairs cannot live in a replayed graph, so the kernel is timed in ONE extra eager pass of the same K steps right after
     # the repeats (same process, same box, same clocks), unless --graph-events put the records into the graph itself.
-    times, launches, ipa_ms = [], 0, 0.0
+    times, launches, ipa_ms, local_times = [], 0, 0.0, []
     for r in range(R):
         times.append(timed_pass(use_graph, events=not args.no_prof))
         if not use_graph and not args.no_prof:
@@ -433,6 +434,15 @@ def main():
             launches, ipa_ms = launches + n_, ipa_ms + ms_
     hip.prof_enable(False)
     log('timed region x%d: %s ms per step' % (R, ', '.join('%.4f' % (t / K * 1e3) for t in times)))
+    # who took part: every rank's device and its OWN median step time, gathered through the process group the timing used -- a SCALE line
+    # can be checked at a glance (all ranks present, one device each, nobody far off the others)
+    ranks_seen = None
+    if dist is not None:
+        prop = torch.cuda.get_device_properties(dev)
+        mine = dict(rank=rank, device=local_dev, name=prop.name, pci_bus_id=getattr(prop, 'pci_bus_id', None), uuid=str(getattr(prop, 'uuid', '')) or None,
+                    ms_per_step=round(sorted(local_times[:R])[R // 2] / K * 1e3, 4))
+        ranks_seen = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks_seen, mine)
     instrumented, eager_events = None, None
     if use_graph and not graph_events and not args.no_prof:
         # (i) one more replay of the SAME graph, its dominant-kernel launches timed by their in-kernel wall-clock spans (first workgroup in,
@@ -517,7 +527,8 @@ def main():
                        'samples_per_gpu': N, 'residues': L, 'sampler_steps': T, 'parallelism': f'independent samples x{world}',
                        'launch': ('hipGraph replay of the K-step loop (captured once, before the timed region; Philox position from device memory)'
                                   if use_graph else 'eager launches'),
-                       'backend': backend, 'ranks_per_device': (world + ndev - 1) // ndev if world > 1 else 1},
+                       'backend': backend, 'ranks_per_device': (world + ndev - 1) // ndev if world > 1 else 1,
+                       'ranks': ranks_seen, 'ranks_note': None if ranks_seen is None else 'gathered through the process group: device and OWN median ms_per_step of every rank (the line\'s ms_per_step is the max over ranks per repeat)'},
             'roofline': {'bound': 'hbm', 'kernel': kernel_name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src, 'launches': launches,
                          'avg_launch_ms': round(per_launch_ms, 4), 'timing': timing, 'instrumented_ms_per_step': instrumented, 'eager_events': eager_events,

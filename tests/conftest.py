@@ -36,3 +36,16 @@ def model_factory():
 
 def max_abs(a, b):
     return (a.double() - b.double()).abs().max().item()
+
+
+@pytest.fixture(autouse=True)
+def _cached_models_stay_as_built():
+    """`build_model` hands every test of the session the SAME module per (num_steps, seed, flavour, device): a test that rewrites one of its
+    weights or calls .to() on it silently changes the inputs of every later test (round 5: a fixture comparison failed only in the full
+    suite, behind a test that had overwritten pair_embed.aapair_to_distcoef of the shared model).  Checked after every test against the
+    fingerprint taken when the model was built."""
+    from ab_opt_amd.utils import synth
+    yield
+    for k, m in synth._MODELS.items():
+        fp, ref = synth.model_fingerprint(m, k[3]), synth._MODEL_FP[k]
+        assert abs(fp - ref) <= 1e-9 * max(1.0, abs(ref)), f'this test changed the weights of the session\'s cached model {k}: use synth.fresh_model(...) for a model you change'

@@ -89,3 +89,54 @@ def ddp_fused_adam_worker(rank, world, port, outdir):
         torch.save(dict(losses=losses, params=sd, refused=refused), os.path.join(outdir, f'ddpadam_{rank}.pt'))
     finally:
         dist.destroy_process_group()
+
+
+def two_device_worker(rank, world, port, outdir):
+    """ONE DEVICE PER RANK over RCCL (backend 'nccl'): what the driver's N > 1 bench and a multi-GPU node run.  Skipped by its test on a
+    one-GPU box.  (i) sharded sampling + the by-complex test-set driver: results must equal the single-process run bit for bit;
+    (ii) DistributedDataParallel(nccl, find_unused_parameters=False, static_graph=True) + FusedAdam: two eager steps, then the WHOLE step
+    (forward, backward with its bucketed all-reduce, clipping + Adam) captured by training.GraphedTrainStep and replayed twice --
+    replicas stay in lock step."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    dev = torch.device('cuda', rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    try:
+        from conftest import build_model
+        from ab_opt_amd import sampler, training
+        from ab_opt_amd.utils import synth
+        m = build_model(10, 3, device=dev)
+        b = {k: v.to(dev) for k, v in synth.make_batch(5, synth.LAYOUT_128, seed=11, replicate=True).items()}
+        traj, (a, e), top, cand = sampler.sample_sharded(m, b, dict(sample_structure=True, sample_sequence=True, contig=''), k=2, seed=42)
+        cx = [{k: v.to(dev) for k, v in synth.make_batch(1, synth.LAYOUT_128, seed=100 + c).items()} for c in range(3)]
+        res = sampler.design_testset_sharded(m, cx, 4, k=2, seed=7, complexes_per_launch=1)
+        out = dict(a=a, e=e, top=top.cpu(), cand=cand.cpu(), p0=traj[0][1].cpu(), testset=res)
+        # ---- data-parallel training, AbDesign flavour (every parameter takes part in every step: no unused-parameter search needed)
+        md = build_model(10, 5, flavour='abdesign', device=dev).train()
+        ddp = sampler.wrap_ddp(md, dev, find_unused_parameters=False, static_graph=True)
+        opt = training.FusedAdam(ddp.parameters(), lr=1e-3)
+        full = synth.make_batch(2, synth.LAYOUT_128, seed=5, lengths=[64, 57])
+        mine = {k: v[rank:rank + 1].to(dev) for k, v in full.items()}
+        losses = []
+        for it in range(2):
+            torch.manual_seed(100 + it)
+            opt.zero_grad(set_to_none=True)
+            loss = sum(ddp(dict(mine)).values())
+            loss.backward()
+            opt.step(max_grad_norm=100.0)
+            losses.append(loss.item())
+        graph_error = None
+        try:
+            gstep = training.GraphedTrainStep(ddp, opt, mine, max_grad_norm=100.0)
+            for it in range(2):
+                losses.append(float(sum(gstep(mine).values()).item()))
+            gstep.close()
+        except Exception as ex:                 # reported, asserted by the test: the eager result is still compared
+            graph_error = repr(ex)
+        out.update(losses=losses, graph_error=graph_error, params={n: p.detach().cpu() for n, p in md.named_parameters()},
+                   backend=dist.get_backend(), device=torch.cuda.current_device())
+        torch.save(out, os.path.join(outdir, f'twodev_{rank}.pt'))
+    finally:
+        dist.destroy_process_group()

@@ -121,22 +121,27 @@ def test_testset_summary_exchange_world2():
 
 
 def test_launch_rng_ranges_never_overlap():
-    """launches of a test set with different padded lengths must own disjoint Philox counter ranges (sample and optimize)."""
+    """launches of a test set whose complexes differ in length must own disjoint Philox counter ranges, and a sample's
+    counters must not depend on how the complexes are grouped into launches or spread over ranks (every launch is padded to the longest
+    complex of the set; sample_init / add_noise / the loop's steps read base + n L + l under different sub-sequence tags)."""
     from ab_opt_amd.sampler import launch_rng_offset, complexes_of_rank
     import random
     rnd = random.Random(5)
     for trial in range(50):
-        n, S, G = rnd.randint(1, 40), rnd.randint(1, 16), rnd.choice([1, 2, 4, 8])
+        n, S = rnd.randint(1, 40), rnd.randint(1, 16)
         lens = [rnd.randint(20, 300) for _ in range(n)]
         L_all = max(lens)
-        for world in (1, 2, 8):
+        first = {}
+        for world, G in ((1, 1), (1, 8), (2, 4), (8, 2), (8, 8)):
             ranges = []
             for r in range(world):
                 own = complexes_of_rank(n, world, r)
                 for lo in range(0, len(own), G):
                     ids = own[lo:lo + G]
-                    L = max(lens[c] for c in ids)
+                    assert ids == list(range(ids[0], ids[0] + len(ids)))       # contiguous: sample n of the launch is complex ids[0] + n // S
                     base = launch_rng_offset(ids[0], S, L_all)
-                    ranges.append((base, base + 2 * len(ids) * S * L))          # optimize(): add_noise at base, the loop G S L behind it
+                    ranges.append((base, base + len(ids) * S * L_all))
+                    for g, c in enumerate(ids):
+                        assert first.setdefault(c, base + g * S * L_all) == base + g * S * L_all == c * S * L_all
             ranges.sort()
-            assert all(a[1] <= b[0] for a, b in zip(ranges, ranges[1:])), (trial, world, ranges)
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])) and ranges[0][0] == 0, (trial, world, ranges)
