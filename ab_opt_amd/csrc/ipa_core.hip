@@ -41,7 +41,7 @@ __device__ long long g_core_timing[3][8];
 #else
 #define TSTAMP(k)
 #define TSYNC(kw, kb) __syncthreads();
-#if defined(PERSIST_TIMING) || defined(C32_TIMING)   // developer builds: per-role clocks of one workgroup
+#if defined(PERSIST_TIMING) || defined(C32_TIMING) || defined(C32_COUNT)   // developer builds: per-role clocks of one workgroup
 #include <cstdio>
 __device__ long long g_core_timing[3][8];
 #endif
@@ -890,11 +890,21 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
 #ifndef C32_RING
 #define C32_RING 3       // slots of the pair waves' z ring (3 or 4)
 #endif
+#ifndef C32_LAZY
+#define C32_LAZY 0       // skip the accumulator rescale of a row (pair waves) / a (head, row tile) (C waves) whose factors are all exactly 1 (wave-uniform; bit-identical)
+#endif
+#ifdef C32_COUNT      // developer build: how often a lazy rescale could skip (printed by the launcher): {pair row-chunks, of them unchanged, C (head, tile, chunk), unchanged, C chunks (6 heads x 32 rows), unchanged}
+__device__ unsigned long long g_c32_count[8];
+#define C32_CNT(k, v) if (lane == 0) atomicAdd(&g_c32_count[k], (unsigned long long)(v));
+#else
+#define C32_CNT(k, v)
+#endif
 #ifndef C32_ABL
-#define C32_ABL 0        // developer ablations (timing only, results wrong): 1 no z / bias loads in the loop | 32 z / bias loads all from one L1-resident address | 64 no softmax arithmetic in rows 1..7 (P = S) | 128 no pair MFMAs | 256 / 512 no A / C MFMAs (nothing instead) | 2 no fragment loads in the loop | 4 / 8 / 16 pair / A / C MFMAs off
+#define C32_ABL 0        // developer ablations (timing only, results wrong): 1 no z / bias loads in the loop | 32 z / bias loads all from one L1-resident address | 64 no softmax arithmetic in rows 1..7 (P = S) | 128 no pair MFMAs | 256 / 512 no A / C MFMAs (nothing instead) | 2 no fragment loads in the loop | 4 / 8 / 16 pair / A / C MFMAs off | 1024 no accumulator rescale (pair and C waves) | 2048 no v_exp_f32 in rows 1..7
 #endif
 constexpr int BI2 = 32, NPW2 = 4, RPW2 = BI2 / NPW2, NTH2 = 512, HPW = 6;
 
+#define C32_EXP2(x) ((C32_ABL & 2048) ? (x) : __builtin_amdgcn_exp2f(x))      // (ablation 2048: no v_exp_f32 in rows 1..7)
 #ifdef C32_OLDMASK
 #define C32_L2(x, r) (((mk4_ >> (8 * (r))) & 0xffu) ? (x) * kScale2 : (x) * kScale2 - kMask2)
 #else
@@ -1227,9 +1237,9 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         const float mn_ = fmaxf(ml_.x, mx_);                                                                             \
         scn_ = __builtin_amdgcn_exp2f(ml_.x - mn_);                                                                      \
         P2_MF(SLOT, II, 5)                                                                                               \
-        pvn_[0] = __builtin_amdgcn_exp2f(l2_[0] - mn_); pvn_[1] = __builtin_amdgcn_exp2f(l2_[1] - mn_);                  \
+        pvn_[0] = C32_EXP2(l2_[0] - mn_); pvn_[1] = C32_EXP2(l2_[1] - mn_);                                              \
         P2_MF(SLOT, II, 6)                                                                                               \
-        pvn_[2] = __builtin_amdgcn_exp2f(l2_[2] - mn_); pvn_[3] = __builtin_amdgcn_exp2f(l2_[3] - mn_);                  \
+        pvn_[2] = C32_EXP2(l2_[2] - mn_); pvn_[3] = C32_EXP2(l2_[3] - mn_);                                              \
         float ps_ = (pvn_[0] + pvn_[1]) + (pvn_[2] + pvn_[3]);                                                           \
         P2_MF(SLOT, II, 7)                                                                                               \
         { auto a_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(ps_), __float_as_uint(ps_), false, false);          \
@@ -1243,15 +1253,22 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         P2_MF(SLOT, II, 10)                                                                                              \
         if (kq == 0) { scl[((CHPAR) * BI2 + il_) * SCLD + fm] = scn_; *reinterpret_cast<float2*>(mlw + ((II) + 1) * 32) = make_float2(mn_, ln_); } \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
+        /* C32_LAZY & 1: no running maximum of this row moved in this chunk (every factor exactly 1) -> the 16 multiplications change */ \
+        /* nothing and are skipped (wave-uniform); they then run as one group behind the row's last MFMAs instead of between them     */ \
+        if (C32_LAZY & 1) {                                                                                              \
+        P2_MF(SLOT, II, 11) P2_MF(SLOT, II, 12) P2_MF(SLOT, II, 13) P2_MF(SLOT, II, 14) P2_MF(SLOT, II, 15)              \
+        if ((__builtin_amdgcn_ballot_w64(scn_ != 1.f) & 0x0fff0fff0fff0fffull) != 0ull) {                                \
+            accP[(II) + 1][0] *= scn_; accP[(II) + 1][1] *= scn_; accP[(II) + 1][2] *= scn_; accP[(II) + 1][3] *= scn_; } \
+        } else {                                                                                                         \
         P2_MF(SLOT, II, 11)                                                                                              \
-        accP[(II) + 1][0] *= scn_;                                                                                       \
+        if (!(C32_ABL & 1024)) accP[(II) + 1][0] *= scn_;                                                                \
         P2_MF(SLOT, II, 12)                                                                                              \
-        accP[(II) + 1][1] *= scn_;                                                                                       \
+        if (!(C32_ABL & 1024)) accP[(II) + 1][1] *= scn_;                                                                \
         P2_MF(SLOT, II, 13)                                                                                              \
-        accP[(II) + 1][2] *= scn_;                                                                                       \
+        if (!(C32_ABL & 1024)) accP[(II) + 1][2] *= scn_;                                                                \
         P2_MF(SLOT, II, 14)                                                                                              \
-        accP[(II) + 1][3] *= scn_;                                                                                       \
-        P2_MF(SLOT, II, 15) }                                                                                            \
+        if (!(C32_ABL & 1024)) accP[(II) + 1][3] *= scn_;                                                                \
+        P2_MF(SLOT, II, 15) } }                                                                                          \
     }
         // the last row of a chunk: nothing to overlap with (the next chunk's logits are behind the barrier)
 #define P2_POS_LAST(SLOT, II, CH)                                                                                        \
@@ -1276,7 +1293,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         const int CHPAR = (CH) & 1;                                                                                      \
         f32x4 pvn_; float scn_;                                                                                          \
         P2_SM(0, K)                                                                                                      \
-        _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[0][mt_] *= scn_;                                        \
+        if (!(C32_ABL & 1024) && !((C32_LAZY & 1) && (__builtin_amdgcn_ballot_w64(scn_ != 1.f) & 0x0fff0fff0fff0fffull) == 0ull)) { _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[0][mt_] *= scn_; } \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
         P2_POS(P2_SLOT(K, 0), 0, CH, K) P2_POS(P2_SLOT(K, 1), 1, CH, K) P2_POS(P2_SLOT(K, 2), 2, CH, K) P2_POS(P2_SLOT(K, 3), 3, CH, K) \
         P2_POS(P2_SLOT(K, 4), 4, CH, K) P2_POS(P2_SLOT(K, 5), 5, CH, K) P2_POS(P2_SLOT(K, 6), 6, CH, K) P2_POS_LAST(P2_SLOT(K, 7), 7, CH) \
@@ -1482,6 +1499,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) vf[B][s_] = fr_[s_ * 64]; }
         auto consume = [&](int c, int buf) {
             const int par = c & 1;
+            unsigned long long anych_ = 0ull;
 #pragma unroll
             for (int hh = 0; hh < HPW; ++hh) {
                 const int h = h0 + hh;
@@ -1490,7 +1508,10 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                 for (int rt = 0; rt < 2; ++rt) {
                     const float sc = scl[(par * BI2 + rt * 16 + fm) * SCLD + h];
                     const f32x4 pa = *reinterpret_cast<const f32x4*>(sp + (buf * BI2 + rt * 16 + fm) * SROW + sp_off(h, kq));
-                    accV[hh][rt][0] *= sc; accV[hh][rt][1] *= sc; accT[hh][rt][0] *= sc; accT[hh][rt][1] *= sc;
+                    C32_CNT(2, 1) C32_CNT(3, __builtin_amdgcn_ballot_w64(sc != 1.f) == 0ull)
+                    anych_ |= __builtin_amdgcn_ballot_w64(sc != 1.f);
+                    // (all 16 rows of the tile kept their running maximum of this head: factors exactly 1, nothing to rescale)
+                    if (!(C32_ABL & 1024) && !((C32_LAZY & 2) && __builtin_amdgcn_ballot_w64(sc != 1.f) == 0ull)) { accV[hh][rt][0] *= sc; accV[hh][rt][1] *= sc; accT[hh][rt][0] *= sc; accT[hh][rt][1] *= sc; }
                     if (C32_ABL & 512) { accV[hh][rt][0] += pa; }
                     else if (C32_ABL & 16) { accV[hh][rt][0] += vf[hh & 1][0] * pa; accV[hh][rt][1] += vf[hh & 1][1] * pa; accT[hh][rt][0] += vf[hh & 1][2] * pa; accT[hh][rt][1] += vf[hh & 1][3] * pa; }
                     else
@@ -1504,6 +1525,8 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            C32_CNT(4, 1) C32_CNT(5, anych_ == 0ull)
+            (void)anych_;
         };
         C2_ISSUE(0, 0, 0)
         fill_mask();
@@ -1835,6 +1858,18 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
                            core32_remap(N, z_shared), z_shared, TailArgs{}, prof::next_span_slot());
         prof::end(st);
         ABOPT_LAUNCH_CHECK();
+#ifdef C32_COUNT
+        {
+            static int calls = 0;
+            if (++calls % 60 == 0) {
+                unsigned long long h[8];
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_c32_count), sizeof(h));
+                fprintf(stderr, "[c32 count after %d launches] pair row-chunks %llu, unchanged %llu (%.1f %%) | C (head, tile, chunk) %llu, unchanged %llu (%.1f %%) | C chunks %llu, unchanged %llu (%.1f %%)\n",
+                        calls, h[0], h[1], 100.0 * h[1] / (h[0] + 1), h[2], h[3], 100.0 * h[3] / (h[2] + 1), h[4], h[5], 100.0 * h[5] / (h[4] + 1));
+            }
+        }
+#endif
 #ifdef C32_TIMING
         {
             long long h[3][8];
