@@ -333,12 +333,18 @@ int launch_colsum(const float* x, int ld, int64_t rows, int cols, float* out, fl
 // the [rows, buckets] one-hot matrix.  One wave walks its rows in order and adds each into its own LDS accumulator [nb][64] (lane = column);
 // the two waves of a workgroup, then the slices, are summed in a fixed order: deterministic.
 constexpr int BKT_MAX = 96;
+// Segmented use (abopt_segment_bucket_colsum): a slice IS a segment (its partial sums are the result), and the bucket of row j of segment s is
+// idx[(s / idx_div) * rows_per_slice + j] -- one index row shared by idx_div consecutive segments (the residue types of the key residues j for
+// every query residue i of a sample).  idx_div = 0: the plain form, idx[r].
 __global__ __launch_bounds__(128) void bucket_colsum_kernel(const float* __restrict__ x, int ld, int64_t rows, int cols, const int* __restrict__ idx, int nb,
-                                                            int64_t rows_per_slice, float* __restrict__ part) {
-    __shared__ float acc[2][BKT_MAX][64];
+                                                            int64_t rows_per_slice, float* __restrict__ part, int idx_div) {
+    extern __shared__ float bkt_acc_[];                            // [2][nb][64]: sized by the launch (22 buckets: 11 KB, 14 workgroups per CU; a fixed 96-bucket tile held a CU to three)
+    float (*acc)[64] = reinterpret_cast<float (*)[64]>(bkt_acc_);
+#define BKT_ACC(W_, B_) acc[(W_) * nb + (B_)]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
-    for (int b = 0; b < nb; ++b) acc[w][b][lane] = 0.f;
+    for (int b = 0; b < nb; ++b) BKT_ACC(w, b)[lane] = 0.f;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
+    if (idx_div > 0) idx += ((int64_t)(blockIdx.y / idx_div)) * rows_per_slice - r0;          // idx[r] below = index of row r - r0 of the shared index row
     if (c < cols) {
         // eight rows per trip: their indices and values are requested together (one row at a time the loop is a chain of memory round trips)
         int64_t r = r0 + w;
@@ -348,16 +354,17 @@ __global__ __launch_bounds__(128) void bucket_colsum_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 8; ++u) { bb[u] = __builtin_amdgcn_readfirstlane(idx[r + 2 * u]); v[u] = x[(r + 2 * u) * ld + c]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (bb[u] >= 0 && bb[u] < nb) acc[w][bb[u]][lane] += v[u];
+            for (int u = 0; u < 8; ++u) if (bb[u] >= 0 && bb[u] < nb) BKT_ACC(w, bb[u])[lane] += v[u];
         }
         for (; r < r1; r += 2) {
             const int b = __builtin_amdgcn_readfirstlane(idx[r]);
-            if (b >= 0 && b < nb) acc[w][b][lane] += x[r * ld + c];
+            if (b >= 0 && b < nb) BKT_ACC(w, b)[lane] += x[r * ld + c];
         }
     }
     __syncthreads();
     if (c < cols)
-        for (int b = w; b < nb; b += 2) part[((int64_t)blockIdx.y * nb + b) * cols + c] = acc[0][b][lane] + acc[1][b][lane];
+        for (int b = w; b < nb; b += 2) part[((int64_t)blockIdx.y * nb + b) * cols + c] = BKT_ACC(0, b)[lane] + BKT_ACC(1, b)[lane];
+#undef BKT_ACC
 }
 
 int launch_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const int* idx, int nb, float* out, float* ws, size_t ws_floats, hipStream_t st) {
@@ -371,13 +378,23 @@ int launch_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const i
     if (!ws) slices = 1;
     while (slices > 1 && (size_t)slices * nb * cols > ws_floats) --slices;
     const int64_t rps = (rows + slices - 1) / slices;
-    hipLaunchKernelGGL(bucket_colsum_kernel, dim3(cblocks, slices), dim3(128), 0, st, x, ld, rows, cols, idx, nb, rps, slices > 1 ? ws : out);
+    hipLaunchKernelGGL(bucket_colsum_kernel, dim3(cblocks, slices), dim3(128), (size_t)2 * nb * 64 * sizeof(float), st, x, ld, rows, cols, idx, nb, rps, slices > 1 ? ws : out, 0);
     ABOPT_LAUNCH_CHECK();
     if (slices > 1) {
         const int64_t n = (int64_t)nb * cols;
         launch_slab_sum(ws, out, n, slices, n, st);
         ABOPT_LAUNCH_CHECK();
     }
+    return ABOPT_OK;
+}
+
+int launch_segment_bucket_colsum(const float* x, int ld, int segments, int rows_per_segment, int cols, const int* idx, int idx_div, int nb, float* out, hipStream_t st) {
+    if (cols <= 0 || nb <= 0 || segments <= 0 || rows_per_segment <= 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(ld >= cols && nb <= BKT_MAX && idx_div >= 1 && segments <= 65535, "segment_bucket_colsum: segments=%d (max 65535) rows_per_segment=%d cols=%d ld=%d buckets=%d (max %d) idx_div=%d",
+                    segments, rows_per_segment, cols, ld, nb, BKT_MAX, idx_div);
+    hipLaunchKernelGGL(bucket_colsum_kernel, dim3((cols + 63) / 64, segments), dim3(128), (size_t)2 * nb * 64 * sizeof(float), st, x, ld, (int64_t)segments * rows_per_segment, cols, idx, nb,
+                       (int64_t)rows_per_segment, out, idx_div);
+    ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }
 
@@ -423,6 +440,12 @@ extern "C" int abopt_bucket_colsum(const float* x, int ld, int64_t rows, int col
                                    abopt_stream stream) {
     ABOPT_CHECK_ARG(x && out && idx, "bucket_colsum: NULL argument");
     return abopt::launch_bucket_colsum(x, ld, rows, cols, idx, buckets, out, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
+}
+
+extern "C" int abopt_segment_bucket_colsum(const float* x, int ld, int segments, int rows_per_segment, int cols, const int32_t* idx, int idx_div, int buckets,
+                                           float* out, abopt_stream stream) {
+    ABOPT_CHECK_ARG(x && out && idx, "segment_bucket_colsum: NULL argument");
+    return abopt::launch_segment_bucket_colsum(x, ld, segments, rows_per_segment, cols, idx, idx_div, buckets, out, (hipStream_t)stream);
 }
 
 extern "C" int abopt_colsum(const float* x, int ld, int64_t rows, int cols, float* out, void* ws, size_t ws_bytes, abopt_stream stream) {

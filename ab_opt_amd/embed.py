@@ -113,11 +113,12 @@ class _PairEmbedFn(torch.autograd.Function):
         dbo2, dbo1, dbo0, dbd1, dbd0 = (db[64 * k:64 * (k + 1)] for k in range(5))
         dwo2, dwo1, dwd1 = _splitk_tn(do2, o1), _splitk_tn(do1, o0), _splitk_tn(dh1, h0)
         # out_mlp.0 columns: [aa-pair embedding | relpos embedding x same-chain | f_dist | f_dih]
-        oh = F.one_hot(aa, nt).to(dout.dtype)
-        # sum over (n, i, j) by the pair of residue types (a of i, b of j).  i is contracted FIRST: x4[n] is then read in place as an
-        # [L, L c] matrix (contracting j first costs a permuted copy of the whole tensor -- 1 GB for ds)
-        pair_sum = lambda x4: torch.einsum('njb,najc->abc', oh, torch.bmm(oh.transpose(1, 2), x4.reshape(N, L, -1)).view(N, nt, L, -1)).reshape(nt * nt, -1)
-        s_aap = pair_sum(do0.reshape(N, L, L, C))
+        # sum over (n, i, j) by the pair of residue types (a of i, b of j): per (n, i) the key rows j summed by type(j) -- read in place, do0 is a
+        # column slice of dys --, then the (n, i) rows by type(i).  (Round 4 ran this as two one-hot batched products per operand through
+        # hipBLASLt plus a 268 MB contiguous copy of do0 and two permuted copies: 0.45 ms per config-5 step.)
+        aa32 = aa.clamp(0, nt - 1).to(torch.int32).contiguous()
+        pair_sum = lambda x2: hip.bucket_colsum(hip.segment_bucket_colsum(x2, N * L, aa32, L, nt).view(N * L, -1), aa32.view(-1), nt).view(nt * nt, -1)
+        s_aap = pair_sum(do0)
         rel = torch.clamp(res_nb[:, :, None] - res_nb[:, None, :], min=-ctx.max_relpos, max=ctx.max_relpos) + ctx.max_relpos
         same = chain_nb[:, :, None] == chain_nb[:, None, :]
         # rows summed by relative-position bucket (other-chain pairs skipped): abopt_bucket_colsum, no one-hot matrix
@@ -127,7 +128,7 @@ class _PairEmbedFn(torch.autograd.Function):
         dE_aap, dE_rel = s_aap @ wo0[:, :C], s_rel @ wo0[:, C:2 * C]
         unpad = lambda m: m.reshape(m.shape[0], A, 16)[:, :, :A].reshape(m.shape[0], A * A)          # [.., a, 16] -> [.., a*A + b]
         dwd0 = unpad(_splitk_tn(dh0, G.view(M, -1)))
-        dcoef = unpad(pair_sum(ds)) * torch.sigmoid(coef)
+        dcoef = unpad(pair_sum(ds.view(M, -1))) * torch.sigmoid(coef)
         return (None,) * 8 + (dE_aap, dE_rel, dcoef, None, dwd0, dbd0, dwd1, dbd1, dwo0, dbo0, dwo1, dbo1, dwo2, dbo2)
 
 

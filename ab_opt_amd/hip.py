@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -73,7 +73,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_dpm_losses', 'abopt_abdock_losses', 'abopt_layer_norm_forward', 'abopt_layer_norm_backward', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek', 'abopt_prof_clock', 'abopt_prof_spans_reset', 'abopt_prof_spans',
+           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_segment_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_dpm_losses', 'abopt_abdock_losses', 'abopt_layer_norm_forward', 'abopt_layer_norm_backward', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek', 'abopt_prof_clock', 'abopt_prof_spans_reset', 'abopt_prof_spans',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward', 'abopt_ipa_dz_assemble',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
@@ -864,9 +864,22 @@ def bucket_colsum(x, idx, buckets):
     if x.stride(1) != 1 or x.dtype != torch.float32 or not x.is_cuda or idx.dtype != torch.int32 or idx.numel() != rows:
         raise TypeError('bucket_colsum: fp32 [rows, cols] with unit column stride and an int32 index per row')
     out = torch.empty(buckets, cols, dtype=torch.float32, device=x.device)
-    ws = Workspace.get(2048 * buckets * max(cols, 64) * 4, x.device)
+    ws = Workspace.get(max(1, min(rows // 64, 2048 // ((cols + 63) // 64))) * buckets * cols * 4, x.device)      # the slices launch_bucket_colsum takes (gemm.hip)
     _check(lib().abopt_bucket_colsum(ptr(x, torch.float32, strided=True), x.stride(0), rows, cols, ptr(idx.contiguous(), torch.int32), buckets, ptr(out),
                                      ptr(ws), ws.numel(), stream()))
+    return out
+
+
+def segment_bucket_colsum(x, segments, idx, idx_div, buckets):
+    """x (2-D fp32 [segments * rows_per_segment, cols], unit column stride, read in place) -> [segments, buckets, cols]: per segment, the rows
+    summed by bucket; the bucket of row j of segment s is idx.flatten()[(s // idx_div) * rows_per_segment + j] (abopt_segment_bucket_colsum)."""
+    rows, cols = x.shape
+    rps = rows // segments
+    if x.stride(1) != 1 or x.dtype != torch.float32 or not x.is_cuda or idx.dtype != torch.int32 or rps * segments != rows or idx.numel() * idx_div != rows:
+        raise TypeError('segment_bucket_colsum: fp32 [segments * rows_per_segment, cols] with unit column stride and an int32 index row per idx_div segments')
+    out = torch.empty(segments, buckets, cols, dtype=torch.float32, device=x.device)
+    _check(lib().abopt_segment_bucket_colsum(ptr(x, torch.float32, strided=True), x.stride(0), segments, rps, cols, ptr(idx.contiguous(), torch.int32), idx_div, buckets,
+                                             ptr(out), stream()))
     return out
 
 

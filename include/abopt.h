@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 37
+#define ABOPT_ABI_VERSION 38
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -452,6 +452,15 @@ int abopt_colsum(const float* x, int ld, int64_t rows, int cols, float* out, voi
  * D/modules/encoders/pair.py:46-53 over its N L^2 pair rows -- without the [rows, buckets] one-hot matrix autograd builds.  Deterministic. */
 int abopt_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const int32_t* idx, int buckets, float* out, void* ws, size_t ws_bytes,
                         abopt_stream stream);
+
+/* The same sum per SEGMENT of rows_per_segment consecutive rows: out[(s*buckets + b)*cols + c] = sum over the rows j of segment s with bucket b of
+ * x[(s*rows_per_segment + j)*ld + c], where the bucket of row j of segment s is idx[(s / idx_div)*rows_per_segment + j] (idx_div consecutive
+ * segments share one index row).  With segment = (sample, query residue i), rows = key residues j and idx = the residue types of the sample this
+ * is the first half of the gradient of the amino-acid-pair tables of D/modules/encoders/pair.py:46-53,66 (aa_pair_embed, aapair_to_distcoef),
+ * summed over j by type(j); abopt_bucket_colsum over the (sample, i) rows by type(i) finishes it -- in place of the two one-hot batched products
+ * (and a 268 MB contiguous copy of the strided operand) autograd would run.  Deterministic.  buckets <= 96, segments <= 65535. */
+int abopt_segment_bucket_colsum(const float* x, int ld, int segments, int rows_per_segment, int cols, const int32_t* idx, int idx_div, int buckets,
+                                float* out, abopt_stream stream);
 
 /* ---- Training path: gradient clipping + Adam for a whole parameter list in a handful of launches.  Replaces, with the same arithmetic,
  *   orig_grad_norm = clip_grad_norm_(model.parameters(), config.train.max_grad_norm); optimizer.step()

@@ -1710,6 +1710,21 @@ def test_bucket_colsum_vs_index_add():
         assert torch.equal(out, hip.bucket_colsum(x, idx, nb))
     with pytest.raises(RuntimeError):
         hip.bucket_colsum(torch.zeros(4, 64, device=DEV), torch.zeros(4, dtype=torch.int32, device=DEV), 97)
+    # the segmented form + the plain one = the sum by PAIR of residue types (a of i, b of j) of the amino-acid-pair tables' gradients
+    # (pair.py:46-53,66 under autograd): against the one-hot contraction autograd would run, in fp64; strided operand read in place
+    for N, L, cols, ld in ((3, 37, 64, 320), (2, 64, 80, 80), (1, 5, 240, 240)):
+        nt = 22
+        y = torch.randn(N * L * L, ld, generator=g).to(DEV)
+        x = y[:, ld - cols:]
+        aa = torch.randint(0, nt, (N, L), generator=g).to(DEV)
+        aa32 = aa.to(torch.int32)
+        s1 = hip.segment_bucket_colsum(x, N * L, aa32, L, nt)
+        assert s1.shape == (N * L, nt, cols)
+        got = hip.bucket_colsum(s1.view(N * L, -1), aa32.view(-1), nt).view(nt, nt, cols)
+        oh = torch.nn.functional.one_hot(aa, nt).double()
+        ref = torch.einsum('nia,njb,nijc->abc', oh, oh, x.double().view(N, L, L, cols))
+        assert (got.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (N, L, cols)
+        assert torch.equal(s1, hip.segment_bucket_colsum(x, N * L, aa32, L, nt))
 
 
 # ------------------------------------------------------------------------------------------ round 3: graph replay, bench N>1 path, edge cases

@@ -11,7 +11,7 @@ dev = torch.device('cuda:0')
 model = build_model(100, 7, flavour='abdesign', device=dev).train()
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(N, LAYOUT_256).items()}
 opt = training.FusedAdam(model.parameters(), lr=1e-4)
-for _ in range(4):
+for _ in range(int(os.environ.get("STEPS", "4"))):
     opt.zero_grad(set_to_none=True)
     sum(model(dict(batch)).values()).backward()
     opt.step(max_grad_norm=100.0)
