@@ -118,3 +118,29 @@ def dockq_edge_cases():
         mods.append((m * 1000).round() / 1000)
     out.append(dict(name='collinear', pos=cpos, mask=cmask, group=cgroup, models=torch.stack(mods, 0), lrms_defined=False))
     return out
+
+
+def encode_full_batch():
+    """encode() at the size of BASELINE config 5's samples (L = 256, one full and one ragged complex, three chains, side chains on every
+    other residue, a missing backbone atom here and there): the batch of the `encode_L256` fixture (reference forward values and the
+    gradients of every embedding parameter)."""
+    L = 256
+    b = synth.make_batch(2, synth.LAYOUT_256, seed=98, lengths=[L, 201])
+    b['pos_heavyatom'][:, :, 5:] = b['pos_heavyatom'][:, :, 1:2] + synth.hash_tensor((2, L, 10, 3), 43, scale=3.0)
+    b['mask_heavyatom'][:, ::2, 5:12] = True
+    b['mask_heavyatom'][:, ::6, 3] = False
+    b['mask_heavyatom'] &= b['mask'][:, :, None]
+    return b
+
+
+def encode_full_distcoef(shape):
+    """aapair_to_distcoef is zero-initialised by the reference (pair.py:28); a trained model's is not: hash values for the fixture."""
+    return synth.hash_tensor(tuple(shape), 23, scale=2.0)
+
+
+ENCODE_FULL_PARAMS = ('pair_embed.aa_pair_embed.weight', 'pair_embed.relpos_embed.weight', 'pair_embed.aapair_to_distcoef.weight',
+                      'pair_embed.distance_embed.0.weight', 'pair_embed.distance_embed.0.bias', 'pair_embed.distance_embed.2.weight', 'pair_embed.distance_embed.2.bias',
+                      'pair_embed.out_mlp.0.weight', 'pair_embed.out_mlp.0.bias', 'pair_embed.out_mlp.2.weight', 'pair_embed.out_mlp.2.bias',
+                      'pair_embed.out_mlp.4.weight', 'pair_embed.out_mlp.4.bias',
+                      'residue_embed.aatype_embed.weight', 'residue_embed.type_embed.weight', 'residue_embed.mlp.0.bias', 'residue_embed.mlp.2.weight',
+                      'residue_embed.mlp.4.weight', 'residue_embed.mlp.6.weight', 'residue_embed.mlp.6.bias')

@@ -583,6 +583,24 @@ def case_encode():
     save('encode_small', res_feat=rf, pair_feat=pf, R0=R0, p0=p0, res_feat_seqkept=rf2, pair_feat_seqkept_sum=pf2.double().sum((1, 2)), **grads)
 
 
+def case_encode_full():
+    """encode() at config-5 sample size (L = 256): the reference's forward values (sub-sampled) and the gradients of EVERY embedding
+    parameter of d/dparams [<res_feat, w1> + <pair_feat, w2>] -- the training path of D/models/diffab.py:39-83 at the size the bench runs it
+    (round 4 pinned encode()'s backward only on the 24 / 19-residue fixture)."""
+    m = abdock_model(10, seed=3)
+    with torch.no_grad():
+        m.pair_embed.aapair_to_distcoef.weight.copy_(cases.encode_full_distcoef(m.pair_embed.aapair_to_distcoef.weight.shape))
+    batch = cases.encode_full_batch()
+    m.zero_grad()
+    rf, pf, R0, p0 = m.encode({k: v.clone() for k, v in batch.items()}, True, True)
+    w1, w2 = synth.hash_tensor(tuple(rf.shape), 71, scale=1.0), synth.hash_tensor(tuple(pf.shape), 72, scale=1.0)
+    ((rf * w1).sum() + (pf * w2).sum()).backward()
+    P = dict(m.named_parameters())
+    grads = {'grad_' + k.replace('.', '__'): P[k].grad for k in cases.ENCODE_FULL_PARAMS}
+    grads['grad_residue_embed__mlp__0__weight_sub'] = P['residue_embed.mlp.0.weight'].grad[::4, ::7]
+    save('encode_L256', res_feat=rf, pair_feat_sub=pf[:, ::9, ::7], pair_feat_sum=pf.double().sum((1, 2)), R0=R0, **grads)
+
+
 def case_reconstruct():
     """reconstruct_backbone_partially (geometry.py:404-480) on a ragged two-chain batch; also dumps the ideal backbone
     tables (constants.py:310-320: data, 21 residue types) the function reads."""
@@ -711,7 +729,7 @@ if __name__ == '__main__':
     sys.path.insert(0, os.path.join(REF, 'AbDock'))
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['so3', 'ga_block', 'eps_net', 'schedule_tables', 'trajectory', 'structonly', 'abdesign_sample',
-                             'training', 'training_abdesign', 'seqdesign', 'training_seqonly', 'steps_T100', 'encode', 'rank', 'reconstruct', 'posterior', 'dockq', 'dockq_edge']
+                             'training', 'training_abdesign', 'seqdesign', 'training_seqonly', 'steps_T100', 'encode', 'encode_full', 'rank', 'reconstruct', 'posterior', 'dockq', 'dockq_edge']
     for w in which:
         print('==', w)
         globals()['case_' + w]()

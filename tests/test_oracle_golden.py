@@ -574,3 +574,32 @@ def test_dockq_superposition_two_algorithms():
     mir = [c for c in all_cases if c['name'] == 'mirror'][0]
     assert g['mirror'][0][1].item() > 1.0
     assert 3 <= int(g['tiny_interface'][0][4]) <= 4
+
+
+def test_encode_L256_values_and_gradients():
+    """The oracle's encode() (values) and the plain torch statement of the two embedding modules under autograd (every parameter gradient)
+    against the reference's `encode_L256` fixture: config-5 sample size, side chains, ragged second complex."""
+    import plain_statement
+    g = load_golden('encode_L256')
+    m = synth.fresh_model(10, 3)
+    with torch.no_grad():
+        m.pair_embed.aapair_to_distcoef.weight.copy_(cases.encode_full_distcoef(m.pair_embed.aapair_to_distcoef.weight.shape))
+    batch = cases.encode_full_batch()
+    rf, pf, R0, _ = embed.encode(m.state_dict(), batch, True, True)
+    sc = g['pair_feat_sub'].abs().max().item()
+    assert max_abs(rf, g['res_feat']) < 1e-4 * g['res_feat'].abs().max().item() and max_abs(pf[:, ::9, ::7], g['pair_feat_sub']) < 1e-4 * sc
+    assert max_abs(R0, g['R0']) < 1e-6
+    m.zero_grad()
+    with torch.enable_grad():
+        rfg, pfg, _, _ = plain_statement.encode(m, {k: v.clone() for k, v in batch.items()}, True, True)
+        w1, w2 = synth.hash_tensor(tuple(rfg.shape), 71, scale=1.0), synth.hash_tensor(tuple(pfg.shape), 72, scale=1.0)
+        ((rfg * w1).sum() + (pfg * w2).sum()).backward()
+    P = dict(m.named_parameters())
+    checked = 0
+    for k in g:
+        if k.startswith('grad_'):
+            name = k[len('grad_'):].replace('__', '.')
+            got = P['residue_embed.mlp.0.weight'].grad[::4, ::7] if name.endswith('_sub') else P[name].grad
+            assert max_abs(got, g[k]) <= 3e-4 * max(1e-6, g[k].abs().max().item()), name
+            checked += 1
+    assert checked == len(cases.ENCODE_FULL_PARAMS) + 1
