@@ -98,3 +98,30 @@ def test_bf16_three_term_split_is_exact():
     exact = x.double() * w.double()
     rel = ((kept - exact).abs() / exact.abs().clamp_min(1e-300))[exact != 0]
     assert rel.max().item() < 2.0 ** -24
+
+
+def test_docs_cite_existing_tests_and_files():
+    """DESIGN.md / README.md / INTEGRATION.md / include/abopt.h must only cite tests that exist (the design document had drifted
+    from the tree), and every profiles/ or tools/ file DESIGN.md section 5 names must be in the tree.  DESIGN_LOG.md is history: not checked."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    defs, files = set(), set()
+    for f in glob.glob(os.path.join(root, 'tests', '*.py')):
+        files.add(os.path.basename(f)[:-3])
+        defs |= set(re.findall(r'^def (test_\w+)', open(f).read(), re.M))
+    missing = []
+    for doc in ('DESIGN.md', 'README.md', 'INTEGRATION.md', os.path.join('include', 'abopt.h')):
+        text = open(os.path.join(root, doc)).read()
+        for name in set(re.findall(r'\btest_[a-z0-9_]+\b', text)):
+            if name in defs or name in files:
+                continue
+            if name.endswith('_') and any(d.startswith(name) for d in defs):      # an abbreviated name ("test_block_tail_...")
+                continue
+            missing.append((doc, name))
+    assert not missing, missing
+    design = open(os.path.join(root, 'DESIGN.md')).read()
+    sec5 = design[design.index('## 5. Measurement'):design.index('## 6. Multi-GPU')]
+    for path in set(re.findall(r'`((?:profiles|tools)/[\w./\[\]*-]+)`', sec5)):
+        pat = re.sub(r'\[([^\]]*)\]', lambda m: '[' + m.group(1).replace('|', '') + ']', path)
+        assert glob.glob(os.path.join(root, pat)) or glob.glob(os.path.join(root, pat) + '*'), f'DESIGN.md section 5 cites {path}, which is not in the tree'
