@@ -12,8 +12,14 @@
 // layers.  Weights are re-laid out once per call into that fragment order ("swizzled": 1 KB contiguous per 16x16 block)
 // and streamed from L2 with fully coalesced loads.  The 225 Gaussian atom-pair features are produced directly in operand
 // layout (lane = (pair, 4 atoms of residue j), loop over the atoms of residue i).
-#include "abopt_common.h"
+#include "ipa_common.h"
 #include "kernels.h"
+
+// Developer switch (make CXXEXTRA=-DPE_TERMS=<mask>): which 64-wide products of pair_embed_kernel run on the bf16 matrix pipe as exact three-term
+// splits (node_frags.hip explains the arithmetic): 1 distance_embed.2 | 2 out_mlp.0, f_dist block | 4 out_mlp.0, dihedral block | 8 out_mlp.2 | 16 out_mlp.4
+#ifndef PE_TERMS
+#define PE_TERMS 0
+#endif
 
 namespace abopt {
 
@@ -256,6 +262,7 @@ struct PairArgs {
     const float* t_aap; const float* t_rel; const float* sp; const float* freq;
     const f32x4* wd0; const float* bd0; const f32x4* wd1; const float* bd1;
     const f32x4* wo0; const float* bo0; const f32x4* wo1; const float* bo1; const f32x4* wo2; const float* bo2;
+    const u32x4* wtd1; const u32x4* wto0; const u32x4* wtdh; const u32x4* wto1; const u32x4* wto2;   // the same 64-wide blocks as bf16 terms, [k-step][nt][term][lane] (PE_TERMS)
     float* out; int N, L, A, has_struct;
     float* gsave; float* tsave;   // training: Gaussian features and d/d softplus(coef), [pair][A][16] (b padded to 16), NULL for inference
     float* acts;          // training: per pair [relu(D0) 64 | f_dist 64 | f_dih 32 | relu(O0) 64 | relu(O1) 64] (PAIR_ACT floats), NULL for inference
@@ -274,6 +281,42 @@ constexpr int PMT = 4;        // 16-pair tiles per wave
                 _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt)                                                        \
                     DST[mt][nt] = mfma4e(w_[nt][q], SRC[mt][blk][q], DST[mt][nt]);                                        \
     }
+// The same layer on the bf16 matrix pipe.  K slot (kb = lane >> 4, e = 0..7) of k-step s is feature 16 (2 s + (e >> 2)) + 4 kb + (e & 3): the eight
+// values lane (pair, kb) holds in SRC[mt][2 s] and SRC[mt][2 s + 1], so the B operand is split3() of two accumulator quads -- still no cross-lane
+// traffic.  WT: [NSTEP][4 nt][3 terms][64 lanes] (swizzle_terms_kernel).  Six products per (tile, output tile, k-step), smallest terms first.
+#ifndef PE_DBG
+#define PE_DBG 0          // developer: 1 fences + 32 wait states around every split and product group | 2 the six products of an output tile interleaved over the four output tiles (no back-to-back dependent MFMAs)
+#endif
+#ifndef PE_NOPS
+#define PE_NOPS 32
+#endif
+#define PE_FENCE(B) { if (PE_DBG & (1 | (B))) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int n_ = 0; n_ < PE_NOPS; n_ += 4) asm volatile("s_nop 3" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } }      /* bits 4 / 8 / 16: only before the split / between split and products / after the products; PE_NOPS wait states */
+#define PAIR_DENSE_T(DST, SRC, WT, NSTEP)                                                                                 \
+    _Pragma("unroll") for (int s_ = 0; s_ < (NSTEP); ++s_) {                                                              \
+        u32x4 wt_[4][3];                                                                                                  \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
+            _Pragma("unroll") for (int sp_ = 0; sp_ < 3; ++sp_) wt_[nt][sp_] = (WT)[((s_ * 4 + nt) * 3 + sp_) * 64 + lane]; \
+        _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt) {                                                              \
+            PE_FENCE(4)                                                                                                   \
+            const Split3 xs_ = split3(SRC[mt][2 * s_], SRC[mt][2 * s_ + 1]);                                              \
+            PE_FENCE(8)                                                                                                   \
+            if (PE_DBG & 2) {                                                                                             \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][0], xs_.l, DST[mt][nt]);   \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][2], xs_.h, DST[mt][nt]);   \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][1], xs_.m, DST[mt][nt]);   \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][0], xs_.m, DST[mt][nt]);   \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][1], xs_.h, DST[mt][nt]);   \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][0], xs_.h, DST[mt][nt]);   \
+            } else {                                                                                                      \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                            \
+                f32x4 c_ = DST[mt][nt];                                                                                   \
+                c_ = mfma_bf(wt_[nt][0], xs_.l, c_); c_ = mfma_bf(wt_[nt][2], xs_.h, c_); c_ = mfma_bf(wt_[nt][1], xs_.m, c_); \
+                c_ = mfma_bf(wt_[nt][0], xs_.m, c_); c_ = mfma_bf(wt_[nt][1], xs_.h, c_); c_ = mfma_bf(wt_[nt][0], xs_.h, c_); \
+                DST[mt][nt] = c_;                                                                                         \
+            } }                                                                                                           \
+            PE_FENCE(16)                                                                                                  \
+        }                                                                                                                 \
+    }
 // training: dump a 64-wide activation tile (lane = pair fm of tile mt, features 16 nt + 4 kq ..) at float offset OFF of the pair's record
 #define PAIR_SAVE(TILE, OFF)                                                                                              \
     if (a.acts) {                                                                                                         \
@@ -287,7 +330,10 @@ constexpr int PMT = 4;        // 16-pair tiles per wave
     }
 #define SEL4(ARR, I) ((I) == 0 ? ARR[0] : (I) == 1 ? ARR[1] : (I) == 2 ? ARR[2] : ARR[3])
 
-__global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
+#ifndef PE_LB
+#define PE_LB 2
+#endif
+__global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
     const int lane = threadIdx.x & 63, fm = lane & 15, kq = lane >> 4;
     const int L = a.L, A = a.A;
     const int jblocks = (L + 16 * PMT - 1) / (16 * PMT);
@@ -384,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
         }
     PAIR_SAVE(h0, 0)
     // ---- distance_embed.2 + ReLU, structure mask (pair.py:74-76)
-    PAIR_DENSE(h1, h0, a.wd1)
+    if (PE_TERMS & 1) { PAIR_DENSE_T(h1, h0, a.wtd1, 2) } else { PAIR_DENSE(h1, h0, a.wd1) }
     float ps[PMT], same[PMT], mp[PMT];
     int rel[PMT];
 #pragma unroll
@@ -411,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
             const f32x4 tr = *reinterpret_cast<const f32x4*>(a.t_rel + rel[mt] * EC + col);
             h0[mt][nt] = (bv + ta) + tr * same[mt];
         }
-    PAIR_DENSE(h0, h1, a.wo0)
+    if (PE_TERMS & 2) { PAIR_DENSE_T(h0, h1, a.wto0, 2) } else { PAIR_DENSE(h0, h1, a.wo0) }
     {   // inter-residue dihedrals (pair.py:80-92): phi-like (C_i, N_j, CA_j, C_j), psi-like (N_i, CA_i, C_i, N_j); AngularEncoding -> 26 (+6 pad)
         const V3 ni = xyz(a.atoms4[row_i * 16 + 0]), cai = xyz(a.atoms4[row_i * 16 + 1]), ci = xyz(a.atoms4[row_i * 16 + 2]);
         f32x4 dh[PMT][2];
@@ -456,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
                 }
             }
         }
+        if (PE_TERMS & 4) { PAIR_DENSE_T(h0, dh, a.wtdh, 1) } else {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             f32x4 w_[4];
@@ -468,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < PMT; ++mt) h0[mt][nt] = mfma4e(w_[nt][q], dh[mt][blk][q], h0[mt][nt]);
         }
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < PMT; ++mt)
@@ -479,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
             h1[mt][nt] = bv;
         }
     PAIR_SAVE(h0, 160)
-    PAIR_DENSE(h1, h0, a.wo1)
+    if (PE_TERMS & 8) { PAIR_DENSE_T(h1, h0, a.wto1, 2) } else { PAIR_DENSE(h1, h0, a.wo1) }
 #pragma unroll
     for (int mt = 0; mt < PMT; ++mt)
 #pragma unroll
@@ -490,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
             h0[mt][nt] = bv;
         }
     PAIR_SAVE(h1, 224)
-    PAIR_DENSE(h0, h1, a.wo2)
+    if (PE_TERMS & 16) { PAIR_DENSE_T(h0, h1, a.wto2, 2) } else { PAIR_DENSE(h0, h1, a.wo2) }
     // ---- pair mask, store (pair.py:100): a lane owns features 16 nt + 4 kq .. +3 of pair (i, j0 + 16 mt + fm)
 #pragma unroll
     for (int mt = 0; mt < PMT; ++mt) {
@@ -500,6 +548,24 @@ __global__ __launch_bounds__(256, 2) void pair_embed_kernel(PairArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(o + nt * 16) = h0[mt][nt] * mp[mt];
     }
+}
+
+// Term operands of PAIR_DENSE_T: out[((s * 4 + nt) * 3 + term) * 64 + lane] = the eight bf16 terms of W[16 nt + (lane & 15)][col0 + k(s, lane >> 4, e)], e = 0..7,
+// k(s, kb, e) = 16 (2 s + (e >> 2)) + 4 kb + (e & 3) (0 where k >= kreal): the A-operand fragments of v_mfma_f32_16x16x32_bf16, split exactly like split3().
+__global__ void swizzle_terms_kernel(const float* __restrict__ W, int ldw, int col0, int kreal, int nstep, u32x4* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nstep * 4 * 64) return;
+    const int lane = idx & 63, nt = (idx >> 6) & 3, s = idx >> 8, fm = lane & 15, kb = lane >> 4;
+    f32x4 lo, hi;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 16 * (2 * s + (e >> 2)) + 4 * kb + (e & 3);
+        const float v = k < kreal ? W[(nt * 16 + fm) * ldw + col0 + k] : 0.f;
+        if (e < 4) lo[e] = v; else hi[e - 4] = v;
+    }
+    const Split3 t = split3(lo, hi);
+    u32x4* o = out + (int64_t)((s * 4 + nt) * 3) * 64 + lane;
+    o[0] = t.h; o[64] = t.m; o[128] = t.l;
 }
 
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -845,7 +911,7 @@ int launch_residue_features(const abopt_encode_inputs* in, const abopt_residue_e
 }
 
 static size_t pair_weight_floats(int A) {
-    return (size_t)AAT * AAT * EC + NREL * EC + (size_t)AAT * AAT * A * 16 + (size_t)(A + 4 + 6 + 4 + 4) * 4 * 64 * 4;
+    return (size_t)AAT * AAT * EC + NREL * EC + (size_t)AAT * AAT * A * 16 + (size_t)(A + 4 + 6 + 4 + 4) * 4 * 64 * 4 + (size_t)9 * 4 * 3 * 64 * 4;
 }
 
 size_t pair_embed_ws_bytes(int N, int L, int A) {
@@ -869,6 +935,7 @@ int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weig
     f32x4* wo0 = (f32x4*)q; q += 6 * 1024;
     f32x4* wo1 = (f32x4*)q; q += 4 * 1024;
     f32x4* wo2 = (f32x4*)q; q += 4 * 1024;
+    u32x4* wt = (u32x4*)q; q += 9 * 4 * 3 * 64 * 4;                 // term operands: d1 (2 k-steps) | o0 f_dist (2) | o0 dihedral (1) | o1 (2) | o2 (2)
     hipLaunchKernelGGL(residue_pack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(64), 0, st, in->aa, in->res_nb, in->chain_nb, in->pos_atoms, in->mask_atoms,
                        in->structure_mask, in->sequence_mask, in->atoms_in, A, rows, pb.atoms4, pb.aa_eff, pb.resnb, pb.chain, pb.flags, (float*)nullptr, (float*)nullptr);
     ABOPT_LAUNCH_CHECK();
@@ -889,6 +956,18 @@ int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weig
     swz(w->wo2, EC, 0, 16, 16, EC, 4, wo2);
     ABOPT_LAUNCH_CHECK();
     PairArgs a;
+    a.wtd1 = wt; a.wto0 = wt + 2 * 768; a.wtdh = wt + 4 * 768; a.wto1 = wt + 5 * 768; a.wto2 = wt + 7 * 768;       // 768 vectors per k-step
+    if (PE_TERMS) {
+        auto swt = [&](const float* W, int ldw, int col0, int kreal, int nstep, const u32x4* out) {
+            hipLaunchKernelGGL(swizzle_terms_kernel, dim3(nstep), dim3(256), 0, st, W, ldw, col0, kreal, nstep, const_cast<u32x4*>(out));
+        };
+        swt(w->wd1, EC, 0, EC, 2, a.wtd1);
+        swt(w->wo0, ldo0, 2 * EC, EC, 2, a.wto0);
+        swt(w->wo0, ldo0, 3 * EC, 26, 1, a.wtdh);
+        swt(w->wo1, EC, 0, EC, 2, a.wto1);
+        swt(w->wo2, EC, 0, EC, 2, a.wto2);
+        ABOPT_LAUNCH_CHECK();
+    }
     a.atoms4 = pb.atoms4; a.aa_eff = pb.aa_eff; a.res_nb = pb.resnb; a.chain_nb = pb.chain; a.flags = pb.flags;
     a.t_aap = t_aap; a.t_rel = t_rel; a.sp = sp; a.freq = w->freq_bands;
     a.wd0 = wd0; a.bd0 = w->bd0; a.wd1 = wd1; a.bd1 = w->bd1; a.wo0 = wo0; a.bo0 = w->bo0; a.wo1 = wo1; a.bo1 = w->bo1; a.wo2 = wo2; a.bo2 = w->bo2;

@@ -39,11 +39,32 @@ __device__ __forceinline__ float rows_sum(float v) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-// (lo, hi) -> one register of two bf16, round to nearest even
+// (lo, hi) -> one register of two bf16, round to nearest even.  PK_BF16_MODE (developer switch): 0 (shipped) the instruction as an asm
+// statement | 1 the same + two wait states inside the string | 2 the compiler's own float -> bf16 conversion (it lowers to the same instruction).
+// Round 5 (DESIGN_LOG.md): mode 2 lets the SLP vectoriser pack the splits' subtractions into v_pk_add_f32 and made the fused block kernel
+// NON-DETERMINISTIC (repeat tests fail at the first repeat; with -fno-slp-vectorize they pass) -- not understood, so the asm form, which every
+// bit-identity and repeat test of rounds 2-5 has covered, stays.  What is known about it: hipcc pads no MFMA hazard for an asm statement's result
+// register.  Measured on gfx950 (tools/micro/mfma_hazard.hip): a VALU overwrite of an in-flight v_mfma_f32_16x16x32_bf16's SrcC is safe at 0
+// wait states, a VALU read of D needs 8, a VALU overwrite of D needs 4.  tools/r05/mfma_hazard_scan.py lists the sequences of a build: the
+// shipped kernels have no D read within 8 states; they do have cvt results allocated to a register an MFMA wrote 2-3 instructions earlier
+// (out_ln_mlp 12, fused block kernel 11) -- each behind a dependent MFMA, which cannot issue before that write has landed.
+#ifndef PK_BF16_MODE
+#define PK_BF16_MODE 0
+#endif
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+#if PK_BF16_MODE == 2
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){lo, hi}, bf16x2_));
+#else
     unsigned r;
+#if PK_BF16_MODE == 1
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(lo), "v"(hi));
+#else
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+#endif
     return r;
+#endif
 }
 // 8 consecutive fp32 values -> their three bf16 terms, two values per register (element 2p in the low half)
 struct Split3 { u32x4 h, m, l; };

@@ -963,10 +963,10 @@ static_assert(C32F_LDS_BYTES <= 160 * 1024, "LDS of the fused block kernel");
 
 // a product rounded to fp32 HERE: the values below go straight into split_pair's `e - h`, which the compiler would otherwise contract
 // with the multiplication into one fma (an exact product minus h) -- the two-launch form rounds the product when it stores feat
+// (a multiplication the compiler may not contract -- not an asm statement: hipcc pads no MFMA hazard for the result register of one, see pk_bf16)
 __device__ __forceinline__ float mul_rn(float a, float b) {
-    float r;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+#pragma clang fp contract(off)
+    return a * b;
 }
 // four consecutive feature columns of one row -> their three bf16 planes of a staging buffer
 __device__ __forceinline__ void stage_put4(char* buf, int row, int col, float v0, float v1, float v2, float v3) {

@@ -1029,7 +1029,10 @@ def test_eps_net_bench_geometry_vs_oracle(flavour, N):
     for t in (63, 2, 21, 100):
         tv, tp, ts, tpr, tpp = d._run((v.clone(), p * 10, s.clone()), t, rf, pf, gen, mres, True, seq, True, {t: nz}, 0, 0, False, stop_after=1)
         v_n, p_n, s_n, ex = den.step(t, c(v), c(p * 10) / 10, c(s), c(rf), c(pf), c(gen), c(mres), cn, sample_sequence=seq)
-        assert max_abs(tp[t - 1][ix].cpu(), p_n * 10) < 1e-4, t
+        # pred_x0 turns the network's position into noise by dividing by sqrt(1 / abar_t - 1) (transition.py:42-50): 0.07 at t = 2, i.e. the
+        # 4e-7 fp32 noise of the network output is 2e-4 A there whatever computes it (two builds of this library that differ in the last bit of
+        # eps_pos -- both 4.1e-7 from the float64 oracle -- measured 0.9e-4 and 2.3e-4); 1e-4 A holds from t = 10 up
+        assert max_abs(tp[t - 1][ix].cpu(), p_n * 10) < (1e-4 if t >= 10 else 1e-3), t
         e = dpm.so3_noise(den.tab_inv, torch.full((len(ids), L), t), cn)
         if t in (2, 21):
             sd_t = inv.stddevs[t]
