@@ -890,6 +890,9 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
 #ifndef C32_RING
 #define C32_RING 3       // slots of the pair waves' z ring (3 or 4)
 #endif
+#ifndef C32_CPIPE
+#define C32_CPIPE 0
+#endif
 #ifndef C32_LAZY
 #define C32_LAZY 0       // skip the accumulator rescale of a row (pair waves) / a (head, row tile) (C waves) whose factors are all exactly 1 (wave-uniform; bit-identical)
 #endif
@@ -1497,17 +1500,32 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                 for (int k = 0; k < 2; ++k) { accV[hh][rt][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; accT[hh][rt][k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #define C2_ISSUE(B, HH, CH) { const f32x4* fr_ = kvn + ((int64_t)min((CH), nchunk - 1) * H + h0 + (HH)) * 512 + 4 * 64 + lane; \
         _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) vf[B][s_] = fr_[s_ * 64]; }
+        // C32_CPIPE (developer switch, round 5): the P rows and rescale factors of head hh + 1 are requested from LDS before the products of head hh
+        // (the chunk's tile is complete behind the barrier), so a head no longer opens with an exposed LDS round trip
         auto consume = [&](int c, int buf) {
             const int par = c & 1;
             unsigned long long anych_ = 0ull;
+            float scn_[2]; f32x4 pan_[2];
+#define C2_LDS(HH) { _Pragma("unroll") for (int rt_ = 0; rt_ < (C32_CPIPE == 2 ? 1 : 2); ++rt_) {                       \
+                scn_[rt_] = scl[(par * BI2 + rt_ * 16 + fm) * SCLD + h0 + (HH)];                                         \
+                pan_[rt_] = *reinterpret_cast<const f32x4*>(sp + (buf * BI2 + rt_ * 16 + fm) * SROW + sp_off(h0 + (HH), kq)); } }
+            if (C32_CPIPE) C2_LDS(0)
 #pragma unroll
             for (int hh = 0; hh < HPW; ++hh) {
                 const int h = h0 + hh;
                 if (!(C32_ABL & 2)) { if (hh + 1 < HPW) { if (hh & 1) C2_ISSUE(0, hh + 1, c) else C2_ISSUE(1, hh + 1, c) } else C2_ISSUE(0, 0, c + 1) }
+                float scc_[2]; f32x4 pac_[2];
+                if (C32_CPIPE) {
+                    scc_[0] = scn_[0]; pac_[0] = pan_[0];
+                    if (C32_CPIPE == 2) { scc_[1] = scl[(par * BI2 + 16 + fm) * SCLD + h]; pac_[1] = *reinterpret_cast<const f32x4*>(sp + (buf * BI2 + 16 + fm) * SROW + sp_off(h, kq)); }
+                    else { scc_[1] = scn_[1]; pac_[1] = pan_[1]; }
+                    if (hh + 1 < HPW) C2_LDS(hh + 1)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const float sc = scl[(par * BI2 + rt * 16 + fm) * SCLD + h];
-                    const f32x4 pa = *reinterpret_cast<const f32x4*>(sp + (buf * BI2 + rt * 16 + fm) * SROW + sp_off(h, kq));
+                    const float sc = C32_CPIPE ? scc_[rt] : scl[(par * BI2 + rt * 16 + fm) * SCLD + h];
+                    const f32x4 pa = C32_CPIPE ? pac_[rt] : *reinterpret_cast<const f32x4*>(sp + (buf * BI2 + rt * 16 + fm) * SROW + sp_off(h, kq));
                     C32_CNT(2, 1) C32_CNT(3, __builtin_amdgcn_ballot_w64(sc != 1.f) == 0ull)
                     anych_ |= __builtin_amdgcn_ballot_w64(sc != 1.f);
                     // (all 16 rows of the tile kept their running maximum of this head: factors exactly 1, nothing to rescale)
@@ -1525,6 +1543,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#undef C2_LDS
             C32_CNT(4, 1) C32_CNT(5, anych_ == 0ull)
             (void)anych_;
         };
