@@ -1922,6 +1922,56 @@ def test_two_devices_rccl_bench_sampling_and_graphed_ddp(tmp_path):
 
 
 @pytest.mark.gpu
+def test_eps_net_shape_fuzz_vs_oracle():
+    """Twelve pseudo-random shapes through the sampler's launch path -- batch size, length (also not a multiple of 16 or 32), ragged masks, flavour,
+    pair features per sample / one complex / groups of four, with and without the pair-bias cache -- against the oracle on the first and the last
+    sample: whichever form of the core the library picks for a shape (one-block, key-split, persistent, 32-row, fused with the tail, grouped)
+    must stay within the per-step tolerance.  (tools/r05/fuzz_eps.py is the long form: 96 cases in round 5, worst R_next 3.6e-6, profiles/r05_fuzz_eps_seed7.txt.)"""
+    import random
+    from ab_opt_amd import hip
+    from oracle import dpm
+    rnd = random.Random(20)
+    models = {'abdesign': (standalone_abdesign_dpm(100, 2), standalone_abdesign_dpm(100, 2).to(DEV)),
+              'abdock': (build_model(100, 2).diffusion, build_model(100, 2, device=DEV).diffusion)}
+    seen = set()
+    for case in range(12):
+        flavour = rnd.choice(['abdesign', 'abdock'])
+        L = rnd.choice([rnd.randint(1, 40), rnd.randint(41, 130), rnd.randint(131, 280), 256, 48, 200])
+        group = rnd.choice([0, 0, 1, 4])
+        N = rnd.randint(1, max(1, min(66, 30000 // (L * L // 64 + 1))))
+        if group > 1:
+            N = max(group, N // group * group)
+        lengths = [max(1, L - rnd.randint(0, L // 3)) if rnd.random() < 0.5 else L for _ in range(N)]
+        d_cpu, d = models[flavour]
+        a, b = sorted(rnd.sample(range(L + 1), 2))
+        v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lengths, 6000 + case, [(a, b)])
+        Nc = N if group == 0 else (1 if group == 1 else N // group)
+        if group > 1:
+            mres = mres[::group].repeat_interleave(group, 0).contiguous()
+            gen = gen & mres
+        pfc = pf[:Nc].contiguous()
+        t = rnd.choice([100, 63, 21, 2])
+        beta = d.trans_pos.var_sched.betas[t].expand([N]).contiguous()
+        use_cache = rnd.random() < 0.8 or group != 0
+        pbc = hip.pair_bias_cache(d.eps_net.encoder.packed_array(), 6, pfc) if use_cache else None
+        net = hip.eps_net_forward(d.eps_net.packed(), v, p, s, rf, pfc, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc, pair_feat_shared=group)
+        sd = {k: x.cpu() for k, x in d_cpu.state_dict().items()}
+        inv = d_cpu.trans_rot.angular_distrib_inv
+        den = dpm.Denoiser(sd, num_steps=100, variant=flavour, obj='pred_x0', mode='mm', pre='', tables=(None, dict(stddevs=inv.stddevs, approx_flag=inv.approx_flag, X=inv.X, Y=None)))
+        for n in sorted({0, N - 1}):
+            c = lambda x_: x_[n:n + 1].cpu()
+            cpf = pfc[(n if group == 0 else (0 if group == 1 else n // group))][None].cpu()
+            ref = den._eps(c(v), c(p), c(s), c(rf), cpf, c(beta), c(gen), c(mres), False)
+            what = (case, flavour, N, L, group, use_cache, n)
+            assert max_abs(c(net['R_next']), ref[1]) < 3e-5 and max_abs(c(net['eps_pos']), ref[2]) < 3e-5 and max_abs(c(net['c']), ref[3]) < 1e-5, what
+            if d.abdock:
+                assert max_abs(c(net['prmsd_logits']), ref[4]) < 3e-5, what
+        assert all(torch.isfinite(x).all() for x in net.values() if x is not None)
+        seen.add((flavour, group > 0, L >= 192))
+    assert len(seen) >= 5                                        # the draw covered both flavours, shared and distinct pair features, short and long crops
+
+
+@pytest.mark.gpu
 def test_launch_spans_time_the_dominant_kernel_inside_a_graph_replay():
     """abopt_prof_spans: the 32-row launches of a captured loop carry span slots; after a reset, one replay yields exactly steps x layers
     launches whose in-kernel wall-clock spans sum to a plausible duration (within a factor of the HIP-event timing of the same steps launched
