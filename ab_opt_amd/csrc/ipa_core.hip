@@ -894,7 +894,10 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
 #define C32_CPIPE 0
 #endif
 #ifndef C32_LAZY
-#define C32_LAZY 0       // skip the accumulator rescale of a row (pair waves) / a (head, row tile) (C waves) whose factors are all exactly 1 (wave-uniform; bit-identical)
+#define C32_LAZY 2       // exact lazy rescale: skip the accumulator rescale where every factor is exactly 1 (wave-uniform branch; bit-identical).  bit 1 = pair waves (a row),
+                         // bit 2 = C waves (a (head, row tile)), in the fused kernel only.  79 % of the rescales qualify at the bench shape.  Round 5, same-box A/Bs of the fused
+                         // kernel on five boxes: C waves -4.5, -0.4 / -2.6, -1.4 / -0.7, -1.5 / -0.2 % (and +4 % once with an earlier build); pair waves too: 0 on average; the
+                         // two-launch core +4.5 % (hence FUSE only).  Shipped for the C waves: a per cent on average, never a different bit.
 #endif
 #ifdef C32_COUNT      // developer build: how often a lazy rescale could skip (printed by the launcher): {pair row-chunks, of them unchanged, C (head, tile, chunk), unchanged, C chunks (6 heads x 32 rows), unchanged}
 __device__ unsigned long long g_c32_count[8];
@@ -1529,7 +1532,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                     C32_CNT(2, 1) C32_CNT(3, __builtin_amdgcn_ballot_w64(sc != 1.f) == 0ull)
                     anych_ |= __builtin_amdgcn_ballot_w64(sc != 1.f);
                     // (all 16 rows of the tile kept their running maximum of this head: factors exactly 1, nothing to rescale)
-                    if (!(C32_ABL & 1024) && !((C32_LAZY & 2) && __builtin_amdgcn_ballot_w64(sc != 1.f) == 0ull)) { accV[hh][rt][0] *= sc; accV[hh][rt][1] *= sc; accT[hh][rt][0] *= sc; accT[hh][rt][1] *= sc; }
+                    if (!(C32_ABL & 1024) && !((C32_LAZY & 2) && FUSE && __builtin_amdgcn_ballot_w64(sc != 1.f) == 0ull)) { accV[hh][rt][0] *= sc; accV[hh][rt][1] *= sc; accT[hh][rt][0] *= sc; accT[hh][rt][1] *= sc; }
                     if (C32_ABL & 512) { accV[hh][rt][0] += pa; }
                     else if (C32_ABL & 16) { accV[hh][rt][0] += vf[hh & 1][0] * pa; accV[hh][rt][1] += vf[hh & 1][1] * pa; accT[hh][rt][0] += vf[hh & 1][2] * pa; accT[hh][rt][1] += vf[hh & 1][3] * pa; }
                     else
