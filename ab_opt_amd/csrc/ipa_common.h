@@ -87,6 +87,46 @@ __device__ __forceinline__ f32x4 mfma_bf(const u32x4& a, const u32x4& b, const f
 __device__ __forceinline__ f32x16 mfma_bf32(const u32x4& a, const u32x4& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// ---- fp32 x fp32 with TWO fp16 terms per operand (round 5; the forward tail of a GABlock, tail_common.h).  h = fp16(x), l = fp16(x - h), both round to
+// nearest: |x - h - l| <= 2^-22 |x| (two 11-bit significands; x - h is exact in fp32), absolute floor 2^-25 where l is subnormal (the gfx950 matrix
+// pipe and both conversions keep fp16 subnormals: tools/micro/f16_denorm.hip).  Weights are multiplied by a power of two S per tensor before the split
+// (max |w| S in [2^14, 2^15): their low terms stay normal) and the result by 1 / S -- both exact.  THREE products per k-step
+//     x w S = h_x l_w + l_x h_w + h_x h_w   [+ l_x l_w, <= 2^-22 relative, dropped]
+// instead of the six of the three-term bf16 scheme, and 4 instead of 6 bytes per staged value.  Error against an exact product <= 3 x 2^-22 relative
+// worst case, ~2^-23 typical: in a K = 128..1824 sum that is the size of the fp32 accumulation error both schemes share (measured on random
+// operands, max / mean error of [512 x 1824] . [1824 x 128] against fp64: 3.9e-6 / 2.1e-7 for this scheme, 4.9e-6 / 2.7e-7 for the six bf16 products,
+// 3.3e-6 / 3.2e-7 for an fp32 GEMM).  Limit: |activation| < 65504 (fp16 overflow -> inf -> NaN in the output, nothing silent).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_f16(float lo, float hi) {          // an asm statement like pk_bf16 (see there)
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float f16lo_f32(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float f16hi_f32(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+// two adjacent fp32 values -> their two packed fp16 term words
+__device__ __forceinline__ void split_pair2(float e0, float e1, unsigned& h, unsigned& l) {
+    h = pk_f16(e0, e1);
+    l = pk_f16(e0 - f16lo_f32(h), e1 - f16hi_f32(h));                     // the differences are exact
+}
+struct Split2 { u32x4 h, l; };
+__device__ __forceinline__ Split2 split2(const f32x4& lo, const f32x4& hi) {
+    Split2 o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float e0 = p < 2 ? lo[2 * p] : hi[2 * p - 4], e1 = p < 2 ? lo[2 * p + 1] : hi[2 * p - 3];
+        unsigned h, l;
+        split_pair2(e0, e1, h, l);
+        o.h[p] = h; o.l[p] = l;
+    }
+    return o;
+}
+__device__ __forceinline__ f32x4 mfma_h(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_h32(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 
 namespace prof { void begin(hipStream_t st); void end(hipStream_t st); int next_span_slot(); }

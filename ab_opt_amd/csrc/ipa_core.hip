@@ -919,11 +919,11 @@ constexpr int BI2 = 32, NPW2 = 4, RPW2 = BI2 / NPW2, NTH2 = 512, HPW = 6;
 // FUSE (round 4): the block's tail -- out_transform, mask, residual, LayerNorm, mlp_transition, LayerNorm (ga.py:174-177) -- runs as the
 // EPILOGUE of this kernel on the 32 rows the workgroup owns; `feat` (7.3 KB per row: 60 MB written here and read back by the tail kernel
 // at the bench shape) never leaves the chip and the block is two launches instead of three.  After the key loop:
-//   C waves   normalise their accumulators; node features -> bf16-term planes of staging buffers 0 / 1 (chunks 4 / 5 of the 1824 feature
+//   C waves   normalise their accumulators; node features -> fp16-term planes of staging buffers 0 / 1 (chunks 4 / 5 of the 1824 feature
 //             columns), aggregated points -> LDS.  From then on A and C waves are the four CONSUMERS (one per SIMD): wave 4 + cb owns the
-//             32 output columns 32 cb .. 32 cb + 31 of u = feat . W_out^T for all 32 rows and every k-step -- the eight accumulator chains
-//             (K group, term pair) the stand-alone tail kernel spreads over four waves, in the same order (tail_common.h: ot_chunk_at,
-//             ot_kstep6); W_out streams from L2 as fp32 and is split in registers between the MFMAs, as there.
+//             32 output columns 32 cb .. 32 cb + 31 of u = feat . W_out^T for all 32 rows and every k-step -- the four accumulator chains
+//             (one per K group) the stand-alone tail kernel spreads over four waves, in the same order (tail_common.h: ot_chunk_at,
+//             ot_kstep3); W_out streams from L2 as pre-split fp16 terms, as there.
 //   pair waves are the PRODUCERS: they split their 32 x 768 normalised pair features once (192 registers of packed terms) and, one
 //             192-column chunk per interval, write them -- then what the point epilogue derives from the aggregated points (local
 //             coordinates, distances, directions: chunks 6..9) -- into the staging buffer the consumers read next.  One barrier per chunk.
@@ -964,25 +964,24 @@ constexpr int C32F_LDS_BYTES = C32F_PTS_OFF + 32 * C32F_PTSLD * 4;
 constexpr int C32F_U_OFF = 0, C32F_YS_OFF = MR * XLD * 4, C32F_APA_OFF = 2 * MR * XLD * 4;
 constexpr int C32F_BIAS_OFF = 2 * OT_STAGE;                                                     // the three MLP biases: free LDS behind the staging buffers, filled during the dump
 static_assert(2 * OT_STAGE <= 3 * 32 * SROW * 4, "staging buffers must fit into the S/P tile");
-static_assert(C32F_BIAS_OFF + 3 * F * 4 <= 3 * 32 * SROW * 4 && C32F_APA_OFF + 3 * AP_PLANE <= 2 * OT_STAGE && 3 * AP_PLANE <= 32 * C32F_PTSLD * 4, "phase-2 buffers of the fused tail");
+static_assert(C32F_BIAS_OFF + 3 * F * 4 <= 3 * 32 * SROW * 4 && C32F_APA_OFF + OT_NT * AP_PLANE <= 2 * OT_STAGE && OT_NT * AP_PLANE <= 32 * C32F_PTSLD * 4, "phase-2 buffers of the fused tail");
 static_assert(C32F_LDS_BYTES <= 160 * 1024, "LDS of the fused block kernel");
 
-// a product rounded to fp32 HERE: the values below go straight into split_pair's `e - h`, which the compiler would otherwise contract
+// a product rounded to fp32 HERE: the values below go straight into split_pair2's `e - h`, which the compiler would otherwise contract
 // with the multiplication into one fma (an exact product minus h) -- the two-launch form rounds the product when it stores feat
 // (a multiplication the compiler may not contract -- not an asm statement: hipcc pads no MFMA hazard for the result register of one, see pk_bf16)
 __device__ __forceinline__ float mul_rn(float a, float b) {
 #pragma clang fp contract(off)
     return a * b;
 }
-// four consecutive feature columns of one row -> their three bf16 planes of a staging buffer
+// four consecutive feature columns of one row -> their two fp16 planes of a staging buffer
 __device__ __forceinline__ void stage_put4(char* buf, int row, int col, float v0, float v1, float v2, float v3) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    split_pair(v0, v1, h0, m0, l0);
-    split_pair(v2, v3, h1, m1, l1);
+    unsigned h0, l0, h1, l1;
+    split_pair2(v0, v1, h0, l0);
+    split_pair2(v2, v3, h1, l1);
     char* d = buf + row * OT_SROW + col * 2;
     *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(d + OT_PLANE) = make_uint2(m0, m1);
-    *reinterpret_cast<uint2*>(d + 2 * OT_PLANE) = make_uint2(l0, l1);
+    *reinterpret_cast<uint2*>(d + OT_PLANE) = make_uint2(l0, l1);
 }
 
 template <bool FUSE>
@@ -1036,41 +1035,43 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
     float* const ptsf = reinterpret_cast<float*>(smem_raw + C32F_PTS_OFF);      // [32][H][24]
     const int64_t row0f = rowbase + i0, row_endf = rowbase + L;               // the 32 rows of this block in the flattened [N L] order
     TailP2Pre<NTH2 / 64> pre;                                                   // what phase 2 needs from global memory: requested while phase 1 finishes
-    constexpr int RD = 8;                                                       // W_out k-steps in flight per consumer wave: 8 x 3 KB of terms, 96 KB per CU
-    // W_out arrives PRE-SPLIT here (ta.wot: the bf16 terms out_ln_mlp_kernel forms in registers, made once per weight version by
-    // out_frag_terms_kernel with the same split): one consumer wave per SIMD has nobody to hide 44 VALU operations per k-step behind --
-    // with the split in registers the phase was bound by that wave's instruction issue (466 cycles per k-step, 64k cycles in all).
-    struct WT { u32x4 h, m, l; };
+#ifndef C32F_RD
+#define C32F_RD 12
+#endif
+    constexpr int RD = C32F_RD;                                                 // W_out k-steps in flight per consumer wave: 12 x 2 KB of terms, 96 KB per CU
+    // W_out arrives PRE-SPLIT (ta.wot: the scaled fp16 terms pack_tail_weights_kernel makes once per weight version; out_ln_mlp_kernel streams
+    // the same layout): one consumer wave per SIMD has nobody to hide a split's VALU operations behind -- with fp32 fragments split in
+    // registers (round 4, first version) the phase was bound by that wave's instruction issue (466 cycles per k-step, 64k cycles in all).
+    struct WT { u32x4 h, l; };
     auto consumer = [&](int cb, WT (&wt)[RD]) {
         // k-step number i of the sequence = position i / 12, (K group, slot) i % 12  ->  k-step 12 chunk(position) + i % 12 of W_out
-        const u32x4* wfr = reinterpret_cast<const u32x4*>(ta.wot) + (int64_t)cb * OT_ST * 192 + lane;
+        const u32x4* wfr = reinterpret_cast<const u32x4*>(ta.wot) + (int64_t)cb * OT_ST * OT_WVEC + lane;
         auto kstep = [&](int i) { return min(ot_chunk_at(min(i / OT_SPC, OT_NCH - 1)) * OT_SPC + (i % OT_SPC), OT_ST - 1); };
-        f32x16 acc[4];                                                          // one chain per K group (ot_kstep6)
+        f32x16 acc[4];                                                          // one chain per K group (ot_kstep3)
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc_zero(acc[g]);
         C32F_STAMP(1)
         __syncthreads();                                                        // E0: staging buffers 0 / 1 and the aggregated points are in LDS
         C32F_STAMP(2)
         const char* xrd = stage + (lane & 31) * OT_SROW + (lane >> 5) * 16;
-        // One k-step: the six products of ot_kstep6 on operands already in registers; the feat terms of the next k-step are requested from
+        // One k-step: the three products of ot_kstep3 on operands already in registers; the feat terms of the next k-step are requested from
         // LDS before the first product (this wave is alone on its SIMD's matrix pipe: nobody else hides an LDS round trip) and the ring
         // slot is refilled with the W terms of k-step i + RD.  Straight-line code per position (a branch per k-step makes the compiler
         // wait for ALL outstanding requests at every block entry).
 #define C32F_KSTEP(P_, KK, NK)                                                                                           \
         {                                                                                                                \
             const int i_ = (P_) * OT_SPC + (KK);                                                                         \
-            const u32x4 wH = wt[(KK) % RD].h, wM = wt[(KK) % RD].m, wL = wt[(KK) % RD].l;                                \
-            const u32x4 xh = xnh, xm = xnm, xl = xnl;                                                                    \
+            const u32x4 wH = wt[(KK) % RD].h, wL = wt[(KK) % RD].l;                                                      \
+            const u32x4 xh = xnh, xl = xnl;                                                                              \
             if ((KK) + 1 < (NK)) {                                                                                       \
-                xnh = *reinterpret_cast<const u32x4*>(xb + ((KK) % OT_SPC + 1) * 32); xnm = *reinterpret_cast<const u32x4*>(xb + ((KK) % OT_SPC + 1) * 32 + OT_PLANE); \
-                xnl = *reinterpret_cast<const u32x4*>(xb + ((KK) % OT_SPC + 1) * 32 + 2 * OT_PLANE);                     \
+                xnh = *reinterpret_cast<const u32x4*>(xb + ((KK) % OT_SPC + 1) * 32); xnl = *reinterpret_cast<const u32x4*>(xb + ((KK) % OT_SPC + 1) * 32 + OT_PLANE); \
             }                                                                                                            \
-            if (C32F_ABL & 2) acc[((KK) % OT_SPC) / OT_SPW][0] += __uint_as_float((wH[0] ^ xh[0]) + (wM[1] ^ xm[1]) + (wL[2] ^ xl[2]));  \
-            else ot_kstep6(wH, wM, wL, xh, xm, xl, acc[((KK) % OT_SPC) / OT_SPW]);                                      \
-            if (!(C32F_ABL & 1) && i_ + RD < OT_ST) { const u32x4* nf_ = wfr + (int64_t)kstep(i_ + RD) * 192; wt[(KK) % RD].h = nf_[0]; wt[(KK) % RD].m = nf_[64]; wt[(KK) % RD].l = nf_[128]; } \
+            if (C32F_ABL & 2) acc[((KK) % OT_SPC) / OT_SPW][0] += __uint_as_float((wH[0] ^ xh[0]) + (wL[2] ^ xl[2]));    \
+            else ot_kstep3(wH, wL, xh, xl, acc[((KK) % OT_SPC) / OT_SPW]);                                               \
+            if (!(C32F_ABL & 1) && i_ + RD < OT_ST) { const u32x4* nf_ = wfr + (int64_t)kstep(i_ + RD) * OT_WVEC; wt[(KK) % RD].h = nf_[0]; wt[(KK) % RD].l = nf_[64]; } \
         }
-#define C32F_XFIRST() { xnh = *reinterpret_cast<const u32x4*>(xb); xnm = *reinterpret_cast<const u32x4*>(xb + OT_PLANE); xnl = *reinterpret_cast<const u32x4*>(xb + 2 * OT_PLANE); }
-        u32x4 xnh, xnm, xnl;
+#define C32F_XFIRST() { xnh = *reinterpret_cast<const u32x4*>(xb); xnl = *reinterpret_cast<const u32x4*>(xb + OT_PLANE); }
+        u32x4 xnh, xnl;
         static_assert(OT_SPC == 12 && OT_ST - (OT_NCH - 1) * OT_SPC == 6 && ot_chunk_at(OT_NCH - 1) == OT_NCH - 1, "positions 0..8 are full chunks, the last one holds six k-steps");
         static_assert((2 * OT_SPC) % RD == 0, "ring slots must repeat every two positions");
         for (int p = 0; p < OT_NCH - 2; p += 2) {                               // two positions per trip: the ring slot of a k-step is a compile-time constant
@@ -1110,7 +1111,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
 #undef C32F_KSTEP
 #undef C32F_XFIRST
         C32F_STAMP(13)
-        // u (without the bias) = ((p0 + p1) + (p2 + p3)): what out_ln_mlp_kernel forms from its four K-group slabs
+        // S_out u (without the bias) = ((p0 + p1) + (p2 + p3)): what out_ln_mlp_kernel forms from its four K-group slabs
         float (*us)[XLD] = reinterpret_cast<float (*)[XLD]>(smem_raw + C32F_U_OFF);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1124,9 +1125,10 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         }
     };
     auto consumer_prefetch = [&](int cb, WT (&wt)[RD]) {
-        const u32x4* wfr = reinterpret_cast<const u32x4*>(ta.wot) + (int64_t)cb * OT_ST * 192 + lane;
+        const u32x4* wfr = reinterpret_cast<const u32x4*>(ta.wot) + (int64_t)cb * OT_ST * OT_WVEC + lane;
 #pragma unroll
-        for (int j = 0; j < RD; ++j) { const u32x4* f = wfr + (int64_t)(ot_chunk_at(0) * OT_SPC + j) * 192; wt[j].h = f[0]; wt[j].m = f[64]; wt[j].l = f[128]; }
+        for (int j = 0; j < RD; ++j) { const u32x4* f = wfr + (int64_t)(ot_chunk_at(0) * OT_SPC + j) * OT_WVEC; wt[j].h = f[0]; wt[j].l = f[64]; }
+        static_assert(RD <= OT_SPC, "the first fragments belong to position 0");
     };
 
     if (wave < NPW2) {

@@ -257,58 +257,43 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
     char* fdst0 = &sm.stage[0][0] + lr * OT_SROW + lo * 16;
     auto chunk_ok = [&](int p) { return ldr && p < OT_NCH && ot_chunk_at(p) * OT_KC + lo * 8 < OT_K; };   // the last chunk is half full
     auto stage_store = [&](int b, const f32x4& v0, const f32x4& v1) {
-        const Split3 sp = split3(v0, v1);
+        const Split2 sp = split2(v0, v1);
         char* d = fdst0 + b * OT_STAGE;
-        *reinterpret_cast<u32x4*>(d) = sp.h; *reinterpret_cast<u32x4*>(d + OT_PLANE) = sp.m; *reinterpret_cast<u32x4*>(d + 2 * OT_PLANE) = sp.l;
+        *reinterpret_cast<u32x4*>(d) = sp.h; *reinterpret_cast<u32x4*>(d + OT_PLANE) = sp.l;
     };
     const int cb = wave & 3, kg = wave >> 2;
-    // this wave's W_out stream: fp32 in operand order, [cb][k-step][lane][8 floats], lane (column lane & 31, k half lane >> 5).
+    // this wave's W_out stream: the pre-split, scaled terms in operand order, [cb][k-step][term][lane] x 8 fp16, lane (column lane & 31, k half lane >> 5).
     // Its k-steps, in order: position p, slot j -> k-step 12 chunk(p) + 3 kg + j (p < 10, j < 3; past 113: nothing to do -- a clamped reload keeps the code uniform)
-    const f32x4* wfr = reinterpret_cast<const f32x4*>(wof) + ((int64_t)cb * OT_ST * 64 + lane) * 2;
+    const u32x4* wfr = reinterpret_cast<const u32x4*>(wof) + (int64_t)cb * OT_ST * OT_WVEC + lane;
     auto kstep = [&](int i) { return min(ot_chunk_at(min(i / OT_SPW, OT_NCH - 1)) * OT_SPC + kg * OT_SPW + (i % OT_SPW), OT_ST - 1); };
-    f32x4 raw[OT_SPW][2];                                                                                 // ring: k-step i lives in slot i % 3
+    constexpr int WRD = 2 * OT_SPW;                                                                       // ring: k-step i lives in slot i % 6, requested six k-steps (two chunks) ahead
+    u32x4 wr[WRD][2];
 #pragma unroll
-    for (int j = 0; j < OT_SPW; ++j) { raw[j][0] = wfr[kstep(j) * 128]; raw[j][1] = wfr[kstep(j) * 128 + 1]; }
+    for (int j = 0; j < WRD; ++j) { wr[j][0] = wfr[(int64_t)kstep(j) * OT_WVEC]; wr[j][1] = wfr[(int64_t)kstep(j) * OT_WVEC + 64]; }
     f32x4 fv0 = (f32x4){0.f, 0.f, 0.f, 0.f}, fv1 = fv0;
     if (chunk_ok(0)) {
         fload(ot_chunk_at(0), fv0, fv1);
         stage_store(0, fv0, fv1);
     }
     if (chunk_ok(1)) fload(ot_chunk_at(1), fv0, fv1);
-    u32x4 nH, nM, nL;                                                                                     // terms of the NEXT k-step
-    { const Split3 w3 = split3(raw[0][0], raw[0][1]); nH = w3.h; nM = w3.m; nL = w3.l; }
-    raw[0][0] = wfr[kstep(OT_SPW) * 128]; raw[0][1] = wfr[kstep(OT_SPW) * 128 + 1];
     __syncthreads();
 #ifdef OT_TIMING
     const long long tc1 = clock64();
 #endif
-    f32x16 acc0;                                                                                          // ONE chain per (column block, K group): see ot_kstep6
+    f32x16 acc0;                                                                                          // ONE chain per (column block, K group): see ot_kstep3
     acc_zero(acc0);
     const char* xrd = &sm.stage[0][0] + (lane & 31) * OT_SROW + (kg * OT_SPW) * 32 + (lane >> 5) * 16;
-    for (int c = 0; c < OT_NCH; ++c) {
+    auto chunk_steps = [&](int c, int half) {                                                            // half = c & 1 as a compile-time constant: ring slots 3 half + j
         const int b = c & 1;
         // the last position (chunk 9) has work for K groups 0 and 1 only (and nothing left to stage): the others go straight to the barrier
         if (ot_chunk_at(c) * OT_SPC + kg * OT_SPW < OT_ST) {
 #pragma unroll
         for (int j = 0; j < OT_SPW; ++j) {
-            const int i = c * OT_SPW + j;
-            const u32x4 wH = nH, wM = nM, wL = nL;
+            const int i = c * OT_SPW + j, slot = half * OT_SPW + j;
             const char* xp = xrd + b * OT_STAGE + j * 32;
-            const u32x4 xh = *reinterpret_cast<const u32x4*>(xp), xm = *reinterpret_cast<const u32x4*>(xp + OT_PLANE),
-                        xl = *reinterpret_cast<const u32x4*>(xp + 2 * OT_PLANE);
-            // the fragment of k-step i + 1 (slot (j + 1) % 3, requested three k-steps ago) is split pair by pair between the MFMAs of k-step i
-            // (same products in the same order as ot_kstep6)
-            const f32x4 r0 = raw[(j + 1) % OT_SPW][0], r1 = raw[(j + 1) % OT_SPW][1];
-            acc0 = mfma_bf32(wH, xl, acc0); acc0 = mfma_bf32(wL, xh, acc0);
-            { unsigned h_, m_, l_; split_pair(r0[0], r0[1], h_, m_, l_); nH[0] = h_; nM[0] = m_; nL[0] = l_; }
-            acc0 = mfma_bf32(wM, xm, acc0);
-            { unsigned h_, m_, l_; split_pair(r0[2], r0[3], h_, m_, l_); nH[1] = h_; nM[1] = m_; nL[1] = l_; }
-            acc0 = mfma_bf32(wH, xm, acc0);
-            { unsigned h_, m_, l_; split_pair(r1[0], r1[1], h_, m_, l_); nH[2] = h_; nM[2] = m_; nL[2] = l_; }
-            acc0 = mfma_bf32(wM, xh, acc0);
-            { unsigned h_, m_, l_; split_pair(r1[2], r1[3], h_, m_, l_); nH[3] = h_; nM[3] = m_; nL[3] = l_; }
-            acc0 = mfma_bf32(wH, xh, acc0);
-            { const int64_t nst = kstep(i + 1 + OT_SPW); raw[(j + 1) % OT_SPW][0] = wfr[nst * 128]; raw[(j + 1) % OT_SPW][1] = wfr[nst * 128 + 1]; }
+            const u32x4 xh = *reinterpret_cast<const u32x4*>(xp), xl = *reinterpret_cast<const u32x4*>(xp + OT_PLANE);
+            ot_kstep3(wr[slot][0], wr[slot][1], xh, xl, acc0);
+            { const int64_t nst = kstep(i + WRD); wr[slot][0] = wfr[nst * OT_WVEC]; wr[slot][1] = wfr[nst * OT_WVEC + 64]; }
             if (j == 0) {                                                                               // feat staging in the shadow of this chunk's MFMAs
                 if (chunk_ok(c + 1)) stage_store(b ^ 1, fv0, fv1);                                      // position c + 1 -> the other buffer
                 if (chunk_ok(c + 2)) fload(ot_chunk_at(c + 2), fv0, fv1);
@@ -316,7 +301,9 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
         }
         }
         __syncthreads();
-    }
+    };
+    static_assert(OT_NCH % 2 == 0, "two positions per trip");
+    for (int c = 0; c < OT_NCH; c += 2) { chunk_steps(c, 0); chunk_steps(c + 1, 1); }
 #ifdef OT_TIMING
     const long long tc2 = clock64();
 #endif
@@ -327,7 +314,7 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
     __syncthreads();
     char* apA = sm.ap;                                                                                   // planes: LayerNorm1 output, later layer-1 output
     char* apB = reinterpret_cast<char*>(&sm.part[2][0][0]);                                              // second set (layer-0 output): part[2..3] are free after LayerNorm1
-    static_assert(3 * AP_PLANE <= (int)(2 * MR * XLD * sizeof(float)), "second activation plane set must fit into two K-group slabs");
+    static_assert(OT_NT * AP_PLANE <= (int)(2 * MR * XLD * sizeof(float)), "second activation plane set must fit into two K-group slabs");
     auto get_u = [&](int rl) {
         const float2 u0 = *reinterpret_cast<const float2*>(&sm.part[0][rl][2 * lane]), u1 = *reinterpret_cast<const float2*>(&sm.part[1][rl][2 * lane]);
         const float2 u2 = *reinterpret_cast<const float2*>(&sm.part[2][rl][2 * lane]), u3 = *reinterpret_cast<const float2*>(&sm.part[3][rl][2 * lane]);
@@ -341,21 +328,17 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
 
 
 size_t out_wfrag_floats() { return (size_t)F * OT_K; }
-size_t out_wterms_floats() { return (size_t)F * OT_K * 3 / 2; }
+size_t out_wterms_floats() { return (size_t)F * OT_K; }
 
-// w_out_frag (fp32, operand order [cb][k-step][lane][8]) -> w_out_terms [cb][k-step][term h | m | l][lane] x 8 bf16: the split the tail kernel
-// performs in registers (split3 = three round-to-nearest bf16 terms, h + m + l == w exactly), done once per weight version for the fused
-// core + tail kernel, whose consumer waves have no VALU time to spare.
+// w_out_terms = w_out_frag: since round 5 pack_tail_weights writes the terms the fused core + tail kernel streams itself, and the stand-alone tail
+// reads the same layout; the entry point stays (callers keep one buffer per role) and copies.
 __global__ __launch_bounds__(256) void out_frag_terms_kernel(const float* __restrict__ wof, float* __restrict__ wot) {
-    const int id = blockIdx.x * 256 + threadIdx.x;                           // (cb, k-step, lane)
-    if (id >= 4 * OT_ST * 64) return;
-    const f32x4* src = reinterpret_cast<const f32x4*>(wof) + (int64_t)id * 2;
-    const Split3 sp = split3(src[0], src[1]);
-    u32x4* dst = reinterpret_cast<u32x4*>(wot) + (int64_t)(id >> 6) * 192 + (id & 63);
-    dst[0] = sp.h; dst[64] = sp.m; dst[128] = sp.l;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id < F * OT_K / 4) reinterpret_cast<f32x4*>(wot)[id] = reinterpret_cast<const f32x4*>(wof)[id];
 }
 int launch_out_frag_terms(const float* wof, float* wot, hipStream_t st) {
-    hipLaunchKernelGGL(out_frag_terms_kernel, dim3((4 * OT_ST * 64 + 255) / 256), dim3(256), 0, st, wof, wot);
+    if (wof == wot) return ABOPT_OK;
+    hipLaunchKernelGGL(out_frag_terms_kernel, dim3((F * OT_K / 4 + 255) / 256), dim3(256), 0, st, wof, wot);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }
@@ -393,22 +376,50 @@ int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, con
 }
 
 // =====================================================================================================================
-// Weights of the tail in MFMA operand order, packed on the device (one launch per block): W_out -> wof [4][114][64][8] fp32 (32x32x16
-// operand order; the tail kernel splits it in registers), W_mlp0..2 -> wmf [3][8][4][64][8] fp32 (16x16x32 operand order, split in
-// registers too; the buffer keeps the size of wmt, its unused third is zeroed), and the TRANSPOSED MLP weights -> wmt [3][4][8][3][64] x 8
-// bf16 (32x32x16 operand order, three bf16 terms: operands of the backward chain).
-// One thread per (matrix, block, step, lane): 8 values -> up to three 16-byte vectors.  Layout: include/abopt.h (w_out_frag, w_mlp_frag).
+// Weights of the tail in MFMA operand order, packed on the device (two launches per block).  Forward operands are TWO fp16 terms of S w, S a power
+// of two per matrix with max |w| S in [2^14, 2^15) (ipa_common.h: split_pair2):
+//   W_out     -> wof [4 cb][114 k-steps][term h | l][64 lanes] x 8 fp16 (32x32x16 operand order, K in staging order ot_feat_col),
+//   W_mlp0..2 -> wmf [3][8 ct][4 k-steps][term][64 lanes] x 8 fp16 (16x16x32 operand order), then at float OT_SCALE_OFF the four S and the four 1 / S
+//                (tail_weight_scales_kernel; the rest of the buffer, which keeps the size of wmt, is zeroed),
+// and the TRANSPOSED MLP weights -> wmt [3][4][8][3][64] x 8 bf16 (32x32x16 operand order, three bf16 terms: operands of the backward chain).
+// One thread per (matrix, block, step, lane): 8 values -> two or three 16-byte vectors.  Layout: include/abopt.h (w_out_frag, w_mlp_frag).
+__global__ __launch_bounds__(1024) void tail_weight_scales_kernel(const float* __restrict__ w_out, const float* __restrict__ w0, const float* __restrict__ w1,
+                                                                  const float* __restrict__ w2, float* __restrict__ scales, int tail_floats) {
+    __shared__ float red[16];
+    for (int e = 8 + blockIdx.x * 1024 + threadIdx.x; e < tail_floats; e += 4 * 1024) scales[e] = 0.f;      // the unused rest of w_mlp_frag
+    const int mtx = blockIdx.x;
+    const float* src = mtx == 0 ? w_out : (mtx == 1 ? w0 : (mtx == 2 ? w1 : w2));
+    const int n = mtx == 0 ? F * OT_K : F * F;
+    float m = 0.f;
+    for (int e = threadIdx.x; e < n; e += 1024) { const float a = fabsf(src[e]); m = (a <= 3.0e38f) ? fmaxf(m, a) : m; }      // NaN / inf do not set the scale
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+        int e = 0;
+        if (m > 0.f) { (void)frexpf(m, &e); e = 15 - e; }                    // m = f 2^(15 - e), f in [0.5, 1)  ->  m 2^e in [2^14, 2^15)
+        e = max(-100, min(100, e));
+        scales[mtx] = ldexpf(1.f, e);
+        scales[4 + mtx] = ldexpf(1.f, -e);
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_tail_weights_kernel(const float* __restrict__ w_out, const float* __restrict__ w0, const float* __restrict__ w1,
                                                                 const float* __restrict__ w2, float* __restrict__ wof, float* __restrict__ wmf,
                                                                 float* __restrict__ wmt) {
     constexpr int NOUT = 4 * OT_ST * 64, NMLP = 4 * OT_MS * 64;          // NMLP = 2048 = 8 ct * 4 k-steps * 64 lanes as well
     int id = blockIdx.x * 256 + threadIdx.x;
-    if (id < NOUT) {                                                     // W_out stays fp32
+    const float* scales = wmf + OT_SCALE_OFF;
+    if (id < NOUT) {
         const int lane = id & 63, st = (id >> 6) % OT_ST, cb = (id >> 6) / OT_ST;
         const float* p = w_out + (int64_t)(cb * 32 + (lane & 31)) * OT_K;
         const int kk = st * 16 + (lane >> 5) * 8, c = kk / OT_KC, j = kk % OT_KC;      // K index in staging order -> feature columns (two quads)
-        f32x4* d32 = reinterpret_cast<f32x4*>(wof) + ((int64_t)(cb * OT_ST + st) * 64 + lane) * 2;
-        d32[0] = *reinterpret_cast<const f32x4*>(p + ot_feat_col(c, j)); d32[1] = *reinterpret_cast<const f32x4*>(p + ot_feat_col(c, j + 4));
+        const float S = scales[0];
+        const Split2 sp = split2(*reinterpret_cast<const f32x4*>(p + ot_feat_col(c, j)) * S, *reinterpret_cast<const f32x4*>(p + ot_feat_col(c, j + 4)) * S);
+        u32x4* d = reinterpret_cast<u32x4*>(wof) + (int64_t)(cb * OT_ST + st) * OT_WVEC + lane;
+        d[0] = sp.h; d[64] = sp.l;
         return;
     }
     id -= NOUT;
@@ -418,27 +429,30 @@ __global__ __launch_bounds__(256) void pack_tail_weights_kernel(const float* __r
     if (tr && !wmt) return;
     const float* src = layer == 0 ? w0 : (layer == 1 ? w1 : w2);
     const int lane = id & 63;
-    f32x4 lo, hi;
-    u32x4* d;
-    if (!tr) {                                                           // forward: fp32 [layer][ct][s][lane (m, kq)][i] = W[16 ct + m][32 s + 8 kq + i]
+    if (!tr) {                                                           // forward: [layer][ct][s][term][lane (m, kq)] x 8 = terms of S W[16 ct + m][32 s + 8 kq + i]
         const int st = (id >> 6) % 4, ct = (id >> 6) / 4;
         const float* p = src + (int64_t)(ct * 16 + (lane & 15)) * F + st * 32 + (lane >> 4) * 8;
-        f32x4* d32 = reinterpret_cast<f32x4*>(wmf) + ((int64_t)((layer * 8 + ct) * 4 + st) * 64 + lane) * 2;
-        d32[0] = *reinterpret_cast<const f32x4*>(p); d32[1] = *reinterpret_cast<const f32x4*>(p + 4);
-        reinterpret_cast<f32x4*>(wmf)[3 * NMLP * 2 + layer * NMLP + id] = (f32x4){0.f, 0.f, 0.f, 0.f};     // the unused third of the buffer
+        const float S = scales[1 + layer];
+        const Split2 sp = split2(*reinterpret_cast<const f32x4*>(p) * S, *reinterpret_cast<const f32x4*>(p + 4) * S);
+        u32x4* d = reinterpret_cast<u32x4*>(wmf) + (int64_t)((layer * 8 + ct) * 4 + st) * OT_WVEC + lane;
+        d[0] = sp.h; d[64] = sp.l;
         return;
-    } else {                                                             // backward: [cb][s][term][lane (c, kh)] = W[16 s + 8 kh + i][32 cb + c]
-        const int st = (id >> 6) % OT_MS, cb = (id >> 6) / OT_MS;
-        const float* p = src + (int64_t)(st * 16 + (lane >> 5) * 8) * F + cb * 32 + (lane & 31);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { lo[i] = p[(int64_t)i * F]; hi[i] = p[(int64_t)(i + 4) * F]; }
-        d = reinterpret_cast<u32x4*>(wmt) + layer * (NMLP * 3) + ((int64_t)(cb * OT_MS + st) * 3) * 64 + lane;
     }
+    // backward: [cb][s][term][lane (c, kh)] = W[16 s + 8 kh + i][32 cb + c]
+    const int st = (id >> 6) % OT_MS, cb = (id >> 6) / OT_MS;
+    const float* p = src + (int64_t)(st * 16 + (lane >> 5) * 8) * F + cb * 32 + (lane & 31);
+    f32x4 lo, hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { lo[i] = p[(int64_t)i * F]; hi[i] = p[(int64_t)(i + 4) * F]; }
+    u32x4* d = reinterpret_cast<u32x4*>(wmt) + layer * (NMLP * 3) + ((int64_t)(cb * OT_MS + st) * 3) * 64 + lane;
     const Split3 sp = split3(lo, hi);
     d[0] = sp.h; d[64] = sp.m; d[128] = sp.l;
 }
 
 int launch_pack_tail_weights(const float* w_out, const float* w0, const float* w1, const float* w2, float* wof, float* wmf, float* wmt, hipStream_t st) {
+    // the scale slots first (the pack kernel reads them)
+    hipLaunchKernelGGL(tail_weight_scales_kernel, dim3(4), dim3(1024), 0, st, w_out, w0, w1, w2, wmf + OT_SCALE_OFF, (int)(mlp_wfrag_floats() - OT_SCALE_OFF));
+    ABOPT_LAUNCH_CHECK();
     const int total = 4 * OT_ST * 64 + 6 * 4 * OT_MS * 64;
     hipLaunchKernelGGL(pack_tail_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w_out, w0, w1, w2, wof, wmf, wmt);
     ABOPT_LAUNCH_CHECK();

@@ -3,6 +3,9 @@
 // the SAME arithmetic in the SAME order per output element -- k-steps of a (column block, K group) chain in the chunk order
 // ot_chunk_at(), partial sums ((p0 + p1) + (p2 + p3)) + bias, phase 2 row-local -- so their results are bit-identical
 // (tests/test_hip_parity.py::test_fused_block_is_bit_identical).
+// Arithmetic of the FORWARD tail since round 5: two fp16 terms per operand, three products per k-step (ipa_common.h: split_pair2); all weights arrive
+// pre-split and scaled by a power of two per matrix (pack_tail_weights_kernel), the inverse scales ride in w_mlp_frag behind the layer weights.  The
+// backward chain (tail_backward_kernel) keeps the three-term bf16 products and its own helpers below (store_terms2, MlpW, mlp_partial).
 #pragma once
 #include "ipa_common.h"
 
@@ -18,17 +21,20 @@ constexpr int OT_ST = OT_K / 16;              // 114 k-steps
 constexpr int OT_SPC = OT_KC / 16, OT_SPW = OT_SPC / 4;                   // 12 k-steps per chunk, 3 per wave
 constexpr int OT_TH = 1024, OT_NW = OT_TH / 64;
 constexpr int OT_SROW = OT_KC * 2 + 16;       // bytes per row of one bf16 plane of a chunk: 400, rows 36 banks apart (conflict-free b128 reads)
-constexpr int OT_PLANE = MR * OT_SROW, OT_STAGE = 3 * OT_PLANE;           // 12800, 38400 bytes
+constexpr int OT_NT = 2;                      // terms per value in the forward tail (fp16 h | l)
+constexpr int OT_PLANE = MR * OT_SROW, OT_STAGE = OT_NT * OT_PLANE;       // 12800, 25600 bytes
 constexpr int AP_ROW = F * 2 + 16, AP_PLANE = MR * AP_ROW;                // activation planes: 272 bytes per row (rows 4 banks apart)
+constexpr int OT_WVEC = OT_NT * 64;           // 16-byte vectors per (column block, k-step) of w_out_frag: [term][lane]
+constexpr int OT_SCALE_OFF = 3 * F * F;       // float offset of {S_out, S_0, S_1, S_2, 1/S_out, 1/S_0, 1/S_1, 1/S_2} in w_mlp_frag
 constexpr int OT_MS = F / 16;                 // 8 k-steps per MLP layer
 static_assert(OT_K % 16 == 0 && OT_KC % 64 == 0 && MR == 32 && F == 128, "out_transform tiling");
 
 struct OtSmem {
     float ys[MR][XLD];                        // y = LayerNorm1(...) in fp32 (residual of the MLP)
     float bias[3][F];                         // b_mlp0..2
-    char ap[3 * AP_PLANE];                    // input of the current layer as [term][row][128 bf16 + pad]
+    char ap[OT_NT * AP_PLANE];                // input of the current layer as [term][row][128 fp16 + pad]
     union {
-        char stage[2][OT_STAGE];              // phase 1: feat chunks as [term][row][192 bf16 + pad]
+        char stage[2][OT_STAGE];              // phase 1: feat chunks as [term][row][192 fp16 + pad]
         float part[4][MR][XLD];               // partial sums of the four K groups
     };
 };
@@ -49,7 +55,14 @@ __device__ __forceinline__ void store_partial(float (*dst)[XLD], const f32x16& a
         *reinterpret_cast<f32x4*>(&dst[lane & 31][cb * 32 + g * 8 + (lane >> 5) * 4]) =
             (f32x4){a0[4 * g] + a1[4 * g], a0[4 * g + 1] + a1[4 * g + 1], a0[4 * g + 2] + a1[4 * g + 2], a0[4 * g + 3] + a1[4 * g + 3]};
 }
-// two adjacent values -> one 4-byte entry in each of the three planes
+// two adjacent values -> one 4-byte entry in each of the two fp16 planes (forward)
+__device__ __forceinline__ void store_terms2h(char* ap, int byte_off, float e0, float e1) {
+    unsigned h, l;
+    split_pair2(e0, e1, h, l);
+    *reinterpret_cast<unsigned*>(ap + byte_off) = h;
+    *reinterpret_cast<unsigned*>(ap + AP_PLANE + byte_off) = l;
+}
+// two adjacent values -> one 4-byte entry in each of the three bf16 planes (backward)
 __device__ __forceinline__ void store_terms2(char* ap, int byte_off, float e0, float e1) {
     const unsigned h = pk_bf16(e0, e1);
     const float r0 = e0 - __uint_as_float(h << 16), r1 = e1 - __uint_as_float(h & 0xffff0000u);
@@ -86,22 +99,21 @@ __device__ __forceinline__ void mlp_partial(const char* ap, const MlpW& w, float
 }
 }  // namespace
 
-// ---- phase-2 layer weights for the 16x16x32 form: wmf [layer][ct 8][k-step 4][lane 64] x 8 fp32, lane (m = lane & 15, kq = lane >> 4)
-// holds W[16 ct + m][32 s + 8 kq + i].  fp32 (4 bytes per weight instead of the 6 of three bf16 terms): the phase is bound by how fast a
-// CU can pull the three layers from L2, and the split costs 176 VALU operations per wave and layer.  Eight waves compute (wave = column
+// ---- phase-2 layer weights for the 16x16x32 form: wmf [layer][ct 8][k-step 4][term 2][lane 64] x 8 fp16, lane (m = lane & 15, kq = lane >> 4)
+// holds the terms of S_layer W[16 ct + m][32 s + 8 kq + i].  4 bytes per weight and no VALU work in the kernel (rounds 2-4 streamed fp32 and
+// split in registers: 176 VALU operations per wave and layer; three bf16 terms would have been 6 bytes).  Eight waves compute (wave = column
 // tile ct, both row tiles with the same weight registers); a layer's fragment is 32 registers, requested one layer ahead.
 namespace {
-struct MlpRaw { f32x4 v[4][2]; };
+struct MlpRaw { u32x4 v[4][2]; };             // [k-step][term]
 __device__ __forceinline__ MlpRaw load_mlp_raw(const float* __restrict__ wm, int layer, int ct, int lane) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(wm) + ((int64_t)((layer * 8 + ct) * 4) * 64 + lane) * 2;
+    const u32x4* p = reinterpret_cast<const u32x4*>(wm) + (int64_t)((layer * 8 + ct) * 4) * OT_WVEC + lane;
     MlpRaw w;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { w.v[s][0] = p[s * 128]; w.v[s][1] = p[s * 128 + 1]; }
+    for (int s = 0; s < 4; ++s) { w.v[s][0] = p[s * OT_WVEC]; w.v[s][1] = p[s * OT_WVEC + 64]; }
     return w;
 }
-// [16 output columns of tile ct] x [32 rows] of one layer, K = 128, no K split: o[rt] register r of lane (n, kq) = output column
-// 16 ct + 4 kq + r of row 16 rt + n.  (Splitting the whole layer before the barrier that publishes its input, with the LDS reads one
-// k-step ahead, was measured: 128 VGPRs + 52 bytes of scratch per lane, no faster.)
+// [16 output columns of tile ct] x [32 rows] of one layer, K = 128, no K split: o[rt] register r of lane (n, kq) = S_layer x output column
+// 16 ct + 4 kq + r of row 16 rt + n (the caller multiplies by 1 / S_layer).
 __device__ __forceinline__ void mlp16_layer(const char* ap, const MlpRaw& w, int lane, f32x4 (&o)[2]) {
     f32x4 a[2][2];
 #pragma unroll
@@ -109,25 +121,18 @@ __device__ __forceinline__ void mlp16_layer(const char* ap, const MlpRaw& w, int
     const char* xp = ap + (lane & 15) * AP_ROW + (lane >> 4) * 16;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const Split3 w3 = split3(w.v[s][0], w.v[s][1]);
+        u32x4 xh[2], xl[2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {   // smallest terms first; two accumulators per row tile so consecutive MFMAs never depend on each other
+        for (int rt = 0; rt < 2; ++rt) {
             const char* xr = xp + rt * 16 * AP_ROW + s * 64;
-            const u32x4 xh = *reinterpret_cast<const u32x4*>(xr), xm = *reinterpret_cast<const u32x4*>(xr + AP_PLANE),
-                        xl = *reinterpret_cast<const u32x4*>(xr + 2 * AP_PLANE);
-            a[rt][0] = mfma_bf(w3.h, xl, a[rt][0]); a[rt][1] = mfma_bf(w3.l, xh, a[rt][1]);
-            a[rt][0] = mfma_bf(w3.m, xm, a[rt][0]); a[rt][1] = mfma_bf(w3.h, xm, a[rt][1]);
-            a[rt][0] = mfma_bf(w3.m, xh, a[rt][0]); a[rt][1] = mfma_bf(w3.h, xh, a[rt][1]);
+            xh[rt] = *reinterpret_cast<const u32x4*>(xr); xl[rt] = *reinterpret_cast<const u32x4*>(xr + AP_PLANE);
         }
+        // small products first; four independent chains (two per row tile) so consecutive MFMAs never depend on each other
+        a[0][0] = mfma_h(w.v[s][0], xl[0], a[0][0]); a[1][0] = mfma_h(w.v[s][0], xl[1], a[1][0]);
+        a[0][1] = mfma_h(w.v[s][1], xh[0], a[0][1]); a[1][1] = mfma_h(w.v[s][1], xh[1], a[1][1]);
+        a[0][0] = mfma_h(w.v[s][0], xh[0], a[0][0]); a[1][0] = mfma_h(w.v[s][0], xh[1], a[1][0]);
     }
     o[0] = a[0][0] + a[0][1]; o[1] = a[1][0] + a[1][1];
-}
-// one pair of adjacent fp32 values -> its three packed bf16 term words
-__device__ __forceinline__ void split_pair(float e0, float e1, unsigned& h, unsigned& m, unsigned& l) {
-    h = pk_bf16(e0, e1);
-    const float r0 = e0 - __uint_as_float(h << 16), r1 = e1 - __uint_as_float(h & 0xffff0000u);
-    m = pk_bf16(r0, r1);
-    l = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
 }
 }  // namespace
 
@@ -145,14 +150,11 @@ __device__ __forceinline__ constexpr int ot_feat_col(int c, int j) {
     return c < 4 ? (j >> 4) * 64 + ((j >> 2) & 3) * 16 + 4 * c + (j & 3) : c * OT_KC + j;
 }
 
-// the six bf16-term products of one k-step (smallest terms first), two independent accumulator chains
-// into ONE accumulator chain per (column block, K group).  (Two chains per K group -- round 3 -- cost the fused kernel's consumer waves,
-// which run all four K groups, 128 accumulator registers; with 64 they keep twelve W_out fragments in flight instead of four, which is
-// what the epilogue needs while other workgroups still stream z: L2 round trips of ~2000 cycles.)
-__device__ __forceinline__ void ot_kstep6(const u32x4& wH, const u32x4& wM, const u32x4& wL, const u32x4& xh, const u32x4& xm, const u32x4& xl, f32x16& acc) {
-    acc = mfma_bf32(wH, xl, acc); acc = mfma_bf32(wL, xh, acc);
-    acc = mfma_bf32(wM, xm, acc); acc = mfma_bf32(wH, xm, acc);
-    acc = mfma_bf32(wM, xh, acc); acc = mfma_bf32(wH, xh, acc);
+// the three fp16-term products of one k-step (small ones first) into ONE accumulator chain per (column block, K group).  (Two chains per K
+// group -- round 3 -- cost the fused kernel's consumer waves, which run all four K groups, 128 accumulator registers; with 64 they keep their
+// W_out fragments in flight, which is what the epilogue needs while other workgroups still stream z: L2 round trips of ~2000 cycles.)
+__device__ __forceinline__ void ot_kstep3(const u32x4& wH, const u32x4& wL, const u32x4& xh, const u32x4& xl, f32x16& acc) {
+    acc = mfma_h32(wH, xl, acc); acc = mfma_h32(wL, xh, acc); acc = mfma_h32(wH, xh, acc);
 }
 
 // ---- phase 2 of the tail: LayerNorm1, three 128 x 128 layers, LayerNorm2 on the 32 rows of a workgroup of NW waves (16 or 8).
@@ -163,6 +165,7 @@ struct TailP2Pre {
     float2 xv[MR / NW];
     bool keep[MR / NW];
     float2 bb, g1v, be1v;
+    f32x4 inv;                                // 1 / S of W_out, W_mlp0..2
     MlpRaw mw;
 };
 template <int NW>
@@ -180,6 +183,7 @@ __device__ __forceinline__ TailP2Pre<NW> tail_p2_prefetch(const float* __restric
     p.bb = ubias ? reinterpret_cast<const float2*>(ubias)[lane] : make_float2(0.f, 0.f);
     p.g1v = reinterpret_cast<const float2*>(g1)[lane];
     p.be1v = reinterpret_cast<const float2*>(be1)[lane];
+    p.inv = *reinterpret_cast<const f32x4*>(wmf + OT_SCALE_OFF + 4);
     if (wave < 8) p.mw = load_mlp_raw(wmf, 0, wave & 7, lane);
     return p;
 }
@@ -190,8 +194,8 @@ __device__ __forceinline__ void tail_p2_stage_bias(float (*bias)[F], const float
         *reinterpret_cast<f32x4*>(&bias[tid >> 5][(tid & 31) * 4]) = *reinterpret_cast<const f32x4*>(bsrc + (tid & 31) * 4);
     }
 }
-// GetU(rl) -> this lane's two columns (2 lane, 2 lane + 1) of u = feat . W_out^T for local row rl, WITHOUT the bias.  The caller has
-// passed the barrier that publishes u and the staged biases.  ys [MR][XLD] fp32, apA / apB two sets of three bf16 planes (AP_PLANE each);
+// GetU(rl) -> this lane's two columns (2 lane, 2 lane + 1) of S_out u, u = feat . W_out^T for local row rl, WITHOUT the bias.  The caller has
+// passed the barrier that publishes u and the staged biases.  ys [MR][XLD] fp32, apA / apB two sets of OT_NT fp16 planes (AP_PLANE each);
 // none of them may alias what GetU reads.  DUMP (training): five [rows, 128] slabs, see out_ln_mlp_kernel.
 template <int NW, bool DUMP, class GetU>
 __device__ __forceinline__ void tail_p2_run(TailP2Pre<NW>& pre, GetU&& get_u, float (*ys)[XLD], float (*bias)[F], char* apA, char* apB,
@@ -211,7 +215,7 @@ __device__ __forceinline__ void tail_p2_run(TailP2Pre<NW>& pre, GetU&& get_u, fl
         for (int rr = 0; rr < RW; ++rr) {
             const int rl = wave * RW + rr;
             const float2 u = get_u(rl);
-            float2 us = make_float2(u.x + pre.bb.x, u.y + pre.bb.y);
+            float2 us = make_float2(fmaf(u.x, pre.inv[0], pre.bb.x), fmaf(u.y, pre.inv[0], pre.bb.y));    // the scaling is exact: one rounding, in the sum
             if (!pre.keep[rr]) us = make_float2(0.f, 0.f);
             a_[rr] = pre.xv[rr].x + us.x; b_[rr] = pre.xv[rr].y + us.y;
             if (DUMP && row0 + rl < row_end) reinterpret_cast<float2*>(dump + (row0 + rl) * F)[lane] = make_float2(a_[rr], b_[rr]);
@@ -226,7 +230,7 @@ __device__ __forceinline__ void tail_p2_run(TailP2Pre<NW>& pre, GetU&& get_u, fl
             const float sd = sqrtf(var[rr] + 1e-10f);
             const float y0 = a_[rr] / sd * g.x + bt.x, y1 = b_[rr] / sd * g.y + bt.y;
             *reinterpret_cast<float2*>(&ys[rl][2 * lane]) = make_float2(y0, y1);
-            store_terms2(apA, rl * AP_ROW + lane * 4, y0, y1);
+            store_terms2h(apA, rl * AP_ROW + lane * 4, y0, y1);
             if (DUMP && row0 + rl < row_end) reinterpret_cast<float2*>(dump + slab + (row0 + rl) * F)[lane] = make_float2(y0, y1);
         }
     }
@@ -242,13 +246,14 @@ __device__ __forceinline__ void tail_p2_run(TailP2Pre<NW>& pre, GetU&& get_u, fl
             mlp16_layer(src, mw, lane, o);
             mw = nxt;
             const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias[layer][ocol]);
+            const float isc = pre.inv[1 + layer];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const int orow = rt * 16 + fm;
-                const f32x4 v = o[rt] + bv;
+                const f32x4 v = (f32x4){fmaf(o[rt][0], isc, bv[0]), fmaf(o[rt][1], isc, bv[1]), fmaf(o[rt][2], isc, bv[2]), fmaf(o[rt][3], isc, bv[3])};
                 const f32x4 hv = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-                store_terms2(dst, orow * AP_ROW + ocol * 2, hv[0], hv[1]);
-                store_terms2(dst, orow * AP_ROW + ocol * 2 + 4, hv[2], hv[3]);
+                store_terms2h(dst, orow * AP_ROW + ocol * 2, hv[0], hv[1]);
+                store_terms2h(dst, orow * AP_ROW + ocol * 2 + 4, hv[2], hv[3]);
                 if (DUMP && row0 + orow < row_end) *reinterpret_cast<f32x4*>(dump + (2 + layer) * slab + (row0 + orow) * F + ocol) = hv;
             }
         }
@@ -263,7 +268,8 @@ __device__ __forceinline__ void tail_p2_run(TailP2Pre<NW>& pre, GetU&& get_u, fl
         for (int rt = 0; rt < 2; ++rt) {
             const int orow = rt * 16 + fm;
             f32x4 yv = *reinterpret_cast<const f32x4*>(&ys[orow][ocol]);
-            yv += o[rt] + bv;
+            const float isc = pre.inv[3];
+            yv += (f32x4){fmaf(o[rt][0], isc, bv[0]), fmaf(o[rt][1], isc, bv[1]), fmaf(o[rt][2], isc, bv[2]), fmaf(o[rt][3], isc, bv[3])};
             *reinterpret_cast<f32x4*>(&ys[orow][ocol]) = yv;
             if (DUMP && row0 + orow < row_end) *reinterpret_cast<f32x4*>(dump + 4 * slab + (row0 + orow) * F + ocol) = yv;
         }

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -285,18 +285,57 @@ def out_feat_order():
     return torch.where(k < 768, perm, k)
 
 
+def tail_weight_scale(w):
+    """Power of two S with max |w| S in [2^14, 2^15) (csrc/mlp.hip: tail_weight_scales_kernel): the weights of the forward tail are split into two
+    fp16 terms of S w, so that the low terms stay normal; 1 for an all-zero matrix."""
+    a = w.detach().float().abs()
+    m = float(a[torch.isfinite(a)].max()) if bool(torch.isfinite(a).any()) else 0.0
+    if m <= 0.0:
+        return 1.0
+    import math
+    e = 15 - math.frexp(m)[1]
+    return math.ldexp(1.0, max(-100, min(100, e)))
+
+
+def _fp16_terms(v):
+    """[..., 8] fp32 -> (h, l) as [..., 4] fp32 words holding 8 fp16 each: h = fp16(v), l = fp16(v - h), round to nearest (csrc/ipa_common.h: split_pair2)."""
+    h = v.half()
+    lo = (v - h.float()).half()
+    return h.contiguous().view(torch.float32), lo.contiguous().view(torch.float32)
+
+
 def pack_out_weights(w_out):
-    """w_out [128, 1824] -> w_out_frag [4, 114, 64, 8] fp32 in operand order (include/abopt.h: abopt_ga_weights.w_out_frag)."""
-    w = w_out.float()[:, out_feat_order().to(w_out.device)]
-    return w.reshape(4, 32, 114, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+    """w_out [128, 1824] -> w_out_frag [4 cb, 114 k-steps, 2 terms, 64 lanes, 8 fp16] (as 128 * 1824 fp32 words) in 32x32x16 operand order
+    (include/abopt.h: abopt_ga_weights.w_out_frag): lane 32 kh + c holds the two fp16 terms of S w_out[32 cb + c][col(16 s + 8 kh + i)]."""
+    w = w_out.float()[:, out_feat_order().to(w_out.device)] * tail_weight_scale(w_out)
+    v = w.reshape(4, 32, 114, 2, 8).permute(0, 2, 3, 1, 4).reshape(4, 114, 64, 8)           # [cb, s, lane = 32 kh + c, i]
+    h, lo = _fp16_terms(v)
+    return torch.stack([h, lo], dim=2).contiguous()                                              # [cb, s, term, lane, 4 words]
 
 
 def pack_mlp_weights(w0, w1, w2):
-    """three [128, 128] layers -> w_mlp_frag (include/abopt.h: abopt_ga_weights.w_mlp_frag): fp32 in 16x16x32 MFMA operand order,
-    [layer][ct][s][lane = 16 kq + m][i] = w[16 ct + m][32 s + 8 kq + i], zero-padded to abopt_mlp_frag_floats() floats."""
-    out = [w.float().reshape(8, 16, 4, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1) for w in (w0, w1, w2)]       # [ct, m, s, kq, i] -> [ct, s, kq, m, i]
+    """three [128, 128] layers -> w_mlp_frag (include/abopt.h: abopt_ga_weights.w_mlp_frag): [layer][ct][s][term][lane = 16 kq + m] x 8 fp16 =
+    the two fp16 terms of S_layer w[16 ct + m][32 s + 8 kq + i], then {S_out = 0 here, S_0, S_1, S_2, 1 / S ...} -- the caller of the device packer
+    gets S_out filled in; this host statement takes it from `pack_mlp_weights.s_out` when set -- zero-padded to abopt_mlp_frag_floats() floats."""
+    out, scales = [], []
+    for w in (w0, w1, w2):
+        S = tail_weight_scale(w)
+        scales.append(S)
+        v = (w.float() * S).reshape(8, 16, 4, 4, 8).permute(0, 2, 3, 1, 4).reshape(8, 4, 64, 8)   # [ct, m, s, kq, i] -> [ct, s, lane = 16 kq + m, i]
+        h, lo = _fp16_terms(v)
+        out.append(torch.stack([h, lo], dim=2).reshape(-1))
     flat = torch.cat(out)
-    return torch.cat([flat, torch.zeros(lib().abopt_mlp_frag_floats() - flat.numel(), dtype=torch.float32, device=flat.device)])
+    return flat, scales
+
+
+def pack_tail_weights_host(w_out, w0, w1, w2):
+    """Host statement of abopt_pack_tail_weights' forward buffers: (w_out_frag, w_mlp_frag), bit for bit what the device packer writes."""
+    wof = pack_out_weights(w_out).flatten()
+    flat, scales = pack_mlp_weights(w0, w1, w2)
+    S = [tail_weight_scale(w_out)] + scales
+    sc = torch.tensor(S + [1.0 / v for v in S], dtype=torch.float32, device=flat.device)
+    pad = torch.zeros(lib().abopt_mlp_frag_floats() - flat.numel() - 8, dtype=torch.float32, device=flat.device)
+    return wof, torch.cat([flat, sc, pad])
 
 
 _NODE_FRAG_INDEX = None
@@ -688,7 +727,8 @@ def pack_tail_weights(w_out, w0, w1, w2, transposed=False):
 
 
 def out_frag_terms(wof):
-    """w_out_frag -> its three bf16 terms in operand order (abopt_out_frag_terms): what the fused core + tail kernel streams."""
+    """w_out_frag -> w_out_terms, what the fused core + tail kernel streams (abopt_out_frag_terms; since ABI 39 the two layouts are the same and
+    this is a copy)."""
     wot = torch.empty(lib().abopt_out_terms_floats(), dtype=torch.float32, device=wof.device)
     _check(lib().abopt_out_frag_terms(ptr(wof, torch.float32), ptr(wot), stream()))
     return wot

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 38
+#define ABOPT_ABI_VERSION 39
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -59,17 +59,21 @@ typedef struct {
     const float* w_node_frag;   /* optional [12, 12, 4, 3, 64, 4]: w_node re-laid out per head in MFMA operand order, every weight as its three
                                    bf16 terms (layout below); when given, the fused projection kernel replaces the GEMM + fragment pass
                                    (same results up to fp32 summation order) */
-    const float* w_out_frag;    /* optional [4, 114, 64, 8]: w_out as fp32 in MFMA operand order: [cb][s][lane = 32 kh + c][i] = w_out[32 cb + c][col(16 s + 8 kh + i)]
-                                   (the kernel splits it into bf16 terms in registers).  col(k) = k for k >= 768; the 768 pair-feature columns
+    const float* w_out_frag;    /* optional, 128 * 1824 4-byte words = [4 cb][114 s][2 terms][64 lanes] x 8 fp16: w_out in MFMA operand order as the two
+                                   fp16 terms h = fp16(S w), l = fp16(S w - h) of [cb][s][lane = 32 kh + c][i] = w_out[32 cb + c][col(16 s + 8 kh + i)],
+                                   S = the power of two with max |w_out| S in [2^14, 2^15) (stored in w_mlp_frag, below; the kernels multiply the
+                                   sums by 1 / S; activations are split the same way in the kernels, three products per k-step: csrc/ipa_common.h,
+                                   split_pair2).  col(k) = k for k >= 768; the 768 pair-feature columns
                                    (head h, channel ch) enter the K index at k = 192 ((ch % 16) / 4) + 16 h + 4 (ch / 16) + ch % 4 -- the order in
                                    which the fused core + tail kernel's lanes hold them (csrc/tail_common.h: ot_feat_col; abopt_pack_tail_weights
                                    produces this layout);
                                    when given together with w_mlp_frag, out_transform runs inside the LayerNorm/MLP kernel (no split-K partial slabs) */
-    const float* w_mlp_frag;    /* optional, abopt_mlp_frag_floats() floats: w_mlp0, w_mlp1, w_mlp2 as fp32 in 16x16x32 MFMA operand order,
-                                   [layer][ct][s][lane = 16 kq + m][i] = w[16 ct + m][32 s + 8 kq + i] (3 * 8 * 4 * 64 * 8 floats, the rest of
-                                   the buffer is zero); the fused tail kernel reads its weights from here and splits them into bf16 terms */
-    const float* w_out_terms;   /* optional, abopt_out_terms_floats() floats: w_out_frag split into its three bf16 terms by abopt_out_frag_terms,
-                                   [cb][s][term][lane] -> 8 bf16.  When given (with w_mlp_frag and a pair-bias cache), the IPA core and the tail of the
+    const float* w_mlp_frag;    /* optional, abopt_mlp_frag_floats() floats: w_mlp0, w_mlp1, w_mlp2 in 16x16x32 MFMA operand order as two fp16 terms of
+                                   S_layer w: [layer][ct][s][term][lane = 16 kq + m] x 8 fp16, entry i = term(S w[16 ct + m][32 s + 8 kq + i])
+                                   (3 * 128 * 128 words), then 8 floats {S_out, S_0, S_1, S_2, 1 / S_out, 1 / S_0, 1 / S_1, 1 / S_2}; the rest of the
+                                   buffer is zero */
+    const float* w_out_terms;   /* optional, abopt_out_terms_floats() floats: a copy of w_out_frag (abopt_out_frag_terms; until ABI 38 the fused kernel
+                                   streamed a different layout).  When given (with w_mlp_frag and a pair-bias cache), the IPA core and the tail of the
                                    block run as ONE kernel wherever the 32-row core applies: feat never leaves the chip (bit-identical results) */
 } abopt_ga_weights;
 
@@ -98,8 +102,7 @@ size_t abopt_heads_frag_floats(void);
 size_t abopt_mixer_frag_floats(void);
 size_t abopt_mlp_frag_floats(void);
 size_t abopt_out_terms_floats(void);
-/* w_out_frag (abopt_pack_tail_weights) -> w_out_terms: the three round-to-nearest bf16 terms of every weight (h + m + l == w exactly), the
- * same split the tail kernel performs in registers. */
+/* w_out_frag (abopt_pack_tail_weights) -> w_out_terms: a copy since ABI 39 (both kernels stream the same pre-split layout). */
 int abopt_out_frag_terms(const float* w_out_frag, float* w_out_terms, abopt_stream stream);
 int abopt_pack_tail_weights(const float* w_out, const float* w_mlp0, const float* w_mlp1, const float* w_mlp2, float* w_out_frag,
                             float* w_mlp_frag, float* w_mlpT_frag, abopt_stream stream);

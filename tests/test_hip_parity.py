@@ -1266,8 +1266,10 @@ def test_fused_node_projection_matches_gemm_path():
     assert 'w_node_frag' in t_ and t_['w_node_frag'].numel() == hip.lib().abopt_node_frag_floats()
     assert t_['w_out_frag'].numel() == 128 * 1824
     # the device packer (abopt_pack_tail_weights) and the host statement of the layouts agree bit for bit
-    assert torch.equal(t_['w_out_frag'], hip.pack_out_weights(t_['w_out']).flatten())
-    assert torch.equal(t_['w_mlp_frag'], hip.pack_mlp_weights(t_['w_mlp0'], t_['w_mlp1'], t_['w_mlp2']).flatten())
+    wof_h, wmf_h = hip.pack_tail_weights_host(t_['w_out'], t_['w_mlp0'], t_['w_mlp1'], t_['w_mlp2'])
+    assert torch.equal(t_['w_out_frag'].view(torch.int32), wof_h.view(torch.int32))
+    assert torch.equal(t_['w_mlp_frag'].view(torch.int32), wmf_h.view(torch.int32))
+    assert torch.equal(t_['w_out_terms'].view(torch.int32), wof_h.view(torch.int32))
     plain = hip.ga_weights_struct({k: v for k, v in t_.items() if k not in ('w_node_frag', 'w_out_frag', 'w_mlp_frag')})
     for N, L, lengths in ((2, 40, [40, 33]), (3, 70, [70, 33, 1]), (8, 256, [256, 250, 256, 231, 256, 256, 17, 256])):
         R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(N, L, lengths, salt=1200 + L)]
