@@ -5,24 +5,23 @@
 //
 // Weight-stationary: a workgroup owns ONE head.  Its 168 weight rows, permuted and zero-padded at pack time to 12 tiles of 16 rows
 //   tile 0,1: q channels 0..15, 16..31   2,3: k   4,5: q_pts points 0..3, 4..7 as (x, y, z, 0) quadruples  |  6,7: k_pts   8,9: v   10,11: v_pts
-// sit in LDS in MFMA operand order (144 KB, loaded once); residues stream through in pairs of 16-row tiles.
+// sit in LDS in MFMA operand order (96 KB, loaded once); residues stream through in pairs of 16-row tiles.
 //
-// Arithmetic: fp32 x fp32 products on the bf16 matrix pipe.  An fp32 number is EXACTLY the sum of three bf16 numbers (8 + 8 + 8
-// significand bits: h = bf16(x), m = bf16(x - h), l = x - h - m, round-to-nearest so |m| <= 2^-9 |x|, |l| <= 2^-17 |x|), so
-//     x w = hH + (hM + mH) + (hL + lH + mM) + [mL + lM + lL, relative size <= 2^-25, dropped]
-// needs six v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32) where the exact-fp32 path needs eight v_mfma_f32_16x16x4_f32 (32
-// cycles each): 2.7x fewer matrix-pipe cycles.  Every bf16 x bf16 product is exact in fp32 and the accumulation is fp32, so the
-// result differs from an fp32 FMA chain by the dropped terms only -- the same order as one fp32 rounding per product.  The weights are
-// split once at pack time (hip.pack_node_weights); x is split in registers (v_cvt_pk_bf16_f32, 11 VALU ops per pair of values).  Measured: 58 us (fp32
-// MFMA, same structure) -> see DESIGN.md; parity tests unchanged.
+// Arithmetic (round 5): fp32 x fp32 products on the fp16 matrix pipe with TWO terms per operand (ipa_common.h: split_pair2): h = fp16(x),
+// l = fp16(x - h), |x - h - l| <= 2^-22 |x|; the weights are multiplied by a power of two S (max |w| S in [2^14, 2^15), so their low terms
+// stay normal), split once at pack time (hip.pack_node_weights) and the sums multiplied by 1 / S (exact) in the epilogue:
+//     x w S = h_x l_w + l_x h_w + h_x h_w   [+ l_x l_w, <= 2^-22 relative, dropped]
+// three v_mfma_f32_16x16x32_f16 (16 cycles each, K = 32) where the exact-fp32 path needs eight v_mfma_f32_16x16x4_f32 (32 cycles each).
+// Rounds 2-4 used three bf16 terms and six products (exact up to 2^-25); the two schemes differ from fp64 by the same amount, the fp32
+// accumulation error they share (ipa_common.h).  x is split in registers (6 VALU ops per pair of values).
 //
-// A task is (32 residues, half of the head's tiles): 6 tiles x 4 k-steps x 2 row tiles x 6 products = 288 MFMAs on 48 accumulator
+// A task is (32 residues, half of the head's tiles): 6 tiles x 4 k-steps x 2 row tiles x 3 products = 144 MFMAs on 48 accumulator
 // registers, with each weight fragment read from LDS once per TWO row tiles (at one row tile per read the kernel would sit exactly on
 // the 128 B/clk LDS limit).  Register-only epilogue: with this row order an accumulator tile IS a fragment slot -- lane (residue, kq)
 // holds 4 consecutive channels, or (x, y, z, pad) of one point, so the frame transform needs no cross-lane traffic.  The value tiles
 // run with the operands swapped (accumulator = [residue 4 kq + r][channel fm]), which is the key-major layout of the aggregation
 // operand.
-// Traffic per launch at M = 8192: x re-read from L2 (24 x 4 MB), weights 12 x 144 KB, fragments written once (75 MB).
+// Traffic per launch at M = 8192: x re-read from L2 (24 x 4 MB), weights 12 x 96 KB, fragments written once (75 MB).
 #include "ipa_common.h"
 #include "kernels.h"
 
@@ -34,9 +33,12 @@ __device__ long long g_nf_timing[16][8];
 namespace abopt {
 
 constexpr int NF_F = 128;                                       // node feature width (ga.py:54-66 with node_feat_dim = 128)
-constexpr int NF_TILES = 12, NF_HT = NF_TILES / 2, NF_WAVES = 12;       // 12 waves = 3 per SIMD (152 VGPRs): the task epilogues of one wave hide behind the MFMAs of two others (8 -> 12 waves: 35.8 -> 34.9 us at M = 8192, 205 -> 188 us at M = 48000, same box)
-constexpr int NF_KS = NF_F / 32, NF_SPL = 3;                // k-steps of 32, bf16 terms per fp32 value
-constexpr int NF_HEAD_VEC = NF_TILES * NF_KS * NF_SPL * 64;    // 16-byte vectors (8 bf16) per head: [tile][k-step][term][lane]
+#ifndef NF_WAVES_
+#define NF_WAVES_ 12
+#endif
+constexpr int NF_TILES = 12, NF_HT = NF_TILES / 2, NF_WAVES = NF_WAVES_;       // 12 waves = 3 per SIMD (152 VGPRs): the task epilogues of one wave hide behind the MFMAs of two others (8 -> 12 waves: 35.8 -> 34.9 us at M = 8192, 205 -> 188 us at M = 48000, same box)
+constexpr int NF_KS = NF_F / 32, NF_SPL = 2;                // k-steps of 32, fp16 terms per fp32 value
+constexpr int NF_HEAD_VEC = NF_TILES * NF_KS * NF_SPL * 64;    // 16-byte vectors (8 fp16) per head: [tile][k-step][term][lane]
 
 
 __device__ __forceinline__ float quad_bcast0(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x00, 0xf, 0xf, false)); }
@@ -47,7 +49,7 @@ __device__ __forceinline__ float quad_bcast2(float v) { return __uint_as_float(_
 template <int HALF>
 __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4* wl, const float* __restrict__ R, const float* __restrict__ t,
                                         float* __restrict__ qfrag, float* __restrict__ kvfrag, int L, int nchunk, int total_tiles, int tile0, int h,
-                                        float ch_, float m2c, int lane, int fm, int kq) {
+                                        float ch_, float m2c, float winv, int lane, int fm, int kq) {
     int64_t rowbase[2], row[2];
     int cbs[2];
 #pragma unroll
@@ -75,7 +77,7 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
     u32x4 wa[2][NF_SPL];
 #pragma unroll
     for (int sp = 0; sp < NF_SPL; ++sp) wa[0][sp] = wh[sp * 64];
-    Split3 xs[2];
+    Split2 xs[2];
 #pragma unroll
     for (int g = 0; g < NF_KS * NF_HT; ++g) {
         const int s = g / NF_HT, T = g % NF_HT;
@@ -86,7 +88,7 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
             if (s == 0)
 #endif
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) xs[rt] = split3(xa[rt][0], xa[rt][1]);
+            for (int rt = 0; rt < 2; ++rt) xs[rt] = split2(xa[rt][0], xa[rt][1]);
 #if defined(NF_ABL) && (NF_ABL & 32)
             if (false) {
 #else
@@ -109,20 +111,16 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
             for (int sp = 0; sp < NF_SPL; ++sp) wa[(g + 1) & 1][sp] = wh[((Tn * NF_KS + sn) * NF_SPL + sp) * 64];
         }
 #if defined(NF_ABL) && (NF_ABL & 8)
-        const u32x4 wH = wa[g ? 1 : 0][0], wM = wa[g ? 1 : 0][1], wL = wa[g ? 1 : 0][2];
+        const u32x4 wH = wa[g ? 1 : 0][0], wL = wa[g ? 1 : 0][1];
 #else
-        const u32x4 wH = wa[g & 1][0], wM = wa[g & 1][1], wL = wa[g & 1][2];
+        const u32x4 wH = wa[g & 1][0], wL = wa[g & 1][1];
 #endif
         const bool swap = (HALF == 1) && (T >= 2);                               // value tiles: x is the A operand -> accumulator [residue 4 kq + r][channel fm]
         // smallest terms first; the two row tiles alternate so consecutive MFMAs never depend on each other
 #define NF_PROD(XT, WT)                                                                                                         \
-        if (swap) { acc[0][T] = mfma_bf(xs[0].XT, WT, acc[0][T]); acc[1][T] = mfma_bf(xs[1].XT, WT, acc[1][T]); }               \
-        else      { acc[0][T] = mfma_bf(WT, xs[0].XT, acc[0][T]); acc[1][T] = mfma_bf(WT, xs[1].XT, acc[1][T]); }
-#if defined(NF_ABL) && (NF_ABL & 64)   // timing only: the three products of a two-term scheme (third terms never computed / read)
-        NF_PROD(m, wH) NF_PROD(h, wM) NF_PROD(h, wH)
-#else
-        NF_PROD(l, wH) NF_PROD(h, wL) NF_PROD(m, wM) NF_PROD(m, wH) NF_PROD(h, wM) NF_PROD(h, wH)
-#endif
+        if (swap) { acc[0][T] = mfma_h(xs[0].XT, WT, acc[0][T]); acc[1][T] = mfma_h(xs[1].XT, WT, acc[1][T]); }               \
+        else      { acc[0][T] = mfma_h(WT, xs[0].XT, acc[0][T]); acc[1][T] = mfma_h(WT, xs[1].XT, acc[1][T]); }
+        NF_PROD(l, wH) NF_PROD(h, wL) NF_PROD(h, wH)
 #undef NF_PROD
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -138,6 +136,8 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
     for (int rt = 0; rt < 2; ++rt) {
         if (tile0 + rt >= total_tiles) break;
         const int tile = tile0 + rt;
+#pragma unroll
+        for (int T = 0; T < NF_HT; ++T) acc[rt][T] *= winv;                      // sums of S w x -> w x (exact)
         // frames are fetched only now: x fragments and weight registers are dead
         float Rm[9], tv[3];
 #pragma unroll
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
                                                                    float* __restrict__ qfrag, float* __restrict__ kvfrag, int L, int nchunk,
                                                                    int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char nf_smem[];
-    u32x4* wl = reinterpret_cast<u32x4*>(nf_smem);                             // [12 tiles][4 k-steps][3 terms][64]
+    u32x4* wl = reinterpret_cast<u32x4*>(nf_smem);                             // [12 tiles][4 k-steps][2 terms][64]
     const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef NF_TIMING
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
         for (int e = 0; e < NF_HEAD_VEC / (NF_WAVES * 64); ++e) wl[e * (NF_WAVES * 64) + tid] = wg[e * (NF_WAVES * 64) + tid];
     }
     const float sc = spatial_coef[h];
+    const float winv = wfrag[(int64_t)H * NF_HEAD_VEC * 4 + 1];                  // 1 / S behind the packed weights
     const float gamma = (sc > 20.f) ? sc : log1pf(expf(sc));                     // softplus, ga.py:108
     const float ch_ = (-1.f * gamma * 0.16666666666666666f) / 2.f;               // -gamma sqrt(2/(9*8)) / 2, ga.py:109-110
     const float m2c = -2.f * ch_;
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
 #endif
     for (int task = t_lo + wave; task < t_hi; task += NF_WAVES) {
         const int tile0 = (task >> 1) * 2;
-        if (task & 1) nf_task<1>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, lane, fm, kq);
-        else          nf_task<0>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, lane, fm, kq);
+        if (task & 1) nf_task<1>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq);
+        else          nf_task<0>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq);
 #ifdef NF_TIMING
         if (ti < 3) te[ti++] = clock64() - c0;
 #endif
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
 #endif
 }
 
-size_t node_wfrag_floats() { return (size_t)H * NF_HEAD_VEC * 4; }
+size_t node_wfrag_floats() { return (size_t)H * NF_HEAD_VEC * 4 + 4; }      // + {S, 1 / S, 0, 0}
 
 int launch_node_frags(const float* x, const float* wfrag, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag,
                       int N, int L, hipStream_t st) {

@@ -353,21 +353,24 @@ def split_bf16x3(w):
 
 
 def pack_node_weights(w_node):
-    """w_node [2016, 128] -> w_node_frag [12 heads, 12 tiles, 4 k-steps, 3 bf16 terms, 64 lanes, 4] (fp32 container of 8 bf16 per
-    lane; include/abopt.h: abopt_node_frag_source_row): the per-head, tile-ordered, operand-order copy the fused projection kernel
-    keeps in LDS.  Index tables come from the library so the layout has one owner."""
+    """w_node [2016, 128] -> w_node_frag [12 heads, 12 tiles, 4 k-steps, 2 fp16 terms, 64 lanes, 4] (fp32 container of 8 fp16 per lane) +
+    {S, 1 / S, 0, 0} (include/abopt.h: abopt_node_frag_source_row): the per-head, tile-ordered, operand-order copy the fused projection kernel keeps
+    in LDS, every weight as h = fp16(S w), l = fp16(S w - h) with S = tail_weight_scale(w_node).  Index tables come from the library so the layout
+    has one owner."""
     global _NODE_FRAG_INDEX
     if _NODE_FRAG_INDEX is None:
         L_ = lib()
         rows = torch.tensor([[[L_.abopt_node_frag_source_row(h, T, m) for m in range(16)] for T in range(12)] for h in range(12)], dtype=torch.long)
         _NODE_FRAG_INDEX = rows
     rows = _NODE_FRAG_INDEX.to(w_node.device)
+    S = tail_weight_scale(w_node)
     wz = torch.cat([w_node, torch.zeros(1, w_node.shape[1], dtype=w_node.dtype, device=w_node.device)], 0)
-    g = wz[torch.where(rows >= 0, rows, torch.full_like(rows, w_node.shape[0]))]          # [12, 12, 16 (m), 128]
-    terms = torch.stack(split_bf16x3(g.float()), 0)                                        # [3, h, T, m, 128] int16
-    terms = terms.reshape(3, 12, 12, 16, 4, 4, 8)                                          # [term, h, T, m, s, kq, i]: k = 32 s + 8 kq + i
+    g = wz[torch.where(rows >= 0, rows, torch.full_like(rows, w_node.shape[0]))].float() * S   # [12, 12, 16 (m), 128]
+    h16 = g.half()
+    terms = torch.stack([h16, (g - h16.float()).half()], 0)                                # [2, h, T, m, 128] fp16
+    terms = terms.reshape(2, 12, 12, 16, 4, 4, 8)                                          # [term, h, T, m, s, kq, i]: k = 32 s + 8 kq + i
     out = terms.permute(1, 2, 4, 0, 5, 3, 6).contiguous()                                  # [h, T, s, term, kq, m, i] == [h][T][s][term][lane = 16 kq + m][i]
-    return out.view(12, 12, 4, 3, 64, 8).view(torch.float32)                               # 8 bf16 = 4 fp32 containers per lane
+    return torch.cat([out.view(-1).view(torch.float32), torch.tensor([S, 1.0 / S, 0.0, 0.0], dtype=torch.float32, device=w_node.device)])
 
 
 def ga_block_forward(ws, R, t, x, z, mask, debug=False):

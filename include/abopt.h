@@ -56,9 +56,9 @@ typedef struct {
     const float* w_mlp1; const float* b_mlp1;
     const float* w_mlp2; const float* b_mlp2;
     const float* ln2_gamma; const float* ln2_beta;
-    const float* w_node_frag;   /* optional [12, 12, 4, 3, 64, 4]: w_node re-laid out per head in MFMA operand order, every weight as its three
-                                   bf16 terms (layout below); when given, the fused projection kernel replaces the GEMM + fragment pass
-                                   (same results up to fp32 summation order) */
+    const float* w_node_frag;   /* optional, abopt_node_frag_floats() floats = [12, 12, 4, 2, 64, 4] + {S, 1 / S, 0, 0}: w_node re-laid out per head in MFMA
+                                   operand order, every weight as the two fp16 terms of S w (layout below); when given, the fused projection kernel
+                                   replaces the GEMM + fragment pass (same results up to fp32 summation order) */
     const float* w_out_frag;    /* optional, 128 * 1824 4-byte words = [4 cb][114 s][2 terms][64 lanes] x 8 fp16: w_out in MFMA operand order as the two
                                    fp16 terms h = fp16(S w), l = fp16(S w - h) of [cb][s][lane = 32 kh + c][i] = w_out[32 cb + c][col(16 s + 8 kh + i)],
                                    S = the power of two with max |w_out| S in [2^14, 2^15) (stored in w_mlp_frag, below; the kernels multiply the
@@ -79,9 +79,10 @@ typedef struct {
 
 /* Host-side description of the w_node_frag layout (used by the binding to pack weights once): for head h, tile T (0,1 q | 2,3 k |
  * 4,5 q_pts | 6,7 k_pts | 8,9 v | 10,11 v_pts), tile row m (0..15) -> source row of w_node, or -1 for a zero row.  Point tiles hold 4
- * points as (x, y, z, pad): m = 4 p + c.  A weight w is stored as three bf16 numbers with h + m + l == w exactly (h = w with the low
- * 16 bits cleared, m = (w - h) likewise, l = w - h - m).  Element [h][T][s][term][lane = 16 kq + m] is a 16-byte vector of 8 bf16:
- * entry i = term(w_node[row][32 s + 8 kq + i]), term 0 = h, 1 = m, 2 = l.  abopt_node_frag_floats() = size in 4-byte units. */
+ * points as (x, y, z, pad): m = 4 p + c.  A weight w is stored as two fp16 numbers h = fp16(S w), l = fp16(S w - h) (round to nearest), S the power
+ * of two with max |w_node| S in [2^14, 2^15).  Element [h][T][s][term][lane = 16 kq + m] is a 16-byte vector of 8 fp16:
+ * entry i = term(S w_node[row][32 s + 8 kq + i]), term 0 = h, 1 = l; the four floats behind the last element are {S, 1 / S, 0, 0}.
+ * abopt_node_frag_floats() = size in 4-byte units. */
 int abopt_node_frag_source_row(int h, int T, int m);
 size_t abopt_node_frag_floats(void);
 

@@ -1309,6 +1309,40 @@ def test_block_tail_autograd_function_vs_torch_statement(N, L, lengths):
     blk.zero_grad()
 
 
+@pytest.mark.parametrize('wscale,fscale', [(1.0, 1.0), (1e-4, 1.0), (300.0, 1.0), (1.0, 1e-3), (1.0, 200.0), (0.0, 1.0)])
+def test_two_term_fp16_products_are_fp32_accurate(wscale, fscale):
+    """The dense layers of the forward tail and the node projections run on the fp16 matrix pipe: two fp16 terms per operand, three products, the
+    weights multiplied by a power of two per matrix before the split (csrc/ipa_common.h: split_pair2; csrc/mlp.hip: tail_weight_scales_kernel).
+    Stated accuracy: the same as an fp32 GEMM.  Checked here against an fp64 statement of ga.py:174-177 with the weights / the aggregated features
+    scaled over six orders of magnitude (the per-matrix scale and the subnormal low terms of small operands), and an all-zero W_out (scale slot = 1):
+    the error of the HIP tail is at most 3x the error of the same statement in torch fp32 (+ 2e-7 of the output range)."""
+    from ab_opt_amd import hip
+    import plain_statement
+    N, L = 3, 70
+    blk = _block_on_device(seed=17)
+    with torch.no_grad():
+        blk.out_transform.weight.mul_(wscale)
+        for i in (0, 2, 4):
+            blk.mlp_transition[i].weight.mul_(max(wscale, 1e-4) if wscale != 300.0 else 3.0)
+    _, _, x, _, mask = [dev(a) for a in cases.ipa_inputs(N, L, [70, 33, 1], salt=4100)]
+    feat = dev(synth.hash_tensor((N, L, 1824), 4101, scale=1.0)) * fscale
+    feat[..., :200] *= 1e-3                                           # columns whose low terms are fp16 subnormals
+    t_ = blk.packed()[0]
+    S = t_['w_mlp_frag'][3 * 128 * 128: 3 * 128 * 128 + 8].cpu()
+    assert torch.equal(S[:4] * S[4:], torch.ones(4)) and all(float(v) == 2.0 ** round(float(torch.log2(v))) for v in S[:4])
+    wmax = blk.out_transform.weight.abs().max().item()
+    assert (S[0].item() == 1.0) if wmax == 0 else (2.0 ** 14 <= wmax * S[0].item() < 2.0 ** 15)
+    out = hip.block_tail_forward(feat.reshape(-1, 1824), t_['w_out_frag'], t_['w_mlp_frag'], x.reshape(-1, 128), t_['b_out'], mask.reshape(-1), t_['ln1_gamma'],
+                                 t_['ln1_beta'], t_['b_mlp0'], t_['b_mlp1'], t_['b_mlp2'], t_['ln2_gamma'], t_['ln2_beta']).reshape(N, L, 128)
+    with torch.no_grad():
+        ref32 = plain_statement.block_tail(blk, x, feat, mask)
+        blk.double()
+        ref64 = plain_statement.block_tail(blk, x.double(), feat.double(), mask)
+    e_hip, e_f32 = max_abs(out, ref64), max_abs(ref32, ref64)
+    assert torch.isfinite(out).all()
+    assert e_hip <= 3.0 * e_f32 + 2e-7 * ref64.abs().max().item(), (wscale, fscale, e_hip, e_f32)
+
+
 @pytest.mark.parametrize('flavour', ['abdesign', 'abdock'])
 def test_fused_heads_match_gemm_path(flavour, monkeypatch):
     """heads.hip (the three denoiser heads as one kernel, time features as an affine term; the mixer as one kernel with the sequence
