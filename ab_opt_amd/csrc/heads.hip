@@ -2,11 +2,11 @@
 // eps_seq_net, each Linear(F+3,F) ReLU Linear(F,F) ReLU Linear(F,out)) in ONE launch; round 1 ran them as nine small GEMMs plus a
 // feature-building pass (81 + 5 us of a 1.5 ms step, each GEMM a 10 us launch with M = 8192, N <= 384, K = 128).
 //
-// One 1024-thread workgroup owns 32 residues.  Everything is K = 128 on the bf16 matrix pipe with exact three-term splits (node_frags.hip
-// explains the arithmetic): the three time features [beta, sin beta, cos beta] of in_feat are constant per sample, so their part of the
+// One 1024-thread workgroup owns 32 residues.  Everything is K = 128 on the fp16 matrix pipe with two-term splits (ipa_common.h: split_pair2
+// explains the arithmetic; one power-of-two scale S for the whole weight buffer, 1 / S behind its last block): the three time features [beta, sin beta, cos beta] of in_feat are constant per sample, so their part of the
 // first layer is an affine term added in the epilogue (3 FMAs per output) instead of a ragged K = 131 product.  Weights arrive pre-split in
 // MFMA operand order from L2 (27 blocks of [32 outputs x 128]: 12 for the fused first layers, 4 per head for the second, one zero-padded
-// block per head for the third), activations live in LDS as bf16 planes.  Wave w < 12 owns one 32-column block of layers 1 and 2; waves
+// block per head for the third), activations live in LDS as fp16 planes.  Wave w < 12 owns one 32-column block of layers 1 and 2; waves
 // 0..2 the three output blocks.  Output: out3 [rows, 32] = eps_crd (0..2) | eps_rot (4..6) | sequence logits (8..27), consumed by the
 // geometric epilogue (rows.hip: heads_epilogue_kernel).
 #include "ipa_common.h"
@@ -15,48 +15,40 @@
 namespace abopt {
 namespace {
 constexpr int HF = 128, HR = 32, HTH = 1024;
-constexpr int HP_ROW = HF * 2 + 16, HP_PLANE = HR * HP_ROW;      // one bf16 plane of [32 rows x 128]: rows 4 banks apart (conflict-free b128 reads)
-constexpr int HBLK = 8 * 3 * 64;                                 // 16-byte vectors per weight block: [k-step][term][lane]
+constexpr int HP_ROW = HF * 2 + 16, HP_PLANE = HR * HP_ROW;      // one fp16 plane of [32 rows x 128]: rows 4 banks apart (conflict-free b128 reads)
+constexpr int HNT = 2;                                           // fp16 terms per value
+constexpr int HBLK = 8 * HNT * 64;                               // 16-byte vectors per weight block: [k-step][term][lane]
 
 struct HeadsSmem {
-    char xp[3 * HP_PLANE];                    // input x as three planes
-    char hp[3][3 * HP_PLANE];                 // per head: hidden activations (layer 1 output, then layer 2 output in place)
+    char xp[HNT * HP_PLANE];                  // input x as two planes (h | l)
+    char hp[3][HNT * HP_PLANE];               // per head: hidden activations (layer 1 output, then layer 2 output in place)
 };
+static_assert(HNT * HP_PLANE >= HR * 32 * 4, "the x planes later hold the rows' 32 head outputs");
 
-// two adjacent values -> one 4-byte entry in each of the three planes
+// two adjacent values -> one 4-byte entry in each of the two planes
 __device__ __forceinline__ void put_terms2(char* planes, int byte_off, float e0, float e1) {
-    const unsigned h = pk_bf16(e0, e1);
-    const float r0 = e0 - __uint_as_float(h << 16), r1 = e1 - __uint_as_float(h & 0xffff0000u);
-    const unsigned m = pk_bf16(r0, r1);
-    const unsigned l = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+    unsigned h, l;
+    split_pair2(e0, e1, h, l);
     *reinterpret_cast<unsigned*>(planes + byte_off) = h;
-    *reinterpret_cast<unsigned*>(planes + HP_PLANE + byte_off) = m;
-    *reinterpret_cast<unsigned*>(planes + 2 * HP_PLANE + byte_off) = l;
+    *reinterpret_cast<unsigned*>(planes + HP_PLANE + byte_off) = l;
 }
 
-// acc[32 rows x 32 outputs] = planes[32 x 128] . block^T ; operands of k-step s + 3 are requested while step s computes
+// a0 + a1 [32 rows x 32 outputs] = S planes[32 x 128] . block^T ; the whole block's operands (8 k-steps x 2 terms = 64 registers) are requested up front
 __device__ __forceinline__ void block_gemm(const char* planes, const u32x4* __restrict__ wb, int lane, f32x16& a0, f32x16& a1) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
     const u32x4* wl = wb + lane;
-    u32x4 w[3][3];
+    u32x4 w[8][HNT];
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 8; ++s)
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) w[s][sp] = wl[(s * 3 + sp) * 64];
+        for (int sp = 0; sp < HNT; ++sp) w[s][sp] = wl[(s * HNT + sp) * 64];
     const char* xp = planes + (lane & 31) * HP_ROW + (lane >> 5) * 16;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const u32x4 wH = w[s % 3][0], wM = w[s % 3][1], wL = w[s % 3][2];
-        if (s + 3 < 8) {
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) w[s % 3][sp] = wl[((s + 3) * 3 + sp) * 64];
-        }
-        const u32x4 xh = *reinterpret_cast<const u32x4*>(xp + s * 32), xm = *reinterpret_cast<const u32x4*>(xp + s * 32 + HP_PLANE),
-                    xl = *reinterpret_cast<const u32x4*>(xp + s * 32 + 2 * HP_PLANE);
-        a0 = mfma_bf32(wH, xl, a0); a1 = mfma_bf32(wL, xh, a1);
-        a0 = mfma_bf32(wM, xm, a0); a1 = mfma_bf32(wH, xm, a1);
-        a0 = mfma_bf32(wM, xh, a0); a1 = mfma_bf32(wH, xh, a1);
+        const u32x4 xh = *reinterpret_cast<const u32x4*>(xp + s * 32), xl = *reinterpret_cast<const u32x4*>(xp + s * 32 + HP_PLANE);
+        a0 = mfma_h32(w[s][0], xl, a0); a1 = mfma_h32(w[s][1], xh, a1);
+        a0 = mfma_h32(w[s][0], xh, a0);
     }
 }
 }  // namespace
@@ -72,6 +64,7 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * HR;
     const u32x4* wf = reinterpret_cast<const u32x4*>(wfrag);
+    const float winv = wfrag[(int64_t)27 * HBLK * 4 + 1];                                            // 1 / S behind the last block
     {   // x rows -> planes: thread -> (row tid >> 5, 4 columns)
         const int r = tid >> 5, c = (tid & 31) * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(xe + min(row0 + r, rows - 1) * HF + c);
@@ -94,7 +87,7 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
             for (int i = 0; i < 4; ++i) {
                 const int o = wave * 32 + g * 8 + csub + i;
                 const float* wt = w1 + (int64_t)o * ld1 + HF;
-                v[i] = fmaxf((a0[4 * g + i] + a1[4 * g + i]) + (b1[o] + (wt[0] * bt + (wt[1] * sb + wt[2] * cb))), 0.f);
+                v[i] = fmaxf(fmaf(a0[4 * g + i] + a1[4 * g + i], winv, b1[o] + (wt[0] * bt + (wt[1] * sb + wt[2] * cb))), 0.f);
             }
             const int col = (wave & 3) * 32 + g * 8 + csub;
             put_terms2(dst, mrow * HP_ROW + col * 2, v[0], v[1]);
@@ -112,7 +105,7 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
             const int col = (wave & 3) * 32 + g * 8 + csub;
             float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf((a0[4 * g + i] + a1[4 * g + i]) + b2[col + i], 0.f);
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(a0[4 * g + i] + a1[4 * g + i], winv, b2[col + i]), 0.f);
             put_terms2(dst, mrow * HP_ROW + col * 2, v[0], v[1]);
             put_terms2(dst, mrow * HP_ROW + col * 2 + 4, v[2], v[3]);
         }
@@ -131,7 +124,7 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int c = g * 8 + csub + i;
-                    if (c < nout) { const float v = (a0[4 * g + i] + a1[4 * g + i]) + b3[c]; o[c] = v; os[c] = v; }
+                    if (c < nout) { const float v = fmaf(a0[4 * g + i] + a1[4 * g + i], winv, b3[c]); o[c] = v; os[c] = v; }
                 }
         }
     }
@@ -157,6 +150,7 @@ __global__ __launch_bounds__(HTH) void mixer_kernel(const float* __restrict__ re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * HR;
     const u32x4* wf = reinterpret_cast<const u32x4*>(wfrag);
+    const float winv = wfrag[(int64_t)8 * HBLK * 4 + 1];
     if (R_out && wave == 4 && lane < HR && row0 + lane < rows) {
         // dpm_full.py:86  R = exp(v_t) of this workgroup's rows, on a wave that has no layer to compute (saves the so3_exp launch of a step)
         const int64_t i = row0 + lane;
@@ -183,7 +177,7 @@ __global__ __launch_bounds__(HTH) void mixer_kernel(const float* __restrict__ re
             const int col = wave * 32 + g * 8 + csub;
             float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = ok ? fmaxf((a0[4 * g + i] + a1[4 * g + i]) + tr[col + i], 0.f) : __builtin_nanf("");
+            for (int i = 0; i < 4; ++i) v[i] = ok ? fmaxf(fmaf(a0[4 * g + i] + a1[4 * g + i], winv, tr[col + i]), 0.f) : __builtin_nanf("");
             put_terms2(sm.hp[0], mrow * HP_ROW + col * 2, v[0], v[1]);
             put_terms2(sm.hp[0], mrow * HP_ROW + col * 2 + 4, v[2], v[3]);
         }
@@ -196,8 +190,8 @@ __global__ __launch_bounds__(HTH) void mixer_kernel(const float* __restrict__ re
             for (int g = 0; g < 4; ++g) {
                 const int col = wave * 32 + g * 8 + csub;
                 *reinterpret_cast<f32x4*>(x_out + (row0 + mrow) * HF + col) =
-                    (f32x4){(a0[4 * g] + a1[4 * g]) + b1[col], (a0[4 * g + 1] + a1[4 * g + 1]) + b1[col + 1], (a0[4 * g + 2] + a1[4 * g + 2]) + b1[col + 2],
-                            (a0[4 * g + 3] + a1[4 * g + 3]) + b1[col + 3]};
+                    (f32x4){fmaf(a0[4 * g] + a1[4 * g], winv, b1[col]), fmaf(a0[4 * g + 1] + a1[4 * g + 1], winv, b1[col + 1]),
+                            fmaf(a0[4 * g + 2] + a1[4 * g + 2], winv, b1[col + 2]), fmaf(a0[4 * g + 3] + a1[4 * g + 3], winv, b1[col + 3])};
             }
         }
     }
@@ -213,8 +207,8 @@ int launch_mixer(const float* res_feat, const int64_t* s_t, const float* wfrag, 
     return ABOPT_OK;
 }
 
-size_t heads_wfrag_floats() { return (size_t)27 * HBLK * 4; }
-size_t mixer_wfrag_floats() { return (size_t)8 * HBLK * 4; }
+size_t heads_wfrag_floats() { return (size_t)27 * HBLK * 4 + 4; }     // + {S, 1 / S, 0, 0}
+size_t mixer_wfrag_floats() { return (size_t)8 * HBLK * 4 + 4; }
 
 int launch_heads_mlp(const float* xe, const float* beta, const float* wfrag, const float* w1, int ld1, const float* b1, const float* b2c,
                      const float* b2r, const float* b2s, const float* b3c, const float* b3r, const float* b3s, float* out3, int64_t rows, int L,

@@ -260,17 +260,21 @@ def ga_weights_struct(t):
 
 
 def pack_mfma_operand(w):
-    """w [32 B, K] (K a multiple of 16) -> [B, K/16, 3, 64, 4]: 32x32x16 MFMA operand order, every weight as its three bf16 terms
-    (fp32 container of 8 bf16 per lane): [cb][step][term][lane = 32 khalf + c][i] = term(w[32 cb + c][16 step + 8 khalf + i])."""
+    """w [32 B, K] (K a multiple of 16) -> [B, K/16, 2, 64, 4] flattened + {S, 1 / S, 0, 0}: 32x32x16 MFMA operand order, every weight as the two
+    fp16 terms of S w (fp32 container of 8 fp16 per lane), S = tail_weight_scale(w):
+    [cb][step][term][lane = 32 khalf + c][i] = term(S w[32 cb + c][16 step + 8 khalf + i])."""
     R, K = w.shape
-    terms = torch.stack(split_bf16x3(w.float()), 0)           # [term, R, K] int16
-    g = terms.reshape(3, R // 32, 32, K // 16, 2, 8)          # [term, cb, col, step, k half, i]
+    S = tail_weight_scale(w)
+    g = w.float() * S
+    h16 = g.half()
+    terms = torch.stack([h16, (g - h16.float()).half()], 0)   # [term, R, K] fp16
+    g = terms.reshape(2, R // 32, 32, K // 16, 2, 8)          # [term, cb, col, step, k half, i]
     out = g.permute(1, 3, 0, 4, 2, 5).contiguous()            # [cb, step, term, k half, col, i]
-    return out.view(R // 32, K // 16, 3, 64, 8).view(torch.float32)
+    return torch.cat([out.view(-1).view(torch.float32), torch.tensor([S, 1.0 / S, 0.0, 0.0], dtype=torch.float32, device=w.device)])
 
 
 def pack_heads_weights(w_head1, w_crd2, w_rot2, w_seq2, w_crd3, w_rot3, w_seq3):
-    """-> w_heads_frag [27, 8, 3, 64, 4] (include/abopt.h: abopt_eps_weights.w_heads_frag)."""
+    """-> w_heads_frag [27, 8, 2, 64, 4] + {S, 1 / S, 0, 0} (include/abopt.h: abopt_eps_weights.w_heads_frag)."""
     pad32 = lambda w: torch.cat([w, torch.zeros(32 - w.shape[0], w.shape[1], dtype=w.dtype, device=w.device)], 0)
     rows = torch.cat([w_head1[:, :128], w_crd2, w_rot2, w_seq2, pad32(w_crd3), pad32(w_rot3), pad32(w_seq3)], 0)      # [27 * 32, 128]
     return pack_mfma_operand(rows.contiguous())

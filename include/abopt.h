@@ -148,12 +148,13 @@ typedef struct {
     const float* w_prmsd1; const float* b_prmsd1;                 /* [F, F+4] (K padded), [F] */
     const float* w_prmsd2; const float* b_prmsd2;                 /* [F, F], [F] */
     const float* w_prmsd3; const float* b_prmsd3; int num_bins;   /* [num_bins, F], [num_bins] */
-    const float* w_heads_frag;  /* optional [27, 8, 3, 64, 4] (abopt_heads_frag_floats() floats): the heads' weights as bf16 terms in MFMA operand order
-                                   (block layout of w_out_frag with one column block per entry: [block][s][term][lane = 32 kh + c] -> 8 bf16,
-                                   entry i = term(W[32 blk + c][16 s + 8 kh + i])): blocks 0..11 = w_head1[:, :F] (crd | rot | seq first layers),
-                                   12..15 w_crd2, 16..19 w_rot2, 20..23 w_seq2, 24 w_crd3, 25 w_rot3, 26 w_seq3 (rows zero-padded to 32).
+    const float* w_heads_frag;  /* optional, abopt_heads_frag_floats() floats = [27, 8, 2, 64, 4] + {S, 1 / S, 0, 0}: the heads' weights as two fp16 terms of S w in
+                                   MFMA operand order (block layout of w_out_frag with one column block per entry: [block][s][term][lane = 32 kh + c] -> 8 fp16,
+                                   entry i = term(S W[32 blk + c][16 s + 8 kh + i]), S one power of two for the whole buffer): blocks 0..11 = w_head1[:, :F]
+                                   (crd | rot | seq first layers), 12..15 w_crd2, 16..19 w_rot2, 20..23 w_seq2, 24 w_crd3, 25 w_rot3, 26 w_seq3 (rows zero-padded to 32).
                                    When given, the three heads run as one kernel (time features enter as an affine term from w_head1[:, F:F+3]). */
-    const float* w_mix_frag;    /* optional [8, 8, 3, 64, 4]: blocks 0..3 = w_mix0[:, :F], 4..7 = w_mix1, same layout; with mix_table the mixer is one kernel */
+    const float* w_mix_frag;    /* optional, abopt_mixer_frag_floats() floats = [8, 8, 2, 64, 4] + {S, 1 / S, 0, 0}: blocks 0..3 = w_mix0[:, :F], 4..7 = w_mix1, same
+                                   layout; with mix_table the mixer is one kernel */
     const float* mix_table;     /* optional [25, F]: row s = w_mix0[:, F:] . seq_embed[s] + b_mix0 (the embedding half of the mixer's first layer) */
 } abopt_eps_weights;
 

@@ -1,3 +1,4 @@
+import math
 """CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/abopt.h declares,
 and the host layer refuses to run anywhere but on a HIP device (no CPU fallback)."""
 import ctypes
@@ -80,7 +81,8 @@ def test_contig_mask_and_registry():
 
 
 def test_bf16_three_term_split_is_exact():
-    """hip.split_bf16x3 (the pack-time half of csrc/node_frags.hip's arithmetic): h + m + l == w bit for bit, every term is a bf16
+    """hip.split_bf16x3 (the host statement of csrc/ipa_common.h: split3 -- since round 5 the arithmetic of the BACKWARD chains only, csrc/mlp.hip:
+    tail_backward_kernel): h + m + l == w bit for bit, every term is a bf16
     number, and the six products the kernel keeps reproduce x * w to 2^-24 (the dropped m*l, l*m, l*l terms).  (Exactness needs the
     residuals to stay normal numbers, i.e. |w| > ~1e-31; below that the error is < 1e-38 absolute.)"""
     g = torch.Generator().manual_seed(5)
@@ -98,6 +100,32 @@ def test_bf16_three_term_split_is_exact():
     exact = x.double() * w.double()
     rel = ((kept - exact).abs() / exact.abs().clamp_min(1e-300))[exact != 0]
     assert rel.max().item() < 2.0 ** -24
+
+
+def test_fp16_two_term_split_and_scale():
+    """The host statement of the forward dense layers' arithmetic (csrc/ipa_common.h: split_pair2; hip.tail_weight_scale, hip._fp16_terms): the
+    scale is a power of two with max |w| S in [2^14, 2^15); h and l are fp16 numbers with |S w - h - l| <= 2^-22 |S w| (+ 2^-25 absolute where l
+    is subnormal); the three products the kernels keep reproduce x w to 3 x 2^-22 relative + the subnormal floor
+    (2^-25 |w| for activations below 2^-3, whose low term is an fp16 subnormal: the rounding of an fp32 number of size 0.5)."""
+    g = torch.Generator().manual_seed(6)
+    for scale in (1e-6, 3e-3, 1.0, 900.0):
+        w = torch.randn(4096, generator=g) * scale
+        S = hip.tail_weight_scale(w)
+        assert S == 2.0 ** round(math.log2(S)) and 2.0 ** 14 <= w.abs().max().item() * S < 2.0 ** 15
+        ws = (w * S).reshape(-1, 8)
+        assert torch.equal(ws / S, w.reshape(-1, 8))                                        # the scaling is exact
+        hw, lw = [t.view(torch.float16).float() for t in hip._fp16_terms(ws)]
+        err = (ws.double() - hw.double() - lw.double()).abs()
+        assert bool((err <= 2.0 ** -22 * ws.abs().double() + 2.0 ** -25).all())
+        x = (torch.randn(4096, generator=g) * torch.logspace(-4, 3, 4096)).reshape(-1, 8)      # activations are not scaled
+        hx, lx = [t.view(torch.float16).float() for t in hip._fp16_terms(x)]
+        assert bool(((x.double() - hx.double() - lx.double()).abs() <= 2.0 ** -22 * x.abs().double() + 2.0 ** -25).all())
+        kept = (hx.double() * lw.double() + lx.double() * hw.double() + hx.double() * hw.double()) / S
+        exact = x.double() * w.reshape(-1, 8).double()
+        wd = w.reshape(-1, 8).abs().double()
+        floor = 2.0 ** -25 * wd + 2.0 ** -25 / S * x.abs().double()          # where a low term is an fp16 subnormal: 2^-25 absolute on x, 2^-25 / S on w
+        assert bool(((kept - exact).abs() <= 3 * 2.0 ** -22 * exact.abs() + 1.01 * floor).all())
+    assert hip.tail_weight_scale(torch.zeros(8)) == 1.0
 
 
 def test_docs_cite_existing_tests_and_files():
