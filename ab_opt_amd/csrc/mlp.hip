@@ -380,30 +380,35 @@ int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, con
 // of two per matrix with max |w| S in [2^14, 2^15) (ipa_common.h: split_pair2):
 //   W_out     -> wof [4 cb][114 k-steps][term h | l][64 lanes] x 8 fp16 (32x32x16 operand order, K in staging order ot_feat_col),
 //   W_mlp0..2 -> wmf [3][8 ct][4 k-steps][term][64 lanes] x 8 fp16 (16x16x32 operand order), then at float OT_SCALE_OFF the four S and the four 1 / S
-//                (tail_weight_scales_kernel; the rest of the buffer, which keeps the size of wmt, is zeroed),
+//                (then 4 x 64 slice maxima, scratch of the two packing kernels; the rest of the buffer, which keeps the size of wmt, is zeroed),
 // and the TRANSPOSED MLP weights -> wmt [3][4][8][3][64] x 8 bf16 (32x32x16 operand order, three bf16 terms: operands of the backward chain).
 // One thread per (matrix, block, step, lane): 8 values -> two or three 16-byte vectors.  Layout: include/abopt.h (w_out_frag, w_mlp_frag).
-__global__ __launch_bounds__(1024) void tail_weight_scales_kernel(const float* __restrict__ w_out, const float* __restrict__ w0, const float* __restrict__ w1,
-                                                                  const float* __restrict__ w2, float* __restrict__ scales, int tail_floats) {
-    __shared__ float red[16];
-    for (int e = 8 + blockIdx.x * 1024 + threadIdx.x; e < tail_floats; e += 4 * 1024) scales[e] = 0.f;      // the unused rest of w_mlp_frag
-    const int mtx = blockIdx.x;
+// Stage 1 of the scales: |w| maxima of 64 slices per matrix -> scales[8 + 64 mtx + slice] (scratch behind the eight scale slots; one workgroup per
+// matrix took 107 us for W_out -- 0.64 ms of a training step, which packs six blocks per step).  The pack kernel folds them.
+constexpr int OT_NSL = 64;
+__global__ __launch_bounds__(256) void tail_weight_absmax_kernel(const float* __restrict__ w_out, const float* __restrict__ w0, const float* __restrict__ w1,
+                                                                 const float* __restrict__ w2, float* __restrict__ scales, int tail_floats) {
+    __shared__ float red[4];
+    const int mtx = blockIdx.y, slice = blockIdx.x;
+    for (int e = 8 + 4 * OT_NSL + (mtx * OT_NSL + slice) * 256 + threadIdx.x; e < tail_floats; e += 4 * OT_NSL * 256) scales[e] = 0.f;      // the unused rest of w_mlp_frag
     const float* src = mtx == 0 ? w_out : (mtx == 1 ? w0 : (mtx == 2 ? w1 : w2));
-    const int n = mtx == 0 ? F * OT_K : F * F;
+    const int n4 = (mtx == 0 ? F * OT_K : F * F) / 4, per = (n4 + OT_NSL - 1) / OT_NSL;
     float m = 0.f;
-    for (int e = threadIdx.x; e < n; e += 1024) { const float a = fabsf(src[e]); m = (a <= 3.0e38f) ? fmaxf(m, a) : m; }      // NaN / inf do not set the scale
+    for (int e = slice * per + threadIdx.x; e < min(n4, (slice + 1) * per); e += 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float a = fabsf(v[i]); m = (a <= 3.0e38f) ? fmaxf(m, a) : m; }      // NaN / inf do not set the scale
+    }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
-        int e = 0;
-        if (m > 0.f) { (void)frexpf(m, &e); e = 15 - e; }                    // m = f 2^(15 - e), f in [0.5, 1)  ->  m 2^e in [2^14, 2^15)
-        e = max(-100, min(100, e));
-        scales[mtx] = ldexpf(1.f, e);
-        scales[4 + mtx] = ldexpf(1.f, -e);
-    }
+    if (threadIdx.x == 0) scales[8 + mtx * OT_NSL + slice] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+// max |w| -> the exponent e of S = 2^e: m = f 2^(15 - e), f in [0.5, 1)  ->  m 2^e in [2^14, 2^15); 0 for an all-zero matrix
+__device__ __forceinline__ int tail_scale_exp(float m) {
+    int e = 0;
+    if (m > 0.f) { (void)frexpf(m, &e); e = 15 - e; }
+    return max(-100, min(100, e));
 }
 
 __global__ __launch_bounds__(256) void pack_tail_weights_kernel(const float* __restrict__ w_out, const float* __restrict__ w0, const float* __restrict__ w1,
@@ -411,7 +416,17 @@ __global__ __launch_bounds__(256) void pack_tail_weights_kernel(const float* __r
                                                                 float* __restrict__ wmt) {
     constexpr int NOUT = 4 * OT_ST * 64, NMLP = 4 * OT_MS * 64;          // NMLP = 2048 = 8 ct * 4 k-steps * 64 lanes as well
     int id = blockIdx.x * 256 + threadIdx.x;
-    const float* scales = wmf + OT_SCALE_OFF;
+    __shared__ float scales[4];
+    {   // wave w folds the 64 slice maxima of matrix w; workgroup 0 publishes S and 1 / S
+        const int w = threadIdx.x >> 6;
+        const float m = wave_max(wmf[OT_SCALE_OFF + 8 + w * OT_NSL + (threadIdx.x & 63)]);
+        if ((threadIdx.x & 63) == 0) {
+            const int e = tail_scale_exp(m);
+            scales[w] = ldexpf(1.f, e);
+            if (blockIdx.x == 0) { wmf[OT_SCALE_OFF + w] = ldexpf(1.f, e); wmf[OT_SCALE_OFF + 4 + w] = ldexpf(1.f, -e); }
+        }
+    }
+    __syncthreads();
     if (id < NOUT) {
         const int lane = id & 63, st = (id >> 6) % OT_ST, cb = (id >> 6) / OT_ST;
         const float* p = w_out + (int64_t)(cb * 32 + (lane & 31)) * OT_K;
@@ -450,8 +465,8 @@ __global__ __launch_bounds__(256) void pack_tail_weights_kernel(const float* __r
 }
 
 int launch_pack_tail_weights(const float* w_out, const float* w0, const float* w1, const float* w2, float* wof, float* wmf, float* wmt, hipStream_t st) {
-    // the scale slots first (the pack kernel reads them)
-    hipLaunchKernelGGL(tail_weight_scales_kernel, dim3(4), dim3(1024), 0, st, w_out, w0, w1, w2, wmf + OT_SCALE_OFF, (int)(mlp_wfrag_floats() - OT_SCALE_OFF));
+    // slice maxima first (the pack kernel folds them into the scales)
+    hipLaunchKernelGGL(tail_weight_absmax_kernel, dim3(OT_NSL, 4), dim3(256), 0, st, w_out, w0, w1, w2, wmf + OT_SCALE_OFF, (int)(mlp_wfrag_floats() - OT_SCALE_OFF));
     ABOPT_LAUNCH_CHECK();
     const int total = 4 * OT_ST * 64 + 6 * 4 * OT_MS * 64;
     hipLaunchKernelGGL(pack_tail_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w_out, w0, w1, w2, wof, wmf, wmt);

@@ -290,7 +290,7 @@ def out_feat_order():
 
 
 def tail_weight_scale(w):
-    """Power of two S with max |w| S in [2^14, 2^15) (csrc/mlp.hip: tail_weight_scales_kernel): the weights of the forward tail are split into two
+    """Power of two S with max |w| S in [2^14, 2^15) (csrc/mlp.hip: tail_weight_absmax_kernel): the weights of the forward tail are split into two
     fp16 terms of S w, so that the low terms stay normal; 1 for an all-zero matrix."""
     a = w.detach().float().abs()
     m = float(a[torch.isfinite(a)].max()) if bool(torch.isfinite(a).any()) else 0.0

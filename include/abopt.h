@@ -70,8 +70,8 @@ typedef struct {
                                    when given together with w_mlp_frag, out_transform runs inside the LayerNorm/MLP kernel (no split-K partial slabs) */
     const float* w_mlp_frag;    /* optional, abopt_mlp_frag_floats() floats: w_mlp0, w_mlp1, w_mlp2 in 16x16x32 MFMA operand order as two fp16 terms of
                                    S_layer w: [layer][ct][s][term][lane = 16 kq + m] x 8 fp16, entry i = term(S w[16 ct + m][32 s + 8 kq + i])
-                                   (3 * 128 * 128 words), then 8 floats {S_out, S_0, S_1, S_2, 1 / S_out, 1 / S_0, 1 / S_1, 1 / S_2}; the rest of the
-                                   buffer is zero */
+                                   (3 * 128 * 128 words), then 8 floats {S_out, S_0, S_1, S_2, 1 / S_out, 1 / S_0, 1 / S_1, 1 / S_2}, then 256 floats of
+                                   packer scratch; the rest of the buffer is zero */
     const float* w_out_terms;   /* optional, abopt_out_terms_floats() floats: a copy of w_out_frag (abopt_out_frag_terms; until ABI 38 the fused kernel
                                    streamed a different layout).  When given (with w_mlp_frag and a pair-bias cache), the IPA core and the tail of the
                                    block run as ONE kernel wherever the 32-row core applies: feat never leaves the chip (bit-identical results) */
