@@ -231,7 +231,7 @@ def secondary_measurements(dev, L):
                              'tflops': round(tb_flops / (best * 1e-3) / 1e12, 2), 'flop_frac': round(tb_flops / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                              'bound': ('fp32 matrix / vector pipes' if tb_flops / (FP32_PEAK_TFLOPS * 1e12) > tb_bytes / (HBM_PEAK_GBS * 1e9) else 'hbm') +
                                       ' (%.2f ms of HBM time against %.2f ms of fp32 FLOPs at peak)' % (tb_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, tb_flops / (FP32_PEAK_TFLOPS * 1e12) * 1e3),
-                             'kernel_share': 'profiles/r05_a_train_steady_step_kernel_stats.txt: steady-state share of GPU time in abopt:: kernels (93-94 %)'}
+                             'kernel_share': 'profiles/r05_i_train_steady_step_kernel_stats.txt: steady-state share of GPU time in abopt:: kernels (94 %)'}
     model.zero_grad(set_to_none=True)
     model.eval()
     del adam, tb
@@ -527,6 +527,9 @@ def main():
                        'samples_per_gpu': N, 'residues': L, 'sampler_steps': T, 'parallelism': f'independent samples x{world}',
                        'launch': ('hipGraph replay of the K-step loop (captured once, before the timed region; Philox position from device memory)'
                                   if use_graph else 'eager launches'),
+                       'arithmetic': 'fp32 storage and accumulation everywhere; attention logits / softmax / aggregations on the fp32 matrix instructions; the dense layers '
+                                     '(node projections, out_transform + MLP, heads, mixer) multiply fp32 operands as two fp16 terms each, three products, fp32-accurate '
+                                     '(tests/test_hip_parity.py::test_two_term_fp16_products_are_fp32_accurate)',
                        'backend': backend, 'ranks_per_device': (world + ndev - 1) // ndev if world > 1 else 1,
                        'ranks': ranks_seen, 'ranks_note': None if ranks_seen is None else 'gathered through the process group: device and OWN median ms_per_step of every rank (the line\'s ms_per_step is the max over ranks per repeat)'},
             'roofline': {'bound': 'hbm', 'kernel': kernel_name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
