@@ -3,9 +3,10 @@
 // point norms, and the re-layout of everything into the MFMA fragment order the IPA core consumes (qfrag / kvfrag, see ipa.hip) --
 // in ONE kernel.  The 67 MB projection buffer is never written or re-read.
 //
-// Weight-stationary: a workgroup owns ONE head.  Its 168 weight rows, permuted and zero-padded at pack time to 12 tiles of 16 rows
+// Weight-stationary: a workgroup owns HALF a head (since round 5; a whole head before).  A head's 168 weight rows, permuted and zero-padded at pack time to 12 tiles of 16 rows
 //   tile 0,1: q channels 0..15, 16..31   2,3: k   4,5: q_pts points 0..3, 4..7 as (x, y, z, 0) quadruples  |  6,7: k_pts   8,9: v   10,11: v_pts
-// sit in LDS in MFMA operand order (96 KB, loaded once); residues stream through in pairs of 16-row tiles.
+// sit in LDS in MFMA operand order (tiles 0..5 or 6..11: 48 KB, loaded once; three 4-wave workgroups per CU -- at the bench shape every wave of the chip
+// runs exactly two tasks, where one 12-wave workgroup per CU and head left 24.4 tasks to 12 waves); residues stream through in pairs of 16-row tiles.
 //
 // Arithmetic (round 5): fp32 x fp32 products on the fp16 matrix pipe with TWO terms per operand (ipa_common.h: split_pair2): h = fp16(x),
 // l = fp16(x - h), |x - h - l| <= 2^-22 |x|; the weights are multiplied by a power of two S (max |w| S in [2^14, 2^15), so their low terms
@@ -33,12 +34,19 @@ __device__ long long g_nf_timing[16][8];
 namespace abopt {
 
 constexpr int NF_F = 128;                                       // node feature width (ga.py:54-66 with node_feat_dim = 128)
+#ifndef NF_SPLIT
+#define NF_SPLIT 1       // 1 (round 5): a workgroup owns HALF a head (six tiles, 48 KB of LDS), three 4-wave workgroups per CU | 0: a whole head (96 KB), one 12-wave workgroup per CU
+#endif
 #ifndef NF_WAVES_
-#define NF_WAVES_ 12
+#define NF_WAVES_ (NF_SPLIT ? 4 : 12)
+#endif
+#ifndef NF_WGPC
+#define NF_WGPC 3        // NF_SPLIT: workgroups per CU the grid is sized for
 #endif
 constexpr int NF_TILES = 12, NF_HT = NF_TILES / 2, NF_WAVES = NF_WAVES_;       // 12 waves = 3 per SIMD (152 VGPRs): the task epilogues of one wave hide behind the MFMAs of two others (8 -> 12 waves: 35.8 -> 34.9 us at M = 8192, 205 -> 188 us at M = 48000, same box)
 constexpr int NF_KS = NF_F / 32, NF_SPL = 2;                // k-steps of 32, fp16 terms per fp32 value
 constexpr int NF_HEAD_VEC = NF_TILES * NF_KS * NF_SPL * 64;    // 16-byte vectors (8 fp16) per head: [tile][k-step][term][lane]
+constexpr int NF_LDS_VEC = NF_SPLIT ? NF_HEAD_VEC / 2 : NF_HEAD_VEC;      // what a workgroup keeps in LDS
 
 
 __device__ __forceinline__ float quad_bcast0(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x00, 0xf, 0xf, false)); }
@@ -72,7 +80,7 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int T = 0; T < NF_HT; ++T) acc[rt][T] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const u32x4* wh = wl + (HALF * NF_HT) * (NF_KS * NF_SPL * 64) + lane;
+    const u32x4* wh = wl + (NF_SPLIT ? 0 : (HALF * NF_HT) * (NF_KS * NF_SPL * 64)) + lane;
     // weight fragments of step g + 1 are read from LDS before the 12 MFMAs of step g are issued (hipcc left to itself hoists every read)
     u32x4 wa[2][NF_SPL];
 #pragma unroll
@@ -192,15 +200,17 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
                                                                    int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char nf_smem[];
     u32x4* wl = reinterpret_cast<u32x4*>(nf_smem);                             // [12 tiles][4 k-steps][2 terms][64]
-    const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
+    const int h = NF_SPLIT ? blockIdx.y >> 1 : blockIdx.y, tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
+    const int half = blockIdx.y & 1;                                           // NF_SPLIT: which six tiles this workgroup owns
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef NF_TIMING
     const long long c0 = clock64(), w0 = wall_clock64();
 #endif
     {
-        const u32x4* wg = reinterpret_cast<const u32x4*>(wfrag) + (int64_t)h * NF_HEAD_VEC;
+        const u32x4* wg = reinterpret_cast<const u32x4*>(wfrag) + (int64_t)h * NF_HEAD_VEC + (NF_SPLIT ? half * NF_LDS_VEC : 0);
+        static_assert(NF_LDS_VEC % (NF_WAVES * 64) == 0, "weight load loop");
 #pragma unroll
-        for (int e = 0; e < NF_HEAD_VEC / (NF_WAVES * 64); ++e) wl[e * (NF_WAVES * 64) + tid] = wg[e * (NF_WAVES * 64) + tid];
+        for (int e = 0; e < NF_LDS_VEC / (NF_WAVES * 64); ++e) wl[e * (NF_WAVES * 64) + tid] = wg[e * (NF_WAVES * 64) + tid];
     }
     const float sc = spatial_coef[h];
     const float winv = wfrag[(int64_t)H * NF_HEAD_VEC * 4 + 1];                  // 1 / S behind the packed weights
@@ -213,15 +223,16 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
 #endif
     // every workgroup owns a contiguous, equal (+-1) share of the head's tasks (pair of row tiles, half of the tiles); its waves take
     // them round-robin, so both halves of a row-tile pair run on neighbouring waves and share the x rows in L1
-    const int ntask = 2 * ((total_tiles + 1) / 2);
+    // (NF_SPLIT: a task index is a pair of row tiles, all of this workgroup's tasks are of its own half)
+    const int ntask = NF_SPLIT ? (total_tiles + 1) / 2 : 2 * ((total_tiles + 1) / 2);
     const int t_lo = (int)((int64_t)ntask * blockIdx.x / gridDim.x), t_hi = (int)((int64_t)ntask * (blockIdx.x + 1) / gridDim.x);
 #ifdef NF_TIMING
     long long te[3] = {0, 0, 0};
     int ti = 0;
 #endif
     for (int task = t_lo + wave; task < t_hi; task += NF_WAVES) {
-        const int tile0 = (task >> 1) * 2;
-        if (task & 1) nf_task<1>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq);
+        const int tile0 = NF_SPLIT ? task * 2 : (task >> 1) * 2;
+        if (NF_SPLIT ? half : (task & 1)) nf_task<1>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq);
         else          nf_task<0>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq);
 #ifdef NF_TIMING
         if (ti < 3) te[ti++] = clock64() - c0;
@@ -244,10 +255,19 @@ int launch_node_frags(const float* x, const float* wfrag, const float* R, const 
     int cus = 0, rc;
     if ((rc = device_cu_count(&cus))) return rc;
     static LdsConfig lds_cfg;
-    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(node_frags_kernel), NF_HEAD_VEC * 16, lds_cfg))) return rc;
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(node_frags_kernel), NF_LDS_VEC * 16, lds_cfg))) return rc;
+#if NF_SPLIT
+    // 24 (head, half) columns of workgroups x `groups` shares of the row-tile pairs; 48 KB of LDS each: NF_WGPC = 3 per CU.  At the bench shape
+    // (256 pairs, 256 CUs): 32 groups of 8 pairs, two tasks for each of the four waves -- every wave of the chip does the same amount of work.
+    const int ntask = (total + 1) / 2;
+    const int groups = max(1, min(cus * NF_WGPC / (2 * H), (ntask + NF_WAVES - 1) / NF_WAVES));
+    const dim3 grid(groups, 2 * H);
+#else
     const int ntask = 2 * ((total + 1) / 2);
-    const int groups = max(1, min(cus / H, (ntask + NF_WAVES - 1) / NF_WAVES));          // one workgroup per CU: 144 KB of LDS each
-    hipLaunchKernelGGL(node_frags_kernel, dim3(groups, H), dim3(NF_WAVES * 64), NF_HEAD_VEC * 16, st, x, wfrag, R, t, spatial_coef,
+    const int groups = max(1, min(cus / H, (ntask + NF_WAVES - 1) / NF_WAVES));          // one workgroup per CU: 96 KB of LDS each
+    const dim3 grid(groups, H);
+#endif
+    hipLaunchKernelGGL(node_frags_kernel, grid, dim3(NF_WAVES * 64), NF_LDS_VEC * 16, st, x, wfrag, R, t, spatial_coef,
                        qfrag, kvfrag, L, nchunk, total);
     ABOPT_LAUNCH_CHECK();
 #ifdef NF_TIMING
