@@ -15,8 +15,8 @@
 #include "ipa_common.h"
 #include "kernels.h"
 
-// Developer switch (make CXXEXTRA=-DPE_TERMS=<mask>): which 64-wide products of pair_embed_kernel run on the bf16 matrix pipe as exact three-term
-// splits (node_frags.hip explains the arithmetic): 1 distance_embed.2 | 2 out_mlp.0, f_dist block | 4 out_mlp.0, dihedral block | 8 out_mlp.2 | 16 out_mlp.4
+// Developer switch (make CXXEXTRA=-DPE_TERMS=<mask>): which 64-wide products of pair_embed_kernel run on the fp16 matrix pipe as two-term
+// splits (ipa_common.h explains the arithmetic; three bf16 terms until round 5): 1 distance_embed.2 | 2 out_mlp.0, f_dist block | 4 out_mlp.0, dihedral block | 8 out_mlp.2 | 16 out_mlp.4
 #ifndef PE_TERMS
 #define PE_TERMS 0
 #endif
@@ -262,7 +262,7 @@ struct PairArgs {
     const float* t_aap; const float* t_rel; const float* sp; const float* freq;
     const f32x4* wd0; const float* bd0; const f32x4* wd1; const float* bd1;
     const f32x4* wo0; const float* bo0; const f32x4* wo1; const float* bo1; const f32x4* wo2; const float* bo2;
-    const u32x4* wtd1; const u32x4* wto0; const u32x4* wtdh; const u32x4* wto1; const u32x4* wto2;   // the same 64-wide blocks as bf16 terms, [k-step][nt][term][lane] (PE_TERMS)
+    const u32x4* wtd1; const u32x4* wto0; const u32x4* wtdh; const u32x4* wto1; const u32x4* wto2;   // the same 64-wide blocks as scaled fp16 terms (PE_TERMS; swizzle_terms_kernel)
     float* out; int N, L, A, has_struct;
     float* gsave; float* tsave;   // training: Gaussian features and d/d softplus(coef), [pair][A][16] (b padded to 16), NULL for inference
     float* acts;          // training: per pair [relu(D0) 64 | f_dist 64 | f_dih 32 | relu(O0) 64 | relu(O1) 64] (PAIR_ACT floats), NULL for inference
@@ -281,41 +281,37 @@ constexpr int PMT = 4;        // 16-pair tiles per wave
                 _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt)                                                        \
                     DST[mt][nt] = mfma4e(w_[nt][q], SRC[mt][blk][q], DST[mt][nt]);                                        \
     }
-// The same layer on the bf16 matrix pipe.  K slot (kb = lane >> 4, e = 0..7) of k-step s is feature 16 (2 s + (e >> 2)) + 4 kb + (e & 3): the eight
-// values lane (pair, kb) holds in SRC[mt][2 s] and SRC[mt][2 s + 1], so the B operand is split3() of two accumulator quads -- still no cross-lane
-// traffic.  WT: [NSTEP][4 nt][3 terms][64 lanes] (swizzle_terms_kernel).  Six products per (tile, output tile, k-step), smallest terms first.
+// The same layer on the fp16 matrix pipe with two terms per operand (ipa_common.h: split_pair2; three-term bf16 products until round 5).  K slot
+// (kb = lane >> 4, e = 0..7) of k-step s is feature 16 (2 s + (e >> 2)) + 4 kb + (e & 3): the eight values lane (pair, kb) holds in SRC[mt][2 s] and
+// SRC[mt][2 s + 1], so the B operand is split2() of two accumulator quads -- still no cross-lane traffic.  WT: [NSTEP][768 vectors: 4 nt x 2 terms x
+// 64 lanes, then unused], the weights scaled by a power of two S per block (swizzle_terms_kernel); bits of 1 / S in the last vector of the buffer.
+// Three products per (tile, output tile, k-step) into a fresh accumulator, then DST += acc / S (exact scaling, one rounding in the sum).
 #ifndef PE_DBG
-#define PE_DBG 0          // developer: 1 fences + 32 wait states around every split and product group | 2 the six products of an output tile interleaved over the four output tiles (no back-to-back dependent MFMAs)
+#define PE_DBG 0          // developer: 1 fences + PE_NOPS wait states around every split and product group | 4 / 8 / 16: only before the split / before / after the products
 #endif
 #ifndef PE_NOPS
 #define PE_NOPS 32
 #endif
-#define PE_FENCE(B) { if (PE_DBG & (1 | (B))) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int n_ = 0; n_ < PE_NOPS; n_ += 4) asm volatile("s_nop 3" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } }      /* bits 4 / 8 / 16: only before the split / between split and products / after the products; PE_NOPS wait states */
+#define PE_FENCE(B) { if (PE_DBG & (1 | (B))) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int n_ = 0; n_ < PE_NOPS; n_ += 4) asm volatile("s_nop 3" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } }
 #define PAIR_DENSE_T(DST, SRC, WT, NSTEP)                                                                                 \
+    {                                                                                                                     \
+    const float inv_ = __uint_as_float((WT)[(NSTEP) * 768 - 1][0]);                                                       \
     _Pragma("unroll") for (int s_ = 0; s_ < (NSTEP); ++s_) {                                                              \
-        u32x4 wt_[4][3];                                                                                                  \
+        u32x4 wt_[4][2];                                                                                                  \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
-            _Pragma("unroll") for (int sp_ = 0; sp_ < 3; ++sp_) wt_[nt][sp_] = (WT)[((s_ * 4 + nt) * 3 + sp_) * 64 + lane]; \
+            _Pragma("unroll") for (int sp_ = 0; sp_ < 2; ++sp_) wt_[nt][sp_] = (WT)[s_ * 768 + (nt * 2 + sp_) * 64 + lane]; \
         _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt) {                                                              \
             PE_FENCE(4)                                                                                                   \
-            const Split3 xs_ = split3(SRC[mt][2 * s_], SRC[mt][2 * s_ + 1]);                                              \
+            const Split2 xs_ = split2(SRC[mt][2 * s_], SRC[mt][2 * s_ + 1]);                                              \
             PE_FENCE(8)                                                                                                   \
-            if (PE_DBG & 2) {                                                                                             \
-                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][0], xs_.l, DST[mt][nt]);   \
-                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][2], xs_.h, DST[mt][nt]);   \
-                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][1], xs_.m, DST[mt][nt]);   \
-                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][0], xs_.m, DST[mt][nt]);   \
-                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][1], xs_.h, DST[mt][nt]);   \
-                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) DST[mt][nt] = mfma_bf(wt_[nt][0], xs_.h, DST[mt][nt]);   \
-            } else {                                                                                                      \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                            \
-                f32x4 c_ = DST[mt][nt];                                                                                   \
-                c_ = mfma_bf(wt_[nt][0], xs_.l, c_); c_ = mfma_bf(wt_[nt][2], xs_.h, c_); c_ = mfma_bf(wt_[nt][1], xs_.m, c_); \
-                c_ = mfma_bf(wt_[nt][0], xs_.m, c_); c_ = mfma_bf(wt_[nt][1], xs_.h, c_); c_ = mfma_bf(wt_[nt][0], xs_.h, c_); \
-                DST[mt][nt] = c_;                                                                                         \
-            } }                                                                                                           \
+                f32x4 c_ = mfma_h(wt_[nt][0], xs_.l, (f32x4){0.f, 0.f, 0.f, 0.f});                                        \
+                c_ = mfma_h(wt_[nt][1], xs_.h, c_); c_ = mfma_h(wt_[nt][0], xs_.h, c_);                                   \
+                _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) DST[mt][nt][r_] = fmaf(c_[r_], inv_, DST[mt][nt][r_]);   \
+            }                                                                                                             \
             PE_FENCE(16)                                                                                                  \
         }                                                                                                                 \
+    }                                                                                                                     \
     }
 // training: dump a 64-wide activation tile (lane = pair fm of tile mt, features 16 nt + 4 kq ..) at float offset OFF of the pair's record
 #define PAIR_SAVE(TILE, OFF)                                                                                              \
@@ -550,9 +546,21 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
     }
 }
 
-// Term operands of PAIR_DENSE_T: out[((s * 4 + nt) * 3 + term) * 64 + lane] = the eight bf16 terms of W[16 nt + (lane & 15)][col0 + k(s, lane >> 4, e)], e = 0..7,
-// k(s, kb, e) = 16 (2 s + (e >> 2)) + 4 kb + (e & 3) (0 where k >= kreal): the A-operand fragments of v_mfma_f32_16x16x32_bf16, split exactly like split3().
-__global__ void swizzle_terms_kernel(const float* __restrict__ W, int ldw, int col0, int kreal, int nstep, u32x4* __restrict__ out) {
+// Term operands of PAIR_DENSE_T: out[s * 768 + (nt * 2 + term) * 64 + lane] = the eight fp16 terms of S W[16 nt + (lane & 15)][col0 + k(s, lane >> 4, e)], e = 0..7,
+// k(s, kb, e) = 16 (2 s + (e >> 2)) + 4 kb + (e & 3) (0 where k >= kreal): the A-operand fragments of v_mfma_f32_16x16x32_f16.  S = the power of two with
+// max |W block| S in [2^14, 2^15) (every workgroup folds the block's 64 x kreal values itself); out[nstep * 768 - 1] = {bits of 1 / S, 0, 0, 0}.
+__global__ __launch_bounds__(256) void swizzle_terms_kernel(const float* __restrict__ W, int ldw, int col0, int kreal, int nstep, u32x4* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int e = threadIdx.x; e < 64 * kreal; e += 256) { const float a = fabsf(W[(e / kreal) * ldw + col0 + e % kreal]); m = (a <= 3.0e38f) ? fmaxf(m, a) : m; }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int ex = 0;
+    if (m > 0.f) { (void)frexpf(m, &ex); ex = 15 - ex; }
+    ex = max(-100, min(100, ex));
+    const float S = ldexpf(1.f, ex);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nstep * 4 * 64) return;
     const int lane = idx & 63, nt = (idx >> 6) & 3, s = idx >> 8, fm = lane & 15, kb = lane >> 4;
@@ -560,12 +568,13 @@ __global__ void swizzle_terms_kernel(const float* __restrict__ W, int ldw, int c
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int k = 16 * (2 * s + (e >> 2)) + 4 * kb + (e & 3);
-        const float v = k < kreal ? W[(nt * 16 + fm) * ldw + col0 + k] : 0.f;
+        const float v = k < kreal ? W[(nt * 16 + fm) * ldw + col0 + k] * S : 0.f;
         if (e < 4) lo[e] = v; else hi[e - 4] = v;
     }
-    const Split3 t = split3(lo, hi);
-    u32x4* o = out + (int64_t)((s * 4 + nt) * 3) * 64 + lane;
-    o[0] = t.h; o[64] = t.m; o[128] = t.l;
+    const Split2 t = split2(lo, hi);
+    u32x4* o = out + (int64_t)s * 768 + (nt * 2) * 64 + lane;
+    o[0] = t.h; o[64] = t.l;
+    if (idx == 0) out[nstep * 768 - 1] = (u32x4){__float_as_uint(ldexpf(1.f, -ex)), 0u, 0u, 0u};
 }
 
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
