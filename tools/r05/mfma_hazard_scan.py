@@ -3,7 +3,7 @@
    RAW  a non-MFMA instruction READS the MFMA's destination (incl. a scratch store of it)
    WAW  a non-MFMA instruction WRITES the MFMA's destination
 python tools/r05/mfma_hazard_scan.py file.s kernel_substring [window]"""
-import re, sys
+import re, sys, os
 lines = open(sys.argv[1]).read().split('\n')
 kern, win = sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 6
 start = [i for i, l in enumerate(lines) if l.startswith('_ZN') and kern in l and (l.split(';')[0].rstrip().endswith(':'))][0]
@@ -29,7 +29,7 @@ def writes_reads(ins):
     return w, r
 found = {'WAR': [], 'RAW': [], 'WAW': []}
 for i, ins in enumerate(body):
-    if not (ins.startswith('v_mfma_f32_') and 'bf16' in ins.split()[0]): continue
+    if not (ins.startswith('v_mfma_f32_') and (os.environ.get('ANY_MFMA') or 'bf16' in ins.split()[0])): continue
     op, ops = split_ops(ins)
     D, A, B, Cc = regs(ops[0]), regs(ops[1]), regs(ops[2]), regs(ops[3])
     states = 0
