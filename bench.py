@@ -329,6 +329,7 @@ def main():
     ap.add_argument('--graph', choices=('on', 'off'), default='on', help='replay the K-step loop from a hipGraph captured before the timed region')
     ap.add_argument('--graph-events', action='store_true', help='(experiment) record the per-launch HIP events inside the captured graph')
     ap.add_argument('--no-prof', action='store_true', help='no HIP events around the IPA-core launches (A/B of their cost)')
+    ap.add_argument('--replay-only', action='store_true', help='skip the eager_events and two_launch_form passes: under rocprofv3 every dominant-kernel launch is then a replayed one (profiles/*_kernel_stats_replay_only.txt)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip train_step_ms / sample_e2e_ms / config3 / poses1000 (N=1 only)')
     args = ap.parse_args()
@@ -454,17 +455,19 @@ def main():
         instrumented = round(dt_i / K * 1e3, 4)
         log('instrumented graph replay: %.4f ms per step, %d launches, %.1f us per launch' % (instrumented, launches, ipa_ms / max(launches, 1) * 1e3))
         # (ii) the eager pass with HIP events around every launch (round 3's method), kept next to it
-        dt_e = timed_pass(False, events=True)
-        n_e, ms_e = hip.prof_collect()
-        hip.prof_enable(False)
-        eager_events = dict(ms_per_step=round(dt_e / K * 1e3, 4), avg_launch_ms=round(ms_e / max(n_e, 1), 4), launches=n_e)
+        n_e, ms_e = 0, 0.0
+        if not args.replay_only or launches == 0:
+            dt_e = timed_pass(False, events=True)
+            n_e, ms_e = hip.prof_collect()
+            hip.prof_enable(False)
+            eager_events = dict(ms_per_step=round(dt_e / K * 1e3, 4), avg_launch_ms=round(ms_e / max(n_e, 1), 4), launches=n_e)
         if launches == 0:                                   # (a shape that does not take the 32-row kernels: events are all there is)
             launches, ipa_ms, instrumented = n_e, ms_e, eager_events['ms_per_step']
     clock = hip.prof_clock()                                    # the clock wave 0 / workgroup 0 of the last dominant-kernel launch ran at
     # the two-launch form of a block (32-row core, then the tail kernel) in one more eager pass: the IPA core ALONE, for continuity with
     # the rounds before the tail was fused into it (bit-identical results; not part of the timed region)
     two_launch = None
-    if rank == 0 and world == 1 and not args.no_prof and os.environ.get('ABOPT_FUSE_TAIL') is None:
+    if rank == 0 and world == 1 and not args.no_prof and not args.replay_only and os.environ.get('ABOPT_FUSE_TAIL') is None:
         os.environ['ABOPT_FUSE_TAIL'] = '0'
         try:
             run(2)
@@ -534,7 +537,7 @@ def main():
                        'ranks': ranks_seen, 'ranks_note': None if ranks_seen is None else 'gathered through the process group: device and OWN median ms_per_step of every rank (the line\'s ms_per_step is the max over ranks per repeat)'},
             'roofline': {'bound': 'hbm', 'kernel': kernel_name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src, 'launches': launches,
-                         'avg_launch_ms': round(per_launch_ms, 4), 'timing': timing, 'instrumented_ms_per_step': instrumented, 'eager_events': eager_events,
+                         'avg_launch_ms': round(per_launch_ms, 4), 'rocprofv3_note': 'a rocprofv3 --kernel-trace --stats summary of this command averages the replayed launches (what avg_launch_ms measures) TOGETHER with the launches of the eager_events pass (eager_events.avg_launch_ms each; eager launches run slower than replayed ones: L2 is written back and invalidated around every eager kernel, so the fragments node_frags has just produced come from HBM) and a few warm-up launches', 'timing': timing, 'instrumented_ms_per_step': instrumented, 'eager_events': eager_events,
                          'algorithmic_bytes_per_launch': alg,
                          'algorithmic_bytes_formula': 'N*(256*L^2 + 1076*L)  [SURVEY 8(d)]',
                          'kernel_io_bytes_per_launch': ipa_kernel_io_bytes(N, L),

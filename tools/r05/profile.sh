@@ -10,6 +10,10 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/stats -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/bench_profiled.log 2>&1
 python $ROOT/tools/rocprof_summary.py $OUT/stats > $OUT/kernel_stats.txt
 rm -rf $OUT/stats
+# the same with replayed launches only (no eager_events / two-launch passes): the average that roofline.avg_launch_ms must agree with
+rocprofv3 --kernel-trace --stats -d $OUT/stats_r -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --replay-only > $OUT/bench_profiled_replay_only.log 2>&1
+python $ROOT/tools/rocprof_summary.py $OUT/stats_r > $OUT/kernel_stats_replay_only.txt
+rm -rf $OUT/stats_r
 CMD="python $ROOT/bench.py --steps 4 --warmup 1 --repeats 1 --graph off --no-prof --no-cpu-baseline --no-secondary"
 i=0
 while read -r grp; do
