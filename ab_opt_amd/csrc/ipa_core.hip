@@ -1795,8 +1795,12 @@ static bool use_core32(int N, int L, int cus) {
     if (L > 2048) return false;                                 // its buffer descriptors address a sample's z slab (L^2 * 256 bytes) with 32-bit offsets
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return L > BI;
-    if (L < 192 || cus < 8) return false;
+    if (cus < 8) return false;
     const int64_t total = (int64_t)N * ((L + BI2 - 1) / BI2), rounds = (total + cus - 1) / cus;
+    // short crops (pose sampling: N = 1000 x L = 48): since the epilogue runs on two fp16 terms (round 5) the fused 32-row kernel wins wherever it fills
+    // the chip once -- 4.10 -> 3.80 ms per step at N = 1000 x L = 48, 3.60 -> 2.88 at 600 x 64, 0.95 -> 0.81 at 64 x 128; it loses below one workgroup
+    // per CU (32 x 128: 0.64 -> 0.72).  Rounds 3-4 had excluded L < 192 (three key chunks did not amortise a 40 us epilogue).
+    if (L < 192) return L > BI && total >= cus;
     if (rounds == 1) return total * 100 >= (int64_t)cus * 53 && (int64_t)N * ((L + BI - 1) / BI) > cus;
     return total * 100 >= rounds * cus * 95;
 }

@@ -2121,12 +2121,13 @@ def test_dockq_superposition_corner_cases():
             assert torch.isfinite(out['Lrms']).all()
 
 
-def test_eps_net_reference_headline_shape_vs_oracle():
+def test_eps_net_reference_headline_shape_vs_oracle(monkeypatch):
     """The reference's own headline invocation (AbDock/README.md:61: dock_pdb.py -n 1000 -b 1000; configs/train/dock_single.yml:12-14
     crops the CDR plus 20 antigen residues): N = 1000 poses of ONE complex, L = 48, AbDock flavour, the context passed once
-    (pair_feat (1,L,L,C), shared pair-bias cache) -- the persistent core with 3000 three-position query blocks on 256 workgroups.  Per-pose masks
-    are ragged (the kernels take one per pose).  A subset of the poses against the oracle; then the whole batch must be bit-identical
-    to the same poses evaluated in small batches through the plain kernel."""
+    (pair_feat (1,L,L,C), shared pair-bias cache).  Since round 5 this shape takes the fused 32-row core + tail kernel (2000 workgroups, the second
+    block of every pose half empty); with ABOPT_CORE32=0 the persistent 16-row core with 3000 three-position query blocks on 256 workgroups + the
+    stand-alone tail.  Per-pose masks are ragged (the kernels take one per pose).  A subset of the poses against the oracle; then the whole batch
+    must be bit-identical to the 16-row form and to the same poses evaluated in small batches through the plain kernel."""
     from ab_opt_amd import hip
     from oracle import dpm
     N, L, T, t = 1000, 48, 100, 63
@@ -2142,6 +2143,11 @@ def test_eps_net_reference_headline_shape_vs_oracle():
     rfN = rf1.expand(N, -1, -1).contiguous()
     net = hip.eps_net_forward(ew, v, p, s, rfN, pf1, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc, pair_feat_shared=True)
     net = {k: (a.clone() if a is not None else None) for k, a in net.items()}
+    monkeypatch.setenv('ABOPT_CORE32', '0')
+    net16 = hip.eps_net_forward(ew, v, p, s, rfN, pf1, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc, pair_feat_shared=True)
+    monkeypatch.delenv('ABOPT_CORE32')
+    for k in ('R_next', 'eps_pos', 'c', 'prmsd_logits'):
+        assert torch.equal(net[k], net16[k]), k
     ids = [0, 1, 499, 998, 999]
     ix = torch.tensor(ids, device=DEV)
     c = lambda a: a[ix].cpu()
