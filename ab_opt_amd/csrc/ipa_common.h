@@ -97,10 +97,19 @@ __device__ __forceinline__ f32x16 mfma_bf32(const u32x4& a, const u32x4& b, cons
 // operands, max / mean error of [512 x 1824] . [1824 x 128] against fp64: 3.9e-6 / 2.1e-7 for this scheme, 4.9e-6 / 2.7e-7 for the six bf16 products,
 // 3.3e-6 / 3.2e-7 for an fp32 GEMM).  Limit: |activation| < 65504 (fp16 overflow -> inf -> NaN in the output, nothing silent).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned pk_f16(float lo, float hi) {          // an asm statement like pk_bf16 (see there)
+#ifndef PK_F16_MODE
+#define PK_F16_MODE 0     // developer switch: 0 (shipped) an asm statement like pk_bf16 (see there) | 2 the compiler's own float -> half conversion
+#endif
+__device__ __forceinline__ unsigned pk_f16(float lo, float hi) {
+#if PK_F16_MODE == 2
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){lo, hi}, f16x2_));
+#else
     unsigned r;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
+#endif
 }
 __device__ __forceinline__ float f16lo_f32(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
 __device__ __forceinline__ float f16hi_f32(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# pair_embed_kernel with 64-wide products on the bf16 matrix pipe (developer builds -DPE_TERMS=<mask>): correctness (encode tests + the 200-repeat race
+# pair_embed_kernel with 64-wide products on the 16-bit matrix pipe (developer builds -DPE_TERMS=<mask>; three bf16 terms until round 5, two fp16 terms since): correctness (encode tests + the 200-repeat race
 # detector) and time of each variant on one box.   bash tools/r05/pe_terms.sh <tag> <mask> [<mask> ...]
 cd "$(dirname "$0")/../.." && ROOT=$(pwd) && OUT=$ROOT/gpurun_out/${1:-pe} && mkdir -p $OUT; shift
 : > $OUT/summary.txt
