@@ -7,6 +7,7 @@
 // eps_* / prmsd heads (dpm_full.py:39-65).
 #include "ipa_common.h"
 #include <cstdlib>
+#include <algorithm>
 #include "kernels.h"
 
 namespace abopt {
@@ -141,19 +142,15 @@ int launch_linear(const float* X, int ldx, const float* W, int ldw, const float*
 // (stride slab_stride); the caller sums the slabs in a fixed order (deterministic, no atomics).
 constexpr int GLT = GBM + 4;          // row stride of a [k][m] staged tile
 
+// one 64 x 64 output tile over K range [kbeg, kend): the body shared by gemm_batched_kernel and gemm_grouped_kernel (A, B, C already point at
+// the batch / slab the workgroup owns)
 template <bool AT, bool BT>
-__global__ __launch_bounds__(256) void gemm_batched_kernel(const float* __restrict__ A, int lda, int64_t sa, const float* __restrict__ B, int ldb, int64_t sb,
-                                                           float* __restrict__ C, int ldc, int64_t sc, int M, int N, int K, int ksplit, int kchunk,
-                                                           int64_t slab_stride, float alpha, const float* __restrict__ bias, int relu) {
-    __shared__ __attribute__((aligned(16))) float As[GBM * GLD > GBK * GLT ? GBM * GLD : GBK * GLT];
-    __shared__ __attribute__((aligned(16))) float Bs[GBN * GLD > GBK * GLT ? GBN * GLD : GBK * GLT];
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                          int M, int N, int m0, int n0, int kbeg, int kend, float alpha, const float* __restrict__ bias, int relu,
+                                          float* __restrict__ As, float* __restrict__ Bs) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int batch = blockIdx.z / ksplit, slice = blockIdx.z % ksplit;
-    A += (int64_t)batch * sa; B += (int64_t)batch * sb; C += (int64_t)batch * sc + (int64_t)slice * slab_stride;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int fm = lane & 15, kq = lane >> 4;
-    const int kbeg = slice * kchunk, kend = min(K, kbeg + kchunk);
     const bool avec = (lda % 4) == 0 && ((uintptr_t)A % 16) == 0, bvec = (ldb % 4) == 0 && ((uintptr_t)B % 16) == 0;
     // staging registers: two float4 per operand and K tile.  k-contiguous: thread -> (row tid >> 3 (+32), k 4 (tid & 7));
     // k-strided: thread -> (k tid >> 4 (+16), m 4 (tid & 15))
@@ -234,6 +231,20 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float* __restri
             if (cvec && col + 3 < N) *reinterpret_cast<f32x4*>(cp) = v;
             else { for (int r = 0; r < 4; ++r) if (col + r < N) cp[r] = v[r]; }
         }
+}
+
+// register budget: 8 waves per SIMD for the forms with a k-strided operand (52-60 VGPRs: -1.4 us per launch on the weight-gradient and
+// d x products, same box, round 5); the nn form needs 70 and spills at 64 (4096 x 256 x 1413: 74 -> 100 us) -- it keeps 4
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256, (AT || BT) ? 8 : 4) void gemm_batched_kernel(const float* __restrict__ A, int lda, int64_t sa, const float* __restrict__ B, int ldb, int64_t sb,
+                                                           float* __restrict__ C, int ldc, int64_t sc, int M, int N, int K, int ksplit, int kchunk,
+                                                           int64_t slab_stride, float alpha, const float* __restrict__ bias, int relu) {
+    __shared__ __attribute__((aligned(16))) float As[GBM * GLD > GBK * GLT ? GBM * GLD : GBK * GLT];
+    __shared__ __attribute__((aligned(16))) float Bs[GBN * GLD > GBK * GLT ? GBN * GLD : GBK * GLT];
+    const int batch = blockIdx.z / ksplit, slice = blockIdx.z % ksplit;
+    const int kbeg = slice * kchunk;
+    gemm_tile<AT, BT>(A + (int64_t)batch * sa, lda, B + (int64_t)batch * sb, ldb, C + (int64_t)batch * sc + (int64_t)slice * slab_stride, ldc, M, N,
+                      blockIdx.y * GBM, blockIdx.x * GBN, kbeg, min(K, kbeg + kchunk), alpha, bias, relu, As, Bs);
 }
 
 // (Round 4 measured this kernel's bf16-term twin -- operands split into three bf16 terms while a K tile is staged, six
@@ -434,7 +445,104 @@ int launch_gemm_batched(const float* A, int lda, int64_t sa, int a_t, const floa
     return ABOPT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Grouped weight-gradient products (round 5): C_p = A_p^T B_p for up to GG_MAX tall operand pairs (K_p rows, both read k-strided in
+// place) in ONE launch plus ONE launch for the split-K slab sums of all of them.  A backward pass of the denoiser has ~44 such products
+// with 2-64 output tiles each; alone, each is a split-K launch that ramps up and drains in 20-45 us plus a slab-sum launch of 3-7 us.
+// Grouped, the workgroups of all problems form one grid (problem p owns workgroups [wg_begin, wg_begin + tiles * ksplit)) and the
+// K split is chosen for the group's tile count, not for each product's.  The descriptors travel by value in the kernel arguments: no device
+// memory, nothing to keep alive, capturable.  Same tile body, same fixed-order slab sum (four slab groups of a 64-element strip, then the
+// groups in order): deterministic; the summation order differs from abopt_gemm's for the same product (another K split).
+constexpr int GG_MAX = 24;
+struct GroupedProblem {
+    const float* A; const float* B; float* C; float* ws;
+    int lda, ldb, M, N, K, tiles_n, tiles, ksplit, kchunk, wg_begin, sum_begin, pad_;
+};
+struct GroupedArgs { int n, pad_; GroupedProblem p[GG_MAX]; };
+
+__global__ __launch_bounds__(256, 8) void gemm_grouped_kernel(const GroupedArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[GBK * GLT];
+    __shared__ __attribute__((aligned(16))) float Bs[GBK * GLT];
+    int pi = 0;
+    for (int q = 1; q < g.n; ++q) if ((int)blockIdx.x >= g.p[q].wg_begin) pi = q;
+    const GroupedProblem& P = g.p[pi];
+    const int local = blockIdx.x - P.wg_begin, slice = local / P.tiles, t = local % P.tiles;
+    const int kbeg = slice * P.kchunk;
+    float* out = P.ksplit > 1 ? P.ws + (int64_t)slice * P.M * P.N : P.C;
+    gemm_tile<true, true>(P.A, P.lda, P.B, P.ldb, out, P.N, P.M, P.N, (t / P.tiles_n) * GBM, (t % P.tiles_n) * GBN, kbeg, min(P.K, kbeg + P.kchunk),
+                          1.f, nullptr, 0, As, Bs);
+}
+
+// C_p[e] = sum over the slabs of ws_p (slab_sum_groups_kernel<4>'s order) for every problem of the group that was split
+__global__ __launch_bounds__(256) void slab_sum_grouped_kernel(const GroupedArgs g) {
+    __shared__ float red[4][64];
+    int pi = 0;
+    for (int q = 1; q < g.n; ++q) if ((int)blockIdx.x >= g.p[q].sum_begin) pi = q;
+    const GroupedProblem& P = g.p[pi];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t n = (int64_t)P.M * P.N, e = (int64_t)(blockIdx.x - P.sum_begin) * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < n) {
+        int k = grp;
+        for (; k + 12 < P.ksplit; k += 16) {
+            s0 += P.ws[(int64_t)k * n + e]; s1 += P.ws[(int64_t)(k + 4) * n + e];
+            s2 += P.ws[(int64_t)(k + 8) * n + e]; s3 += P.ws[(int64_t)(k + 12) * n + e];
+        }
+        for (; k < P.ksplit; k += 4) s0 += P.ws[(int64_t)k * n + e];
+    }
+    red[grp][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && e < n) P.C[e] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+int launch_gemm_tn_grouped(const abopt_gemm_tn_problem* probs, int count, float* ws, size_t ws_floats, hipStream_t st) {
+    if (count <= 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(probs && count <= GG_MAX, "gemm_tn_grouped: %d problems (1..%d)", count, GG_MAX);
+    GroupedArgs g;
+    g.n = count; g.pad_ = 0;
+    int total_tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        const abopt_gemm_tn_problem& q = probs[i];
+        ABOPT_CHECK_ARG(q.a && q.b && q.c && q.m >= 1 && q.n >= 1 && q.k >= 0 && q.lda >= q.m && q.ldb >= q.n,
+                        "gemm_tn_grouped: problem %d: M=%d N=%d K=%d lda=%d ldb=%d", i, q.m, q.n, q.k, q.lda, q.ldb);
+        total_tiles += ((q.m + GBM - 1) / GBM) * ((q.n + GBN - 1) / GBN);
+    }
+    // K split for the GROUP: enough workgroups to fill the chip about four times over, slabs of at least 256 rows of K (the same rule
+    // abopt_gemm applies to a single product), limited by the workspace
+    const int want = total_tiles < 256 ? std::max(1024 / total_tiles, 1) : 1;
+    size_t ws_used = 0;
+    int wg = 0, sum_blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const abopt_gemm_tn_problem& q = probs[i];
+        GroupedProblem& P = g.p[i];
+        P.A = q.a; P.B = q.b; P.C = q.c; P.lda = q.lda; P.ldb = q.ldb; P.M = q.m; P.N = q.n; P.K = q.k; P.pad_ = 0;
+        P.tiles_n = (q.n + GBN - 1) / GBN;
+        P.tiles = ((q.m + GBM - 1) / GBM) * P.tiles_n;
+        int ks = std::max(1, std::min(want, q.k / 256));
+        const size_t mn = (size_t)q.m * q.n;
+        while (ks > 1 && (!ws || ws_used + (size_t)ks * mn > ws_floats)) --ks;
+        P.ksplit = ks;
+        P.kchunk = ks == 1 ? std::max(q.k, 1) : ((q.k + ks * GBK - 1) / (ks * GBK)) * GBK;
+        P.ws = ks > 1 ? ws + ws_used : nullptr;
+        if (ks > 1) ws_used += (size_t)ks * mn;
+        P.wg_begin = wg; wg += P.tiles * ks;
+        P.sum_begin = sum_blocks; if (ks > 1) sum_blocks += (int)((mn + 63) / 64);
+    }
+    hipLaunchKernelGGL(gemm_grouped_kernel, dim3((unsigned)wg), dim3(256), 0, st, g);
+    ABOPT_LAUNCH_CHECK();
+    if (sum_blocks > 0) {
+        // problems that were not split own no blocks: give them an empty range that the scan skips (sum_begin of the next split problem)
+        hipLaunchKernelGGL(slab_sum_grouped_kernel, dim3((unsigned)sum_blocks), dim3(256), 0, st, g);
+        ABOPT_LAUNCH_CHECK();
+    }
+    return ABOPT_OK;
+}
+
 }  // namespace abopt
+
+extern "C" int abopt_gemm_tn_grouped(const abopt_gemm_tn_problem* problems, int count, void* ws, size_t ws_bytes, abopt_stream stream) {
+    return abopt::launch_gemm_tn_grouped(problems, count, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
+}
 
 extern "C" int abopt_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const int32_t* idx, int buckets, float* out, void* ws, size_t ws_bytes,
                                    abopt_stream stream) {

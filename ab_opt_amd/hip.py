@@ -12,11 +12,16 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
 c_u8 = C.c_void_p       # device uint8*
+
+
+class GemmTnProblem(C.Structure):
+    """abopt_gemm_tn_problem (include/abopt.h)"""
+    _fields_ = [('a', C.c_void_p), ('b', C.c_void_p), ('c', C.c_void_p), ('lda', C.c_int), ('ldb', C.c_int), ('m', C.c_int), ('n', C.c_int), ('k', C.c_int)]
 
 
 class GaWeights(C.Structure):
@@ -73,7 +78,7 @@ class StepNoise(C.Structure):
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
            'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
-           'abopt_add_noise', 'abopt_gemm', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_segment_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_dpm_losses', 'abopt_abdock_losses', 'abopt_layer_norm_forward', 'abopt_layer_norm_backward', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek', 'abopt_prof_clock', 'abopt_prof_spans_reset', 'abopt_prof_spans',
+           'abopt_add_noise', 'abopt_gemm', 'abopt_gemm_tn_grouped', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_segment_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_dpm_losses', 'abopt_abdock_losses', 'abopt_layer_norm_forward', 'abopt_layer_norm_backward', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek', 'abopt_prof_clock', 'abopt_prof_spans_reset', 'abopt_prof_spans',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward', 'abopt_ipa_dz_assemble',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
            'abopt_pair_embed_backward_workspace_bytes', 'abopt_pair_embed_backward', 'abopt_dockq_workspace_bytes', 'abopt_dockq_lite', 'abopt_node_frag_source_row', 'abopt_node_frag_floats',
@@ -126,6 +131,7 @@ def lib():
         L.abopt_gemm.argtypes = [c_f, C.c_int, C.c_int64, C.c_int, c_f, C.c_int, C.c_int64, C.c_int, c_f, C.c_int, C.c_int64,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_colsum.argtypes = [c_f, C.c_int, C.c_int64, C.c_int, c_f, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_gemm_tn_grouped.argtypes = [C.POINTER(GemmTnProblem), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_prof_enable.argtypes = [C.c_int]
         L.abopt_prof_collect.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.abopt_prof_peek.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
@@ -815,6 +821,36 @@ def gemm(a, b, alpha=1.0, out=None, bias=None, relu=False):
     _check(lib().abopt_gemm(ptr(a, torch.float32, strided=True), lda, sa, at, ptr(b, torch.float32, strided=True), ldb, sb, bt, ptr(c, torch.float32, strided=True), ldc, sc, M, N, K, nb, float(alpha),
                             ptr(bias, torch.float32, optional=True), int(bool(relu)), ptr(ws, optional=True), ws.numel() if ws is not None else 0, stream()))
     return c
+
+
+GEMM_TN_GROUP_MAX = 24
+
+
+def gemm_tn_grouped(pairs, outs=None):
+    """[a_p^T @ b_p for (a_p, b_p) in pairs] -- tall 2-D fp32 operands (K_p, M_p), (K_p, N_p) with unit column stride, column slices of wider
+    matrices read in place -- as ONE product launch + ONE slab-sum launch per 24 pairs (include/abopt.h: abopt_gemm_tn_grouped): the
+    weight-gradient products of a backward pass.  Returns the list of (M_p, N_p) results (`outs`: contiguous fp32 tensors to write, else fresh ones)."""
+    res = []
+    for i0 in range(0, len(pairs), GEMM_TN_GROUP_MAX):
+        chunk = pairs[i0:i0 + GEMM_TN_GROUP_MAX]
+        arr = (GemmTnProblem * len(chunk))()
+        keep, tiles = [], 0
+        for j, (q, (a, b)) in enumerate(zip(arr, chunk)):
+            if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0] or a.stride(1) != 1 or b.stride(1) != 1 or a.shape[0] == 0:
+                raise TypeError(f'gemm_tn_grouped: operands must be 2-D (K, M) / (K, N) with unit column stride and K > 0, got {tuple(a.shape)} {tuple(a.stride())} / {tuple(b.shape)} {tuple(b.stride())}')
+            c = torch.empty(a.shape[1], b.shape[1], dtype=torch.float32, device=a.device) if outs is None else outs[i0 + j]
+            if tuple(c.shape) != (a.shape[1], b.shape[1]):
+                raise TypeError(f'gemm_tn_grouped: out {tuple(c.shape)} for operands {tuple(a.shape)} / {tuple(b.shape)}')
+            q.a, q.b, q.c = ptr(a, torch.float32, strided=True), ptr(b, torch.float32, strided=True), ptr(c)
+            q.lda, q.ldb, q.m, q.n, q.k = a.stride(0), b.stride(0), a.shape[1], b.shape[1], a.shape[0]
+            tiles += ((q.m + 63) // 64) * ((q.n + 63) // 64)
+            keep.append(c)
+        want = max(1024 // tiles, 1) if tiles < 256 else 1
+        need = sum(min(want, q.k // 256) * q.m * q.n for q in arr if min(want, q.k // 256) > 1)
+        ws = Workspace.get(need * 4, chunk[0][0].device) if need else None
+        _check(lib().abopt_gemm_tn_grouped(arr, len(chunk), ptr(ws, optional=True), ws.numel() if ws is not None else 0, stream()))
+        res += keep
+    return res
 
 
 def colsum(x):

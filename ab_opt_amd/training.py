@@ -45,6 +45,87 @@ def _ln(x, mod):
     return NativeLayerNorm.apply(x, mod.gamma, mod.beta, float(mod.epsilon))
 
 
+# ------------------------------------------------------------------ weight gradients of a backward pass as grouped launches
+import os as _os
+
+
+class WgradGroup:
+    """The weight-gradient products of backward (d W = d y^T x of every nn.Linear: `loss.backward()` of train.py:101-114) are leaves of the
+    pass: nothing reads them before the optimizer.  Alone, each is a split-K launch with 2-64 output tiles plus a slab-sum launch (~44
+    products, ~90 launches per config-5 step).  Here a product only QUEUES (operands + a fresh output tensor, which autograd's AccumulateGrad
+    adopts without a kernel while `.grad is None`); the queue is flushed as one `abopt_gemm_tn_grouped` call (one product launch + one slab-sum
+    launch, include/abopt.h) whenever it holds enough tiles to fill the chip -- about once per GABlock, while its operands are still in
+    the cache -- and when the autograd engine finishes the pass (its final callback).  Same stream, same tile kernel; the K split is the
+    group's, so a gradient differs from the ungrouped product's by fp32 summation order only.
+
+    A product runs at once instead (hip.gemm) when its result is not a leaf's gradient (it feeds further autograd nodes), when the
+    leaf already holds a gradient or has one queued in this pass (AccumulateGrad would ADD, reading the unfinished tensor), and in a process
+    group of more than one rank (DistributedDataParallel's bucket hooks read gradients during backward).  Hooks a caller registers on
+    parameters see a queued gradient before it is computed: switch the queue off (ABOPT_WGRAD_GROUP=0 / WgradGroup.enabled = False) for those."""
+    enabled = _os.environ.get('ABOPT_WGRAD_GROUP', '1') != '0'
+    flush_tiles = 128
+    _state = None          # the running backward pass: stream, queued (a, b, out), their tile count, ids of parameters with a queued gradient
+
+    @classmethod
+    def active(cls):
+        if not cls.enabled:
+            return False
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+    @classmethod
+    def flush(cls, close=False):
+        st = cls._state
+        if st is None:
+            return
+        if close:
+            cls._state = None
+        if st['items']:
+            from . import hip
+            items, st['items'], st['tiles'] = st['items'], [], 0
+            with torch.cuda.stream(st['stream']):
+                hip.gemm_tn_grouped([(a, b) for a, b, _ in items], outs=[c for _, _, c in items])
+        if close:
+            st['pending'].clear()
+
+    @classmethod
+    def sync(cls):
+        """Flush and close (a backward pass that raised never reaches its final callback; the next forward and the optimizer call this)."""
+        cls.flush(close=True)
+
+    @classmethod
+    def product(cls, a, b, params):
+        """a^T @ b for tall (K, M), (K, N) operands, the gradient of the leaf parameter(s) `params` (reached through view-only autograd nodes)."""
+        from . import hip
+        now = lambda: hip.gemm(a.t(), b.t())[0]
+        if not cls.active() or params is None or not all(p is not None and p.is_leaf for p in params):
+            return now()
+        if a.dim() != 2 or b.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1 or a.dtype != torch.float32 or b.dtype != torch.float32:
+            return now()
+        main = torch.cuda.current_stream()
+        st = cls._state
+        if st is not None and st['stream'] != main:
+            cls.flush(close=True)
+            st = None
+        if st is not None and any(id(p) in st['pending'] for p in params):
+            cls.flush()                    # a weight used twice in one pass: AccumulateGrad adds the two results
+            return now()
+        if any(p.grad is not None for p in params):
+            return now()                   # accumulation over micro-batches: the same add, onto a gradient of an earlier (closed) pass
+        if st is None:
+            st = cls._state = dict(stream=main, items=[], tiles=0, pending=set())
+            torch.autograd.Variable._execution_engine.queue_callback(cls.sync)
+        out = torch.empty(a.shape[1], b.shape[1], dtype=torch.float32, device=a.device)
+        # the queue keeps an ALIAS of the storage, not the tensor handed to autograd: AccumulateGrad adopts a gradient only if nobody else
+        # holds a reference to the tensor object (otherwise it clones it -- here: before it has been computed)
+        st['items'].append((a, b, out.detach()))
+        st['tiles'] += ((a.shape[1] + 63) // 64) * ((b.shape[1] + 63) // 64)
+        st['pending'].update(id(p) for p in params)
+        if st['tiles'] >= cls.flush_tiles:
+            cls.flush()
+        return out
+
+
 # ------------------------------------------------------------------ dense layers on the library's own GEMM (csrc/gemm.hip: gemm_batched_kernel)
 class NativeLinear(torch.autograd.Function):
     """y = x W^T (+ b) with forward and both gradients on abopt_gemm: d x = d y W, d W = d y^T x (split-K over the rows, summed in a
@@ -52,13 +133,15 @@ class NativeLinear(torch.autograd.Function):
     dpm_full.py:39-59)."""
 
     @staticmethod
-    def forward(ctx, x, w, b=None, relu=False):
-        """relu=True: y = relu(x W^T + b) as ONE launch (bias and clamp in the product's epilogue); the backward masks d y with y > 0."""
+    def forward(ctx, x, w, b=None, relu=False, leaves=None):
+        """relu=True: y = relu(x W^T + b) as ONE launch (bias and clamp in the product's epilogue); the backward masks d y with y > 0.
+        leaves: the parameters `w` was assembled from when it is not one itself (ga_block's stacked projections) -- for WgradGroup."""
         from . import hip
         x2 = x.reshape(-1, x.shape[-1])
         y = hip.gemm(x2, w, bias=b, relu=relu)[0]
         ctx.save_for_backward(x2, w, y if relu else None)
         ctx.has_bias = b is not None
+        ctx.leaves = tuple(leaves) if leaves is not None else (w,)
         return y.view(x.shape[:-1] + (w.shape[0],))
 
     @staticmethod
@@ -69,8 +152,8 @@ class NativeLinear(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         dy2 = torch.ops.aten.threshold_backward(dy2.contiguous(), y, 0.0) if y is not None else dy2.contiguous()      # d relu: one kernel
         dx = hip.gemm(dy2, w.t())[0].view(dy.shape[:-1] + (w.shape[1],)) if ctx.needs_input_grad[0] else None
-        dw = hip.gemm(dy2.t(), x2.t())[0]
-        return dx, dw, (hip.colsum(dy2) if ctx.has_bias else None), None
+        dw = WgradGroup.product(dy2, x2, ctx.leaves)
+        return dx, dw, (hip.colsum(dy2) if ctx.has_bias else None), None, None
 
 
 def _linear(mod, x, relu=False):
@@ -95,7 +178,6 @@ def _mlp(seq, x):
 
 
 # ------------------------------------------------------------------ IPA core as an autograd function on the HIP kernels
-import os as _os
 DEFER_DZ = _os.environ.get('ABOPT_DZ_DEFER', '1') != '0'
 
 
@@ -179,6 +261,7 @@ class BlockTail(torch.autograd.Function):
         feat2 = feat.reshape(-1, feat.shape[-1]).contiguous()
         out, saved = hip.block_tail_forward(feat2, wof, wmf, x.reshape(-1, 128), b_out, mask.reshape(-1), g1, be1, b0, b1, b2, g2, be2, save=True)
         ctx.save_for_backward(feat2, mask, saved, wmt, w_out, g1, g2)
+        ctx.leaves = (w_out, w0, w1, w2)
         return out.view(shape)
 
     @staticmethod
@@ -188,8 +271,9 @@ class BlockTail(torch.autograd.Function):
         feat2, mask, saved, wmt, w_out, g1, g2 = ctx.saved_tensors
         dpre, da1, du, cs = hip.block_tail_backward(dout.reshape(-1, 128), saved, wmt, mask.reshape(-1), g1, g2)
         dfeat = hip.gemm(du, w_out.t())[0].view(dout.shape[:-1] + (w_out.shape[1],))
-        dw_out = hip.gemm(du.t(), feat2.t())[0]
-        dw0, dw1, dw2 = hip.gemm(dpre.transpose(1, 2), saved[1:4].transpose(1, 2)).unbind(0)      # d W_l = d pre_l^T . input_l, one batched launch
+        lv = ctx.leaves
+        dw_out = WgradGroup.product(du, feat2, lv[:1])
+        dw0, dw1, dw2 = (WgradGroup.product(dpre[l], saved[1 + l], lv[1 + l:2 + l]) for l in range(3))      # d W_l = d pre_l^T . input_l
         #      x               feat   mask  w_out   b_out  g1     be1    w0   b0     w1   b1     w2   b2     g2     be2
         return da1.view(dout.shape), dfeat, None, dw_out, cs[7], cs[6], cs[5], dw0, cs[4], dw1, cs[3], dw2, cs[2], cs[1], cs[0]
 
@@ -204,9 +288,10 @@ def _block_tail(blk, x, feat, mask):
 def ga_block(blk, R, t, x, z, mask, pbc=None, zsink=None):
     """GABlock.forward under autograd (ga.py:149-178).  pbc: this block's slice of hip.pair_bias_cache_layers (forward-only shortcut: the
     core reads proj_pair_bias(z) instead of recomputing it; gradients of z and the weight still come from the backward kernel)."""
-    w_node = torch.cat([blk.proj_query.weight, blk.proj_key.weight, blk.proj_value.weight,
-                        blk.proj_query_point.weight, blk.proj_key_point.weight, blk.proj_value_point.weight], dim=0)
-    feat = IpaCore.apply(NativeLinear.apply(x, w_node), z, R.detach(), t.detach(), mask, blk.proj_pair_bias.weight, blk.spatial_coef, pbc, zsink)
+    leaves = (blk.proj_query.weight, blk.proj_key.weight, blk.proj_value.weight,
+              blk.proj_query_point.weight, blk.proj_key_point.weight, blk.proj_value_point.weight)
+    w_node = torch.cat(leaves, dim=0)
+    feat = IpaCore.apply(NativeLinear.apply(x, w_node, None, False, leaves), z, R.detach(), t.detach(), mask, blk.proj_pair_bias.weight, blk.spatial_coef, pbc, zsink)
     return _block_tail(blk, x, feat, mask)
 
 
@@ -307,6 +392,7 @@ def fulldpm_loss(dpm, v_0, p_0, s_0, res_feat, pair_feat, mask_generate, mask_re
     """FullDPM.forward -> dict of scalar losses (AbDock: prmsd, dist (pred_x0), rot, pos, seq; AbDesign: rot, pos, seq)."""
     from . import hip
     hip.lib()
+    WgradGroup.sync()
     N, L = res_feat.shape[:2]
     dev = res_feat.device
     vs = dpm.trans_pos.var_sched
@@ -393,6 +479,7 @@ class FusedAdam(torch.optim.Optimizer):
         from . import hip
         if closure is not None:
             raise NotImplementedError('FusedAdam: closures are not supported')
+        WgradGroup.sync()
         norms = []
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group['params'] if p.grad is not None]

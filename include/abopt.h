@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 39
+#define ABOPT_ABI_VERSION 40
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -447,6 +447,16 @@ int abopt_reconstruct_backbone_partially(const float* pos_ctx, const float* R_ne
 int abopt_gemm(const float* A, int lda, int64_t stride_a, int a_transposed, const float* B, int ldb, int64_t stride_b, int b_transposed,
                float* C, int ldc, int64_t stride_c, int M, int N, int K, int batch, float alpha, const float* bias, int relu,
                void* ws, size_t ws_bytes, abopt_stream stream);
+
+/* The weight-gradient products of one backward pass as a group: C_p = A_p^T . B_p for count <= 24 tall operand pairs, i.e.
+ *   C_p[m*n_p + n] = sum over k < k_p of a_p[k*lda_p + m] * b_p[k*ldb_p + n]      (C_p dense [m_p, n_p]; a_p, b_p read in place)
+ * -- d W = d y^T x of every nn.Linear the backward of the denoiser walks (D/modules/encoders/ga.py:54-79, D/modules/diffusion/dpm_full.py:39-65
+ * under `loss.backward()`, D/train.py:101-114) -- in ONE launch plus one for the split-K slab sums of all of them, instead of two launches per
+ * product.  Exact fp32 FMA chains on the matrix cores; the K split is chosen for the group's tile count; partial slabs are summed in a fixed order
+ * (deterministic; the order differs from abopt_gemm's for the same product).  ws: scratch for the slabs, up to
+ * sum_p min(1024 / total 64x64 tiles, k_p / 256) * m_p * n_p floats are used (less workspace: fewer slabs, never an error). */
+typedef struct { const float* a; const float* b; float* c; int lda, ldb, m, n, k; } abopt_gemm_tn_problem;
+int abopt_gemm_tn_grouped(const abopt_gemm_tn_problem* problems, int count, void* ws, size_t ws_bytes, abopt_stream stream);
 
 /* out[c] = sum over rows of x[r*ld + c] (bias gradients and per-row partials of weight gradients on the training path); deterministic:
  * row slices are summed in a fixed order.  ws (optional): slices * cols floats of scratch. */

@@ -2506,3 +2506,105 @@ def test_inverse_igso3_gaussian_branch_on_device_rng(t):
     assert abs(theta.mean().item() - 2 * sig) < 0.02 * sig + 0.05 * sig            # folded tail moves the mean by 0.0085 sigma
     axis = (out['v'] / out['v'].norm(dim=-1, keepdim=True)).reshape(-1, 3).cpu()
     assert axis.mean(0).abs().max() < 0.02
+
+
+# ------------------------------------------------------------------------------------------ grouped weight-gradient products
+@pytest.mark.gpu
+def test_gemm_tn_grouped_vs_fp64():
+    """abopt_gemm_tn_grouped (include/abopt.h): C_p = A_p^T B_p for a group of tall operand pairs in one product launch + one slab-sum
+    launch -- odd sizes (M, N not multiples of 64 or 4, K not a multiple of 32), column slices of wider matrices read in place, K too short
+    to split, more problems than one launch carries (24), a single fat problem that is not split at all -- against float64, and bit for bit
+    against itself on a second call and against the same products issued one per call."""
+    from ab_opt_amd import hip
+    g = torch.Generator().manual_seed(12)
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(DEV)
+    wide_a, wide_b = rnd(4096, 300), rnd(4096, 2100)
+    pairs = [(rnd(4096, 128), rnd(4096, 128)), (wide_a[:, 4:135], wide_b[:, 64:64 + 1824]), (rnd(4099, 26), rnd(4099, 64)),
+             (rnd(200, 64), rnd(200, 240)), (wide_a[:, 200:264], wide_b[:, 0:2016]), (rnd(777, 5), rnd(777, 3))]
+    pairs += [(rnd(1024 + 32 * i, 128), rnd(1024 + 32 * i, 131)) for i in range(22)]          # 28 problems: two launches
+    got = hip.gemm_tn_grouped(pairs)
+    again = hip.gemm_tn_grouped(pairs)
+    for (a, b), c, c2 in zip(pairs, got, again):
+        ref = a.double().t() @ b.double()
+        assert c.shape == ref.shape and torch.equal(c, c2)
+        assert (c.double() - ref).abs().max().item() <= 2e-6 * (a.double().abs().t() @ b.double().abs()).max().item(), (a.shape, b.shape)
+    one = hip.gemm_tn_grouped([(wide_b, wide_b[:, :512])])[0]                                   # 33 x 8 tiles: no K split, no slab sum
+    assert (one.double() - wide_b.double().t() @ wide_b[:, :512].double()).abs().max().item() <= 2e-6 * 4096 * 16
+    outs = [torch.full((p[0].shape[1], p[1].shape[1]), float('nan'), device=DEV) for p in pairs[:3]]
+    res = hip.gemm_tn_grouped(pairs[:3], outs=outs)
+    assert all(r is o and torch.isfinite(o).all() for r, o in zip(res, outs))
+    with pytest.raises(TypeError):
+        hip.gemm_tn_grouped([(rnd(64, 8).t(), rnd(8, 8))])
+
+
+@pytest.mark.gpu
+def test_wgrad_group_matches_ungrouped_backward():
+    """training.WgradGroup: the weight-gradient products of a backward pass queue and run as grouped launches (about one per GABlock + one
+    when the engine finishes the pass).  Against the one-product-per-launch form: every gradient within fp32 summation-order distance
+    (another K split), the gradients that do not go through the queue (res_feat, pair_feat, biases, LayerNorm) bit for bit; the grouped form
+    repeats bit for bit, pass after pass (an unflushed queue or an operand freed early would show up here); a second backward without
+    zero_grad accumulates like the ungrouped form (those products run at once); a step captured by GraphedTrainStep replays
+    deterministically."""
+    from ab_opt_amd import training
+    N, L = 4, 128
+    d = standalone_abdesign_dpm(100, 2).to(DEV).train()
+    v, p, s, res_feat, pair_feat, _, gen, mres = synth.eps_inputs(N, L, [128, 120, 97, 128], [(25, 33), (51, 57), (94, 106)], salt=901)
+    s = s.clamp(max=19)
+    t = dev(torch.tensor([3, 40, 77, 99]))
+
+    def grads(accumulate=False):
+        d.zero_grad(set_to_none=True)
+        out = None
+        for rep in range(2 if accumulate else 1):
+            rf, pf = dev(res_feat).clone().requires_grad_(True), dev(pair_feat).clone().requires_grad_(True)
+            torch.manual_seed(123 + rep)                                    # the noising kernel's Philox seed comes from torch's host generator
+            loss = d(dev(v), dev(p) * 10, dev(s), rf, pf, dev(gen), dev(mres), True, True, t=t)
+            sum(loss.values()).backward()
+            out = {n: q.grad for n, q in d.named_parameters() if q.grad is not None}
+            out['res_feat'], out['pair_feat'] = rf.grad, pf.grad
+        torch.cuda.synchronize()
+        return {k: a.detach().clone() for k, a in out.items()}
+
+    was = training.WgradGroup.enabled
+    try:
+        training.WgradGroup.enabled = False
+        ref, ref_acc = grads(), grads(True)
+        training.WgradGroup.enabled = True
+        assert training.WgradGroup.active()
+        first = grads()
+        assert training.WgradGroup._state is None                          # closed by the engine's final callback
+        assert set(first) == set(ref) and len(first) > 140
+        moved = 0
+        for k in ref:
+            if k.endswith('weight') and ref[k].dim() == 2 and 'embed' not in k:
+                assert (first[k] - ref[k]).abs().max().item() <= 2e-5 * ref[k].abs().max().item() + 1e-12, k
+                moved += int(not torch.equal(first[k], ref[k]))
+            else:
+                assert torch.equal(first[k], ref[k]), k
+        assert moved > 20                                                   # otherwise the queue did not run and this test tests nothing
+        for rep in range(6):
+            got = grads()
+            for k in first:
+                assert torch.equal(got[k], first[k]), (rep, k)
+        acc = grads(True)
+        for k in ref_acc:
+            assert (acc[k] - ref_acc[k]).abs().max().item() <= 2e-5 * ref_acc[k].abs().max().item() + 1e-12, k
+        # a step captured by GraphedTrainStep (the flushes are ordinary launches of the capture): two identical builds replay to identical parameters
+        from ab_opt_amd.utils import synth as sy
+        finals = []
+        for build in range(2):
+            m = sy.fresh_model(10, 3, device=DEV).train()
+            opt = training.FusedAdam(m.parameters(), lr=1e-3)
+            batch = {k: dev(a) for k, a in sy.make_batch(2, sy.LAYOUT_128, seed=5, lengths=[64, 57]).items()}
+            torch.manual_seed(5); torch.cuda.manual_seed(5)                 # step indices (device generator) and Philox seeds (host generator)
+            step = training.GraphedTrainStep(m, opt, batch, max_grad_norm=100.0, warmup=1)
+            for _ in range(3):
+                losses = step(batch)
+            torch.cuda.synchronize()
+            assert all(torch.isfinite(a) for a in losses.values())
+            finals.append({n: q.detach().clone() for n, q in m.named_parameters()})
+        for n in finals[0]:
+            assert torch.equal(finals[0][n], finals[1][n]), n
+    finally:
+        training.WgradGroup.enabled = was
+        d.zero_grad(set_to_none=True)
