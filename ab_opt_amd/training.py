@@ -63,7 +63,8 @@ class WgradGroup:
     group of more than one rank (DistributedDataParallel's bucket hooks read gradients during backward).  Hooks a caller registers on
     parameters see a queued gradient before it is computed: switch the queue off (ABOPT_WGRAD_GROUP=0 / WgradGroup.enabled = False) for those."""
     enabled = _os.environ.get('ABOPT_WGRAD_GROUP', '1') != '0'
-    flush_tiles = 128
+    flush_tiles = int(_os.environ.get('ABOPT_WGRAD_FLUSH_TILES', '128'))      # (developer knob)
+    _ones = {}
     _state = None          # the running backward pass: stream, queued (a, b, out), their tile count, ids of parameters with a queued gradient
 
     @classmethod
@@ -92,6 +93,23 @@ class WgradGroup:
     def sync(cls):
         """Flush and close (a backward pass that raised never reaches its final callback; the next forward and the optimizer call this)."""
         cls.flush(close=True)
+
+    @classmethod
+    def colsum(cls, a, params):
+        """Column sums of the tall (K, M) matrix a -- a bias gradient -- as the product a^T 1 riding in the group (one more 64 x 64 tile of a
+        launch that exists anyway, instead of a partial-sum launch + a slab-sum launch of its own)."""
+        from . import hip
+        if not cls.active() or params is None or not all(p is not None and p.is_leaf and p.grad is None for p in params) or a.dim() != 2 or a.stride(1) != 1:
+            return hip.colsum(a)
+        key = (a.device, a.shape[0])
+        ones = cls._ones.get(key)
+        if ones is None:
+            ones = torch.ones(a.shape[0], 1, dtype=torch.float32, device=a.device)
+            if not torch.cuda.is_current_stream_capturing():        # (a tensor filled inside a capture holds nothing until the first replay: not cached)
+                if len(cls._ones) > 16:
+                    cls._ones.clear()
+                cls._ones[key] = ones
+        return cls.product(a, ones, params).view(-1)
 
     @classmethod
     def product(cls, a, b, params):
@@ -142,6 +160,7 @@ class NativeLinear(torch.autograd.Function):
         ctx.save_for_backward(x2, w, y if relu else None)
         ctx.has_bias = b is not None
         ctx.leaves = tuple(leaves) if leaves is not None else (w,)
+        ctx.bias_leaf = (b,) if b is not None else None
         return y.view(x.shape[:-1] + (w.shape[0],))
 
     @staticmethod
@@ -153,7 +172,7 @@ class NativeLinear(torch.autograd.Function):
         dy2 = torch.ops.aten.threshold_backward(dy2.contiguous(), y, 0.0) if y is not None else dy2.contiguous()      # d relu: one kernel
         dx = hip.gemm(dy2, w.t())[0].view(dy.shape[:-1] + (w.shape[1],)) if ctx.needs_input_grad[0] else None
         dw = WgradGroup.product(dy2, x2, ctx.leaves)
-        return dx, dw, (hip.colsum(dy2) if ctx.has_bias else None), None, None
+        return dx, dw, (WgradGroup.colsum(dy2, ctx.bias_leaf) if ctx.has_bias else None), None, None
 
 
 def _linear(mod, x, relu=False):
