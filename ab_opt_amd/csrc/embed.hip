@@ -319,7 +319,7 @@ constexpr int PMT = 4;        // 16-pair tiles per wave
         _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt) {                                                              \
             const int j_ = j0 + mt * 16 + fm;                                                                             \
             if (j_ < L) {                                                                                                 \
-                float* d_ = a.acts + ((row_i * L) + j_) * PAIR_ACT + (OFF) + kq * 4;                                      \
+                float* d_ = a.acts + prow * PAIR_ACT + (unsigned)(j_ * PAIR_ACT + (OFF) + kq * 4);                        \
                 _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(d_ + nt * 16) = TILE[mt][nt];  \
             }                                                                                                             \
         }                                                                                                                 \
@@ -341,12 +341,21 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
     const int aa_i = a.aa_eff[row_i], res_i = a.res_nb[row_i], chain_i = a.chain_nb[row_i];
     const uint8_t fl_i = a.flags[row_i];
 
-    int64_t jrow[PMT];
+    // Addresses = a wave-uniform 64-bit base (the sample's first row / this query row: SGPRs) + an unsigned 32-bit lane offset.  (Per-lane 64-bit
+    // row numbers and sign-extended offsets kept live across the five layers were what the register allocator spilled: 104 bytes of scratch per lane
+    // until round 5.)
+    const int* __restrict__ aa_b = a.aa_eff + base;
+    const int* __restrict__ res_b = a.res_nb + base;
+    const int* __restrict__ chain_b = a.chain_nb + base;
+    const uint8_t* __restrict__ flags_b = a.flags + base;
+    const f32x4* __restrict__ atoms_b = a.atoms4 + base * 16;
+    const int64_t prow = row_i * L;                                    // first pair record of this query row
+    unsigned jl[PMT];
     int aap[PMT];
 #pragma unroll
     for (int mt = 0; mt < PMT; ++mt) {
-        jrow[mt] = base + min(j0 + mt * 16 + fm, L - 1);
-        aap[mt] = aa_i * AAT + a.aa_eff[jrow[mt]];
+        jl[mt] = (unsigned)min(j0 + mt * 16 + fm, L - 1);
+        aap[mt] = aa_i * AAT + aa_b[jl[mt]];
     }
 
     // ---- distance_embed.0: 225 Gaussian atom-pair features -> 64, K block = atom a of residue i, lane group kq = atoms 4kq..4kq+3 of j
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
 #pragma unroll
         for (int mt = 0; mt < PMT; ++mt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pj[mt][q] = a.atoms4[jrow[mt] * 16 + kq * 4 + q];
+            for (int q = 0; q < 4; ++q) pj[mt][q] = atoms_b[jl[mt] * 16u + (unsigned)(kq * 4 + q)];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bd0 + nt * 16 + kq * 4);
@@ -374,9 +383,9 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
                     for (int mt = 0; mt < PMT; ++mt) {
                         const int j_ = j0 + mt * 16 + fm;
                         if (j_ < L) {
-                            const int64_t o_ = (((row_i * L) + j_) * A + at) * 16 + kq * 4;
-                            *reinterpret_cast<f32x4*>(a.gsave + o_) = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            if (a.tsave) *reinterpret_cast<f32x4*>(a.tsave + o_) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            const unsigned o_ = (unsigned)((j_ * A + at) * 16 + kq * 4);
+                            *reinterpret_cast<f32x4*>(a.gsave + prow * A * 16 + o_) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (a.tsave) *reinterpret_cast<f32x4*>(a.tsave + prow * A * 16 + o_) = (f32x4){0.f, 0.f, 0.f, 0.f};
                         }
                     }
                 }
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
             f32x4 g[PMT];
 #pragma unroll
             for (int mt = 0; mt < PMT; ++mt) {
-                const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.sp + ((int64_t)aap[mt] * A + at) * 16 + kq * 4);
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.sp + (unsigned)((aap[mt] * A + at) * 16 + kq * 4));
                 f32x4 tq;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -401,9 +410,9 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
                 if (a.gsave) {
                     const int j_ = j0 + mt * 16 + fm;
                     if (j_ < L) {
-                        const int64_t o_ = (((row_i * L) + j_) * A + at) * 16 + kq * 4;
-                        *reinterpret_cast<f32x4*>(a.gsave + o_) = g[mt];
-                        if (a.tsave) *reinterpret_cast<f32x4*>(a.tsave + o_) = tq;
+                        const unsigned o_ = (unsigned)((j_ * A + at) * 16 + kq * 4);
+                        *reinterpret_cast<f32x4*>(a.gsave + prow * A * 16 + o_) = g[mt];
+                        if (a.tsave) *reinterpret_cast<f32x4*>(a.tsave + prow * A * 16 + o_) = tq;
                     }
                 }
             }
@@ -429,13 +438,18 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
     if (PE_TERMS & 1) { PAIR_DENSE_T(h1, h0, a.wtd1, 2) } else { PAIR_DENSE(h1, h0, a.wd1) }
     float ps[PMT], same[PMT], mp[PMT];
     int rel[PMT];
+    // the key rows are re-derived from the lane index here and in the dihedral block (two VALU operations) instead of living in registers across
+    // distance_embed: the empty asm statement keeps the compiler from merging them with the copies above
+    int fm_late = fm;
+    asm volatile("" : "+v"(fm_late));
 #pragma unroll
     for (int mt = 0; mt < PMT; ++mt) {
-        const uint8_t fl_j = a.flags[jrow[mt]];
+        const unsigned jl_ = (unsigned)min(j0 + mt * 16 + fm_late, L - 1);
+        const uint8_t fl_j = flags_b[jl_];
         ps[mt] = (!a.has_struct || ((fl_i & 2) && (fl_j & 2))) ? 1.f : 0.f;
         mp[mt] = ((fl_i & 1) && (fl_j & 1)) ? 1.f : 0.f;
-        same[mt] = (a.chain_nb[jrow[mt]] == chain_i) ? 1.f : 0.f;
-        rel[mt] = min(max(res_i - a.res_nb[jrow[mt]], -32), 32) + 32;                           // pair.py:55-60
+        same[mt] = (chain_b[jl_] == chain_i) ? 1.f : 0.f;
+        rel[mt] = min(max(res_i - res_b[jl_], -32), 32) + 32;                           // pair.py:55-60
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -449,8 +463,8 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
         for (int nt = 0; nt < 4; ++nt) {
             const int col = nt * 16 + kq * 4;
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bo0 + col);
-            const f32x4 ta = *reinterpret_cast<const f32x4*>(a.t_aap + (int64_t)aap[mt] * EC + col);
-            const f32x4 tr = *reinterpret_cast<const f32x4*>(a.t_rel + rel[mt] * EC + col);
+            const f32x4 ta = *reinterpret_cast<const f32x4*>(a.t_aap + (unsigned)(aap[mt] * EC + col));
+            const f32x4 tr = *reinterpret_cast<const f32x4*>(a.t_rel + (unsigned)(rel[mt] * EC + col));
             h0[mt][nt] = (bv + ta) + tr * same[mt];
         }
     if (PE_TERMS & 2) { PAIR_DENSE_T(h0, h1, a.wto0, 2) } else { PAIR_DENSE(h0, h1, a.wo0) }
@@ -459,9 +473,9 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
         f32x4 dh[PMT][2];
 #pragma unroll 1
         for (int mt = 0; mt < PMT; ++mt) {
-            const int64_t jr = SEL4(jrow, mt);
+            const unsigned jr = (unsigned)min(j0 + mt * 16 + fm_late, L - 1);
             const float psm = SEL4(ps, mt);
-            const V3 nj = xyz(a.atoms4[jr * 16 + 0]), caj = xyz(a.atoms4[jr * 16 + 1]), cj = xyz(a.atoms4[jr * 16 + 2]);
+            const V3 nj = xyz(atoms_b[jr * 16u + 0u]), caj = xyz(atoms_b[jr * 16u + 1u]), cj = xyz(atoms_b[jr * 16u + 2u]);
 #if defined(PE_ABL) && (PE_ABL & 1)      // developer build: no dihedral geometry
             const float x0 = nj.x, x1 = caj.y;
 #else
@@ -493,7 +507,7 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
             for (int mt = 0; mt < PMT; ++mt) {
                 const int j_ = j0 + mt * 16 + fm;
                 if (j_ < L) {
-                    float* d_ = a.acts + ((row_i * L) + j_) * PAIR_ACT + 128 + kq * 4;
+                    float* d_ = a.acts + prow * PAIR_ACT + (unsigned)(j_ * PAIR_ACT + 128 + kq * 4);
                     *reinterpret_cast<f32x4*>(d_) = dh[mt][0]; *reinterpret_cast<f32x4*>(d_ + 16) = dh[mt][1];
                 }
             }
@@ -540,7 +554,7 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
     for (int mt = 0; mt < PMT; ++mt) {
         const int j = j0 + mt * 16 + fm;
         if (j >= L) continue;
-        float* o = a.out + ((row_i * L) + j) * EC + kq * 4;
+        float* o = a.out + prow * EC + (unsigned)(j * EC + kq * 4);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(o + nt * 16) = h0[mt][nt] * mp[mt];
     }
@@ -983,7 +997,16 @@ int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weig
     a.out = pair_feat; a.N = N; a.L = L; a.A = A; a.has_struct = in->structure_mask ? 1 : 0; a.acts = acts; a.gsave = gsave; a.tsave = tsave;
     const int jblocks = (L + 16 * PMT - 1) / (16 * PMT);
     const int64_t units = rows * jblocks;
-    hipLaunchKernelGGL(pair_embed_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, a);
+    size_t dyn_lds = 0;
+#if PE_TERMS
+    {   // developer experiment: ABOPT_PE_LDS=<bytes> of (unused) dynamic LDS per workgroup limits how many workgroups share a CU -- the SAME binary at
+        // one wave per SIMD (> 80 KB) against two
+        static const int e = getenv("ABOPT_PE_LDS") ? atoi(getenv("ABOPT_PE_LDS")) : 0;
+        dyn_lds = (size_t)e;
+        if (e > 0) ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_embed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e));
+    }
+#endif
+    hipLaunchKernelGGL(pair_embed_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), dyn_lds, st, a);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }
