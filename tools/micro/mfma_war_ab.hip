@@ -36,11 +36,20 @@ template <> struct T<K> {                                                       
                      : "=v"(o) : "v"(c0), "v"(ab), "v"(other) : CLOB); return o; }                                                      \
     static __device__ float raw(float c0, unsigned ab, unsigned other) { float o;                                                      \
         asm volatile(SETUP MF NOPS##K "v_mov_b32 %0, v108\n" TAIL : "=&v"(o) : "v"(c0), "v"(ab), "v"(other) : CLOB); return o; }         \
+    static __device__ float chain3(float c0, unsigned ab, unsigned other) { float o;     /* c = A.B + 0; c = A.B + c; c = A.B + c (in place, K states between) */ \
+        asm volatile(SETUP "v_mfma_f32_16x16x32_f16 v[108:111], v[104:107], v[112:115], 0\n" NOPS##K                                    \
+                           "v_mfma_f32_16x16x32_f16 v[108:111], v[104:107], v[112:115], v[108:111]\n" NOPS##K                          \
+                           "v_mfma_f32_16x16x32_f16 v[108:111], v[104:107], v[112:115], v[108:111]\n" TAIL "v_mov_b32 %0, v108\n"    \
+                     : "=v"(o) : "v"(c0), "v"(ab), "v"(other) : CLOB); return o; }                                                      \
+    static __device__ float chain2x(float c0, unsigned ab, unsigned other) { float o;    /* d = A.B + c0 (into another register); e = A.B + d */ \
+        asm volatile(SETUP "v_mfma_f32_16x16x32_f16 v[116:119], v[104:107], v[112:115], v[100:103]\n" NOPS##K                         \
+                           "v_mfma_f32_16x16x32_f16 v[108:111], v[104:107], v[112:115], v[116:119]\n" TAIL "v_mov_b32 %0, v108\n"    \
+                     : "=v"(o) : "v"(c0), "v"(ab), "v"(other) : CLOB, "v116", "v117", "v118", "v119"); return o; }                      \
     static __device__ float waw(float c0, unsigned ab, unsigned other) { float o;                                                      \
         asm volatile(SETUP MF NOPS##K "v_mov_b32 v108, 0x44424000\n" TAIL "v_mov_b32 %0, v108\n" : "=v"(o) : "v"(c0), "v"(ab), "v"(other) : CLOB); return o; } \
 };
 DEF(0) DEF(1) DEF(2) DEF(3) DEF(4) DEF(6) DEF(8) DEF(12) DEF(16)
-__device__ unsigned g_bad[4][9];
+__device__ unsigned g_bad[6][9];
 template <int K, int SLOT> __device__ void run(float c0, unsigned ab, float ab_dot, int iters) {
     const unsigned other = 0x40004000u;       // 2.0, 2.0 in fp16: a product that read it gives 64 (one operand) per 32 of K instead of 32
     for (int it = 0; it < iters; ++it) {
@@ -48,6 +57,8 @@ template <int K, int SLOT> __device__ void run(float c0, unsigned ab, float ab_d
         if (T<K>::warb(c0, ab, other) != ab_dot + c0) atomicAdd(&g_bad[1][SLOT], 1u);
         if (T<K>::raw(c0, ab, other) != ab_dot + c0) atomicAdd(&g_bad[2][SLOT], 1u);
         if (T<K>::waw(c0, ab, other) != 777.f) atomicAdd(&g_bad[3][SLOT], 1u);
+        if (T<K>::chain3(c0, ab, other) != 3.f * ab_dot) atomicAdd(&g_bad[4][SLOT], 1u);
+        if (T<K>::chain2x(c0, ab, other) != 2.f * ab_dot + c0) atomicAdd(&g_bad[5][SLOT], 1u);
     }
 }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -90,21 +101,21 @@ __global__ __launch_bounds__(64 * WAVES) void k(int partner, int testers_per_sim
 }
 int main() {
     const int ks[9] = {0, 1, 2, 3, 4, 6, 8, 12, 16};
-    const char* names[4] = {"VALU overwrites SrcA (WAR)   ", "VALU overwrites SrcB (WAR)   ", "VALU reads D (RAW)           ", "VALU overwrites D (WAW)      "};
+    const char* names[6] = {"VALU overwrites SrcA (WAR)   ", "VALU overwrites SrcB (WAR)   ", "VALU reads D (RAW)           ", "VALU overwrites D (WAW)      ", "3 dependent MFMAs in place   ", "MFMA reads another MFMA's D  "};
     const char* pn[5] = {"no partner wave", "partner: f16 16x16x32 MFMAs (4 passes)", "partner: f32 16x16x4 MFMAs (8 passes)", "partner: f32 32x32x2 MFMAs (16 passes)", "partner: VALU only"};
     for (int cfg = 0; cfg < 3; ++cfg) {
         const int waves = cfg == 0 ? 8 : 16, testers = cfg == 2 ? 2 : 1;          // 2 waves per SIMD (1 tester + 1 partner) | 4 per SIMD (1 + 3) | 4 per SIMD (2 + 2)
         for (int partner = 0; partner < 5; ++partner) {
-            unsigned z[4][9] = {};
+            unsigned z[6][9] = {};
             hipMemcpyToSymbol(HIP_SYMBOL(g_bad), z, sizeof(z));
             if (waves == 8) hipLaunchKernelGGL(k<8>, dim3(512), dim3(512), 0, 0, partner, testers);
             else hipLaunchKernelGGL(k<16>, dim3(512), dim3(1024), 0, 0, partner, testers);
             hipDeviceSynchronize();
-            unsigned h[4][9]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bad), sizeof(h));
+            unsigned h[6][9]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bad), sizeof(h));
             printf("v_mfma_f32_16x16x32_f16, %d waves per SIMD (%d testing), %s: wrong results by wait states between the MFMA and the VALU instruction\n   states:                    ", waves / 4, testers, pn[partner]);
             for (int i = 0; i < 9; ++i) printf(" %8d", ks[i]);
             printf("\n");
-            for (int t = 0; t < 4; ++t) { printf("   %s", names[t]); for (int i = 0; i < 9; ++i) printf(" %8u", h[t][i]); printf("\n"); }
+            for (int t = 0; t < 6; ++t) { printf("   %s", names[t]); for (int i = 0; i < 9; ++i) printf(" %8u", h[t][i]); printf("\n"); }
         }
     }
     return 0;
