@@ -242,7 +242,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
             else if (fm < H) {                                                                                           \
                 const int j0_ = chunk_of(CH) * JC + kq * 4;                                                              \
                 if (dvec) { if (j0_ < L) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv_), drsrc, dvoff, so_, 0); } \
-                else { _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) if (j0_ + r_ < L) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv_[r_]), drsrc, dvoff + 4 * r_, so_, 0); } \
+                else { _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) if (j0_ + r_ < L) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv_[r_]), drsrc, dvoff, so_ + 4 * r_, 0); } \
             }                                                                                                            \
         }                                                                                                                \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                               \

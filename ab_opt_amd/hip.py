@@ -579,10 +579,11 @@ def ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, spatial_coef):
     return dproj, e
 
 
-def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias, dz_into=None, want_dz=True):
+def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias, dz_into=None, want_dz=True, reduce=None):
     """alpha, dalpha_node head-major (N,12,L,L) -> g (N,12,L,L), dz (N,L,L,C), dWb (12,C)  (include/abopt.h: abopt_ipa_pair_backward).
     dz_into: an existing d pair_feat buffer this block's gradient is ADDED to (returned as dz).  want_dz=False: dz is None -- the caller
-    assembles d pair_feat of all blocks at once (ipa_dz_assemble)."""
+    assembles d pair_feat of all blocks at once (ipa_dz_assemble).  reduce: the column-sum function for the per-row partials of dWb (default
+    hip.colsum; training passes WgradGroup's, which rides in the grouped weight-gradient launch)."""
     N, L = z.shape[:2]
     g = torch.empty_like(alpha)
     dz = None if not want_dz else (torch.empty_like(z) if dz_into is None else dz_into)
@@ -591,7 +592,7 @@ def ipa_pair_backward(z, alpha, dalpha_node, delta, dfeat, w_pair_bias, dz_into=
     _check(lib().abopt_ipa_pair_backward(ptr(z, torch.float32), ptr(alpha, torch.float32), ptr(dalpha_node, torch.float32),
                                          ptr(delta, torch.float32), ptr(dfeat, torch.float32), dfeat.shape[-1],
                                          ptr(w_pair_bias, torch.float32), ptr(g), ptr(dz, torch.float32, optional=True), ptr(dwb_rows), int(dz_into is not None), N, L, z.shape[-1], stream()))
-    return g, dz, colsum(dwb_rows).view(12, z.shape[-1])
+    return g, dz, (reduce or colsum)(dwb_rows).view(12, z.shape[-1])
 
 
 def ipa_dz_assemble(alphas, gs, dfeats, wbs, like):
@@ -760,8 +761,9 @@ def block_tail_forward(feat, wof, wmf, x, b_out, mask, g1, be1, b0, b1, b2, g2, 
     return (out, saved) if save else out
 
 
-def block_tail_backward(dout, saved, wmt, mask, g1, g2):
-    """Row-local backward of the tail (abopt_block_tail_backward) -> dpre [3, rows, 128], da1, du [rows, 128], colsum [8, 128]."""
+def block_tail_backward(dout, saved, wmt, mask, g1, g2, reduce=None):
+    """Row-local backward of the tail (abopt_block_tail_backward) -> dpre [3, rows, 128], da1, du [rows, 128], colsum [8, 128].
+    reduce: the column-sum function for the per-workgroup partials (default hip.colsum; see ipa_pair_backward)."""
     rows = saved.shape[1]
     dout, mask, g1, g2 = _contig(dout, mask, g1, g2)
     dev = dout.device
@@ -772,7 +774,7 @@ def block_tail_backward(dout, saved, wmt, mask, g1, g2):
     f = lambda t: ptr(t, torch.float32)
     _check(lib().abopt_block_tail_backward(f(dout), f(saved), f(wmt), ptr(mask, torch.bool), f(g1), f(g2), ptr(dpre), ptr(da1), ptr(du), ptr(colpart),
                                            rows, stream()))
-    return dpre, da1, du, colsum(colpart.view(colpart.shape[0], -1)).view(8, 128)
+    return dpre, da1, du, (reduce or colsum)(colpart.view(colpart.shape[0], -1)).view(8, 128)
 
 
 def _operand(t):

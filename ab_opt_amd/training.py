@@ -65,6 +65,7 @@ class WgradGroup:
     enabled = _os.environ.get('ABOPT_WGRAD_GROUP', '1') != '0'
     flush_tiles = int(_os.environ.get('ABOPT_WGRAD_FLUSH_TILES', '128'))      # (developer knob)
     _ones = {}
+    colsum_max_cols = int(_os.environ.get('ABOPT_WGRAD_COLSUM_COLS', '100000'))       # (developer knob: wider column sums keep their own kernels)
     _state = None          # the running backward pass: stream, queued (a, b, out), their tile count, ids of parameters with a queued gradient
 
     @classmethod
@@ -99,7 +100,8 @@ class WgradGroup:
         """Column sums of the tall (K, M) matrix a -- a bias gradient -- as the product a^T 1 riding in the group (one more 64 x 64 tile of a
         launch that exists anyway, instead of a partial-sum launch + a slab-sum launch of its own)."""
         from . import hip
-        if not cls.active() or params is None or not all(p is not None and p.is_leaf and p.grad is None for p in params) or a.dim() != 2 or a.stride(1) != 1:
+        if not cls.active() or params is None or not all(p is not None and p.is_leaf and p.grad is None for p in params) or a.dim() != 2 or a.stride(1) != 1 \
+                or a.shape[1] > cls.colsum_max_cols:
             return hip.colsum(a)
         key = (a.device, a.shape[0])
         ones = cls._ones.get(key)
@@ -211,6 +213,7 @@ class IpaCore(torch.autograd.Function):
         from . import hip
         feat, alpha = hip.ipa_core_train_forward(proj, R, t, z, mask, w_pair_bias, spatial_coef.reshape(-1), pbc)
         ctx.save_for_backward(proj, z, R, t, w_pair_bias, spatial_coef, feat, alpha)
+        ctx.row_leaves = (w_pair_bias, spatial_coef)               # the parameters whose gradients are column sums of per-row partials (WgradGroup)
         ctx.zsink = zsink
         if zsink is not None:
             zsink['users'] += 1
@@ -231,6 +234,7 @@ class IpaCore(torch.autograd.Function):
         b3 = lambda a: a.reshape(N * H, a.shape[-2], a.shape[-1])                   # (N,H,.,.) -> batch of N*H matrices (a view)
         mm = lambda a, b_nk: hip.gemm(b3(a), b3(b_nk)).view(N, H, a.shape[-2], b_nk.shape[-2])      # a @ b_nk^T, operands read in place
         da_node = mm(dout_cat, Av)                                                  # (N,H,L,L) = dout_cat Av^T
+        wb_sum = lambda rows_: WgradGroup.colsum(rows_, ctx.row_leaves[:1])                       # d proj_pair_bias.weight: column sums of per-row partials, in the group
         # the z-streaming part (incl. d proj_pair_bias.weight).  The blocks of one encoder pass share ONE d pair_feat buffer (zsink): each
         # backward adds into it in the kernel and only the last one to run hands it to autograd -- instead of six 268 MB tensors and five
         # elementwise additions
@@ -240,13 +244,13 @@ class IpaCore(torch.autograd.Function):
         # abopt_ipa_dz_assemble sums the terms of at most 6 blocks (its LDS tile); deeper encoders (the library takes up to 8 layers) and
         # the developer A/B ABOPT_DZ_DEFER=0 use the round-3 form: every block adds into one shared buffer
         if sink is not None and (not DEFER_DZ or sink['total'] > 6):
-            g, dz, dWb = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb, dz_into=sink['buf'])
+            g, dz, dWb = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb, dz_into=sink['buf'], reduce=wb_sum)
             sink['buf'] = dz
             sink['users'] -= 1
             dz = None if sink['users'] > 0 else dz
             sink = None
         else:
-            g, dz, dWb = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb, want_dz=sink is None)
+            g, dz, dWb = hip.ipa_pair_backward(z, alpha, da_node, delta, dfeat, Wb, want_dz=sink is None, reduce=wb_sum)
         if sink is not None:
             # the blocks of one encoder pass leave (alpha, g, d feat, W_b) behind; the LAST backward to run sums all their d pair_feat terms
             # in one pass with one write (abopt_ipa_dz_assemble) -- each block adding into a shared buffer was a read-modify-write of
@@ -263,7 +267,7 @@ class IpaCore(torch.autograd.Function):
         P3 = mm(T(alpha), T(dout_cat))                                              # sum_i alpha_ij [dfn_i | dag_i]
         # scale, spatial-term chain rule, rotation back to the residue frames, re-layout to (N,L,2016): one kernel
         dproj, e = hip.ipa_backward_assemble(P1, P2, P3, Aq, Ak, R, gamma_raw.reshape(-1))
-        dgamma = hip.colsum(e.reshape(-1, e.shape[-1])).reshape(gamma_raw.shape)      # the kernel applies d(-softplus(x) sqrt(2/(9P))/2)/dx
+        dgamma = WgradGroup.colsum(e.reshape(-1, e.shape[-1]), ctx.row_leaves[1:]).reshape(gamma_raw.shape)      # the kernel applies d(-softplus(x) sqrt(2/(9P))/2)/dx
         return dproj, dz, None, None, None, dWb, dgamma, None, None
 
 
@@ -281,6 +285,7 @@ class BlockTail(torch.autograd.Function):
         out, saved = hip.block_tail_forward(feat2, wof, wmf, x.reshape(-1, 128), b_out, mask.reshape(-1), g1, be1, b0, b1, b2, g2, be2, save=True)
         ctx.save_for_backward(feat2, mask, saved, wmt, w_out, g1, g2)
         ctx.leaves = (w_out, w0, w1, w2)
+        ctx.row_leaves = (b_out, g1, be1, b0, b1, b2, g2, be2)
         return out.view(shape)
 
     @staticmethod
@@ -288,7 +293,9 @@ class BlockTail(torch.autograd.Function):
     def backward(ctx, dout):
         from . import hip
         feat2, mask, saved, wmt, w_out, g1, g2 = ctx.saved_tensors
-        dpre, da1, du, cs = hip.block_tail_backward(dout.reshape(-1, 128), saved, wmt, mask.reshape(-1), g1, g2)
+        rl = ctx.row_leaves
+        dpre, da1, du, cs = hip.block_tail_backward(dout.reshape(-1, 128), saved, wmt, mask.reshape(-1), g1, g2,
+                                                    reduce=lambda part_: WgradGroup.colsum(part_, rl))      # bias / LayerNorm gradients: in the group
         dfeat = hip.gemm(du, w_out.t())[0].view(dout.shape[:-1] + (w_out.shape[1],))
         lv = ctx.leaves
         dw_out = WgradGroup.product(du, feat2, lv[:1])
