@@ -33,10 +33,12 @@ class _TallLinear(torch.autograd.Function):
         # bias and ReLU in the product's epilogue: one launch
         y = hip.gemm(x.reshape(-1, x.shape[-1]), weight, bias=bias, relu=relu)[0].view(x.shape[:-1] + (weight.shape[0],))
         ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.leaves = ((weight,), (bias,))
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        from .training import WgradGroup
         x, weight, y = ctx.saved_tensors
         if y is not None:
             dy = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0)
@@ -44,6 +46,9 @@ class _TallLinear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = hip.gemm(dy2, weight.t())[0].view_as(x)
+        if dy2.shape[0] <= 65536:          # per-residue layers: in the backward pass's grouped launch; the per-pair layers (N L^2 rows) are HBM streams of their own
+            dyc = dy2.contiguous()
+            return dx, WgradGroup.product(dyc, x2, ctx.leaves[0]), WgradGroup.colsum(dyc, ctx.leaves[1]), None
         return dx, _splitk_tn(dy2, x2), hip.colsum(dy2), None
 
 
