@@ -28,7 +28,7 @@ namespace abopt {
 // (ga.py:84-85,108-111; the cancellation error of the expanded square is <= 2e-6 on the logit in the global frame, |p| <~ 10).
 __global__ __launch_bounds__(256) void ipa_frags_kernel(const float* __restrict__ proj, const float* __restrict__ R, const float* __restrict__ t,
                                                         const float* __restrict__ spatial_coef, float* __restrict__ qfrag,
-                                                        float* __restrict__ kvfrag, int L, int nchunk) {
+                                                        float* __restrict__ kvfrag, int L, int nchunk, int ldp) {
     __shared__ float pts[JC][3 * NPT + 2 * H + 4];               // q_pts | k_pts | v_pts (global frame) | |q_pts|^2 | |k_pts|^2 of the block's 16 rows
     __shared__ float coef[H];
     const int n = blockIdx.x / nchunk, ch = blockIdx.x % nchunk, tid = threadIdx.x;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void ipa_frags_kernel(const float* __restrict_
     for (int item = tid; item < JC * 3 * H; item += 256) {
         const int r = item / (3 * H), sh = item % (3 * H), set = sh / H, h = sh % H;
         const int64_t row = rowbase + min(ch * JC + r, L - 1);                        // rows past the end are clamped copies (finite, never stored by the core)
-        const float* p = proj + row * NP + OFF_QP + set * NPT + h * (P * 3);
+        const float* p = proj + row * ldp + OFF_QP + set * NPT + h * (P * 3);
         const float* Rr = R + row * 9;
         const float* tr = t + row * 3;
         const float r0 = Rr[0], r1 = Rr[1], r2 = Rr[2], r3 = Rr[3], r4 = Rr[4], r5 = Rr[5], r6 = Rr[6], r7 = Rr[7], r8 = Rr[8];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void ipa_frags_kernel(const float* __restrict_
         float4 o;
         if (slot < 2) {
             const int64_t row = rowbase + min(ch * JC + fm, L - 1);
-            o = *reinterpret_cast<const float4*>(proj + row * NP + OFF_K + h * D + slot * 16 + kq * 4);
+            o = *reinterpret_cast<const float4*>(proj + row * ldp + OFF_K + h * D + slot * 16 + kq * 4);
         } else if (slot == 2) {
             const float* kp = &pts[fm][NPT + h * (P * 3) + kq * 3];
             o = make_float4(kp[0], kp[1], kp[2], kq == 0 ? 1.f : (kq == 1 ? pts[fm][3 * NPT + H + h] : 0.f));
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void ipa_frags_kernel(const float* __restrict_
         } else {
             const int r = kq * 4 + (slot - 4);
             const int64_t row = rowbase + min(ch * JC + r, L - 1);
-            const float* vrow = proj + row * NP + OFF_V + h * D;
+            const float* vrow = proj + row * ldp + OFF_V + h * D;
             const float* vp = &pts[r][2 * NPT + h * (P * 3)];
             const int pt = fm >> 2, c = fm & 3;
             o = make_float4(vrow[fm], vrow[16 + fm], c < 3 ? vp[pt * 3 + c] : 0.f, c < 3 ? vp[(4 + pt) * 3 + c] : 0.f);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void ipa_frags_kernel(const float* __restrict_
         float4 o;
         if (slot < 2) {
             const int64_t row = rowbase + min(ch * JC + fm, L - 1);
-            const float4 qv = *reinterpret_cast<const float4*>(proj + row * NP + OFF_Q + h * D + slot * 16 + kq * 4);
+            const float4 qv = *reinterpret_cast<const float4*>(proj + row * ldp + OFF_Q + h * D + slot * 16 + kq * 4);
             const float s = 0.17677669529663687f;                                      // 1 / sqrt(D), ga.py:84
             o = make_float4(qv.x * s, qv.y * s, qv.z * s, qv.w * s);
         } else if (slot == 2) {
@@ -110,10 +110,10 @@ static_assert(BI == JC, "a 16-residue block is both a key chunk and a query bloc
 size_t ipa_kvfrag_floats(int N, int L) { return (size_t)N * ((L + JC - 1) / JC) * H * 8 * 64 * 4; }
 size_t ipa_qfrag_floats(int N, int L) { return (size_t)N * ((L + BI - 1) / BI) * H * 4 * 64 * 4; }
 
-int launch_ipa_frags(const float* proj, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag, int N, int L, hipStream_t st) {
+int launch_ipa_frags(const float* proj, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag, int N, int L, hipStream_t st, int ldp) {
     if ((int64_t)N * L == 0) return ABOPT_OK;
     const int nchunk = (L + JC - 1) / JC;
-    hipLaunchKernelGGL(ipa_frags_kernel, dim3((unsigned)(N * nchunk)), dim3(256), 0, st, proj, R, t, spatial_coef, qfrag, kvfrag, L, nchunk);
+    hipLaunchKernelGGL(ipa_frags_kernel, dim3((unsigned)(N * nchunk)), dim3(256), 0, st, proj, R, t, spatial_coef, qfrag, kvfrag, L, nchunk, ldp);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

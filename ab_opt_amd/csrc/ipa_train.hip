@@ -446,13 +446,12 @@ int launch_ipa_train_forward(const float* proj_local, const float* R, const floa
                              hipStream_t st) {
     const int64_t M = (int64_t)N * L;
     if (M == 0) return ABOPT_OK;
-    float* proj = ws;
     float* kvf = ws + (size_t)M * NP;
-    ABOPT_HIP(hipMemcpy2DAsync(proj, (size_t)NP * sizeof(float), proj_local, (size_t)ABOPT_NODE_PROJ * sizeof(float),
-                               (size_t)ABOPT_NODE_PROJ * sizeof(float), (size_t)M, hipMemcpyDeviceToDevice, st));
     int rc;
     float* qf = kvf + ipa_kvfrag_floats(N, L);
-    if ((rc = launch_ipa_frags(proj, R, t, spatial_coef, qf, kvf, N, L, st))) return rc;
+    // the fragment kernel reads the projections' output in place (row stride 2016; until round 5 a 2-D copy re-strode it to 2048 first: 10.5 us per block)
+    ABOPT_CHECK_ARG(((uintptr_t)proj_local % 16) == 0, "ipa_core_train_forward: proj must be 16-byte aligned");
+    if ((rc = launch_ipa_frags(proj_local, R, t, spatial_coef, qf, kvf, N, L, st, ABOPT_NODE_PROJ))) return rc;
     float* stats = qf + ipa_qfrag_floats(N, L);
     // the core writes its scaled logits head-major into the alpha buffer; one elementwise pass turns them into alpha in place
     if ((rc = launch_ipa_core_kernel(qf, kvf, z, mask, R, t, Wb, feat, alpha, stats, pbc, N, L, st, 0))) return rc;

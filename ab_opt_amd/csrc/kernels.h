@@ -24,7 +24,8 @@ int launch_colsum(const float* x, int ld, int64_t rows, int cols, float* out, fl
 size_t ipa_kvfrag_floats(int N, int L);
 size_t ipa_qfrag_floats(int N, int L);
 size_t pair_bias_layer_floats(int N, int L);
-int launch_ipa_frags(const float* proj, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag, int N, int L, hipStream_t st);
+// ldp: row stride of proj in floats (NP for the library's own buffer; 2016 reads the projections' output in place: rows stay 16-byte aligned)
+int launch_ipa_frags(const float* proj, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag, int N, int L, hipStream_t st, int ldp = 2048);
 int launch_ipa_core(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                     const float* w_pair_bias, float* feat, float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache,
                     int N, int L, hipStream_t st, int z_shared = 0 /* 1: z and the pair-bias cache hold ONE sample that every batch entry shares */,
