@@ -108,6 +108,10 @@ def _object_worker(rank, world, port, out):
         cand = torch.zeros(1 if rank == 0 else 0, 4, 3)
         allc = sampler.all_gather_candidates(cand, [1, 0])
         assert allc.shape == (1, 4, 3)
+        # data-parallel training: DDP's bucket hooks read gradients DURING backward, so the queue of grouped weight-gradient launches
+        # (training.WgradGroup: gradients are computed when the queue is flushed) must be off in a process group of more than one rank
+        from ab_opt_amd import training
+        assert training.WgradGroup.enabled and not training.WgradGroup.active()
     finally:
         dist.destroy_process_group()
 
@@ -118,6 +122,11 @@ def test_testset_summary_exchange_world2():
     out = mgr.dict()
     mp.spawn(_object_worker, args=(2, port, out), nprocs=2, join=True)
     assert out[0] == out[1] == [(0, 0, [0, 1]), (1, 0, [1, 2]), (2, 0, [2, 3]), (3, 1, [3, 4]), (4, 1, [4, 5])]      # contiguous blocks: rank 0 owns 0..2
+
+
+def test_wgrad_group_is_on_in_a_single_process():
+    from ab_opt_amd import training
+    assert training.WgradGroup.enabled and training.WgradGroup.active() and training.WgradGroup._state is None
 
 
 def test_launch_rng_ranges_never_overlap():
