@@ -34,7 +34,8 @@ for k in ipa_core node_frags_kernel; do
     python tools/pmc_summary.py $OUT/pmc --kernel $k; } > $OUT/pmc_$k.txt
 done
 rm -rf $OUT/pmc
-# ---- 4. read traffic by source
+# ---- 4. read traffic by source (needs the developer builds abl1 / abl2 / fabl1 under ab_opt_amd/variants; PROFILE_PARTS=123 stops here)
+if [ "${PROFILE_PARTS:-123456}" = 123 ]; then tail -1 $OUT/bench_full.log | cut -c1-1200; head -14 $OUT/kernel_stats.txt | cut -c1-60,92-140; head -8 $OUT/kernel_stats_replay_only.txt | cut -c1-60,92-140; exit 0; fi
 cd /tmp
 { echo "# HBM read traffic of the dominant kernel by source: rocprofv3 --pmc FETCH_SIZE (KiB; x2 = the gfx950 correction of MI355X_MICROARCH.md) of developer builds with ONE stream removed";
   echo "# (timing-only builds: their results are wrong by construction).  Command: $CMD  with ABOPT_LIB_PATH=<variant> [ABOPT_FUSE_TAIL=0]"; } > $OUT/traffic_by_source.txt
