@@ -149,11 +149,16 @@ __global__ __launch_bounds__(256) void ipa_pair_backward_kernel(const float* __r
 // per block (2.95 GB per step at config 5).  The terms need no z, only what the blocks' backward passes leave behind anyway (alpha, g,
 // d feat, the weights), so they are summed here with ONE write of dz: a K = 32 nl contraction per (row, key chunk), same tiling as above.
 struct DzLayers { const float* alpha[8]; const float* g[8]; const float* dfeat[8]; const float* wb[8]; int nl; int ld_dfeat; };
+// K = 24 per block (12 heads of alpha . dfp + 12 of g . Wb) as six 16x16x4 steps: lane group kq supplies slot kq * 4 + m in steps m = 0..3 (one 16-byte
+// LDS read) and slot 16 + kq * 2 + (m - 4) in steps 4, 5 (one 8-byte read); slots 0..11 = heads of the first term, 12..23 = heads of the second, the same
+// for both operands.  (Until the end of round 5 the heads were padded to 16 per term: 8 steps, a quarter of them on zeros, and 64.5 KB of LDS -- two
+// workgroups per CU; 50 KB now: three.)
+constexpr int DZK = 24, DZLD = 28;
 struct DzSmem {
-    float at[6][C][36];              // per block: [c][0:16] = dfp^T of this row, [16:32] = Wb^T
-    float ag[4][JC][36];             // per wave: [key][0:16] = alpha over heads, [16:32] = g over heads (one block at a time)
+    float at[6][C][DZLD];            // per block: [c][0:12] = dfp^T of this row, [12:24] = Wb^T
+    float ag[4][JC][DZLD];           // per wave: [key][0:12] = alpha over heads, [12:24] = g over heads (one block at a time)
 };
-__global__ __launch_bounds__(256) void ipa_dz_assemble_kernel(DzLayers a, float* __restrict__ dz, int L) {
+__global__ __launch_bounds__(256, 3) void ipa_dz_assemble_kernel(DzLayers a, float* __restrict__ dz, int L) {
     extern __shared__ __attribute__((aligned(16))) char dz_raw[];
     DzSmem& sm = *reinterpret_cast<DzSmem*>(dz_raw);
     const int64_t row = blockIdx.x;
@@ -164,8 +169,7 @@ __global__ __launch_bounds__(256) void ipa_dz_assemble_kernel(DzLayers a, float*
         const float* dfp = a.dfeat[l] + row * a.ld_dfeat;
         for (int e = tid; e < 16 * C; e += 256) {
             const int h = e / C, c = e % C;
-            sm.at[l][c][h] = (h < H) ? dfp[h * C + c] : 0.f;
-            sm.at[l][c][16 + h] = (h < H) ? a.wb[l][h * C + c] : 0.f;
+            if (h < H) { sm.at[l][c][h] = dfp[h * C + c]; sm.at[l][c][H + h] = a.wb[l][h * C + c]; }
         }
     }
     __syncthreads();
@@ -205,20 +209,22 @@ __global__ __launch_bounds__(256) void ipa_dz_assemble_kernel(DzLayers a, float*
         for (int l = 0; l < 6; ++l) {
             if (l >= a.nl) break;
             wave_lds_sync();
+            if (fm < H) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sm.ag[wave][kq * 4 + r][fm] = ac[l][r]; sm.ag[wave][kq * 4 + r][16 + fm] = gc[l][r]; }
+                for (int r = 0; r < 4; ++r) { sm.ag[wave][kq * 4 + r][fm] = ac[l][r]; sm.ag[wave][kq * 4 + r][H + fm] = gc[l][r]; }
+            }
             wave_lds_sync();
-            f32x4 bq[2];
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sm.ag[wave][fm][kq * 4]);
+            const float2 b2 = *reinterpret_cast<const float2*>(&sm.ag[wave][fm][16 + kq * 2]);
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) bq[blk] = *reinterpret_cast<const f32x4*>(&sm.ag[wave][fm][blk * 16 + kq * 4]);
+            for (int ct = 0; ct < 4; ++ct) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sm.at[l][ct * 16 + fm][kq * 4]);
+                const float2 a2 = *reinterpret_cast<const float2*>(&sm.at[l][ct * 16 + fm][16 + kq * 2]);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    const f32x4 aq = *reinterpret_cast<const f32x4*>(&sm.at[l][ct * 16 + fm][blk * 16 + kq * 4]);
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) o[ct] = mfma4(aq[s_], bq[blk][s_], o[ct]);
-                }
+                for (int s_ = 0; s_ < 4; ++s_) o[ct] = mfma4(a4[s_], b4[s_], o[ct]);
+                o[ct] = mfma4(a2.x, b2.x, o[ct]);
+                o[ct] = mfma4(a2.y, b2.y, o[ct]);
+            }
         }
         if (j0 + fm < L) {
             float* dzj = dzrow + (int64_t)(j0 + fm) * C + kq * 4;
