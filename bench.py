@@ -311,6 +311,22 @@ def poses_measurement(dev, N, L, key, abdesign=False, K=20):
                               'step_hbm_frac = SURVEY 8(d) bytes (z once per distinct complex) / time / 8 TB/s; step_tflops = 8(d) FLOPs / time')}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command under torch.distributed.run with N ranks on 127.0.0.1 (a free port),
+    stdout / stderr inherited.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] --gpus %d without WORLD_SIZE: launching %s' % (n, ' '.join(cmd[1:8])), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def log(*a):
     print('[bench %.1fs]' % (time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
 
@@ -334,10 +350,16 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip train_step_ms / sample_e2e_ms / config3 / poses1000 (N=1 only)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # the plain command shape `python bench.py --gpus N ...`: launch the N ranks ourselves (one process per GPU over RCCL, the command of
+        # the module docstring) and hand their output through -- rank 0 alone prints the JSON line
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; start it as `python bench.py --gpus {args.gpus} ...` '
+                 f'(self-launching) or under torch.distributed.run with --nproc-per-node {args.gpus}')
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
     ndev = torch.cuda.device_count()
     local_dev = local % ndev                   # more ranks than devices (the 2-ranks-on-one-GPU test of this path): ranks share a device
@@ -464,6 +486,20 @@ def main():
         if launches == 0:                                   # (a shape that does not take the 32-row kernels: events are all there is)
             launches, ipa_ms, instrumented = n_e, ms_e, eager_events['ms_per_step']
     clock = hip.prof_clock()                                    # the clock wave 0 / workgroup 0 of the last dominant-kernel launch ran at
+    # the WHOLE loop the metric names (all T steps from noise to t = 1, one graph replay each), next to the K-step headline: the headline's K
+    # steps are t = T .. T-K+1 and carry the one-off pair-bias cache build, so a reader can tell how the 20-step line relates to a full call
+    loop_full = None
+    if rank == 0 and world == 1 and use_graph and K < T and not args.no_prof:
+        run(T, graph=True)                                      # capture + first replay
+        torch.cuda.synchronize()
+        lt = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            run(T, graph=True)
+            torch.cuda.synchronize()
+            lt.append((time.perf_counter() - t0) / T * 1e3)
+        loop_full = dict(loop100_ms_per_step=round(sorted(lt)[1], 4), loop100_sample_steps_per_s=round(N / (sorted(lt)[1] * 1e-3), 1), repeats_ms=[round(x, 4) for x in lt],
+                         note=f'all T={T} steps of the sampler (t = {T} .. 1) replayed from one hipGraph, pair-bias cache build included once; median of 3')
     # the two-launch form of a block (32-row core, then the tail kernel) in one more eager pass: the IPA core ALONE, for continuity with
     # the rounds before the tail was fused into it (bit-identical results; not part of the timed region)
     two_launch = None
@@ -550,6 +586,11 @@ def main():
                                   'share_note': 'kernel time and step time of the SAME (instrumented, eager) pass'}},
             'box': box,
         }
+        if loop_full is not None:
+            line['loop100_ms_per_step'] = loop_full['loop100_ms_per_step']
+            line['loop100'] = loop_full
+        elif K == T:
+            line['loop100_ms_per_step'] = round(step_s * 1e3, 4)
         if two_launch:
             u = two_launch['ipa_core_avg_launch_ms']
             two_launch.update(ipa_core_frac=round(alg / (u * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -153,3 +153,9 @@ def test_docs_cite_existing_tests_and_files():
     for path in set(re.findall(r'`((?:profiles|tools)/[\w./\[\]*-]+)`', sec5)):
         pat = re.sub(r'\[([^\]]*)\]', lambda m: '[' + m.group(1).replace('|', '') + ']', path)
         assert glob.glob(os.path.join(root, pat)) or glob.glob(os.path.join(root, pat) + '*'), f'DESIGN.md section 5 cites {path}, which is not in the tree'
+    # ... and the ABI number: every "abopt_abi_version() == N" / "ABI number N" the documents state is the header's (INTEGRATION.md said 39)
+    abi = int(re.search(r'#define ABOPT_ABI_VERSION (\d+)', open(os.path.join(root, 'include', 'abopt.h')).read()).group(1))
+    for doc in ('DESIGN.md', 'README.md', 'INTEGRATION.md'):
+        text = open(os.path.join(root, doc)).read()
+        for n in re.findall(r'abopt_abi_version\(\)\s*==\s*(\d+)', text) + re.findall(r'ABI number (\d+)', text):
+            assert int(n) == abi, f'{doc} states ABI {n}, include/abopt.h is {abi}'

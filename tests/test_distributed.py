@@ -154,3 +154,37 @@ def test_launch_rng_ranges_never_overlap():
                         assert first.setdefault(c, base + g * S * L_all) == base + g * S * L_all == c * S * L_all
             ranges.sort()
             assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])) and ranges[0][0] == 0, (trial, world, ranges)
+
+
+def test_bench_self_launch_command_shape(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE re-runs itself under torch.distributed.run with N ranks on 127.0.0.1 (bench.self_launch);
+    with a launcher's WORLD_SIZE that disagrees with --gpus it exits with a message instead of an AssertionError."""
+    import subprocess
+    import sys
+    import importlib
+    import pytest
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    class Done:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen['cmd'], seen['env'] = cmd, env
+        return Done()
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '20', '--warmup', '5'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-6:] == ['--gpus', '4', '--steps', '20', '--warmup', '5']
+    assert cmd[-7].endswith('bench.py') and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert 'WORLD_SIZE=2' in str(e.value.code)

@@ -1924,6 +1924,27 @@ def test_bench_two_ranks_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_plain_command_self_launches_two_ranks():
+    """The driver's N = 1 command shape with N = 2 -- `python bench.py --gpus 2 ...`, no launcher, no WORLD_SIZE -- must start its own two
+    ranks (bench.self_launch: torch.distributed.run on 127.0.0.1) and print ONE line that carries both of them."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--repeats', '2', '--batch', '8',
+                        '--no-cpu-baseline', '--no-secondary'], capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 4 and line['value'] > 0
+    assert [x['rank'] for x in line['config']['ranks']] == [0, 1]
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two devices: one rank per GPU over RCCL')
 def test_two_devices_rccl_bench_sampling_and_graphed_ddp(tmp_path):
     """The first multi-GPU run must be boring.  With >= 2 devices: (i) `bench.py --gpus 2` as the driver launches it --

@@ -18,7 +18,7 @@ rows = []
 for k in set(a) | set(b):
     ca, ta = a.get(k, (0, 0.0)); cb, tb = b.get(k, (0, 0.0))
     dc, dt = (cb - ca) / (nb - na), (tb - ta) / (nb - na)
-    if dc > 0 or abs(dt) > 0.5:
+    if dc > 0:          # a kernel with the same call count in both runs is a one-off of the process (its duration jitter is not per-step time)
         rows.append((dt, dc, k))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
@@ -27,4 +27,4 @@ print(f'# steady-state training step (config 5: N=16, L=256, AbDesign flavour, F
 print(f'# GPU time per step {tot / 1e3:.3f} ms, {own / 1e3:.3f} ms ({100 * own / tot:.1f} %) in abopt:: kernels; {sum(r[1] for r in rows):.0f} launches per step, {sum(r[1] for r in rows if "abopt::" not in r[2]):.0f} of them outside abopt::')
 print(f'{"kernel":<92}{"calls/step":>11}{"us/step":>12}{"avg_us":>10}{"pct":>7}')
 for dt, dc, k in rows[:70]:
-    print(f'{short(k):<92}{dc:>11.2f}{dt:>12.1f}{dt / max(dc, 1e-9):>10.2f}{100 * dt / tot:>7.2f}')
+    print(f'{short(k):<92}{dc:>11.2f}{dt:>12.1f}{dt / dc:>10.2f}{100 * dt / tot:>7.2f}')
