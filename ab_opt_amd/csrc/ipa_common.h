@@ -133,6 +133,12 @@ __device__ __forceinline__ Split2 split2(const f32x4& lo, const f32x4& hi) {
 __device__ __forceinline__ f32x4 mfma_h(const u32x4& a, const u32x4& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// K = 16 form (two registers per operand): the second product of a K-packed pair, P_l against the high terms only
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 mfma_h16(const u32x2& a, const u32x2& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x16 mfma_h32(const u32x4& a, const u32x4& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }

@@ -908,6 +908,13 @@ __device__ unsigned long long g_c32_count[8];
 #ifndef C32_ABL
 #define C32_ABL 0        // developer ablations (timing only, results wrong): 1 no z / bias loads in the loop | 32 z / bias loads all from one L1-resident address | 64 no softmax arithmetic in rows 1..7 (P = S) | 128 no pair MFMAs | 256 / 512 no A / C MFMAs (nothing instead) | 2 no fragment loads in the loop | 4 / 8 / 16 pair / A / C MFMAs off | 1024 no accumulator rescale (pair and C waves) | 2048 no v_exp_f32 in rows 1..7
 #endif
+#ifndef C32_ZAUX
+#define C32_ZAUX 2       // cache policy bits of the z / bias stream's buffer loads (2 = nt)
+#endif
+#ifndef C32_HX
+#define C32_HX 0         // round-6 TIMING-ONLY experiment (results wrong unless the host hands over z as K-packed fp16 terms): 1 pair waves: P . z as 8 v_mfma_f32_16x16x32_f16 per row
+                         // (terms packed along K) instead of 16 fp32 MFMAs, P published as fp16 planes | 2 C waves: P . v on 8 f16 MFMAs per (head, row tile) | 4 A waves: q . k channel part on 3 f16 MFMAs
+#endif
 constexpr int BI2 = 32, NPW2 = 4, RPW2 = BI2 / NPW2, NTH2 = 512, HPW = 6;
 
 #define C32_EXP2(x) ((C32_ABL & 2048) ? (x) : __builtin_amdgcn_exp2f(x))      // (ablation 2048: no v_exp_f32 in rows 1..7)
@@ -1167,8 +1174,8 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
 #else
 #define P2_ISSUE_Z(SLOT, II)                                                                                            \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                \
-            ring[SLOT][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, koff_[r_], zrow[(C32_ABL & 32) ? 0 : II], 2));   /* aux 2 = nt, as ZLOAD */
-#define P2_ISSUE_B(SLOT, II) ringb[SLOT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, boff_, pbrow[(C32_ABL & 32) ? 0 : II], 2));
+            ring[SLOT][r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, koff_[r_], zrow[(C32_ABL & 32) ? 0 : II], C32_ZAUX));   /* aux 2 = nt, as ZLOAD */
+#define P2_ISSUE_B(SLOT, II) ringb[SLOT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, boff_, pbrow[(C32_ABL & 32) ? 0 : II], C32_ZAUX));
 #endif
         P2_KOFF(0) P2_BOFF(0)
         P2_ISSUE_B(0, 0) P2_ISSUE_Z(0, 0) P2_ISSUE_B(1, 1) P2_ISSUE_Z(1, 1) P2_ISSUE_B(2, 2)
@@ -1209,6 +1216,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
     }
         // one MFMA of row II (k-step K_ >> 2, channel tile K_ & 3) and a fence: the source order below IS the issue order
 #define P2_MF(SLOT, II, K_)                                                                                              \
+        if (C32_ABL & 4096) accP[II][(K_) & 3][(K_) >> 2] += ring[SLOT][(K_) >> 2][(K_) & 3] * pvc_[(K_) >> 2]; else     /* (ablation 4096: one VALU fma per operand instead of the MFMA: the loads stay alive) */ \
         if (!(C32_ABL & 128)) accP[II][(K_) & 3] = mfma4(ring[SLOT][(K_) >> 2][(K_) & 3], pvc_[(K_) >> 2], accP[II][(K_) & 3]);                \
         __builtin_amdgcn_sched_barrier(0);
         // rows 0..6 of a chunk: the 16 MFMAs of row II, each followed by a piece of row II + 1's softmax and accumulator rescale
@@ -1289,17 +1297,120 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
             P2_ISSUE_Z(((SLOT) + C32_RING - 1) % C32_RING, ((II) + C32_RING - 1) & 7)                                    \
         }                                                                                                                \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                 \
-            _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[II][mt_] = mfma4(ring[SLOT][r_][mt_], pvc_[r_], accP[II][mt_]); \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) { if (C32_ABL & 4096) accP[II][mt_][r_] += ring[SLOT][r_][mt_] * pvc_[r_]; else accP[II][mt_] = mfma4(ring[SLOT][r_][mt_], pvc_[r_], accP[II][mt_]); } \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
+#if C32_HX & 1
+        // ---- K-packed fp16 form (timing experiment): the ring slot r of a row IS the A operand of channel tile r -- 8 halves {z_h(keys 4 kq .. + 3), z_l(same keys)} of
+        // channel 4 fm + r -- and the lane's own four probabilities are the B operand: {P_h, P_h} against {z_h, z_l}, then {P_l, 0} against {z_h, -}
+#undef P2_SM
+#undef P2_MF
+#undef P2_POS
+#undef P2_POS_LAST
+#define P2H_SPLIT()                                                                                                      \
+        { unsigned h01_, l01_, h23_, l23_;                                                                               \
+          split_pair2(pvn_[0], pvn_[1], h01_, l01_); split_pair2(pvn_[2], pvn_[3], h23_, l23_);                          \
+          pkn_ = (u32x4){h01_, h23_, l01_, l23_}; }
+#define P2_SM(II, BUF)                                                                                                   \
+    {                                                                                                                    \
+        const int il_ = il0 + (II);                                                                                      \
+        float* spp_ = sp + ((BUF) * BI2 + il_) * SROW + spo;                                                             \
+        f32x4 sv_ = *reinterpret_cast<const f32x4*>(spp_);                                                               \
+        const float2 ml_ = *reinterpret_cast<const float2*>(mlw + (II) * 32);                                            \
+        sv_ += ringb[(II) & 3];                                                                                          \
+        float l2_[4];                                                                                                    \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) l2_[r_] = C32_L2(sv_[r_], r_);                                  \
+        const float mx_ = rows_max(fmaxf(fmaxf(l2_[0], l2_[1]), fmaxf(l2_[2], l2_[3])));                                 \
+        const float mn_ = fmaxf(ml_.x, mx_);                                                                             \
+        scn_ = __builtin_amdgcn_exp2f(ml_.x - mn_);                                                                      \
+        const float mo_ = mn_ - 14.f;                                       /* P carries 2^14: its low fp16 term stays normal */ \
+        f32x4 pvn_;                                                                                                      \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) pvn_[r_] = __builtin_amdgcn_exp2f(l2_[r_] - mo_);               \
+        const float ps_ = rows_sum((pvn_[0] + pvn_[1]) + (pvn_[2] + pvn_[3]));                                           \
+        const float ln_ = ml_.y * scn_ + ps_;                                                                            \
+        P2H_SPLIT()                                                                                                      \
+        if (C32_HX & 2) *reinterpret_cast<u32x4*>(spp_) = pkn_; else *reinterpret_cast<f32x4*>(spp_) = pvn_;             \
+        if (kq == 0) { scl[((CHPAR) * BI2 + il_) * SCLD + fm] = scn_; *reinterpret_cast<float2*>(mlw + (II) * 32) = make_float2(mn_, ln_); } \
+    }
+        // MFMA number K_ of row II: channel tile K_ & 3, term K_ >> 2
+#define P2_MF(SLOT, II, K_)                                                                                              \
+        { const u32x4 za_ = __builtin_bit_cast(u32x4, ring[SLOT][(K_) & 3]);                                              \
+          if ((K_) >> 2) accP[II][(K_) & 3] = mfma_h16((u32x2){za_[0], za_[1]}, bl_, accP[II][(K_) & 3]);                 \
+          else accP[II][(K_) & 3] = mfma_h(za_, bh_, accP[II][(K_) & 3]); }                                              \
+        __builtin_amdgcn_sched_barrier(0);
+#define P2_POS(SLOT, II, CH, BUF)                                                                                        \
+    {                                                                                                                    \
+        const u32x4 bh_ = (u32x4){pkn_[0], pkn_[1], pkn_[0], pkn_[1]}; const u32x2 bl_ = (u32x2){pkn_[2], pkn_[3]};          \
+        if ((II) + 3 == 8) P2_BOFF((CH) + 1)                                /* the requests move on to the next chunk */ \
+        if ((II) + C32_RING - 1 == 8) P2_KOFF((CH) + 1)                                                                  \
+        if (!(C32_ABL & 1)) {                                                                                            \
+            P2_ISSUE_B(((II) + 3) & 3, ((II) + 3) & 7)                                                                   \
+            P2_ISSUE_Z(((SLOT) + C32_RING - 1) % C32_RING, ((II) + C32_RING - 1) & 7)                                    \
+        }                                                                                                                \
+        const int il_ = il0 + (II) + 1;                                                                                  \
+        float* spp_ = sp + ((BUF) * BI2 + il_) * SROW + spo;                                                             \
+        f32x4 sv_ = *reinterpret_cast<const f32x4*>(spp_);                                                               \
+        const float2 ml_ = *reinterpret_cast<const float2*>(mlw + ((II) + 1) * 32);                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        P2_MF(SLOT, II, 0) P2_MF(SLOT, II, 1)                                                                            \
+        sv_ += ringb[((II) + 1) & 3];                                                                                    \
+        float l2_[4];                                                                                                    \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) l2_[r_] = C32_L2(sv_[r_], r_);                                  \
+        P2_MF(SLOT, II, 2)                                                                                               \
+        float mx_ = fmaxf(fmaxf(l2_[0], l2_[1]), fmaxf(l2_[2], l2_[3]));                                                 \
+        { auto a_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx_), __float_as_uint(mx_), false, false);          \
+          mx_ = fmaxf(__uint_as_float(a_[0]), __uint_as_float(a_[1])); }                                                 \
+        P2_MF(SLOT, II, 3)                                                                                               \
+        { auto b_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx_), __float_as_uint(mx_), false, false);          \
+          mx_ = fmaxf(__uint_as_float(b_[0]), __uint_as_float(b_[1])); }                                                 \
+        const float mn_ = fmaxf(ml_.x, mx_);                                                                             \
+        scn_ = __builtin_amdgcn_exp2f(ml_.x - mn_);                                                                      \
+        const float mo_ = mn_ - 14.f;                                                                                    \
+        P2_MF(SLOT, II, 4)                                                                                               \
+        f32x4 pvn_;                                                                                                      \
+        pvn_[0] = C32_EXP2(l2_[0] - mo_); pvn_[1] = C32_EXP2(l2_[1] - mo_);                                              \
+        pvn_[2] = C32_EXP2(l2_[2] - mo_); pvn_[3] = C32_EXP2(l2_[3] - mo_);                                              \
+        P2_MF(SLOT, II, 5)                                                                                               \
+        float ps_ = (pvn_[0] + pvn_[1]) + (pvn_[2] + pvn_[3]);                                                           \
+        { auto a_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(ps_), __float_as_uint(ps_), false, false);          \
+          ps_ = __uint_as_float(a_[0]) + __uint_as_float(a_[1]); }                                                       \
+        P2H_SPLIT()                                                                                                      \
+        P2_MF(SLOT, II, 6)                                                                                               \
+        { auto b_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps_), __float_as_uint(ps_), false, false);          \
+          ps_ = __uint_as_float(b_[0]) + __uint_as_float(b_[1]); }                                                       \
+        const float ln_ = ml_.y * scn_ + ps_;                                                                            \
+        if (C32_HX & 2) *reinterpret_cast<u32x4*>(spp_) = pkn_; else *reinterpret_cast<f32x4*>(spp_) = pvn_;             \
+        P2_MF(SLOT, II, 7)                                                                                               \
+        if (kq == 0) { scl[((CHPAR) * BI2 + il_) * SCLD + fm] = scn_; *reinterpret_cast<float2*>(mlw + ((II) + 1) * 32) = make_float2(mn_, ln_); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        if ((__builtin_amdgcn_ballot_w64(scn_ != 1.f) & 0x0fff0fff0fff0fffull) != 0ull) {                                \
+            accP[(II) + 1][0] *= scn_; accP[(II) + 1][1] *= scn_; accP[(II) + 1][2] *= scn_; accP[(II) + 1][3] *= scn_; } \
+    }
+#define P2_POS_LAST(SLOT, II, CH)                                                                                        \
+    {                                                                                                                    \
+        const u32x4 bh_ = (u32x4){pkn_[0], pkn_[1], pkn_[0], pkn_[1]}; const u32x2 bl_ = (u32x2){pkn_[2], pkn_[3]};          \
+        if ((II) + 3 == 8) P2_BOFF((CH) + 1)                                                                             \
+        if ((II) + C32_RING - 1 == 8) P2_KOFF((CH) + 1)                                                                  \
+        if (!(C32_ABL & 1)) {                                                                                            \
+            P2_ISSUE_B(((II) + 3) & 3, ((II) + 3) & 7)                                                                   \
+            P2_ISSUE_Z(((SLOT) + C32_RING - 1) % C32_RING, ((II) + C32_RING - 1) & 7)                                    \
+        }                                                                                                                \
+        P2_MF(SLOT, II, 0) P2_MF(SLOT, II, 1) P2_MF(SLOT, II, 2) P2_MF(SLOT, II, 3) P2_MF(SLOT, II, 4) P2_MF(SLOT, II, 5) P2_MF(SLOT, II, 6) P2_MF(SLOT, II, 7) \
+    }
+#endif
 #define P2_SLOT(K, II) ((8 * (K) + (II)) % C32_RING)
+#if C32_HX & 1
+#define C32_PCARRY u32x4 pkn_;
+#else
+#define C32_PCARRY f32x4 pvn_;
+#endif
 #define P2_CHUNK(K, CH)                                                                                                  \
     {                                                                                                                    \
         const uint32_t mk4_ = *reinterpret_cast<const uint32_t*>(&mk[(CH) * JC + kq * 4]);                               \
         float mterm_[4];                                                    /* x k + (0 | -1e5 log2 e) in one fma: the values of the 16-row kernels' (mask ? x k : x k - 1e5 log2 e), whose second form the compiler contracts to the same fma */ \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) mterm_[r_] = ((mk4_ >> (8 * r_)) & 0xffu) ? 0.f : -kMask2;      \
         const int CHPAR = (CH) & 1;                                                                                      \
-        f32x4 pvn_; float scn_;                                                                                          \
+        C32_PCARRY float scn_;                                                                                           \
         P2_SM(0, K)                                                                                                      \
         if (!(C32_ABL & 1024) && !((C32_LAZY & 1) && (__builtin_amdgcn_ballot_w64(scn_ != 1.f) & 0x0fff0fff0fff0fffull) == 0ull)) { _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[0][mt_] *= scn_; } \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
@@ -1454,6 +1565,16 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
                     if (C32_ABL & 8) { acc0 = kf[hh & 1][0] * q0 + kf[hh & 1][1] * q1; acc1 = kf[hh & 1][2] * q2 + kf[hh & 1][3] * q3; }
                     else if (C32_ABL & 256) { acc0 = kf[hh & 1][0]; acc1 = q0; }
+                    else if (C32_HX & 4) {
+                        // channel part on three fp16 products (slot 0 = high terms, slot 1 = low terms of the 32 channels), point part + norm step on the fp32 chain
+                        const u32x4 kh = __builtin_bit_cast(u32x4, kf[hh & 1][0]), kl = __builtin_bit_cast(u32x4, kf[hh & 1][1]);
+                        const u32x4 qh = __builtin_bit_cast(u32x4, q0), ql = __builtin_bit_cast(u32x4, q1);
+                        acc0 = mfma_h(kl, qh, acc0); acc0 = mfma_h(kh, ql, acc0);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) { acc1 = mfma4(kf[hh & 1][2][s], q2[s], acc1); if (s == 1) acc0 = mfma_h(kh, qh, acc0); }
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) acc1 = mfma4(kf[hh & 1][3][s], q3[s], acc1);
+                    }
                     else {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) { acc0 = mfma4(kf[hh & 1][0][s], q0[s], acc0); acc1 = mfma4(kf[hh & 1][2][s], q2[s], acc1); }
@@ -1535,6 +1656,23 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                     anych_ |= __builtin_amdgcn_ballot_w64(sc != 1.f);
                     // (all 16 rows of the tile kept their running maximum of this head: factors exactly 1, nothing to rescale)
                     if (!(C32_ABL & 1024) && !((C32_LAZY & 2) && FUSE && __builtin_amdgcn_ballot_w64(sc != 1.f) == 0ull)) { accV[hh][rt][0] *= sc; accV[hh][rt][1] *= sc; accT[hh][rt][0] *= sc; accT[hh][rt][1] *= sc; }
+                    if (C32_HX & 2) {
+                        // K-packed fp16 form: pa = {P_h(keys 4 kq, + 1), P_h(+ 2, + 3), P_l(..), P_l(..)} of row fm; fragment slot t = {v_h(keys 4 kq .. + 3), v_l(same)} of channel / coordinate fm of tile t
+                        const u32x4 pu = __builtin_bit_cast(u32x4, pa);
+                        const u32x4 bh = (u32x4){pu[0], pu[1], pu[0], pu[1]};
+                        const u32x2 bl = (u32x2){pu[2], pu[3]};
+#pragma unroll
+                        for (int t_ = 0; t_ < 4; ++t_) {
+                            f32x4& a_ = t_ < 2 ? accV[hh][rt][t_] : accT[hh][rt][t_ - 2];
+                            a_ = mfma_h(__builtin_bit_cast(u32x4, vf[hh & 1][t_]), bh, a_);
+                        }
+#pragma unroll
+                        for (int t_ = 0; t_ < 4; ++t_) {
+                            f32x4& a_ = t_ < 2 ? accV[hh][rt][t_] : accT[hh][rt][t_ - 2];
+                            const u32x4 v_ = __builtin_bit_cast(u32x4, vf[hh & 1][t_]);
+                            a_ = mfma_h16((u32x2){v_[0], v_[1]}, bl, a_);
+                        }
+                    } else
                     if (C32_ABL & 512) { accV[hh][rt][0] += pa; }
                     else if (C32_ABL & 16) { accV[hh][rt][0] += vf[hh & 1][0] * pa; accV[hh][rt][1] += vf[hh & 1][1] * pa; accT[hh][rt][0] += vf[hh & 1][2] * pa; accT[hh][rt][1] += vf[hh & 1][3] * pa; }
                     else

@@ -14,6 +14,7 @@ deliberate and MI355X-first:
 """
 import collections
 import weakref
+import os
 import torch
 import torch.nn as nn
 
@@ -192,6 +193,18 @@ class FullDPM(nn.Module):
         # pair_feat and the weights are constant over the loop: project the pair bias of all blocks once (dpm_full.py:274-283 feeds
         # the same pair_feat to every step); ~0.4 ms at N=32, L=256, outside nothing -- it is part of this call
         pbc = hip.pair_bias_cache(self.eps_net.encoder.packed_array(), len(self.eps_net.encoder.blocks), pair_feat) if use_bias_cache else None
+        if os.environ.get('ABOPT_DEV_ZTERMS') == '1' and use_bias_cache:
+            # developer hook of the round-6 timing experiment (csrc/ipa_core.hip, -DC32_HX): the core reads z as K-packed fp16 terms
+            # [row][chunk][key group kq][channel tile mt][channel 4 fm + mt][{h(keys 4 kq .. + 3), l(same)}] -- laid out here with torch
+            key_ = (pair_feat.data_ptr(), tuple(pair_feat.shape))
+            if getattr(self, '_dev_zt', (None, None))[0] != key_:         # (cached: a graph capture must not record these passes)
+                Nz, nch = pair_feat.shape[0], L // 16
+                zz = pair_feat.view(Nz, L, nch, 4, 4, 16, 4)                # n, i, ch, kq, e, fm, mt
+                zh = zz.half()
+                zl = (zz - zh.float()).half()
+                self._dev_zt = (key_, torch.stack([zh, zl], dim=-1).permute(0, 1, 2, 3, 6, 5, 7, 4).contiguous().view(torch.float32).view(Nz, L, L, 64))
+                del zz, zh, zl
+            pair_feat = self._dev_zt[1]
         h = self._sched_host()
         inv = self.trans_rot.angular_distrib_inv
         X, cdf = inv.X, (inv.cdf() if noise is None else None)
