@@ -73,7 +73,8 @@ static GaScratch carve_ga(Carver& cv, int64_t M, int N, int L) {
 }
 
 static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, const float* x, const float* z, const uint8_t* mask,
-                    float* x_out, int N, int L, const abopt_ga_debug* dbg, const GaScratch& s, hipStream_t st, const float* pbc = nullptr, int z_shared = 0) {
+                    float* x_out, int N, int L, const abopt_ga_debug* dbg, const GaScratch& s, hipStream_t st, const float* pbc = nullptr, int z_shared = 0,
+                    const float* pair_terms = nullptr, float* feat_out = nullptr) {
     const int64_t M = (int64_t)N * L;
     int rc;
     // node projections q|k|v|qp|kp|vp, points to the global frame, MFMA fragment layout: one fused kernel when the packed weights are given
@@ -83,16 +84,16 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
         if ((rc = launch_linear(x, F, w->w_node, F, nullptr, s.proj, NP, (int)M, ABOPT_NODE_PROJ, F, false, st))) return rc;
         if ((rc = launch_ipa_frags(s.proj, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st))) return rc;
     }
-    if (!dbg && pbc && w->w_out_terms && w->w_mlp_frag) {
+    if (!dbg && !feat_out && pbc && w->w_out_terms && w->w_mlp_frag) {
         // core + tail as one kernel (feat stays on the chip) wherever the 32-row core is the one to run; bit-identical to the two launches below
         int fused = 0;
         if ((rc = launch_ipa_block_fused(s.qf, s.kvf, z, mask, R, t, pbc, N, L, st, z_shared, w->w_out_terms, w->w_mlp_frag, x, w->b_out, w->ln1_gamma,
-                                         w->ln1_beta, w->b_mlp0, w->b_mlp1, w->b_mlp2, w->ln2_gamma, w->ln2_beta, x_out, &fused))) return rc;
+                                         w->ln1_beta, w->b_mlp0, w->b_mlp1, w->b_mlp2, w->ln2_gamma, w->ln2_beta, x_out, &fused, pair_terms))) return rc;
         if (fused) return ABOPT_OK;
     }
-    float* feat = (dbg && dbg->feat) ? dbg->feat : s.feat;
+    float* feat = (dbg && dbg->feat) ? dbg->feat : (feat_out ? feat_out : s.feat);
     if ((rc = launch_ipa_core(s.qf, s.kvf, z, mask, R, t, w->w_pair_bias, feat,
-                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, N, L, st, z_shared, s.split, s.split_floats))) return rc;
+                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, N, L, st, z_shared, s.split, s.split_floats, dbg ? nullptr : pair_terms))) return rc;
     // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
     if (w->w_out_frag && w->w_mlp_frag)
         return launch_out_ln_mlp(feat, w->w_out_frag, w->w_mlp_frag, x, w->b_out, mask, w->ln1_gamma, w->ln1_beta, w->b_mlp0, w->b_mlp1, w->b_mlp2,
@@ -379,15 +380,31 @@ extern "C" int abopt_ga_block_forward(const abopt_ga_weights* w, const float* R,
     return ga_block(w, R, t, x, z, mask, x_out, N, L, dbg, s, (hipStream_t)stream);
 }
 
+extern "C" int abopt_ga_block_forward_cached(const abopt_ga_weights* w, const float* R, const float* t, const float* x, const float* z,
+                                             const uint8_t* mask, float* x_out, int N, int L, int Fd, int Cd, const float* pair_bias_cache,
+                                             const float* pair_terms, int pair_feat_shared, float* feat_out, void* ws, size_t ws_bytes, abopt_stream stream) {
+    int rc;
+    if ((rc = check_dims(N, L, Fd, Cd))) return rc;
+    if ((rc = check_ga_weights(w))) return rc;
+    if ((int64_t)N * L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(R && t && x && z && mask && x_out && ws && pair_bias_cache, "ga_block_forward_cached: NULL argument");
+    ABOPT_CHECK_ARG(pair_feat_shared >= 0 && (pair_feat_shared <= 1 || N % pair_feat_shared == 0), "ga_block_forward_cached: pair_feat_shared=%d does not divide N=%d", pair_feat_shared, N);
+    Carver cv(ws, ws_bytes);
+    GaScratch s = carve_ga(cv, (int64_t)N * L, N, L);
+    if (!cv.ok) { set_error("ga_block_forward_cached: workspace too small (%zu bytes given)", ws_bytes); return ABOPT_EWORKSPACE; }
+    const int zg = pair_feat_shared == 1 ? N : pair_feat_shared;
+    return ga_block(w, R, t, x, z, mask, x_out, N, L, nullptr, s, (hipStream_t)stream, pair_bias_cache, zg, pair_terms, feat_out);
+}
+
 static int ga_encoder(const abopt_ga_weights* blocks, int num_layers, const float* R, const float* t, const float* x, const float* z,
                       const uint8_t* mask, float* x_out, int N, int L, const GaScratch& s, float* pong, hipStream_t st,
-                      const float* pair_bias_cache = nullptr, int z_shared = 0) {
+                      const float* pair_bias_cache = nullptr, int z_shared = 0, const float* pair_terms = nullptr) {
     // ga.py:190-193: the same R, t, z feed every block.  Ping-pong so the last block writes x_out.
     const float* cur = x;
     for (int i = 0; i < num_layers; ++i) {
         float* dst = ((num_layers - 1 - i) % 2 == 0) ? x_out : pong;
         int rc = ga_block(&blocks[i], R, t, cur, z, mask, dst, N, L, nullptr, s, st,
-                          pair_bias_cache ? pair_bias_cache + (size_t)i * pair_bias_layer_floats(z_shared ? N / z_shared : N, L) : nullptr, z_shared);
+                          pair_bias_cache ? pair_bias_cache + (size_t)i * pair_bias_layer_floats(z_shared ? N / z_shared : N, L) : nullptr, z_shared, pair_bias_cache ? pair_terms : nullptr);
         if (rc) return rc;
         cur = dst;
     }
@@ -415,6 +432,22 @@ extern "C" int abopt_ga_encoder_forward(const abopt_ga_weights* blocks, int num_
 
 extern "C" size_t abopt_pair_bias_cache_bytes(int N, int L, int num_layers) {
     return (size_t)num_layers * pair_bias_layer_floats(N, L) * sizeof(float);
+}
+
+extern "C" size_t abopt_pair_terms_bytes(int N, int L) { return pair_terms_blob_floats(N, L) * sizeof(float); }
+
+extern "C" int abopt_pair_terms_used(int N, int L, int pair_feat_shared) {
+    (void)pair_feat_shared;
+    if (N <= 0 || L <= 0) return 0;
+    return ipa_core32_applies(N, L) ? 1 : 0;
+}
+
+extern "C" int abopt_pair_terms(const float* pair_feat, float* terms, int N, int L, int Cd, abopt_stream stream) {
+    int rc;
+    if ((rc = check_dims(N, L, 128, Cd))) return rc;
+    ABOPT_CHECK_ARG(pair_feat && terms, "pair_terms: NULL argument");
+    ABOPT_CHECK_ARG(L <= 2048, "pair_terms: L=%d (the kernels that read the terms address a sample's slab with 32-bit offsets: L <= 2048)", L);
+    return launch_pair_terms(pair_feat, terms, N, L, (hipStream_t)stream);
 }
 
 extern "C" int abopt_pair_bias_cache(const abopt_ga_weights* blocks, int num_layers, const float* pair_feat, float* cache,
@@ -462,7 +495,7 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
                                      const uint8_t* mask_generate, const uint8_t* mask_res,
                                      float* v_next, float* R_next, float* eps_pos, float* c_denoised, float* prmsd_logits,
                                      int N, int L, int Fd, int Cd, int grad_mode, const float* pair_bias_cache, int pair_feat_shared,
-                                     void* ws, size_t ws_bytes, abopt_stream stream) {
+                                     const float* pair_terms, void* ws, size_t ws_bytes, abopt_stream stream) {
     int rc;
     if ((rc = check_dims(N, L, Fd, Cd))) return rc;
     ABOPT_CHECK_ARG(w && w->seq_embed && w->w_mix0 && w->b_mix0 && w->w_mix1 && w->b_mix1 && w->blocks && w->w_head1 && w->b_head1 &&
@@ -481,6 +514,7 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
     // pair_feat_shared: 0 distinct | 1 one entry for the whole batch | g > 1 consecutive groups of g samples share an entry
     ABOPT_CHECK_ARG(pair_feat_shared >= 0 && (pair_feat_shared <= 1 || N % pair_feat_shared == 0), "eps_net_forward: pair_feat_shared=%d does not divide N=%d", pair_feat_shared, N);
     ABOPT_CHECK_ARG(!pair_feat_shared || pair_bias_cache, "eps_net_forward: a shared pair_feat comes with its pair-bias cache");
+    ABOPT_CHECK_ARG(!pair_terms || pair_bias_cache, "eps_net_forward: pair_terms come with the pair-bias cache of the same pair_feat");
     const int zg = pair_feat_shared == 1 ? N : pair_feat_shared;
     Carver cv(ws, ws_bytes);
     EpsScratch e = carve_eps(cv, M, N, L, 64);
@@ -496,7 +530,7 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
         if ((rc = launch_linear(e.x0, F, w->w_mix1, F, w->b_mix1, e.cat, F, (int)M, F, F, false, st))) return rc;   // reuse cat[:, :F] as x (ld = F)
     }
     // dpm_full.py:90  encoder
-    if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st, pair_bias_cache, zg))) return rc;
+    if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st, pair_bias_cache, zg, pair_terms))) return rc;
     bool heads_fused = false;
     if (w->w_heads_frag) {
         // dpm_full.py:92-101: time features + the three heads in one launch (heads.hip)

@@ -166,13 +166,13 @@ void end(hipStream_t st) {
 
 int launch_ipa_core(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                     const float* w_pair_bias, float* feat, float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache,
-                    int N, int L, hipStream_t st, int z_shared, float* split_ws, size_t split_ws_floats) {
+                    int N, int L, hipStream_t st, int z_shared, float* split_ws, size_t split_ws_floats, const float* pair_terms) {
     if (N == 0 || L == 0) return ABOPT_OK;
     const int nib = (L + BI - 1) / BI;
     ABOPT_CHECK_ARG((int64_t)N * nib < (1ll << 31), "ipa_core: grid too large");
     ABOPT_CHECK_ARG(!z_shared || pair_bias_cache, "ipa_core: a shared pair_feat comes with its shared pair-bias cache");
     if (!dbg_logits && !dbg_alpha)
-        return launch_ipa_core_kernel(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, nullptr, nullptr, pair_bias_cache, N, L, st, z_shared, split_ws, split_ws_floats);
+        return launch_ipa_core_kernel(qfrag, kvfrag, z, mask, R, t, w_pair_bias, feat, nullptr, nullptr, pair_bias_cache, N, L, st, z_shared, split_ws, split_ws_floats, pair_terms);
     // parity-test path only: a stream-ordered temporary for the head-major dump (the product path never allocates)
     const size_t nd = (size_t)N * H * L * L, ns = (size_t)N * L * H * 2;
     float* tmp = nullptr;

@@ -908,12 +908,14 @@ __device__ unsigned long long g_c32_count[8];
 #ifndef C32_ABL
 #define C32_ABL 0        // developer ablations (timing only, results wrong): 1 no z / bias loads in the loop | 32 z / bias loads all from one L1-resident address | 64 no softmax arithmetic in rows 1..7 (P = S) | 128 no pair MFMAs | 256 / 512 no A / C MFMAs (nothing instead) | 2 no fragment loads in the loop | 4 / 8 / 16 pair / A / C MFMAs off | 1024 no accumulator rescale (pair and C waves) | 2048 no v_exp_f32 in rows 1..7
 #endif
+#ifndef ZT_LAYOUT
+#define ZT_LAYOUT 0       // developer A/B of the pair terms' layout: 0 [chunk][tile][lane] (1 KB per request) | 1 [chunk][key group][tile][fm] (the fp32 stream's addresses)
+#endif
+#ifndef ZT_DEV
+#define ZT_DEV 0          // developer timing switches of the term path (results wrong): 1 no per-channel factors in the epilogue | 2 no 2^14 on the probabilities
+#endif
 #ifndef C32_ZAUX
 #define C32_ZAUX 2       // cache policy bits of the z / bias stream's buffer loads (2 = nt)
-#endif
-#ifndef C32_HX
-#define C32_HX 0         // round-6 TIMING-ONLY experiment (results wrong unless the host hands over z as K-packed fp16 terms): 1 pair waves: P . z as 8 v_mfma_f32_16x16x32_f16 per row
-                         // (terms packed along K) instead of 16 fp32 MFMAs, P published as fp16 planes | 2 C waves: P . v on 8 f16 MFMAs per (head, row tile) | 4 A waves: q . k channel part on 3 f16 MFMAs
 #endif
 constexpr int BI2 = 32, NPW2 = 4, RPW2 = BI2 / NPW2, NTH2 = 512, HPW = 6;
 
@@ -935,7 +937,7 @@ constexpr int BI2 = 32, NPW2 = 4, RPW2 = BI2 / NPW2, NTH2 = 512, HPW = 6;
 //             192-column chunk per interval, write them -- then what the point epilogue derives from the aggregated points (local
 //             coordinates, distances, directions: chunks 6..9) -- into the staging buffer the consumers read next.  One barrier per chunk.
 //   all waves the stand-alone kernel's phase 2 (tail_common.h: tail_p2_run) on 8 waves.
-// Same arithmetic in the same order as ipa_core32_kernel<false> followed by out_ln_mlp_kernel: bit-identical
+// Same arithmetic in the same order as ipa_core32_kernel<false, ZT> followed by out_ln_mlp_kernel: bit-identical
 // (tests/test_hip_parity.py::test_fused_block_is_bit_identical).
 // Clock probe (abopt_prof_clock): wave 0 of workgroup 0 of the last 32-row launch leaves {shader cycles, 100 MHz wall ticks} from its first to
 // its last instruction -- the clock the chip sustained under THAT kernel (DVFS moves it between 1.7 and 2.2 GHz), so a
@@ -991,11 +993,18 @@ __device__ __forceinline__ void stage_put4(char* buf, int row, int col, float v0
     *reinterpret_cast<uint2*>(d + OT_PLANE) = make_uint2(l0, l1);
 }
 
-template <bool FUSE>
+// ZT (round 6): the pair aggregation sum_j P z on the fp16 matrix instructions.  z arrives PRE-SPLIT (`zt`, pair_terms_kernel: once per sample() call,
+// like the bias cache) as two fp16 terms of S_ic z packed along K -- per (query row, chunk, channel tile) a lane's 16 bytes are {h(keys 4 kq .. + 3),
+// l(same keys)} of channel 4 fm + tile: exactly one A operand of v_mfma_f32_16x16x32_f16, and the same 4 bytes per value the fp32 stream has.  The lane's own
+// four probabilities (times 2^14, so that their low terms are normal fp16 numbers) are split in registers (16 VALU operations per row-chunk) and form the
+// B operand {P_h, P_h}: one 16-cycle MFMA per channel tile gives P_h z_h + P_h z_l, a K = 16 MFMA P_l z_h -- 8 MFMAs of 16 cycles per row-chunk instead
+// of 16 of 32 (P_l z_l <= 2^-22 relative is dropped, as in ipa_common.h).  S_ic is a power of two per (query row, channel) (max_j |z[i,j,c]| S_ic in [2^13, 2^14)),
+// 2^-14 / S_ic (`zsc`, [rows][64]) leaves through the final normalisation: exact.  P itself, its row sums and everything the C waves compute are those of the fp32 form, bit for bit.  Measured (profiles/r06_a_*): -7 % of the replayed step.
+template <bool FUSE, bool ZT>
 __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restrict__ qfrag, const float* __restrict__ kvfrag, const float* __restrict__ z,
                                                           const uint8_t* __restrict__ mask, const float* __restrict__ R, const float* __restrict__ t,
                                                           float* __restrict__ feat, const float* __restrict__ pbc, int L, int nib2, int xcd_remap, int z_shared,
-                                                          TailArgs ta, int prof_slot) {
+                                                          TailArgs ta, int prof_slot, const float* __restrict__ zt, const float* __restrict__ zsc) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sp = reinterpret_cast<float*>(smem_raw);                     // [3][BI2][SROW]
     float* scl = sp + 3 * BI2 * SROW;                                   // [2][BI2][SCLD]
@@ -1143,13 +1152,15 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         const int il0 = wave * RPW2;
         // z and the bias cache are read through buffer descriptors of this sample's slabs: a request is ONE instruction -- descriptor (SGPRs),
         // the row's byte offset (an SGPR, added by the hardware) and the lane's offset inside a row (a VGPR that lives for a whole chunk)
-        const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(z + zbase * (int64_t)L * C), 0, L * L * C * 4, 0x00020000);
+        // (ZT: the same bytes per row-chunk, 4 KB, in the term layout [chunk][channel tile][lane]: every request is 1 KB contiguous, chunks past L are zero-padded)
+        const __amdgpu_buffer_rsrc_t zrs = ZT ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zt + zbase * (int64_t)nchunk * (JC * C)), 0, L * nchunk * (JC * C * 4), 0x00020000)
+                                              : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(z + zbase * (int64_t)L * C), 0, L * L * C * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pbc + zbase * (int64_t)nchunk * (H * JC)), 0, L * nchunk * (H * JC) * 4, 0x00020000);
         int zrow[RPW2], pbrow[RPW2];
 #pragma unroll
         for (int ii = 0; ii < RPW2; ++ii) {
             const int row = min(i0 + il0 + ii, L - 1);
-            zrow[ii] = row * L * (C * 4);
+            zrow[ii] = ZT ? row * nchunk * (JC * C * 4) : row * L * (C * 4);
             pbrow[ii] = row * nchunk * (H * JC * 4);
         }
         const unsigned lane_b = (unsigned)fm * 16u;
@@ -1161,7 +1172,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
 #define P2_KOFF(CH)                                                                                                      \
     {                                                                                                                    \
         const int ch_ = (C32_ABL & 32) ? 0 : min((CH), nchunk - 1);             /* past the end: harmless re-read */      \
-        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) koff_[r_] = (unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b; \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) koff_[r_] = ZT ? (ZT_LAYOUT ? (unsigned)(ch_ * (JC * C * 4) + kq * 1024 + r_ * 256 + fm * 16) : (unsigned)(ch_ * (JC * C * 4) + r_ * 1024 + lane * 16)) : (unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b; \
     }
 #define P2_BOFF(CH) boff_ = (unsigned)((C32_ABL & 32) ? 0 : min((CH), nchunk - 1)) * (unsigned)(H * JC * 4) + pb_lane;
 #ifdef C32_OLDLOAD
@@ -1300,18 +1311,14 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
             _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) { if (C32_ABL & 4096) accP[II][mt_][r_] += ring[SLOT][r_][mt_] * pvc_[r_]; else accP[II][mt_] = mfma4(ring[SLOT][r_][mt_], pvc_[r_], accP[II][mt_]); } \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
-#if C32_HX & 1
-        // ---- K-packed fp16 form (timing experiment): the ring slot r of a row IS the A operand of channel tile r -- 8 halves {z_h(keys 4 kq .. + 3), z_l(same keys)} of
+        // ---- ZT (round 6): z arrives as K-packed two-term fp16 (pair_terms_kernel): the ring slot r of a row IS the A operand of channel tile r -- 8 halves {z_h(keys 4 kq .. + 3), z_l(same keys)} of
         // channel 4 fm + r -- and the lane's own four probabilities are the B operand: {P_h, P_h} against {z_h, z_l}, then {P_l, 0} against {z_h, -}
-#undef P2_SM
-#undef P2_MF
-#undef P2_POS
-#undef P2_POS_LAST
+        // the lane's four probabilities times 2^14 (exact; their low fp16 terms are then normal numbers down to P = 2^-28) -> {P_h(k0, k1), P_h(k2, k3), P_l(..), P_l(..)}
 #define P2H_SPLIT()                                                                                                      \
         { unsigned h01_, l01_, h23_, l23_;                                                                               \
-          split_pair2(pvn_[0], pvn_[1], h01_, l01_); split_pair2(pvn_[2], pvn_[3], h23_, l23_);                          \
+          split_pair2(pvn_[0] * ((ZT_DEV & 2) ? 1.f : 16384.f), pvn_[1] * ((ZT_DEV & 2) ? 1.f : 16384.f), h01_, l01_); split_pair2(pvn_[2] * ((ZT_DEV & 2) ? 1.f : 16384.f), pvn_[3] * ((ZT_DEV & 2) ? 1.f : 16384.f), h23_, l23_); \
           pkn_ = (u32x4){h01_, h23_, l01_, l23_}; }
-#define P2_SM(II, BUF)                                                                                                   \
+#define P2H_SM(II, BUF)                                                                                                   \
     {                                                                                                                    \
         const int il_ = il0 + (II);                                                                                      \
         float* spp_ = sp + ((BUF) * BI2 + il_) * SROW + spo;                                                             \
@@ -1323,22 +1330,21 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         const float mx_ = rows_max(fmaxf(fmaxf(l2_[0], l2_[1]), fmaxf(l2_[2], l2_[3])));                                 \
         const float mn_ = fmaxf(ml_.x, mx_);                                                                             \
         scn_ = __builtin_amdgcn_exp2f(ml_.x - mn_);                                                                      \
-        const float mo_ = mn_ - 14.f;                                       /* P carries 2^14: its low fp16 term stays normal */ \
         f32x4 pvn_;                                                                                                      \
-        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) pvn_[r_] = __builtin_amdgcn_exp2f(l2_[r_] - mo_);               \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) pvn_[r_] = __builtin_amdgcn_exp2f(l2_[r_] - mn_);               \
         const float ps_ = rows_sum((pvn_[0] + pvn_[1]) + (pvn_[2] + pvn_[3]));                                           \
         const float ln_ = ml_.y * scn_ + ps_;                                                                            \
         P2H_SPLIT()                                                                                                      \
-        if (C32_HX & 2) *reinterpret_cast<u32x4*>(spp_) = pkn_; else *reinterpret_cast<f32x4*>(spp_) = pvn_;             \
+        *reinterpret_cast<f32x4*>(spp_) = pvn_;                              /* the C waves read P as fp32, as before */ \
         if (kq == 0) { scl[((CHPAR) * BI2 + il_) * SCLD + fm] = scn_; *reinterpret_cast<float2*>(mlw + (II) * 32) = make_float2(mn_, ln_); } \
     }
         // MFMA number K_ of row II: channel tile K_ & 3, term K_ >> 2
-#define P2_MF(SLOT, II, K_)                                                                                              \
+#define P2H_MF(SLOT, II, K_)                                                                                              \
         { const u32x4 za_ = __builtin_bit_cast(u32x4, ring[SLOT][(K_) & 3]);                                              \
           if ((K_) >> 2) accP[II][(K_) & 3] = mfma_h16((u32x2){za_[0], za_[1]}, bl_, accP[II][(K_) & 3]);                 \
           else accP[II][(K_) & 3] = mfma_h(za_, bh_, accP[II][(K_) & 3]); }                                              \
         __builtin_amdgcn_sched_barrier(0);
-#define P2_POS(SLOT, II, CH, BUF)                                                                                        \
+#define P2H_POS(SLOT, II, CH, BUF)                                                                                        \
     {                                                                                                                    \
         const u32x4 bh_ = (u32x4){pkn_[0], pkn_[1], pkn_[0], pkn_[1]}; const u32x2 bl_ = (u32x2){pkn_[2], pkn_[3]};          \
         if ((II) + 3 == 8) P2_BOFF((CH) + 1)                                /* the requests move on to the next chunk */ \
@@ -1352,41 +1358,40 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         f32x4 sv_ = *reinterpret_cast<const f32x4*>(spp_);                                                               \
         const float2 ml_ = *reinterpret_cast<const float2*>(mlw + ((II) + 1) * 32);                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
-        P2_MF(SLOT, II, 0) P2_MF(SLOT, II, 1)                                                                            \
+        P2H_MF(SLOT, II, 0) P2H_MF(SLOT, II, 1)                                                                            \
         sv_ += ringb[((II) + 1) & 3];                                                                                    \
         float l2_[4];                                                                                                    \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) l2_[r_] = C32_L2(sv_[r_], r_);                                  \
-        P2_MF(SLOT, II, 2)                                                                                               \
+        P2H_MF(SLOT, II, 2)                                                                                               \
         float mx_ = fmaxf(fmaxf(l2_[0], l2_[1]), fmaxf(l2_[2], l2_[3]));                                                 \
         { auto a_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx_), __float_as_uint(mx_), false, false);          \
           mx_ = fmaxf(__uint_as_float(a_[0]), __uint_as_float(a_[1])); }                                                 \
-        P2_MF(SLOT, II, 3)                                                                                               \
+        P2H_MF(SLOT, II, 3)                                                                                               \
         { auto b_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx_), __float_as_uint(mx_), false, false);          \
           mx_ = fmaxf(__uint_as_float(b_[0]), __uint_as_float(b_[1])); }                                                 \
         const float mn_ = fmaxf(ml_.x, mx_);                                                                             \
         scn_ = __builtin_amdgcn_exp2f(ml_.x - mn_);                                                                      \
-        const float mo_ = mn_ - 14.f;                                                                                    \
-        P2_MF(SLOT, II, 4)                                                                                               \
+        P2H_MF(SLOT, II, 4)                                                                                               \
         f32x4 pvn_;                                                                                                      \
-        pvn_[0] = C32_EXP2(l2_[0] - mo_); pvn_[1] = C32_EXP2(l2_[1] - mo_);                                              \
-        pvn_[2] = C32_EXP2(l2_[2] - mo_); pvn_[3] = C32_EXP2(l2_[3] - mo_);                                              \
-        P2_MF(SLOT, II, 5)                                                                                               \
+        pvn_[0] = C32_EXP2(l2_[0] - mn_); pvn_[1] = C32_EXP2(l2_[1] - mn_);                                              \
+        pvn_[2] = C32_EXP2(l2_[2] - mn_); pvn_[3] = C32_EXP2(l2_[3] - mn_);                                              \
+        P2H_MF(SLOT, II, 5)                                                                                               \
         float ps_ = (pvn_[0] + pvn_[1]) + (pvn_[2] + pvn_[3]);                                                           \
         { auto a_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(ps_), __float_as_uint(ps_), false, false);          \
           ps_ = __uint_as_float(a_[0]) + __uint_as_float(a_[1]); }                                                       \
         P2H_SPLIT()                                                                                                      \
-        P2_MF(SLOT, II, 6)                                                                                               \
+        P2H_MF(SLOT, II, 6)                                                                                               \
         { auto b_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps_), __float_as_uint(ps_), false, false);          \
           ps_ = __uint_as_float(b_[0]) + __uint_as_float(b_[1]); }                                                       \
         const float ln_ = ml_.y * scn_ + ps_;                                                                            \
-        if (C32_HX & 2) *reinterpret_cast<u32x4*>(spp_) = pkn_; else *reinterpret_cast<f32x4*>(spp_) = pvn_;             \
-        P2_MF(SLOT, II, 7)                                                                                               \
+        *reinterpret_cast<f32x4*>(spp_) = pvn_;                              /* the C waves read P as fp32, as before */ \
+        P2H_MF(SLOT, II, 7)                                                                                               \
         if (kq == 0) { scl[((CHPAR) * BI2 + il_) * SCLD + fm] = scn_; *reinterpret_cast<float2*>(mlw + ((II) + 1) * 32) = make_float2(mn_, ln_); } \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
         if ((__builtin_amdgcn_ballot_w64(scn_ != 1.f) & 0x0fff0fff0fff0fffull) != 0ull) {                                \
             accP[(II) + 1][0] *= scn_; accP[(II) + 1][1] *= scn_; accP[(II) + 1][2] *= scn_; accP[(II) + 1][3] *= scn_; } \
     }
-#define P2_POS_LAST(SLOT, II, CH)                                                                                        \
+#define P2H_POS_LAST(SLOT, II, CH)                                                                                        \
     {                                                                                                                    \
         const u32x4 bh_ = (u32x4){pkn_[0], pkn_[1], pkn_[0], pkn_[1]}; const u32x2 bl_ = (u32x2){pkn_[2], pkn_[3]};          \
         if ((II) + 3 == 8) P2_BOFF((CH) + 1)                                                                             \
@@ -1395,22 +1400,16 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
             P2_ISSUE_B(((II) + 3) & 3, ((II) + 3) & 7)                                                                   \
             P2_ISSUE_Z(((SLOT) + C32_RING - 1) % C32_RING, ((II) + C32_RING - 1) & 7)                                    \
         }                                                                                                                \
-        P2_MF(SLOT, II, 0) P2_MF(SLOT, II, 1) P2_MF(SLOT, II, 2) P2_MF(SLOT, II, 3) P2_MF(SLOT, II, 4) P2_MF(SLOT, II, 5) P2_MF(SLOT, II, 6) P2_MF(SLOT, II, 7) \
+        P2H_MF(SLOT, II, 0) P2H_MF(SLOT, II, 1) P2H_MF(SLOT, II, 2) P2H_MF(SLOT, II, 3) P2H_MF(SLOT, II, 4) P2H_MF(SLOT, II, 5) P2H_MF(SLOT, II, 6) P2H_MF(SLOT, II, 7) \
     }
-#endif
 #define P2_SLOT(K, II) ((8 * (K) + (II)) % C32_RING)
-#if C32_HX & 1
-#define C32_PCARRY u32x4 pkn_;
-#else
-#define C32_PCARRY f32x4 pvn_;
-#endif
 #define P2_CHUNK(K, CH)                                                                                                  \
     {                                                                                                                    \
         const uint32_t mk4_ = *reinterpret_cast<const uint32_t*>(&mk[(CH) * JC + kq * 4]);                               \
         float mterm_[4];                                                    /* x k + (0 | -1e5 log2 e) in one fma: the values of the 16-row kernels' (mask ? x k : x k - 1e5 log2 e), whose second form the compiler contracts to the same fma */ \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) mterm_[r_] = ((mk4_ >> (8 * r_)) & 0xffu) ? 0.f : -kMask2;      \
         const int CHPAR = (CH) & 1;                                                                                      \
-        C32_PCARRY float scn_;                                                                                           \
+        f32x4 pvn_; float scn_;                                                                                                  \
         P2_SM(0, K)                                                                                                      \
         if (!(C32_ABL & 1024) && !((C32_LAZY & 1) && (__builtin_amdgcn_ballot_w64(scn_ != 1.f) & 0x0fff0fff0fff0fffull) == 0ull)) { _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[0][mt_] *= scn_; } \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
@@ -1418,12 +1417,40 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         P2_POS(P2_SLOT(K, 4), 4, CH, K) P2_POS(P2_SLOT(K, 5), 5, CH, K) P2_POS(P2_SLOT(K, 6), 6, CH, K) P2_POS_LAST(P2_SLOT(K, 7), 7, CH) \
         C32_SYNC()                                                          /* barrier #(CH + 1) */                      \
     }
+#define P2H_CHUNK(K, CH)                                                                                                  \
+    {                                                                                                                    \
+        const uint32_t mk4_ = *reinterpret_cast<const uint32_t*>(&mk[(CH) * JC + kq * 4]);                               \
+        float mterm_[4];                                                    /* x k + (0 | -1e5 log2 e) in one fma: the values of the 16-row kernels' (mask ? x k : x k - 1e5 log2 e), whose second form the compiler contracts to the same fma */ \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) mterm_[r_] = ((mk4_ >> (8 * r_)) & 0xffu) ? 0.f : -kMask2;      \
+        const int CHPAR = (CH) & 1;                                                                                      \
+        u32x4 pkn_; float scn_;                                                                                                  \
+        P2H_SM(0, K)                                                                                                      \
+        if (!(C32_ABL & 1024) && !((C32_LAZY & 1) && (__builtin_amdgcn_ballot_w64(scn_ != 1.f) & 0x0fff0fff0fff0fffull) == 0ull)) { _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) accP[0][mt_] *= scn_; } \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        P2H_POS(P2_SLOT(K, 0), 0, CH, K) P2H_POS(P2_SLOT(K, 1), 1, CH, K) P2H_POS(P2_SLOT(K, 2), 2, CH, K) P2H_POS(P2_SLOT(K, 3), 3, CH, K) \
+        P2H_POS(P2_SLOT(K, 4), 4, CH, K) P2H_POS(P2_SLOT(K, 5), 5, CH, K) P2H_POS(P2_SLOT(K, 6), 6, CH, K) P2H_POS_LAST(P2_SLOT(K, 7), 7, CH) \
+        C32_SYNC()                                                          /* barrier #(CH + 1) */                      \
+    }
         int ch = 0;
+        if constexpr (ZT) {
+        for (; ch + 3 <= nchunk; ch += 3) { P2H_CHUNK(0, ch) P2H_CHUNK(1, ch + 1) P2H_CHUNK(2, ch + 2) }
+        if (ch < nchunk) {
+            P2H_CHUNK(0, ch)
+            if (ch + 1 < nchunk) P2H_CHUNK(1, ch + 1)
+        }
+        } else {
         for (; ch + 3 <= nchunk; ch += 3) { P2_CHUNK(0, ch) P2_CHUNK(1, ch + 1) P2_CHUNK(2, ch + 2) }
         if (ch < nchunk) {
             P2_CHUNK(0, ch)
             if (ch + 1 < nchunk) P2_CHUNK(1, ch + 1)
         }
+        }
+#undef P2H_CHUNK
+#undef P2H_POS
+#undef P2H_POS_LAST
+#undef P2H_MF
+#undef P2H_SM
+#undef P2H_SPLIT
 #undef P2_CHUNK
 #undef P2_SLOT
 #undef P2_POS
@@ -1446,8 +1473,13 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                 const float inv = mi ? 1.f / l_fin : 0.f;
                 float* fo = feat + (rowbase + i) * FEAT + fm * C + kq * 16;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (ZT) {                                     // 1 / S_ic of channels 16 kq + 4 r .. + 3 (powers of two: the products with inv are exact)
+                        const f32x4 zs = *reinterpret_cast<const f32x4*>(zsc + (zbase + i) * C + kq * 16 + r * 4);
+                        reinterpret_cast<f32x4*>(fo)[r] = (f32x4){mul_rn(accP[ii][0][r], inv * zs[0]), mul_rn(accP[ii][1][r], inv * zs[1]), mul_rn(accP[ii][2][r], inv * zs[2]), mul_rn(accP[ii][3][r], inv * zs[3])};
+                    } else
                     reinterpret_cast<f32x4*>(fo)[r] = (f32x4){accP[ii][0][r] * inv, accP[ii][1][r] * inv, accP[ii][2][r] * inv, accP[ii][3][r] * inv};
+                }
             }
         }
         C32_REPORT(0)
@@ -1514,9 +1546,15 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                 if (c < 4) {                                                // pair features, channels 16 kq + 4 c + 0..3 of every head (ot_feat_col)
                     if (fm < H) {
 #pragma unroll
-                        for (int ii = 0; ii < RPW2; ++ii)
+                        for (int ii = 0; ii < RPW2; ++ii) {
+                            if constexpr (ZT && !(ZT_DEV & 1)) {            // 1 / S_ic of channels 16 kq + 4 c .. + 3 of row ii (powers of two: the products with rinv are exact)
+                                const f32x4 zs = *reinterpret_cast<const f32x4*>(zsc + (zbase + min(i0 + il0 + ii, L - 1)) * C + kq * 16 + c * 4);
+                                stage_put4(buf, il0 + ii, fm * 16 + kq * 4, mul_rn(accP[ii][0][c], rinv[ii] * zs[0]), mul_rn(accP[ii][1][c], rinv[ii] * zs[1]),
+                                           mul_rn(accP[ii][2][c], rinv[ii] * zs[2]), mul_rn(accP[ii][3][c], rinv[ii] * zs[3]));
+                            } else
                             stage_put4(buf, il0 + ii, fm * 16 + kq * 4, mul_rn(accP[ii][0][c], rinv[ii]), mul_rn(accP[ii][1][c], rinv[ii]),
                                        mul_rn(accP[ii][2][c], rinv[ii]), mul_rn(accP[ii][3][c], rinv[ii]));
+                        }
                     }
                 } else if (c == 6) {                                        // columns 1152..1343: coordinates of points 0..63
                     put_points(buf, psub * 24, psub * 8, 8, false);
@@ -1565,16 +1603,6 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
                     if (C32_ABL & 8) { acc0 = kf[hh & 1][0] * q0 + kf[hh & 1][1] * q1; acc1 = kf[hh & 1][2] * q2 + kf[hh & 1][3] * q3; }
                     else if (C32_ABL & 256) { acc0 = kf[hh & 1][0]; acc1 = q0; }
-                    else if (C32_HX & 4) {
-                        // channel part on three fp16 products (slot 0 = high terms, slot 1 = low terms of the 32 channels), point part + norm step on the fp32 chain
-                        const u32x4 kh = __builtin_bit_cast(u32x4, kf[hh & 1][0]), kl = __builtin_bit_cast(u32x4, kf[hh & 1][1]);
-                        const u32x4 qh = __builtin_bit_cast(u32x4, q0), ql = __builtin_bit_cast(u32x4, q1);
-                        acc0 = mfma_h(kl, qh, acc0); acc0 = mfma_h(kh, ql, acc0);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) { acc1 = mfma4(kf[hh & 1][2][s], q2[s], acc1); if (s == 1) acc0 = mfma_h(kh, qh, acc0); }
-#pragma unroll
-                        for (int s = 0; s < 3; ++s) acc1 = mfma4(kf[hh & 1][3][s], q3[s], acc1);
-                    }
                     else {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) { acc0 = mfma4(kf[hh & 1][0][s], q0[s], acc0); acc1 = mfma4(kf[hh & 1][2][s], q2[s], acc1); }
@@ -1656,23 +1684,6 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                     anych_ |= __builtin_amdgcn_ballot_w64(sc != 1.f);
                     // (all 16 rows of the tile kept their running maximum of this head: factors exactly 1, nothing to rescale)
                     if (!(C32_ABL & 1024) && !((C32_LAZY & 2) && FUSE && __builtin_amdgcn_ballot_w64(sc != 1.f) == 0ull)) { accV[hh][rt][0] *= sc; accV[hh][rt][1] *= sc; accT[hh][rt][0] *= sc; accT[hh][rt][1] *= sc; }
-                    if (C32_HX & 2) {
-                        // K-packed fp16 form: pa = {P_h(keys 4 kq, + 1), P_h(+ 2, + 3), P_l(..), P_l(..)} of row fm; fragment slot t = {v_h(keys 4 kq .. + 3), v_l(same)} of channel / coordinate fm of tile t
-                        const u32x4 pu = __builtin_bit_cast(u32x4, pa);
-                        const u32x4 bh = (u32x4){pu[0], pu[1], pu[0], pu[1]};
-                        const u32x2 bl = (u32x2){pu[2], pu[3]};
-#pragma unroll
-                        for (int t_ = 0; t_ < 4; ++t_) {
-                            f32x4& a_ = t_ < 2 ? accV[hh][rt][t_] : accT[hh][rt][t_ - 2];
-                            a_ = mfma_h(__builtin_bit_cast(u32x4, vf[hh & 1][t_]), bh, a_);
-                        }
-#pragma unroll
-                        for (int t_ = 0; t_ < 4; ++t_) {
-                            f32x4& a_ = t_ < 2 ? accV[hh][rt][t_] : accT[hh][rt][t_ - 2];
-                            const u32x4 v_ = __builtin_bit_cast(u32x4, vf[hh & 1][t_]);
-                            a_ = mfma_h16((u32x2){v_[0], v_[1]}, bl, a_);
-                        }
-                    } else
                     if (C32_ABL & 512) { accV[hh][rt][0] += pa; }
                     else if (C32_ABL & 16) { accV[hh][rt][0] += vf[hh & 1][0] * pa; accV[hh][rt][1] += vf[hh & 1][1] * pa; accT[hh][rt][0] += vf[hh & 1][2] * pa; accT[hh][rt][1] += vf[hh & 1][3] * pa; }
                     else
@@ -1838,6 +1849,73 @@ int launch_pair_bias_cache(const float* z, const float* const* wb, int num_layer
     return ABOPT_OK;
 }
 
+// Pair terms (round 6): pair_feat as the K-packed two-term fp16 operands of ipa_core32_kernel<*, true> -- built once per sample() / optimize() call, like the
+// bias cache (z is constant over the steps, dpm_full.py:274-283).  One workgroup per query row (n, i): pass A folds max_j |z[n, i, j, c]| per CHANNEL (the
+// row's 64 KB come from HBM once; pass B re-reads them from L2), S_ic = 2^k with max |z| S_ic in [2^13, 2^14) -- every value within 2^-17 of the largest of
+// its (row, channel) column keeps a NORMAL low term, i.e. 22 significant bits, whatever the magnitudes of other channels or rows; pass B writes, per chunk of
+// 16 keys and channel tile mt, lane (fm, kq)'s 16 bytes
+//     {h(k0), h(k1) | h(k2), h(k3) | l(k0), l(k1) | l(k2), l(k3)},  k_e = key 16 ch + 4 kq + e, of channel c = 4 fm + mt;  h = fp16(S z), l = fp16(S z - h)
+// at float offset ((row nchunk + ch) 4 + mt) 256 + 4 lane (keys past L: zeros), and the 64 factors 2^-14 / S_ic of every row (the consumer multiplies its probabilities by 2^14) behind the terms.  Same bytes as z (+ 1.6 %).
+size_t pair_terms_floats(int Nz, int L) { return (size_t)Nz * L * ((L + JC - 1) / JC) * (JC * C); }
+size_t pair_terms_blob_floats(int Nz, int L) { return pair_terms_floats(Nz, L) + (size_t)Nz * L * C; }
+
+__global__ __launch_bounds__(256) void pair_terms_kernel(const float* __restrict__ z, float* __restrict__ terms, float* __restrict__ zsc, int L, int nchunk) {
+    __shared__ float wmax[4][C];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fm = lane & 15, kq = lane >> 4;
+    const int64_t row = blockIdx.x;
+    const float* zi = z + (row * (int64_t)L) * C;
+    auto load = [&](int ch, f32x4 (&zn)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = ch * JC + kq * 4 + r;
+            zn[r] = key < L ? *(reinterpret_cast<const f32x4*>(zi + (int64_t)key * C) + fm) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 am = (f32x4){0.f, 0.f, 0.f, 0.f};                                  // channels 4 fm .. 4 fm + 3
+    for (int ch = wave; ch < nchunk; ch += 4) {
+        f32x4 zn[4];
+        load(ch, zn);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) am[e] = fmaxf(am[e], fabsf(zn[r][e]));        // (a NaN is dropped here and travels through the split below)
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { am[e] = fmaxf(am[e], __shfl_xor(am[e], 16)); am[e] = fmaxf(am[e], __shfl_xor(am[e], 32)); }
+    if (kq == 0) *reinterpret_cast<f32x4*>(&wmax[wave][fm * 4]) = am;
+    __syncthreads();
+    f32x4 S;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float m = fmaxf(fmaxf(wmax[0][fm * 4 + e], wmax[1][fm * 4 + e]), fmaxf(wmax[2][fm * 4 + e], wmax[3][fm * 4 + e]));
+        // S = 2^(13 - floor(log2 m)); exponent field clamped so that S, 1 / S and the products with the softmax normalisation stay normal numbers whatever the column holds
+        const int ex = min(max((int)((__float_as_uint(m) >> 23) & 0xffu), 64), 190);
+        S[e] = __uint_as_float((unsigned)(267 - ex) << 23);
+        if (wave == 0 && kq == 0) zsc[row * C + fm * 4 + e] = __uint_as_float((unsigned)(ex - 27) << 23);     // 2^-14 / S: the consumer's probabilities carry 2^14
+    }
+    u32x4* out = reinterpret_cast<u32x4*>(terms) + row * (int64_t)nchunk * 256 + lane;
+    for (int ch = wave; ch < nchunk; ch += 4) {
+        f32x4 zn[4];
+        load(ch, zn);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            unsigned h01, l01, h23, l23;
+            split_pair2(zn[0][mt] * S[mt], zn[1][mt] * S[mt], h01, l01);
+            split_pair2(zn[2][mt] * S[mt], zn[3][mt] * S[mt], h23, l23);
+            if (ZT_LAYOUT) out[ch * 256 + kq * 64 + mt * 16 + fm - lane] = (u32x4){h01, h23, l01, l23}; else
+            out[(ch * 4 + mt) * 64] = (u32x4){h01, h23, l01, l23};
+        }
+    }
+}
+
+int launch_pair_terms(const float* z, float* blob, int Nz, int L, hipStream_t st) {
+    if ((int64_t)Nz * L == 0) return ABOPT_OK;
+    const int nchunk = (L + JC - 1) / JC;
+    hipLaunchKernelGGL(pair_terms_kernel, dim3((unsigned)((int64_t)Nz * L)), dim3(256), 0, st, z, blob, blob + pair_terms_floats(Nz, L), L, nchunk);
+    ABOPT_LAUNCH_CHECK();
+    return ABOPT_OK;
+}
+
 // Softmax merge of the key slices of a SPLIT launch + the point epilogue (ga.py:133-139): one workgroup per query row.
 //   w_s[h] = 2^(m_s - M) / sum_s' l_s' 2^(m_s' - M),  M = max_s m_s   (0 for a masked query row, ga.py:24-25)
 __global__ __launch_bounds__(256) void ipa_split_merge_kernel(const float* __restrict__ part, const float* __restrict__ pstats, const uint8_t* __restrict__ mask,
@@ -1943,13 +2021,19 @@ static bool use_core32(int N, int L, int cus) {
     return total * 100 >= rounds * cus * 95;
 }
 
-// The whole block behind the projections in ONE launch (ipa_core32_kernel<true>: core + tail) where the 32-row kernel is the core of
+bool ipa_core32_applies(int N, int L) {
+    int cus = 0;
+    if (device_cu_count(&cus)) return false;
+    return !CORE_ABL && use_core32(N, L, cus);
+}
+
+// The whole block behind the projections in ONE launch (ipa_core32_kernel<true, ZT>: core + tail) where the 32-row kernel is the core of
 // choice; *fused = 0 and nothing launched otherwise (the caller then runs core and tail separately -- same results bit for bit).
 // ABOPT_FUSE_TAIL=0 keeps the two-launch form (A/B, tests).
 int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                            const float* pair_bias_cache, int N, int L, hipStream_t st, int z_shared, const float* wot, const float* wmf, const float* x,
                            const float* ubias, const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2,
-                           const float* be2, float* out, int* fused) {
+                           const float* be2, float* out, int* fused, const float* pair_terms) {
     *fused = 0;
     const char* e = getenv("ABOPT_FUSE_TAIL");
     if (!pair_bias_cache || !wot || !wmf || (e && e[0] == '0') || CORE_ABL || C32_ABL) return ABOPT_OK;
@@ -1957,12 +2041,20 @@ int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float*
     if (int rc = device_cu_count(&cus)) return rc;
     if (!use_core32(N, L, cus)) return ABOPT_OK;
     const int nib2 = (L + BI2 - 1) / BI2;
-    static LdsConfig lds_cfg;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel<true>), C32F_LDS_BYTES, lds_cfg)) return rc;
+    static LdsConfig lds_cfg, lds_cfg_t;
     TailArgs ta{wot, wmf, x, ubias, g1, be1, b0, b1, b2, g2, be2, out};
-    prof::begin(st);
-    hipLaunchKernelGGL(ipa_core32_kernel<true>, dim3((unsigned)(N * nib2)), dim3(NTH2), C32F_LDS_BYTES, st, qfrag, kvfrag, z, mask, R, t, (float*)nullptr,
-                       pair_bias_cache, L, nib2, core32_remap(N, z_shared), z_shared, ta, prof::next_span_slot());
+    const float* zsc = pair_terms ? pair_terms + pair_terms_floats(z_shared ? N / z_shared : N, L) : nullptr;
+    if (pair_terms) {
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel<true, true>), C32F_LDS_BYTES, lds_cfg_t)) return rc;
+        prof::begin(st);
+        hipLaunchKernelGGL((ipa_core32_kernel<true, true>), dim3((unsigned)(N * nib2)), dim3(NTH2), C32F_LDS_BYTES, st, qfrag, kvfrag, z, mask, R, t, (float*)nullptr,
+                           pair_bias_cache, L, nib2, core32_remap(N, z_shared), z_shared, ta, prof::next_span_slot(), pair_terms, zsc);
+    } else {
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel<true, false>), C32F_LDS_BYTES, lds_cfg)) return rc;
+        prof::begin(st);
+        hipLaunchKernelGGL((ipa_core32_kernel<true, false>), dim3((unsigned)(N * nib2)), dim3(NTH2), C32F_LDS_BYTES, st, qfrag, kvfrag, z, mask, R, t, (float*)nullptr,
+                           pair_bias_cache, L, nib2, core32_remap(N, z_shared), z_shared, ta, prof::next_span_slot(), (const float*)nullptr, (const float*)nullptr);
+    }
     prof::end(st);
     ABOPT_LAUNCH_CHECK();
 #ifdef C32F_TIMING
@@ -2008,7 +2100,7 @@ int read_clock_probe(long long* cycles, long long* wall_ticks) {
 
 int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                            const float* w_pair_bias, float* feat, float* dump, float* dump_stats, const float* pair_bias_cache, int N, int L, hipStream_t st,
-                           int z_shared, float* split_ws, size_t split_ws_floats) {
+                           int z_shared, float* split_ws, size_t split_ws_floats, const float* pair_terms) {
     ABOPT_CHECK_ARG(!dump == !dump_stats, "ipa_core: the logits dump and its row statistics come together");
     ABOPT_CHECK_ARG(!dump || (int64_t)H * L * L * 4 < (1ll << 31), "ipa_core: L=%d too long for the logits dump", L);
     int cus32 = 0;
@@ -2017,11 +2109,18 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
         const int nib2 = (L + BI2 - 1) / BI2, nchunk = (L + JC - 1) / JC;
         const size_t lds = sizeof(float) * (3 * BI2 * SROW + 2 * BI2 * SCLD + BI2 * SCLD + BI2 * 32) + (size_t)nchunk * JC;
         ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core: L=%d needs %zu bytes of LDS for the key mask (max 163840)", L, lds);
-        static LdsConfig lds_cfg;
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel<false>), lds, lds_cfg)) return rc;
-        prof::begin(st);
-        hipLaunchKernelGGL(ipa_core32_kernel<false>, dim3((unsigned)(N * nib2)), dim3(NTH2), lds, st, qfrag, kvfrag, z, mask, R, t, feat, pair_bias_cache, L, nib2,
-                           core32_remap(N, z_shared), z_shared, TailArgs{}, prof::next_span_slot());
+        static LdsConfig lds_cfg, lds_cfg_t;
+        if (pair_terms) {
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel<false, true>), lds, lds_cfg_t)) return rc;
+            prof::begin(st);
+            hipLaunchKernelGGL((ipa_core32_kernel<false, true>), dim3((unsigned)(N * nib2)), dim3(NTH2), lds, st, qfrag, kvfrag, z, mask, R, t, feat, pair_bias_cache, L, nib2,
+                               core32_remap(N, z_shared), z_shared, TailArgs{}, prof::next_span_slot(), pair_terms, pair_terms + pair_terms_floats(z_shared ? N / z_shared : N, L));
+        } else {
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel<false, false>), lds, lds_cfg)) return rc;
+            prof::begin(st);
+            hipLaunchKernelGGL((ipa_core32_kernel<false, false>), dim3((unsigned)(N * nib2)), dim3(NTH2), lds, st, qfrag, kvfrag, z, mask, R, t, feat, pair_bias_cache, L, nib2,
+                               core32_remap(N, z_shared), z_shared, TailArgs{}, prof::next_span_slot(), (const float*)nullptr, (const float*)nullptr);
+        }
         prof::end(st);
         ABOPT_LAUNCH_CHECK();
 #ifdef C32_COUNT

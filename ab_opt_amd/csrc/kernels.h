@@ -29,13 +29,14 @@ int launch_ipa_frags(const float* proj, const float* R, const float* t, const fl
 int launch_ipa_core(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                     const float* w_pair_bias, float* feat, float* dbg_logits, float* dbg_alpha, const float* pair_bias_cache,
                     int N, int L, hipStream_t st, int z_shared = 0 /* 1: z and the pair-bias cache hold ONE sample that every batch entry shares */,
-                    float* split_ws = nullptr, size_t split_ws_floats = 0 /* scratch of the key-split form (small batches), ipa_split_ws_floats(N, L) */);
+                    float* split_ws = nullptr, size_t split_ws_floats = 0 /* scratch of the key-split form (small batches), ipa_split_ws_floats(N, L) */,
+                    const float* pair_terms = nullptr /* abopt_pair_terms blob of the same pair_feat: the 32-row kernels then aggregate on the fp16 matrix instructions */);
 
 // ipa_core.hip: core + tail of a block in one launch where the 32-row core applies (sets *fused; otherwise launches nothing)
 int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                            const float* pair_bias_cache, int N, int L, hipStream_t st, int z_shared, const float* wot /* W_out as bf16 terms */, const float* wmf, const float* x,
                            const float* ubias, const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2,
-                           const float* be2, float* out, int* fused);
+                           const float* be2, float* out, int* fused, const float* pair_terms = nullptr);
 
 // node_frags.hip: x [N*L,128] -> qfrag / kvfrag directly (projection GEMM + frame transform + fragment layout in one kernel)
 size_t node_wfrag_floats();

@@ -162,13 +162,8 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
         if (HALF == 0) {
             // ---- q, k: accumulator row 4 kq + r = channel, column fm = residue
             const float s = 0.17677669529663687f;                                // 1 / sqrt(D), ga.py:84
-#if defined(C32_HX) && (C32_HX & 4)      // timing-only experiment (ipa_core.hip): the channel slots are read as packed fp16 there -- keep every half finite
-            { auto fin = [](f32x4 v) { u32x4 u = __builtin_bit_cast(u32x4, v); u &= 0x3fff3fffu; return __builtin_bit_cast(f32x4, u); };
-              outq[0] = fin(acc[rt][0] * s); outq[64] = fin(acc[rt][1] * s); outk[0] = fin(acc[rt][2]); outk[64] = fin(acc[rt][3]); }
-#else
             outq[0] = acc[rt][0] * s; outq[64] = acc[rt][1] * s;
             outk[0] = acc[rt][2]; outk[64] = acc[rt][3];
-#endif
             // ---- q_pts: point kq (tile A) and 4 + kq (tile B) of residue fm
             f32x4 ga = to_global(acc[rt][4]), gb = to_global(acc[rt][5]);
             const float nq = rows_sum(sq(ga) + sq(gb));                          // |q_pts|^2 over the head's 8 points
@@ -193,11 +188,7 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
                 float g0 = r0 * xa_ + r1 * ya + r2 * za + r3;
                 float g1 = r0 * xb + r1 * yb + r2 * zb + r3;
                 if (c == 3) { g0 = 0.f; g1 = 0.f; }
-#if defined(C32_HX) && (C32_HX & 2)
-                { u32x4 u = __builtin_bit_cast(u32x4, (f32x4){acc[rt][2][r], acc[rt][3][r], g0, g1}); u &= 0x3fff3fffu; outk[(4 + r) * 64] = __builtin_bit_cast(f32x4, u); }
-#else
                 outk[(4 + r) * 64] = (f32x4){acc[rt][2][r], acc[rt][3][r], g0, g1};
-#endif
             }
         }
     }

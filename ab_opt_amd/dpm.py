@@ -149,11 +149,25 @@ class FullDPM(nn.Module):
         holds but is not using, so the choice does not depend on what ran before in this process."""
         if dev.type != 'cuda':
             return False
-        need = hip.pair_bias_cache_bytes(n_pair, L, len(self.eps_net.encoder.blocks))
+        need = hip.pair_bias_cache_bytes(n_pair, L, len(self.eps_net.encoder.blocks)) + (hip.pair_terms_bytes(n_pair, L) if L <= 2048 else 0)
         if graph:
             need += n_pair * L * L * 64 * 4
         free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
         return need <= free // 2
+
+    def _pair_terms_wanted(self, N, L, n_pair, dev):
+        """The fp16 pair terms pay where the library's launch geometry takes the 32-row block kernels (abopt_pair_terms_used) and their
+        n_pair * L^2 * 256 B fit next to everything else; ABOPT_PAIR_TERMS=0 / 1 overrides (0: the fp32 stream everywhere)."""
+        e = os.environ.get('ABOPT_PAIR_TERMS')
+        if e == '0' or dev.type != 'cuda' or L > 2048:
+            return False
+        # Measured (profiles/r06_b_pair_terms_ab.txt): with DISTINCT pair features per sample the block kernel is bound by its 742 MB of streams and the
+        # cheaper aggregation buys nothing (0 +- 1 % on two boxes, and the terms cost 0.25 ms per call to build); with pair features SHARED by the samples of
+        # a complex (the reference's own batches: one crop replicated N times) z comes from the caches and the term path is 2-4 % faster -> default there only
+        if e != '1' and (n_pair == N or not hip.pair_terms_used(N, L, N // n_pair)):
+            return False
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        return hip.pair_terms_bytes(n_pair, L) <= free // 2
 
     def _run_eager(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
                    ppl_masked, noise, seed, rng_offset, pbar, stop_after=None, optimize_mode=False, use_bias_cache=None, seed_dev=None):
@@ -193,18 +207,8 @@ class FullDPM(nn.Module):
         # pair_feat and the weights are constant over the loop: project the pair bias of all blocks once (dpm_full.py:274-283 feeds
         # the same pair_feat to every step); ~0.4 ms at N=32, L=256, outside nothing -- it is part of this call
         pbc = hip.pair_bias_cache(self.eps_net.encoder.packed_array(), len(self.eps_net.encoder.blocks), pair_feat) if use_bias_cache else None
-        if os.environ.get('ABOPT_DEV_ZTERMS') == '1' and use_bias_cache:
-            # developer hook of the round-6 timing experiment (csrc/ipa_core.hip, -DC32_HX): the core reads z as K-packed fp16 terms
-            # [row][chunk][key group kq][channel tile mt][channel 4 fm + mt][{h(keys 4 kq .. + 3), l(same)}] -- laid out here with torch
-            key_ = (pair_feat.data_ptr(), tuple(pair_feat.shape))
-            if getattr(self, '_dev_zt', (None, None))[0] != key_:         # (cached: a graph capture must not record these passes)
-                Nz, nch = pair_feat.shape[0], L // 16
-                zz = pair_feat.view(Nz, L, nch, 4, 4, 16, 4)                # n, i, ch, kq, e, fm, mt
-                zh = zz.half()
-                zl = (zz - zh.float()).half()
-                self._dev_zt = (key_, torch.stack([zh, zl], dim=-1).permute(0, 1, 2, 3, 6, 5, 7, 4).contiguous().view(torch.float32).view(Nz, L, L, 64))
-                del zz, zh, zl
-            pair_feat = self._dev_zt[1]
+        # ... and, where the 32-row block kernels will run, re-lay pair_feat once as the fp16 operands of their pair aggregation (hip.pair_terms; ~0.25 ms)
+        pterms = hip.pair_terms(pair_feat) if (use_bias_cache and self._pair_terms_wanted(N, L, Nc, dev)) else None
         h = self._sched_host()
         inv = self.trans_rot.angular_distrib_inv
         X, cdf = inv.X, (inv.cdf() if noise is None else None)
@@ -224,7 +228,7 @@ class FullDPM(nn.Module):
                 break
             beta = beta_rows[t]
             hip.eps_net_forward(ew, tv[t], p_norm, ts[t], res_feat, pair_feat, beta, mask_generate, mask_res,
-                                self.abdock, self.num_bins, False, out=net, pair_bias_cache=pbc, pair_feat_shared=(group if shared else 0))
+                                self.abdock, self.num_bins, False, out=net, pair_bias_cache=pbc, pair_feat_shared=(group if shared else 0), pair_terms=pterms)
             sp = self._step_params(t, sample_structure, sample_sequence, ppl_masked, optimize_mode)
             out = dict(v=tv[t - 1], p=tp[t - 1], s=ts[t - 1], p_norm=p_norm)
             if self.abdock:
@@ -232,7 +236,7 @@ class FullDPM(nn.Module):
             hip.denoise_step(sp, noise[t] if noise is not None else None, seed, rng_offset,
                              tv[t], tp[t], ts[t], net['v_next'], net['eps_pos'], net['c'], net['prmsd_logits'], mask_generate,
                              X[t], cdf[t] if cdf is not None else None, self.num_bins, out, seed_dev=seed_dev)
-        self.last_run_info = dict(bias_cache=bool(use_bias_cache), shared_context=bool(shared), graph=seed_dev is not None)
+        self.last_run_info = dict(bias_cache=bool(use_bias_cache), pair_terms=pterms is not None, shared_context=bool(shared), graph=seed_dev is not None)
         return tv, tp, ts, tpr, tpp
 
     def _to_traj(self, T0, tv, tp, ts, tpr, tpp, first_extra):

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABOPT_LIB_PATH: developer override to load a variant build of the same ABI (csrc/Makefile VARIANT=...: timing / ablation / A-B builds)
 LIB_PATH = os.environ.get('ABOPT_LIB_PATH') or os.path.join(_HERE, 'libabopt_hip.so')
-ABI_VERSION = 40
+ABI_VERSION = 41
 
 c_f = C.c_void_p        # device float*
 c_i64 = C.c_void_p      # device int64*
@@ -76,8 +76,8 @@ class StepNoise(C.Structure):
 
 
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
-           'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_encoder_forward',
-           'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_denoise_step', 'abopt_sample_init',
+           'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_block_forward_cached', 'abopt_ga_encoder_forward',
+           'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_pair_terms_bytes', 'abopt_pair_terms', 'abopt_pair_terms_used', 'abopt_denoise_step', 'abopt_sample_init',
            'abopt_add_noise', 'abopt_gemm', 'abopt_gemm_tn_grouped', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_segment_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_dpm_losses', 'abopt_abdock_losses', 'abopt_layer_norm_forward', 'abopt_layer_norm_backward', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek', 'abopt_prof_clock', 'abopt_prof_spans_reset', 'abopt_prof_spans',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward', 'abopt_ipa_dz_assemble',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
@@ -114,8 +114,14 @@ def lib():
         L.abopt_ga_encoder_forward.argtypes = [C.POINTER(GaWeights), C.c_int, c_f, c_f, c_f, c_f, c_u8, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_void_p, C.c_size_t, C.c_void_p]
         L.abopt_eps_net_forward.argtypes = [C.POINTER(EpsWeights), c_f, c_f, c_i64, c_f, c_f, c_f, c_u8, c_u8,
-                                            c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f, C.c_int,
+                                            c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f, C.c_int, c_f,
                                             C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_ga_block_forward_cached.argtypes = [C.POINTER(GaWeights), c_f, c_f, c_f, c_f, c_u8, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_int, c_f,
+                                                    C.c_void_p, C.c_size_t, C.c_void_p]
+        L.abopt_pair_terms_bytes.restype = C.c_size_t
+        L.abopt_pair_terms_bytes.argtypes = [C.c_int] * 2
+        L.abopt_pair_terms.argtypes = [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.abopt_pair_terms_used.argtypes = [C.c_int] * 3
         L.abopt_pair_bias_cache_bytes.restype = C.c_size_t
         L.abopt_pair_bias_cache_bytes.argtypes = [C.c_int] * 3
         L.abopt_pair_bias_cache.argtypes = [C.POINTER(GaWeights), C.c_int, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -401,6 +407,22 @@ def ga_block_forward(ws, R, t, x, z, mask, debug=False):
     return (out, extras) if debug else out
 
 
+def ga_block_forward_cached(ws, R, t, x, z, mask, pair_bias_cache, pair_terms=None, pair_feat_shared=0, want_feat=False):
+    """One block with this block's slice of the bias cache and (optionally) the pair terms (include/abopt.h: abopt_ga_block_forward_cached)."""
+    N, L, F = x.shape
+    Cd = z.shape[-1]
+    out = torch.empty_like(x)
+    feat = torch.empty(N, L, 1824, device=x.device) if want_feat else None
+    nb = lib().abopt_ga_workspace_bytes(N, L, F, Cd)
+    buf = Workspace.get(nb, x.device)
+    R, t, x, z, mask = _contig(R, t, x, z, mask)
+    _check(lib().abopt_ga_block_forward_cached(C.byref(ws), ptr(R, torch.float32), ptr(t, torch.float32), ptr(x, torch.float32), ptr(z, torch.float32),
+                                               ptr(mask, torch.bool), ptr(out), N, L, F, Cd, ptr(pair_bias_cache, torch.float32),
+                                               ptr(pair_terms, torch.float32, optional=True), int(pair_feat_shared), ptr(feat, optional=True),
+                                               ptr(buf), buf.numel(), stream()))
+    return (out, feat) if want_feat else out
+
+
 def ga_encoder_forward(ws_array, num_layers, R, t, x, z, mask):
     N, L, F = x.shape
     Cd = z.shape[-1]
@@ -414,7 +436,7 @@ def ga_encoder_forward(ws_array, num_layers, R, t, x, z, mask):
 
 
 def eps_net_forward(ew, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res, has_prmsd, num_bins, grad_mode=False, out=None,
-                    pair_bias_cache=None, pair_feat_shared=False):
+                    pair_bias_cache=None, pair_feat_shared=False, pair_terms=None):
     N, L = mask_res.shape
     F, Cd = res_feat.shape[-1], pair_feat.shape[-1]
     dev = res_feat.device
@@ -429,12 +451,32 @@ def eps_net_forward(ew, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate,
                                        ptr(pair_feat, torch.float32), ptr(beta, torch.float32), ptr(mask_generate, torch.bool), ptr(mask_res, torch.bool),
                                        ptr(out['v_next']), ptr(out['R_next']), ptr(out['eps_pos']), ptr(out['c']),
                                        ptr(out['prmsd_logits'], optional=True), N, L, F, Cd, int(grad_mode),
-                                       ptr(pair_bias_cache, torch.float32, optional=True), int(pair_feat_shared), ptr(buf), buf.numel(), stream()))
+                                       ptr(pair_bias_cache, torch.float32, optional=True), int(pair_feat_shared),
+                                       ptr(pair_terms, torch.float32, optional=True), ptr(buf), buf.numel(), stream()))
     return out
 
 
 def pair_bias_cache_bytes(N, L, num_layers):
     return lib().abopt_pair_bias_cache_bytes(N, L, num_layers)
+
+
+def pair_terms_bytes(N, L):
+    return lib().abopt_pair_terms_bytes(N, L)
+
+
+def pair_terms_used(N, L, pair_feat_shared=0):
+    """Whether eps_net_forward(N, L) with a bias cache takes the kernels that read pair terms on this device (include/abopt.h: abopt_pair_terms_used)."""
+    return bool(lib().abopt_pair_terms_used(N, L, int(pair_feat_shared)))
+
+
+def pair_terms(pair_feat):
+    """pair_feat as K-packed two-term fp16 operands of the pair aggregation + one power-of-two scale per query row, once per sampling call
+    (include/abopt.h: abopt_pair_terms).  Returns the blob eps_net_forward(pair_terms=...) takes."""
+    N, L = pair_feat.shape[:2]
+    blob = torch.empty(lib().abopt_pair_terms_bytes(N, L) // 4, dtype=torch.float32, device=pair_feat.device)
+    pair_feat, = _contig(pair_feat)
+    _check(lib().abopt_pair_terms(ptr(pair_feat, torch.float32), ptr(blob), N, L, pair_feat.shape[-1], stream()))
+    return blob
 
 
 def pair_bias_cache(blocks_array, num_layers, pair_feat):

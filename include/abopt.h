@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ABOPT_ABI_VERSION 40
+#define ABOPT_ABI_VERSION 41
 
 enum { ABOPT_OK = 0, ABOPT_EINVAL = 1, ABOPT_EHIP = 2, ABOPT_EUNSUPPORTED = 3, ABOPT_EWORKSPACE = 4 };
 
@@ -126,6 +126,14 @@ int abopt_ga_block_forward(const abopt_ga_weights* w, const float* R, const floa
                            const float* z, const uint8_t* mask, float* x_out, int N, int L, int F, int C,
                            const abopt_ga_debug* dbg, void* ws, size_t ws_bytes, abopt_stream stream);
 
+/* The same block with what a sampling loop carries from call to call (ABI 41): this block's slice of abopt_pair_bias_cache and, optionally, the
+ * abopt_pair_terms of the same z (pair_feat_shared as in abopt_eps_net_forward).  feat_out (optional, [N,L,1824]): the IPA features feeding
+ * out_transform (ga.py:141-145) -- asking for them keeps the core and the tail as two launches (same results bit for bit). */
+int abopt_ga_block_forward_cached(const abopt_ga_weights* w, const float* R, const float* t, const float* x,
+                                  const float* z, const uint8_t* mask, float* x_out, int N, int L, int F, int C,
+                                  const float* pair_bias_cache, const float* pair_terms, int pair_feat_shared, float* feat_out,
+                                  void* ws, size_t ws_bytes, abopt_stream stream);
+
 /* GAEncoder.forward (ga.py:181-193): num_layers blocks over the same R, t, z. */
 int abopt_ga_encoder_forward(const abopt_ga_weights* blocks, int num_layers, const float* R, const float* t,
                              const float* x, const float* z, const uint8_t* mask, float* x_out,
@@ -168,6 +176,20 @@ size_t abopt_pair_bias_cache_bytes(int N, int L, int num_layers);
 int abopt_pair_bias_cache(const abopt_ga_weights* blocks, int num_layers, const float* pair_feat, float* cache,
                           int N, int L, int C, abopt_stream stream);
 
+/* Per-call pair terms (ABI 41): pair_feat re-laid as the fp16 operands of the pair aggregation sum_j alpha[i,j,h] z[i,j,:] (ga.py:114-118), built once per
+ * FullDPM.sample / optimize call next to the bias cache (same constancy argument).  Every value becomes two fp16 terms h = fp16(S_i z), l = fp16(S_i z - h)
+ * with one power of two S_ic per (query row, channel) (max_j |z[n,i,j,c]| S_ic in [2^13, 2^14)): 22 significant bits for every value within 2^-17 of the
+ * largest of its (row, channel) column over the keys, the same 4 bytes per value; terms are packed along the contraction (key) index in the operand order of
+ * v_mfma_f32_16x16x32_f16, the factors 2^-14 / S_ic follow them (the consuming kernel multiplies its probabilities by 2^14 before their split).
+ * With the terms the 32-row block kernels run that aggregation on the fp16 matrix instructions (products exact, fp32 accumulation; error against the fp32
+ * statement: that of fp32 accumulation itself, tests/test_hip_parity.py::test_pair_aggregation_on_fp16_terms_vs_fp64); without them (NULL) on the fp32 ones.
+ * terms: abopt_pair_terms_bytes(N, L) bytes, caller-owned; N = number of DISTINCT pair_feat entries (as for the bias cache); L <= 2048. */
+size_t abopt_pair_terms_bytes(int N, int L);
+int abopt_pair_terms(const float* pair_feat, float* terms, int N, int L, int C, abopt_stream stream);
+/* 1 if abopt_eps_net_forward(N samples, L residues, a bias cache, pair_feat_shared) would launch the kernels that read the terms on the current device
+ * (the 32-row block kernels: shapes that fill the chip in whole rounds), 0 otherwise -- a caller need not build terms nobody reads. */
+int abopt_pair_terms_used(int N, int L, int pair_feat_shared);
+
 /* EpsilonNet.forward (dpm_full.py:70-112).  beta [N].  Outputs: v_next [N,L,3], R_next [N,L,3,3],
  * eps_pos [N,L,3], c_denoised [N,L,20], prmsd_logits [N,num_bins] (NULL when the head is absent). */
 int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_t, const float* p_t, const int64_t* s_t,
@@ -181,6 +203,7 @@ int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_t, const fl
                                                   D/tools/runner/design_for_pdb.py:141-147.  g > 1 (g divides N): pair_feat is [N/g,L,L,C] and
                                                   samples g c .. g c + g - 1 share entry c -- a test set of complexes x g samples in ONE launch
                                                   (D/tools/runner/design_for_testset.py:556-589; BASELINE config 4) */,
+                          const float* pair_terms /* optional (needs pair_bias_cache): abopt_pair_terms of the same pair_feat */,
                           void* ws, size_t ws_bytes, abopt_stream stream);
 
 /* ---- Per-step transitions: D/modules/diffusion/transition.py:42-50,80-101 (position), :146-160

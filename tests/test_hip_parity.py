@@ -1005,7 +1005,9 @@ def test_eps_net_bench_geometry_vs_oracle(flavour, N):
     v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lengths, 2000 + N, [(25, 33), (51, 57), (94, 106), (133, 144), (159, 166), (198, 207)])
     beta = d.trans_pos.var_sched.betas[t].expand([N]).contiguous()
     pbc = hip.pair_bias_cache(d.eps_net.encoder.packed_array(), 6, pf)
-    net = hip.eps_net_forward(d.eps_net.packed(), v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc)
+    # ... and with the fp16 pair terms the sampler builds next to it at these shapes (round 6: the pair aggregation on the fp16 matrix instructions)
+    assert hip.pair_terms_used(N, L)
+    net = hip.eps_net_forward(d.eps_net.packed(), v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc, pair_terms=hip.pair_terms(pf))
     ids = [0, 5, N // 2 + 1, N - 1]
     ix = torch.tensor(ids, device=DEV)
     c = lambda a: a[ix].cpu()
@@ -1162,6 +1164,11 @@ def test_config4_rank_leg_grouped_launch(monkeypatch):
     grouped = hip.eps_net_forward(ew, v, p, s, rf.repeat_interleave(S, 0), pf, beta, gen, mres, d.abdock, d.num_bins, False,
                                   pair_bias_cache=hip.pair_bias_cache(arr, 6, pf), pair_feat_shared=S)
     grouped = {k: (a.clone() if a is not None else None) for k, a in grouped.items()}
+    # the same launch with the fp16 pair terms the sampler builds at this shape (one set of terms per complex, shared like the bias cache)
+    assert hip.pair_terms_used(N, L, S)
+    grouped_t = hip.eps_net_forward(ew, v, p, s, rf.repeat_interleave(S, 0), pf, beta, gen, mres, d.abdock, d.num_bins, False,
+                                    pair_bias_cache=hip.pair_bias_cache(arr, 6, pf), pair_feat_shared=S, pair_terms=hip.pair_terms(pf))
+    grouped_t = {k: (a.clone() if a is not None else None) for k, a in grouped_t.items()}
     # (i) oracle on a subset
     sd = {k: a.detach().cpu() for k, a in m.state_dict().items()}
     for n in (0, S - 1, 5 * S + 3, N - 1):
@@ -1171,6 +1178,7 @@ def test_config4_rank_leg_grouped_launch(monkeypatch):
                            mres[sl].cpu(), num_layers=6, prmsd_head=True, mode='mm')
         for name, kk in (('R_next', 1), ('eps_pos', 2), ('c', 3)):
             assert (grouped[name][sl].cpu() - ref[kk]).abs().max().item() < 5e-5, (n, name)
+            assert (grouped_t[name][sl].cpu() - ref[kk]).abs().max().item() < 5e-5, (n, name)
     # (ii) replicated pair features, and per-complex launches
     rep = hip.eps_net_forward(ew, v[:4 * S], p[:4 * S], s[:4 * S], rf[:4].repeat_interleave(S, 0), pf[:4].repeat_interleave(S, 0).contiguous(), beta[:4 * S],
                               gen[:4 * S], mres[:4 * S], d.abdock, d.num_bins, False, pair_bias_cache=hip.pair_bias_cache(arr, 6, pf[:4].repeat_interleave(S, 0).contiguous()))
@@ -1182,7 +1190,10 @@ def test_config4_rank_leg_grouped_launch(monkeypatch):
                                   pair_bias_cache=hip.pair_bias_cache(arr, 6, pf[c:c + 1]), pair_feat_shared=True)
         for k in ('R_next', 'eps_pos', 'c', 'prmsd_logits'):
             assert torch.equal(one[k], grouped[k][sl]), (c, k)
-    # (iii) the driver: eight different complexes, 16 samples each
+    # (iii) the driver: eight different complexes, 16 samples each.  Bit-identity between launch geometries is a statement about ONE arithmetic form: the
+    # grouped launch of 128 samples takes the 32-row kernels (pair aggregation on fp16 terms since round 6), a launch of 16 samples the 16-row kernels
+    # (fp32 products) -- equal within fp32 noise per step, not bit for bit; with ABOPT_PAIR_TERMS=0 both aggregate in fp32 and the bits agree
+    monkeypatch.setenv('ABOPT_PAIR_TERMS', '0')
     cx = [{k: dev(a) for k, a in synth.make_batch(1, synth.LAYOUT_256, seed=300 + c).items()} for c in range(G)]
     a = sampler.design_testset_sharded(m, cx, S, k=3, seed=11, native=True)
     b = sampler.design_testset_sharded(m, cx, S, k=3, seed=11, native=True, complexes_per_launch=1)
@@ -1202,6 +1213,10 @@ def test_config4_rank_leg_grouped_launch(monkeypatch):
     for ra, rb in zip(r3, r1):
         assert torch.equal(ra['ca'], rb['ca']) and torch.equal(ra['top'], rb['top'])
     assert not torch.equal(r3[0]['ca'][0], r3[1]['ca'][0]) and not torch.equal(r3[1]['ca'][0], r3[2]['ca'][0])
+    # the driver's default at this size (pair terms on): finite, ranked, and the terms were in fact used
+    monkeypatch.delenv('ABOPT_PAIR_TERMS')
+    at = sampler.design_testset_sharded(m, cx, S, k=3, seed=11, native=True)
+    assert m.diffusion.last_run_info['pair_terms'] and all(torch.isfinite(r['ca']).all() and r['top'].numel() == 3 for r in at)
 
 
 def test_two_rank_ddp_gradients_equal_the_mean(tmp_path):
@@ -1349,6 +1364,90 @@ def test_two_term_fp16_products_are_fp32_accurate(wscale, fscale):
     e_hip, e_f32 = max_abs(out, ref64), max_abs(ref32, ref64)
     assert torch.isfinite(out).all()
     assert e_hip <= 3.0 * e_f32 + 2e-7 * ref64.abs().max().item(), (wscale, fscale, e_hip, e_f32)
+
+
+def _pair_terms_statement(z, L):
+    """torch statement of abopt_pair_terms (include/abopt.h): per (row, channel) power-of-two scale, two fp16 terms, K-packed layout."""
+    N = z.shape[0]
+    nch = (L + 15) // 16
+    zp = torch.zeros(N, L, nch * 16, 64, device=z.device)
+    zp[:, :, :L] = z
+    am = zp.abs().amax(dim=2)                                             # [N, L, 64]
+    ex = ((am.view(torch.int32) >> 23) & 0xff).clamp(64, 190)
+    S = ((267 - ex) << 23).view(torch.float32)
+    invS = ((ex - 27) << 23).view(torch.float32)                          # 2^-14 / S: the consumer's probabilities carry 2^14
+    zs = zp * S[:, :, None, :]
+    h = zs.half()
+    l = (zs - h.float()).half()
+    # [n, i, ch, kq, e, fm, mt] -> [n, i, ch, mt, kq, fm, term, e]
+    t = torch.stack([h.view(N, L, nch, 4, 4, 16, 4), l.view(N, L, nch, 4, 4, 16, 4)], dim=-1).permute(0, 1, 2, 6, 3, 5, 7, 4).contiguous()
+    return t, invS, S
+
+
+def test_pair_terms_layout_and_scales():
+    """abopt_pair_terms against its torch statement, bit for bit: scales (powers of two, max |z| S in [2^13, 2^14) per (row, channel)), the two fp16 terms,
+    the K-packed operand order, zeros for keys past L, columns of zeros, magnitudes from 1e-6 to 1e4 across channels and rows."""
+    from ab_opt_amd import hip
+    for N, L in ((2, 50), (1, 16), (3, 129)):
+        z = dev(synth.hash_tensor((N, L, L, 64), 9000 + L, scale=2.0))
+        z = z * (10.0 ** torch.linspace(-6, 4, 64, device=DEV)) * (10.0 ** torch.linspace(-2, 2, L, device=DEV))[None, :, None, None]
+        z[0, 3, :, 5] = 0.0
+        z[0, 4] = 0.0
+        blob = hip.pair_terms(z)
+        nch = (L + 15) // 16
+        nt = N * L * nch * 1024
+        assert blob.numel() == nt + N * L * 64 == hip.pair_terms_bytes(N, L) // 4
+        t, invS, S = _pair_terms_statement(z, L)
+        assert torch.equal(blob[nt:].view(N, L, 64), invS)
+        assert torch.equal(blob[:nt].view(torch.float16).view(N, L, nch, 4, 4, 16, 2, 4), t)
+        am = z.abs().amax(dim=2)
+        nz = am > 0
+        assert ((am * S)[nz] >= 2.0 ** 13).all() and ((am * S)[nz] < 2.0 ** 14).all() and torch.equal((S * invS), torch.full_like(S, 2.0 ** -14))
+        # the terms carry 22 bits of every value within 2^-17 of its column's largest
+        rec = (t[..., 0, :].float() + t[..., 1, :].float())                # [n, i, ch, mt, kq, fm, e]
+        zr = rec.permute(0, 1, 2, 4, 6, 5, 3).reshape(N, L, nch * 16, 64)[:, :, :L] * (invS * 2.0 ** 14)[:, :, None, :]
+        big = z.abs() >= am[:, :, None, :] * 2.0 ** -17
+        assert ((zr - z).abs()[big] <= z.abs()[big] * 2.0 ** -21).all()
+        assert ((zr - z).abs() <= am[:, :, None, :] * 2.0 ** -37).logical_or(big).all()
+
+
+@pytest.mark.parametrize('N,L,lengths', [(3, 100, [100, 77, 1]), (9, 130, None), (32, 256, None)])
+def test_pair_aggregation_on_fp16_terms_vs_fp64(N, L, lengths, monkeypatch):
+    """Round 6: the 32-row block kernels aggregate sum_j alpha[i,j,h] z[i,j,c] (ga.py:114-118) on the fp16 matrix instructions when handed abopt_pair_terms
+    (z and the probabilities as two fp16 terms each, packed along the key index; per-(row, channel) power-of-two scales).  Stated accuracy: that of the fp32
+    statement.  Checked on the pair features of a block (feat[:, :, :768]) against an fp64 contraction of the kernel's own alpha with z, with z scaled over
+    SIX orders of magnitude across channels and over four across query rows: per channel, the error of the term path is at most 3x the error of the fp32
+    path (+ 2e-7 of the channel's range); everything else the block computes (node / point features, block output) does not change by a bit or stays at
+    fp32 summation noise."""
+    from ab_opt_amd import hip
+    monkeypatch.setenv('ABOPT_CORE32', '1')
+    monkeypatch.setenv('ABOPT_CORE_NO_SPLIT', '1')
+    blk = _block_on_device(seed=23)
+    lens = [L] * N if lengths is None else lengths
+    R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(N, L, lens, salt=8100 + N)]
+    cs = 10.0 ** torch.linspace(-3, 3, 64, device=DEV)[torch.randperm(64, generator=torch.Generator().manual_seed(5)).to(DEV)]
+    z = z * cs * (10.0 ** torch.linspace(-2, 2, L, device=DEV))[None, :, None, None]
+    with torch.no_grad():
+        blk.proj_pair_bias.weight.div_(cs * 30.0)                             # keep the pair logits O(1): the softmax must not collapse onto one key
+    tns, st = blk.packed()
+    arr = (hip.GaWeights * 1)(st)
+    pbc = hip.pair_bias_cache(arr, 1, z)
+    terms = hip.pair_terms(z)
+    out32, feat32 = hip.ga_block_forward_cached(st, R, t, x, z, mask, pbc, None, want_feat=True)
+    out16, feat16 = hip.ga_block_forward_cached(st, R, t, x, z, mask, pbc, terms, want_feat=True)
+    fused = hip.ga_block_forward_cached(st, R, t, x, z, mask, pbc, terms)                     # core + tail in one launch: the same bits
+    assert torch.isfinite(out16).all() and torch.equal(fused, out16)
+    assert torch.equal(feat16[..., 768:], feat32[..., 768:])                               # node features, points, distances, directions: untouched
+    _, parts = hip.ga_block_forward(st, R, t, x, z, mask, debug=True)
+    ref64 = torch.einsum('nijh,nijc->nihc', parts['alpha'].double(), z.double()).reshape(N, L, 768)
+    e16 = (feat16[..., :768].double() - ref64).abs().reshape(-1, 12, 64).amax(dim=(0, 1))
+    e32 = (feat32[..., :768].double() - ref64).abs().reshape(-1, 12, 64).amax(dim=(0, 1))
+    rng = ref64.abs().reshape(-1, 12, 64).amax(dim=(0, 1))
+    assert (e16 <= 3.0 * e32 + 2e-7 * rng).all(), (e16 / (e32 + 1e-30)).max().item()
+    # per element, relative to what the row's column of z can produce at all
+    zmax = z.abs().amax(dim=2)[:, :, None, :].expand(N, L, 12, 64).reshape(N, L, 768).double()
+    assert ((feat16[..., :768].double() - ref64).abs() <= 2e-6 * zmax + 1e-30).all()
+    assert max_abs(out16, out32) < 2e-5 * max(1.0, out32.abs().max().item())
 
 
 @pytest.mark.parametrize('flavour', ['abdesign', 'abdock'])
