@@ -110,8 +110,13 @@ __device__ __forceinline__ Mat3 quat1ijk_to_rot(float qb, float qc, float qd) {
 // (global memory: heads_epilogue_kernel; LDS: the tail of heads_mlp_kernel).  seq == nullptr: training path, the softmax stays in autograd.
 __device__ __forceinline__ void heads_epilogue_row(int64_t i, const float* __restrict__ R, const float* __restrict__ v_t, const float* crd, const float* rot,
                                                    const float* seq, const uint8_t* __restrict__ mask_generate, float* __restrict__ v_next,
-                                                   float* __restrict__ R_next, float* __restrict__ eps_pos, float* __restrict__ c_den, int grad_mode) {
+                                                   float* __restrict__ R_next, float* __restrict__ eps_pos, float* __restrict__ c_den, int grad_mode,
+                                                   unsigned* __restrict__ nonfinite = nullptr) {
     const bool gen = mask_generate[i] != 0;
+    // Range guard (round 6): the dense layers multiply on two fp16 terms per operand, so an activation beyond 65504 becomes inf and reaches the heads'
+    // outputs as inf / NaN through every path (LayerNorm, attention); a non-finite head output of ANY row raises the flag the host reads once per call
+    // (abopt_nonfinite_flag) and answers with the fp32-range GEMM path.  One compare per row; the racing stores all write 1.
+    if (nonfinite && !(fabsf(crd[0] + crd[1] + crd[2] + rot[0] + rot[1] + rot[2]) < INFINITY)) *nonfinite = 1u;
     Mat3 Rm;
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rm.m[k] = R[i * 9 + k];
@@ -134,6 +139,7 @@ __device__ __forceinline__ void heads_epilogue_row(int64_t i, const float* __res
     float lgt[ABOPT_AA], mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < ABOPT_AA; ++k) { lgt[k] = seq[k]; mx = fmaxf(mx, lgt[k]); }
+    if (nonfinite && !(fabsf(mx) < INFINITY)) *nonfinite = 1u;
     float sm = 0.f;
 #pragma unroll
     for (int k = 0; k < ABOPT_AA; ++k) { lgt[k] = expf(lgt[k] - mx); sm += lgt[k]; }

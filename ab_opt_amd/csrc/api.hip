@@ -434,6 +434,12 @@ extern "C" size_t abopt_pair_bias_cache_bytes(int N, int L, int num_layers) {
     return (size_t)num_layers * pair_bias_layer_floats(N, L) * sizeof(float);
 }
 
+extern "C" int abopt_nonfinite_flag(int reset, abopt_stream stream) {
+    int flag = 0;
+    const int rc = nonfinite_flag_read(reset, (hipStream_t)stream, &flag);
+    return rc ? -1 : flag;
+}
+
 extern "C" size_t abopt_pair_terms_bytes(int N, int L) { return pair_terms_blob_floats(N, L) * sizeof(float); }
 
 extern "C" int abopt_pair_terms_used(int N, int L, int pair_feat_shared) {
@@ -538,7 +544,7 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
         // ... and, unless ABOPT_FUSE_HEADS=0 (A/B, tests), their geometric epilogue as the tail of the same kernel
         const char* fh = getenv("ABOPT_FUSE_HEADS");
         heads_fused = !(fh && fh[0] == '0');
-        const HeadsEpilogue hep{e.R, v_t, mask_generate, v_next, R_next, eps_pos, c_denoised, grad_mode};
+        const HeadsEpilogue hep{e.R, v_t, mask_generate, v_next, R_next, eps_pos, c_denoised, grad_mode, nonfinite_flag_ptr()};
         if ((rc = launch_heads_mlp(e.xe, beta, w->w_heads_frag, w->w_head1, FI, w->b_head1, w->b_crd2, w->b_rot2, w->b_seq2, w->b_crd3, w->b_rot3,
                                    w->b_seq3, e.out3, M, L, st, heads_fused ? &hep : nullptr))) return rc;
     } else {

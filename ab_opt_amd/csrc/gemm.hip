@@ -401,11 +401,16 @@ int launch_bucket_colsum(const float* x, int ld, int64_t rows, int cols, const i
 
 int launch_segment_bucket_colsum(const float* x, int ld, int segments, int rows_per_segment, int cols, const int* idx, int idx_div, int nb, float* out, hipStream_t st) {
     if (cols <= 0 || nb <= 0 || segments <= 0 || rows_per_segment <= 0) return ABOPT_OK;
-    ABOPT_CHECK_ARG(ld >= cols && nb <= BKT_MAX && idx_div >= 1 && segments <= 65535, "segment_bucket_colsum: segments=%d (max 65535) rows_per_segment=%d cols=%d ld=%d buckets=%d (max %d) idx_div=%d",
+    ABOPT_CHECK_ARG(ld >= cols && nb <= BKT_MAX && idx_div >= 1 && idx_div <= 65535, "segment_bucket_colsum: segments=%d rows_per_segment=%d cols=%d ld=%d buckets=%d (max %d) idx_div=%d (1..65535)",
                     segments, rows_per_segment, cols, ld, nb, BKT_MAX, idx_div);
-    hipLaunchKernelGGL(bucket_colsum_kernel, dim3((cols + 63) / 64, segments), dim3(128), (size_t)2 * nb * 64 * sizeof(float), st, x, ld, (int64_t)segments * rows_per_segment, cols, idx, nb,
-                       (int64_t)rows_per_segment, out, idx_div);
-    ABOPT_LAUNCH_CHECK();
+    // a segment is a grid row (grid.y <= 65535): more segments go in several launches, cut at multiples of idx_div so that every launch starts on an index row
+    const int chunk = (65535 / idx_div) * idx_div;
+    for (int s0 = 0; s0 < segments; s0 += chunk) {
+        const int ns = min(chunk, segments - s0);
+        hipLaunchKernelGGL(bucket_colsum_kernel, dim3((cols + 63) / 64, ns), dim3(128), (size_t)2 * nb * 64 * sizeof(float), st, x + (int64_t)s0 * rows_per_segment * ld, ld,
+                           (int64_t)ns * rows_per_segment, cols, idx + (int64_t)(s0 / idx_div) * rows_per_segment, nb, (int64_t)rows_per_segment, out + (int64_t)s0 * nb * cols, idx_div);
+        ABOPT_LAUNCH_CHECK();
+    }
     return ABOPT_OK;
 }
 

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
     __syncthreads();
     if (wave == 3 && lane < HR && row0 + lane < rows) {
         const float* os = reinterpret_cast<const float*>(sm.xp) + lane * 32;
-        heads_epilogue_row(row0 + lane, ep.R, ep.v_t, os, os + 4, os + 8, ep.mask_generate, ep.v_next, ep.R_next, ep.eps_pos, ep.c_den, ep.grad_mode);
+        heads_epilogue_row(row0 + lane, ep.R, ep.v_t, os, os + 4, os + 8, ep.mask_generate, ep.v_next, ep.R_next, ep.eps_pos, ep.c_den, ep.grad_mode, ep.nonfinite);
     }
 }
 

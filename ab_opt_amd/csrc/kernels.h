@@ -61,7 +61,10 @@ size_t mixer_wfrag_floats();
 int launch_mixer(const float* res_feat, const int64_t* s_t, const float* wfrag, const float* table, const float* b1, float* x_out, int64_t rows,
                  hipStream_t st, const float* v_t = nullptr, float* R_out = nullptr /* optional: R = exp(v_t) of the same rows, fused */);
 // arguments of the heads' geometric epilogue (launch_heads_epilogue) when it runs as the tail of launch_heads_mlp
-struct HeadsEpilogue { const float *R = nullptr, *v_t = nullptr; const uint8_t* mask_generate = nullptr; float *v_next = nullptr, *R_next = nullptr, *eps_pos = nullptr, *c_den = nullptr; int grad_mode = 0; };
+struct HeadsEpilogue { const float *R = nullptr, *v_t = nullptr; const uint8_t* mask_generate = nullptr; float *v_next = nullptr, *R_next = nullptr, *eps_pos = nullptr, *c_den = nullptr; int grad_mode = 0; unsigned* nonfinite = nullptr; };
+// rows.hip: the device word the heads' epilogue raises on a non-finite output (abopt_nonfinite_flag)
+unsigned* nonfinite_flag_ptr();
+int nonfinite_flag_read(int reset, hipStream_t st, int* flag);
 int launch_heads_mlp(const float* xe, const float* beta, const float* wfrag, const float* w1, int ld1, const float* b1, const float* b2c,
                      const float* b2r, const float* b2s, const float* b3c, const float* b3r, const float* b3s, float* out3, int64_t rows, int L,
                      hipStream_t st,

@@ -112,11 +112,28 @@ __global__ __launch_bounds__(256) void heads_epilogue_kernel(const float* __rest
                                                              const float* __restrict__ seq_logits, int ld3, int ldseq,
                                                              const uint8_t* __restrict__ mask_generate, float* __restrict__ v_next,
                                                              float* __restrict__ R_next, float* __restrict__ eps_pos,
-                                                             float* __restrict__ c_den, int64_t rows, int grad_mode) {
+                                                             float* __restrict__ c_den, int64_t rows, int grad_mode, unsigned* __restrict__ nonfinite) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     heads_epilogue_row(i, R, v_t, eps_crd + i * ld3, eps_rot + i * ld3, seq_logits ? seq_logits + i * ldseq : nullptr, mask_generate, v_next, R_next, eps_pos, c_den,
-                       grad_mode);
+                       grad_mode, nonfinite);
+}
+
+__device__ unsigned g_nonfinite_flag;
+unsigned* nonfinite_flag_ptr() {
+    static unsigned* p = nullptr;
+    if (!p && hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_nonfinite_flag)) != hipSuccess) p = nullptr;
+    return p;
+}
+int nonfinite_flag_read(int reset, hipStream_t st, int* flag) {
+    unsigned* p = nonfinite_flag_ptr();
+    ABOPT_CHECK_ARG(p != nullptr, "nonfinite_flag: no device symbol");
+    unsigned h = 0;
+    ABOPT_HIP(hipMemcpyAsync(&h, p, sizeof(h), hipMemcpyDeviceToHost, st));
+    ABOPT_HIP(hipStreamSynchronize(st));
+    if (reset && h) ABOPT_HIP(hipMemsetAsync(p, 0, sizeof(h), st));
+    *flag = h ? 1 : 0;
+    return ABOPT_OK;
 }
 
 int launch_heads_epilogue(const float* R, const float* v_t, const float* eps_crd, const float* eps_rot, const float* seq_logits,
@@ -124,7 +141,7 @@ int launch_heads_epilogue(const float* R, const float* v_t, const float* eps_crd
                           int64_t rows, int grad_mode, hipStream_t st) {
     if (rows == 0) return ABOPT_OK;
     hipLaunchKernelGGL(heads_epilogue_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, R, v_t, eps_crd, eps_rot, seq_logits,
-                       ld3, ldseq, mask_generate, v_next, R_next, eps_pos, c_den, rows, grad_mode);
+                       ld3, ldseq, mask_generate, v_next, R_next, eps_pos, c_den, rows, grad_mode, seq_logits ? nonfinite_flag_ptr() : nullptr);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

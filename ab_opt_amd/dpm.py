@@ -170,8 +170,9 @@ class FullDPM(nn.Module):
         return hip.pair_terms_bytes(n_pair, L) <= free // 2
 
     def _run_eager(self, state, t_start, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence,
-                   ppl_masked, noise, seed, rng_offset, pbar, stop_after=None, optimize_mode=False, use_bias_cache=None, seed_dev=None):
-        """The loop itself, one C call per network evaluation and one per transition.  seed_dev: device {seed, offset} (graph capture)."""
+                   ppl_masked, noise, seed, rng_offset, pbar, stop_after=None, optimize_mode=False, use_bias_cache=None, seed_dev=None, range_safe=False):
+        """The loop itself, one C call per network evaluation and one per transition.  seed_dev: device {seed, offset} (graph capture).
+        range_safe: the dense layers as fp32 GEMMs (the answer to a raised range guard, _guarded)."""
         dev = res_feat.device
         N, L = mask_res.shape
         T0 = t_start
@@ -203,7 +204,7 @@ class FullDPM(nn.Module):
             res_feat = res_feat.repeat_interleave(group, dim=0)
         res_feat, pair_feat = res_feat.contiguous().float(), pair_feat.contiguous().float()
         mask_generate, mask_res = mask_generate.contiguous(), mask_res.contiguous()
-        ew = self.eps_net.packed()
+        ew = self.eps_net.packed_fp32() if range_safe else self.eps_net.packed()
         # pair_feat and the weights are constant over the loop: project the pair bias of all blocks once (dpm_full.py:274-283 feeds
         # the same pair_feat to every step); ~0.4 ms at N=32, L=256, outside nothing -- it is part of this call
         pbc = hip.pair_bias_cache(self.eps_net.encoder.packed_array(), len(self.eps_net.encoder.blocks), pair_feat) if use_bias_cache else None
@@ -239,6 +240,20 @@ class FullDPM(nn.Module):
         self.last_run_info = dict(bias_cache=bool(use_bias_cache), pair_terms=pterms is not None, shared_context=bool(shared), graph=seed_dev is not None)
         return tv, tp, ts, tpr, tpp
 
+    def _guarded(self, run, rerun):
+        """Range guard of the two-term fp16 layers (include/abopt.h: abopt_nonfinite_flag): the reference's fp32 layers take activations beyond 65504, the
+        fp16 terms do not (inf -> NaN in the heads' outputs, which raises a device flag).  One flag read per call; if it is up, the whole loop is repeated
+        with the dense layers as fp32 GEMMs -- the caller gets what the reference's arithmetic gives (NaN only where fp32 itself overflows)."""
+        hip.nonfinite_flag(reset=True)
+        out = run()
+        if hip.nonfinite_flag(reset=True):
+            import warnings
+            warnings.warn('ab_opt_amd: a denoiser activation left the fp16 range (|x| >= 65504) or an input was not finite; this call is repeated with '
+                          'the dense layers as fp32 GEMMs (slower, fp32 range)', RuntimeWarning, stacklevel=3)
+            out = rerun()
+            hip.nonfinite_flag(reset=True)
+        return out
+
     def _to_traj(self, T0, tv, tp, ts, tpr, tpp, first_extra):
         """Reference layout: dict t -> [v, p, s(, prmsd, ppl)], t>0 on the host, t=0 on the device."""
         hv, hp, hs = tv[1:].cpu(), tp[1:].cpu(), ts[1:].cpu()       # one bulk D2H each
@@ -267,8 +282,10 @@ class FullDPM(nn.Module):
         state = hip.sample_init(v.float(), p.float(), s, mask_generate, noise['init'] if noise is not None else None, seed, rng_offset,
                                 h['scale'], h['mean'], sample_structure, sample_sequence)
         T = self.num_steps
-        out = self._run(state, T, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, True,
-                        noise, seed, rng_offset, pbar, use_bias_cache=use_bias_cache, graph=graph)
+        out = self._guarded(lambda: self._run(state, T, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, True,
+                                              noise, seed, rng_offset, pbar, use_bias_cache=use_bias_cache, graph=graph),
+                            lambda: self._run_eager(state, T, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, True,
+                                                    noise, seed, rng_offset, pbar, use_bias_cache=use_bias_cache, range_safe=True))
         # dpm_full.py:269: the first entry carries zeros_like(s) / ones_like(s) in the two extra slots
         return self._to_traj(T, *out, first_extra=lambda s_: (torch.zeros_like(s_), torch.ones_like(s_)))
 
@@ -289,8 +306,10 @@ class FullDPM(nn.Module):
         state = (state[0], state[1], torch.where(mask_generate, state[2], s))       # dpm_full.py:335
         # dpm_full.py:351-358: the loop feeds the net's third output to the position update as noise whatever `obj` is,
         # and averages the perplexity over all residues (calc_perplexity(logits) without a mask)
-        out = self._run(state, opt_step, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, False,
-                        noise, seed, rng_offset, pbar, optimize_mode=True, use_bias_cache=use_bias_cache, graph=graph)     # same counters as add_noise, other sub-sequence tags (csrc/denoise.hip): a sample's stream position does not depend on the batch it sits in
+        out = self._guarded(lambda: self._run(state, opt_step, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, False,
+                                              noise, seed, rng_offset, pbar, optimize_mode=True, use_bias_cache=use_bias_cache, graph=graph),
+                            lambda: self._run_eager(state, opt_step, res_feat, pair_feat, mask_generate, mask_res, sample_structure, sample_sequence, False,
+                                                    noise, seed, rng_offset, pbar, optimize_mode=True, use_bias_cache=use_bias_cache, range_safe=True))     # same counters as add_noise, other sub-sequence tags (csrc/denoise.hip): a sample's stream position does not depend on the batch it sits in
         traj = self._to_traj(opt_step, *out, first_extra=lambda s_: (torch.zeros_like(s_), torch.ones_like(s_)))
         return {k: tuple(e) for k, e in traj.items()}
 

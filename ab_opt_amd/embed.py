@@ -121,7 +121,8 @@ class _PairEmbedFn(torch.autograd.Function):
         # sum over (n, i, j) by the pair of residue types (a of i, b of j): per (n, i) the key rows j summed by type(j) -- read in place, do0 is a
         # column slice of dys --, then the (n, i) rows by type(i).  (Round 4 ran this as two one-hot batched products per operand through
         # hipBLASLt plus a 268 MB contiguous copy of do0 and two permuted copies: 0.45 ms per config-5 step.)
-        aa32 = aa.clamp(0, nt - 1).to(torch.int32).contiguous()
+        torch._assert_async(((aa >= 0) & (aa < nt)).all())      # (F.one_hot, which this replaced, raises on a residue type outside the table; the kernels would skip the row)
+        aa32 = aa.to(torch.int32).contiguous()
         pair_sum = lambda x2: hip.bucket_colsum(hip.segment_bucket_colsum(x2, N * L, aa32, L, nt).view(N * L, -1), aa32.view(-1), nt).view(nt * nt, -1)
         s_aap = pair_sum(do0)
         rel = torch.clamp(res_nb[:, :, None] - res_nb[:, None, :], min=-ctx.max_relpos, max=ctx.max_relpos) + ctx.max_relpos

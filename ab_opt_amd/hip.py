@@ -77,7 +77,7 @@ class StepNoise(C.Structure):
 
 EXPORTS = ['abopt_abi_version', 'abopt_last_error', 'abopt_device_info', 'abopt_so3_exp', 'abopt_so3_log',
            'abopt_ga_workspace_bytes', 'abopt_ga_block_forward', 'abopt_ga_block_forward_cached', 'abopt_ga_encoder_forward',
-           'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_pair_terms_bytes', 'abopt_pair_terms', 'abopt_pair_terms_used', 'abopt_denoise_step', 'abopt_sample_init',
+           'abopt_eps_workspace_bytes', 'abopt_eps_net_forward', 'abopt_pair_bias_cache_bytes', 'abopt_pair_bias_cache', 'abopt_pair_terms_bytes', 'abopt_pair_terms', 'abopt_pair_terms_used', 'abopt_nonfinite_flag', 'abopt_denoise_step', 'abopt_sample_init',
            'abopt_add_noise', 'abopt_gemm', 'abopt_gemm_tn_grouped', 'abopt_colsum', 'abopt_adam_step', 'abopt_adam_ws_floats', 'abopt_bucket_colsum', 'abopt_segment_bucket_colsum', 'abopt_heads_epilogue_forward', 'abopt_heads_epilogue_backward', 'abopt_dpm_losses', 'abopt_abdock_losses', 'abopt_layer_norm_forward', 'abopt_layer_norm_backward', 'abopt_residue_features', 'abopt_residue_features_workspace_bytes', 'abopt_commonness_score', 'abopt_prof_enable', 'abopt_prof_collect', 'abopt_prof_peek', 'abopt_prof_clock', 'abopt_prof_spans_reset', 'abopt_prof_spans',
            'abopt_reconstruct_backbone_partially', 'abopt_ipa_train_workspace_bytes', 'abopt_ipa_core_train_forward', 'abopt_ipa_points_backward', 'abopt_ipa_backward_operands', 'abopt_ipa_backward_assemble', 'abopt_ipa_pair_backward', 'abopt_ipa_dz_assemble',
            'abopt_residue_embed_workspace_bytes', 'abopt_residue_embed_forward', 'abopt_pair_embed_workspace_bytes', 'abopt_pair_embed_forward',
@@ -122,6 +122,7 @@ def lib():
         L.abopt_pair_terms_bytes.argtypes = [C.c_int] * 2
         L.abopt_pair_terms.argtypes = [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.abopt_pair_terms_used.argtypes = [C.c_int] * 3
+        L.abopt_nonfinite_flag.argtypes = [C.c_int, C.c_void_p]
         L.abopt_pair_bias_cache_bytes.restype = C.c_size_t
         L.abopt_pair_bias_cache_bytes.argtypes = [C.c_int] * 3
         L.abopt_pair_bias_cache.argtypes = [C.POINTER(GaWeights), C.c_int, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -458,6 +459,15 @@ def eps_net_forward(ew, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate,
 
 def pair_bias_cache_bytes(N, L, num_layers):
     return lib().abopt_pair_bias_cache_bytes(N, L, num_layers)
+
+
+def nonfinite_flag(reset=True):
+    """Synchronises the current stream and returns whether any eps_net_forward since the last reset produced a non-finite head output
+    (include/abopt.h: abopt_nonfinite_flag -- the range guard of the two-term fp16 layers)."""
+    r = lib().abopt_nonfinite_flag(int(reset), stream())
+    if r < 0:
+        raise RuntimeError('abopt_nonfinite_flag: ' + last_error())
+    return bool(r)
 
 
 def pair_terms_bytes(N, L):

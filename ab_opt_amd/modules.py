@@ -264,10 +264,38 @@ class EpsilonNet(nn.Module):
         return ew
 
     @torch.no_grad()
+    def packed_fp32(self):
+        """The same weights WITHOUT the packed two-term fp16 operands: every dense layer then runs as an fp32 GEMM (fp32's range; the fallback of the
+        range guard, include/abopt.h: abopt_nonfinite_flag).  Cached next to packed()."""
+        ew = self.packed()
+        if getattr(self, '_pack32', None) is not None and self._pack32[0] is ew:
+            return self._pack32[2]
+        n = len(self.encoder.blocks)
+        arr = (hip.GaWeights * max(n, 1))()
+        for i, b in enumerate(self.encoder.blocks):
+            src = b.packed()[1]
+            for name, _ in hip.GaWeights._fields_:
+                setattr(arr[i], name, None if name in ('w_node_frag', 'w_out_frag', 'w_out_terms', 'w_mlp_frag') else getattr(src, name))
+        plain = hip.EpsWeights()
+        for name, _ in hip.EpsWeights._fields_:
+            setattr(plain, name, None if name in ('w_heads_frag', 'w_mix_frag', 'mix_table') else getattr(ew, name))
+        plain.blocks = C.cast(arr, C.POINTER(hip.GaWeights))
+        self._pack32 = (ew, arr, plain)
+        return plain
+
+    @torch.no_grad()
     def forward(self, v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res, grad_mode=False):
         """dpm_full.py:70-112 -> (v_next, R_next, eps_pos, c_denoised[, prmsd_logits])."""
+        hip.nonfinite_flag(reset=True)
         o = hip.eps_net_forward(self.packed(), v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res,
                                 self.no_bins is not None, self.no_bins or 0, grad_mode)
+        if hip.nonfinite_flag(reset=True):          # range guard of the two-term fp16 layers (include/abopt.h: abopt_nonfinite_flag): repeat on fp32 GEMMs
+            import warnings
+            warnings.warn('ab_opt_amd: a denoiser activation left the fp16 range (|x| >= 65504) or an input was not finite; EpsilonNet.forward is repeated '
+                          'with the dense layers as fp32 GEMMs', RuntimeWarning, stacklevel=2)
+            o = hip.eps_net_forward(self.packed_fp32(), v_t, p_t, s_t, res_feat, pair_feat, beta, mask_generate, mask_res,
+                                    self.no_bins is not None, self.no_bins or 0, grad_mode)
+            hip.nonfinite_flag(reset=True)
         if self.no_bins is not None:
             return o['v_next'], o['R_next'], o['eps_pos'], o['c'], o['prmsd_logits']
         return o['v_next'], o['R_next'], o['eps_pos'], o['c']

@@ -60,11 +60,19 @@ class WgradGroup:
 
     A product runs at once instead (hip.gemm) when its result is not a leaf's gradient (it feeds further autograd nodes), when the
     leaf already holds a gradient or has one queued in this pass (AccumulateGrad would ADD, reading the unfinished tensor), and in a process
-    group of more than one rank (DistributedDataParallel's bucket hooks read gradients during backward).  Hooks a caller registers on
-    parameters see a queued gradient before it is computed: switch the queue off (ABOPT_WGRAD_GROUP=0 / WgradGroup.enabled = False) for those."""
+    group of more than one rank (DistributedDataParallel's bucket hooks read gradients during backward), when the parameter is not contiguous
+    (AccumulateGrad would clone the unfinished tensor), carries tensor / post-accumulate hooks (they would see it before it is computed), or under
+    create_graph (grad mode on inside backward).
+
+    LIMITATION: a queued parameter must receive its gradient of this pass from the queued product ALONE.  A parameter that ALSO enters the
+    loss through an operation outside this module's functions (weight tying, a regulariser written with plain torch operations) gets a second
+    gradient that the autograd engine adds to the queued tensor before it has been computed; the queue cannot see that use.  The models of this
+    package use every parameter once per pass; for anything else set ABOPT_WGRAD_GROUP=0 (WgradGroup.enabled = False).  ABOPT_WGRAD_CHECK=1 verifies
+    the assumption after every pass: each queued leaf's .grad must be the very tensor the group computed, else a RuntimeError names the parameter."""
     enabled = _os.environ.get('ABOPT_WGRAD_GROUP', '1') != '0'
     flush_tiles = int(_os.environ.get('ABOPT_WGRAD_FLUSH_TILES', '128'))      # (developer knob)
-    _ones = {}
+    check = _os.environ.get('ABOPT_WGRAD_CHECK', '0') == '1'
+    _ones = {}             # (K, 1) ones per (device, K): a few KB each, NEVER evicted -- a captured training step bakes their addresses into its graph
     colsum_max_cols = int(_os.environ.get('ABOPT_WGRAD_COLSUM_COLS', '100000'))       # (developer knob: wider column sums keep their own kernels)
     _state = None          # the running backward pass: stream, queued (a, b, out), their tile count, ids of parameters with a queued gradient
 
@@ -87,8 +95,19 @@ class WgradGroup:
             items, st['items'], st['tiles'] = st['items'], [], 0
             with torch.cuda.stream(st['stream']):
                 hip.gemm_tn_grouped([(a, b) for a, b, _ in items], outs=[c for _, _, c in items])
+            # the engine has already ordered the caller's stream behind the backward nodes when its final callback runs: order it behind THIS launch too
+            # when backward() was called under another stream than the one the nodes ran on
+            cur = torch.cuda.current_stream()
+            if cur != st['stream']:
+                cur.wait_stream(st['stream'])
         if close:
+            if cls.check:
+                for p_, out_ in st['checked']:
+                    if p_.grad is None or p_.grad.data_ptr() != out_.data_ptr():
+                        raise RuntimeError('WgradGroup: a queued weight gradient was cloned or accumulated before it had been computed (parameter of shape '
+                                           f'{tuple(p_.shape)}): this parameter enters the loss more than once per pass -- set ABOPT_WGRAD_GROUP=0')
             st['pending'].clear()
+            st['checked'].clear()
 
     @classmethod
     def sync(cls):
@@ -108,8 +127,6 @@ class WgradGroup:
         if ones is None:
             ones = torch.ones(a.shape[0], 1, dtype=torch.float32, device=a.device)
             if not torch.cuda.is_current_stream_capturing():        # (a tensor filled inside a capture holds nothing until the first replay: not cached)
-                if len(cls._ones) > 16:
-                    cls._ones.clear()
                 cls._ones[key] = ones
         return cls.product(a, ones, params).view(-1)
 
@@ -132,8 +149,10 @@ class WgradGroup:
             return now()
         if any(p.grad is not None for p in params):
             return now()                   # accumulation over micro-batches: the same add, onto a gradient of an earlier (closed) pass
+        if torch.is_grad_enabled() or any((not p.is_contiguous()) or p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None) for p in params):
+            return now()                   # create_graph / a layout AccumulateGrad would clone / hooks that would read the unfinished tensor
         if st is None:
-            st = cls._state = dict(stream=main, items=[], tiles=0, pending=set())
+            st = cls._state = dict(stream=main, items=[], tiles=0, pending=set(), checked=[])
             torch.autograd.Variable._execution_engine.queue_callback(cls.sync)
         out = torch.empty(a.shape[1], b.shape[1], dtype=torch.float32, device=a.device)
         # the queue keeps an ALIAS of the storage, not the tensor handed to autograd: AccumulateGrad adopts a gradient only if nobody else
@@ -141,6 +160,8 @@ class WgradGroup:
         st['items'].append((a, b, out.detach()))
         st['tiles'] += ((a.shape[1] + 63) // 64) * ((b.shape[1] + 63) // 64)
         st['pending'].update(id(p) for p in params)
+        if cls.check and len(params) == 1 and tuple(params[0].shape) == tuple(out.shape):
+            st['checked'].append((params[0], out.detach()))
         if st['tiles'] >= cls.flush_tiles:
             cls.flush()
         return out

@@ -176,6 +176,14 @@ size_t abopt_pair_bias_cache_bytes(int N, int L, int num_layers);
 int abopt_pair_bias_cache(const abopt_ga_weights* blocks, int num_layers, const float* pair_feat, float* cache,
                           int N, int L, int C, abopt_stream stream);
 
+/* Range guard (ABI 41).  The dense layers of abopt_eps_net_forward (node projections, out_transform + MLP, heads, mixer) multiply fp32 operands as two fp16
+ * terms when the packed weights (w_node_frag, w_out_frag / w_out_terms, w_mlp_frag, w_heads_frag, w_mix_frag) are given: an activation beyond 65504 -- which
+ * the fp32 reference handles -- becomes inf there and reaches the outputs as inf / NaN.  Every abopt_eps_net_forward raises a device flag when a head output
+ * of any row is not finite; abopt_nonfinite_flag synchronises `stream`, returns the flag (1 / 0; -1 on error) and clears it if `reset`.  A caller that
+ * sees 1 repeats the work with the packed-weight pointers set to NULL: the same layers then run as fp32 GEMMs with fp32's range (ab_opt_amd/dpm.py does,
+ * once per sample() / optimize() call; tests/test_hip_parity.py::test_fp16_range_guard_falls_back_to_fp32_layers). */
+int abopt_nonfinite_flag(int reset, abopt_stream stream);
+
 /* Per-call pair terms (ABI 41): pair_feat re-laid as the fp16 operands of the pair aggregation sum_j alpha[i,j,h] z[i,j,:] (ga.py:114-118), built once per
  * FullDPM.sample / optimize call next to the bias cache (same constancy argument).  Every value becomes two fp16 terms h = fp16(S_i z), l = fp16(S_i z - h)
  * with one power of two S_ic per (query row, channel) (max_j |z[n,i,j,c]| S_ic in [2^13, 2^14)): 22 significant bits for every value within 2^-17 of the

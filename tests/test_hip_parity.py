@@ -1034,7 +1034,8 @@ def test_eps_net_bench_geometry_vs_oracle(flavour, N):
         # pred_x0 turns the network's position into noise by dividing by sqrt(1 / abar_t - 1) (transition.py:42-50): 0.07 at t = 2, i.e. the
         # 4e-7 fp32 noise of the network output is 2e-4 A there whatever computes it (two builds of this library that differ in the last bit of
         # eps_pos -- both 4.1e-7 from the float64 oracle -- measured 0.9e-4 and 2.3e-4); 1e-4 A holds from t = 10 up
-        assert max_abs(tp[t - 1][ix].cpu(), p_n * 10) < (1e-4 if t >= 10 else 1e-3), t
+        # ... for the AbDock flavour (obj = pred_x0) only: the AbDesign flavour predicts the noise itself (pred_noise) and holds 1e-4 A at every t
+        assert max_abs(tp[t - 1][ix].cpu(), p_n * 10) < (1e-4 if (t >= 10 or flavour == 'abdesign') else 1e-3), t
         e = dpm.so3_noise(den.tab_inv, torch.full((len(ids), L), t), cn)
         if t in (2, 21):
             sd_t = inv.stddevs[t]
@@ -1364,6 +1365,49 @@ def test_two_term_fp16_products_are_fp32_accurate(wscale, fscale):
     e_hip, e_f32 = max_abs(out, ref64), max_abs(ref32, ref64)
     assert torch.isfinite(out).all()
     assert e_hip <= 3.0 * e_f32 + 2e-7 * ref64.abs().max().item(), (wscale, fscale, e_hip, e_f32)
+
+
+def test_fp16_range_guard_falls_back_to_fp32_layers():
+    """The dense layers multiply on two fp16 terms per operand: an activation beyond 65504 -- which the fp32 reference takes -- becomes inf there and NaN
+    in the outputs.  Not silently: the heads' epilogue raises a device flag (abopt_nonfinite_flag), EpsilonNet.forward and FullDPM.sample / optimize
+    read it once per call and repeat the call with the dense layers as fp32 GEMMs.  Node features of 1e5: the fp16
+    path returns NaN and raises the flag; the guarded entry points warn and return what the fp32 path returns (bit for bit), finite and close to the
+    oracle; ordinary inputs neither warn nor raise the flag."""
+    import warnings
+    from ab_opt_amd import hip
+    from oracle import dpm as odpm
+    T, N, L = 10, 2, 48
+    d = build_model(T, 3, device=DEV).diffusion
+    v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, [48, 40], 5100, [(6, 17), (30, 37)])
+    beta = d.trans_pos.var_sched.betas[7].expand([N]).contiguous()
+    net = d.eps_net
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                                      # ordinary magnitudes: no warning, flag down
+        ok = net(v, p, s, rf, pf, beta, gen, mres)
+    assert not hip.nonfinite_flag() and all(torch.isfinite(o).all() for o in ok)
+    big = rf * (1.0e5 / rf.abs().max())
+    raw = hip.eps_net_forward(net.packed(), v, p, s, big, pf, beta, gen, mres, d.abdock, d.num_bins, False)
+    assert not torch.isfinite(raw['R_next']).all() and hip.nonfinite_flag(reset=True) and not hip.nonfinite_flag()       # NaN, flag up, then cleared
+    safe = hip.eps_net_forward(net.packed_fp32(), v, p, s, big, pf, beta, gen, mres, d.abdock, d.num_bins, False)
+    safe = {k: a.clone() for k, a in safe.items() if a is not None}
+    assert all(torch.isfinite(a).all() for a in safe.values()) and not hip.nonfinite_flag()
+    with pytest.warns(RuntimeWarning, match='fp16 range'):
+        got = net(v, p, s, big, pf, beta, gen, mres)
+    assert torch.equal(got[1], safe['R_next']) and torch.equal(got[2], safe['eps_pos']) and torch.equal(got[3], safe['c'])
+    sd = {k: a.detach().cpu() for k, a in d.state_dict().items()}
+    ref = odpm.eps_net(sd, 'eps_net.', v.cpu(), p.cpu(), s.cpu(), big.cpu(), pf.cpu(), beta.cpu(), gen.cpu(), mres.cpu(), num_layers=6, prmsd_head=True, mode='mm')
+    assert max_abs(got[2].cpu(), ref[2]) < 1e-3 * max(1.0, ref[2].abs().max().item()) and max_abs(got[3].cpu(), ref[3]) < 1e-3
+    # the sampling loop: one flag read per call, the whole call repeated on the fp32 layers
+    with pytest.warns(RuntimeWarning, match='fp16 range'):
+        traj = d.sample(v, p * 10, s, big, pf, gen, mres, seed=5)
+    assert all(torch.isfinite(traj[t][1]).all() for t in traj)
+    hh = d._sched_host()
+    state = hip.sample_init(v.float(), (p * 10).float(), s, gen, None, 5, 0, hh['scale'], hh['mean'], True, True)
+    tv, tp, ts, _, _ = d._run_eager(state, T, big, pf, gen, mres, True, True, True, None, 5, 0, False, range_safe=True)
+    assert torch.equal(traj[0][1], tp[0]) and torch.equal(traj[0][2], ts[0])
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        d.sample(v, p * 10, s, rf, pf, gen, mres, seed=5)
 
 
 def _pair_terms_statement(z, L):
@@ -1934,7 +1978,7 @@ def test_bucket_colsum_vs_index_add():
         hip.bucket_colsum(torch.zeros(4, 64, device=DEV), torch.zeros(4, dtype=torch.int32, device=DEV), 97)
     # the segmented form + the plain one = the sum by PAIR of residue types (a of i, b of j) of the amino-acid-pair tables' gradients
     # (pair.py:46-53,66 under autograd): against the one-hot contraction autograd would run, in fp64; strided operand read in place
-    for N, L, cols, ld in ((3, 37, 64, 320), (2, 64, 80, 80), (1, 5, 240, 240)):
+    for N, L, cols, ld in ((3, 37, 64, 320), (2, 64, 80, 80), (1, 5, 240, 240), (35000, 2, 64, 64)):       # (the last: 70 000 segments, more than one grid holds -- ADVICE r05)
         nt = 22
         y = torch.randn(N * L * L, ld, generator=g).to(DEV)
         x = y[:, ld - cols:]
