@@ -105,6 +105,10 @@ __device__ __forceinline__ Mat3 quat1ijk_to_rot(float qb, float qc, float qd) {
     return o;
 }
 
+// ReLU that lets a NaN through, like torch.relu (v_max_f32 returns the other operand): the range guard of the two-term fp16 layers needs an overflow (inf -> NaN in the
+// products) to REACH the heads' outputs, and the reference's own relu(NaN) is NaN.  One compare + select.
+__device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+
 // Geometric epilogue of the three denoiser heads for ONE residue i (dpm_full.py:95-107): eps_pos = gen ? R eps_crd : 0;
 // R_next = R * U(eps_rot); v_next = gen ? log(R_next) : v_t; c = softmax(seq logits).  crd / rot / seq point at the row's head outputs
 // (global memory: heads_epilogue_kernel; LDS: the tail of heads_mlp_kernel).  seq == nullptr: training path, the softmax stays in autograd.

@@ -15,12 +15,6 @@
 #include "ipa_common.h"
 #include "kernels.h"
 
-// Developer switch (make CXXEXTRA=-DPE_TERMS=<mask>): which 64-wide products of pair_embed_kernel run on the fp16 matrix pipe as two-term
-// splits (ipa_common.h explains the arithmetic; three bf16 terms until round 5): 1 distance_embed.2 | 2 out_mlp.0, f_dist block | 4 out_mlp.0, dihedral block | 8 out_mlp.2 | 16 out_mlp.4
-#ifndef PE_TERMS
-#define PE_TERMS 0
-#endif
-
 namespace abopt {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -262,7 +256,6 @@ struct PairArgs {
     const float* t_aap; const float* t_rel; const float* sp; const float* freq;
     const f32x4* wd0; const float* bd0; const f32x4* wd1; const float* bd1;
     const f32x4* wo0; const float* bo0; const f32x4* wo1; const float* bo1; const f32x4* wo2; const float* bo2;
-    const u32x4* wtd1; const u32x4* wto0; const u32x4* wtdh; const u32x4* wto1; const u32x4* wto2;   // the same 64-wide blocks as scaled fp16 terms (PE_TERMS; swizzle_terms_kernel)
     float* out; int N, L, A, has_struct;
     float* gsave; float* tsave;   // training: Gaussian features and d/d softplus(coef), [pair][A][16] (b padded to 16), NULL for inference
     float* acts;          // training: per pair [relu(D0) 64 | f_dist 64 | f_dih 32 | relu(O0) 64 | relu(O1) 64] (PAIR_ACT floats), NULL for inference
@@ -280,38 +273,6 @@ constexpr int PMT = 4;        // 16-pair tiles per wave
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                              \
                 _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt)                                                        \
                     DST[mt][nt] = mfma4e(w_[nt][q], SRC[mt][blk][q], DST[mt][nt]);                                        \
-    }
-// The same layer on the fp16 matrix pipe with two terms per operand (ipa_common.h: split_pair2; three-term bf16 products until round 5).  K slot
-// (kb = lane >> 4, e = 0..7) of k-step s is feature 16 (2 s + (e >> 2)) + 4 kb + (e & 3): the eight values lane (pair, kb) holds in SRC[mt][2 s] and
-// SRC[mt][2 s + 1], so the B operand is split2() of two accumulator quads -- still no cross-lane traffic.  WT: [NSTEP][768 vectors: 4 nt x 2 terms x
-// 64 lanes, then unused], the weights scaled by a power of two S per block (swizzle_terms_kernel); bits of 1 / S in the last vector of the buffer.
-// Three products per (tile, output tile, k-step) into a fresh accumulator, then DST += acc / S (exact scaling, one rounding in the sum).
-#ifndef PE_DBG
-#define PE_DBG 0          // developer: 1 fences + PE_NOPS wait states around every split and product group | 4 / 8 / 16: only before the split / before / after the products
-#endif
-#ifndef PE_NOPS
-#define PE_NOPS 32
-#endif
-#define PE_FENCE(B) { if (PE_DBG & (1 | (B))) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int n_ = 0; n_ < PE_NOPS; n_ += 4) asm volatile("s_nop 3" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } }
-#define PAIR_DENSE_T(DST, SRC, WT, NSTEP)                                                                                 \
-    {                                                                                                                     \
-    const float inv_ = __uint_as_float((WT)[(NSTEP) * 768 - 1][0]);                                                       \
-    _Pragma("unroll") for (int s_ = 0; s_ < (NSTEP); ++s_) {                                                              \
-        u32x4 wt_[4][2];                                                                                                  \
-        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
-            _Pragma("unroll") for (int sp_ = 0; sp_ < 2; ++sp_) wt_[nt][sp_] = (WT)[s_ * 768 + (nt * 2 + sp_) * 64 + lane]; \
-        _Pragma("unroll") for (int mt = 0; mt < PMT; ++mt) {                                                              \
-            PE_FENCE(4)                                                                                                   \
-            const Split2 xs_ = split2(SRC[mt][2 * s_], SRC[mt][2 * s_ + 1]);                                              \
-            PE_FENCE(8)                                                                                                   \
-            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                            \
-                f32x4 c_ = mfma_h(wt_[nt][0], xs_.l, (f32x4){0.f, 0.f, 0.f, 0.f});                                        \
-                c_ = mfma_h(wt_[nt][1], xs_.h, c_); c_ = mfma_h(wt_[nt][0], xs_.h, c_);                                   \
-                _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) DST[mt][nt][r_] = fmaf(c_[r_], inv_, DST[mt][nt][r_]);   \
-            }                                                                                                             \
-            PE_FENCE(16)                                                                                                  \
-        }                                                                                                                 \
-    }                                                                                                                     \
     }
 // training: dump a 64-wide activation tile (lane = pair fm of tile mt, features 16 nt + 4 kq ..) at float offset OFF of the pair's record
 #define PAIR_SAVE(TILE, OFF)                                                                                              \
@@ -430,12 +391,12 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bd1 + nt * 16 + kq * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h0[mt][nt][r] = fmaxf(h0[mt][nt][r], 0.f);
+            for (int r = 0; r < 4; ++r) h0[mt][nt][r] = relu_nan(h0[mt][nt][r]);
             h1[mt][nt] = bv;
         }
     PAIR_SAVE(h0, 0)
     // ---- distance_embed.2 + ReLU, structure mask (pair.py:74-76)
-    if (PE_TERMS & 1) { PAIR_DENSE_T(h1, h0, a.wtd1, 2) } else { PAIR_DENSE(h1, h0, a.wd1) }
+    PAIR_DENSE(h1, h0, a.wd1)
     float ps[PMT], same[PMT], mp[PMT];
     int rel[PMT];
     // the key rows are re-derived from the lane index here and in the dihedral block (two VALU operations) instead of living in registers across
@@ -453,7 +414,7 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h1[mt][nt][r] = fmaxf(h1[mt][nt][r], 0.f) * ps[mt];
+            for (int r = 0; r < 4; ++r) h1[mt][nt][r] = relu_nan(h1[mt][nt][r]) * ps[mt];
     }
     PAIR_SAVE(h1, 64)
     // ---- out_mlp.0: folded embedding tables + f_dist block + dihedral block
@@ -467,7 +428,7 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
             const f32x4 tr = *reinterpret_cast<const f32x4*>(a.t_rel + (unsigned)(rel[mt] * EC + col));
             h0[mt][nt] = (bv + ta) + tr * same[mt];
         }
-    if (PE_TERMS & 2) { PAIR_DENSE_T(h0, h1, a.wto0, 2) } else { PAIR_DENSE(h0, h1, a.wo0) }
+    PAIR_DENSE(h0, h1, a.wo0)
     {   // inter-residue dihedrals (pair.py:80-92): phi-like (C_i, N_j, CA_j, C_j), psi-like (N_i, CA_i, C_i, N_j); AngularEncoding -> 26 (+6 pad)
         const V3 ni = xyz(a.atoms4[row_i * 16 + 0]), cai = xyz(a.atoms4[row_i * 16 + 1]), ci = xyz(a.atoms4[row_i * 16 + 2]);
         f32x4 dh[PMT][2];
@@ -512,7 +473,6 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
                 }
             }
         }
-        if (PE_TERMS & 4) { PAIR_DENSE_T(h0, dh, a.wtdh, 1) } else {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             f32x4 w_[4];
@@ -525,7 +485,6 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < PMT; ++mt) h0[mt][nt] = mfma4e(w_[nt][q], dh[mt][blk][q], h0[mt][nt]);
         }
-        }
     }
 #pragma unroll
     for (int mt = 0; mt < PMT; ++mt)
@@ -533,22 +492,22 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bo1 + nt * 16 + kq * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h0[mt][nt][r] = fmaxf(h0[mt][nt][r], 0.f);
+            for (int r = 0; r < 4; ++r) h0[mt][nt][r] = relu_nan(h0[mt][nt][r]);
             h1[mt][nt] = bv;
         }
     PAIR_SAVE(h0, 160)
-    if (PE_TERMS & 8) { PAIR_DENSE_T(h1, h0, a.wto1, 2) } else { PAIR_DENSE(h1, h0, a.wo1) }
+    PAIR_DENSE(h1, h0, a.wo1)
 #pragma unroll
     for (int mt = 0; mt < PMT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bo2 + nt * 16 + kq * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h1[mt][nt][r] = fmaxf(h1[mt][nt][r], 0.f);
+            for (int r = 0; r < 4; ++r) h1[mt][nt][r] = relu_nan(h1[mt][nt][r]);
             h0[mt][nt] = bv;
         }
     PAIR_SAVE(h1, 224)
-    if (PE_TERMS & 16) { PAIR_DENSE_T(h0, h1, a.wto2, 2) } else { PAIR_DENSE(h0, h1, a.wo2) }
+    PAIR_DENSE(h0, h1, a.wo2)
     // ---- pair mask, store (pair.py:100): a lane owns features 16 nt + 4 kq .. +3 of pair (i, j0 + 16 mt + fm)
 #pragma unroll
     for (int mt = 0; mt < PMT; ++mt) {
@@ -558,37 +517,6 @@ __global__ __launch_bounds__(256, PE_LB) void pair_embed_kernel(PairArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(o + nt * 16) = h0[mt][nt] * mp[mt];
     }
-}
-
-// Term operands of PAIR_DENSE_T: out[s * 768 + (nt * 2 + term) * 64 + lane] = the eight fp16 terms of S W[16 nt + (lane & 15)][col0 + k(s, lane >> 4, e)], e = 0..7,
-// k(s, kb, e) = 16 (2 s + (e >> 2)) + 4 kb + (e & 3) (0 where k >= kreal): the A-operand fragments of v_mfma_f32_16x16x32_f16.  S = the power of two with
-// max |W block| S in [2^14, 2^15) (every workgroup folds the block's 64 x kreal values itself); out[nstep * 768 - 1] = {bits of 1 / S, 0, 0, 0}.
-__global__ __launch_bounds__(256) void swizzle_terms_kernel(const float* __restrict__ W, int ldw, int col0, int kreal, int nstep, u32x4* __restrict__ out) {
-    __shared__ float red[4];
-    float m = 0.f;
-    for (int e = threadIdx.x; e < 64 * kreal; e += 256) { const float a = fabsf(W[(e / kreal) * ldw + col0 + e % kreal]); m = (a <= 3.0e38f) ? fmaxf(m, a) : m; }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    int ex = 0;
-    if (m > 0.f) { (void)frexpf(m, &ex); ex = 15 - ex; }
-    ex = max(-100, min(100, ex));
-    const float S = ldexpf(1.f, ex);
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nstep * 4 * 64) return;
-    const int lane = idx & 63, nt = (idx >> 6) & 3, s = idx >> 8, fm = lane & 15, kb = lane >> 4;
-    f32x4 lo, hi;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = 16 * (2 * s + (e >> 2)) + 4 * kb + (e & 3);
-        const float v = k < kreal ? W[(nt * 16 + fm) * ldw + col0 + k] * S : 0.f;
-        if (e < 4) lo[e] = v; else hi[e - 4] = v;
-    }
-    const Split2 t = split2(lo, hi);
-    u32x4* o = out + (int64_t)s * 768 + (nt * 2) * 64 + lane;
-    o[0] = t.h; o[64] = t.l;
-    if (idx == 0) out[nstep * 768 - 1] = (u32x4){__float_as_uint(ldexpf(1.f, -ex)), 0u, 0u, 0u};
 }
 
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -934,7 +862,7 @@ int launch_residue_features(const abopt_encode_inputs* in, const abopt_residue_e
 }
 
 static size_t pair_weight_floats(int A) {
-    return (size_t)AAT * AAT * EC + NREL * EC + (size_t)AAT * AAT * A * 16 + (size_t)(A + 4 + 6 + 4 + 4) * 4 * 64 * 4 + (size_t)9 * 4 * 3 * 64 * 4;
+    return (size_t)AAT * AAT * EC + NREL * EC + (size_t)AAT * AAT * A * 16 + (size_t)(A + 4 + 6 + 4 + 4) * 4 * 64 * 4;
 }
 
 size_t pair_embed_ws_bytes(int N, int L, int A) {
@@ -958,7 +886,6 @@ int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weig
     f32x4* wo0 = (f32x4*)q; q += 6 * 1024;
     f32x4* wo1 = (f32x4*)q; q += 4 * 1024;
     f32x4* wo2 = (f32x4*)q; q += 4 * 1024;
-    u32x4* wt = (u32x4*)q; q += 9 * 4 * 3 * 64 * 4;                 // term operands: d1 (2 k-steps) | o0 f_dist (2) | o0 dihedral (1) | o1 (2) | o2 (2)
     hipLaunchKernelGGL(residue_pack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(64), 0, st, in->aa, in->res_nb, in->chain_nb, in->pos_atoms, in->mask_atoms,
                        in->structure_mask, in->sequence_mask, in->atoms_in, A, rows, pb.atoms4, pb.aa_eff, pb.resnb, pb.chain, pb.flags, (float*)nullptr, (float*)nullptr);
     ABOPT_LAUNCH_CHECK();
@@ -979,34 +906,13 @@ int launch_pair_embed(const abopt_encode_inputs* in, const abopt_pair_embed_weig
     swz(w->wo2, EC, 0, 16, 16, EC, 4, wo2);
     ABOPT_LAUNCH_CHECK();
     PairArgs a;
-    a.wtd1 = wt; a.wto0 = wt + 2 * 768; a.wtdh = wt + 4 * 768; a.wto1 = wt + 5 * 768; a.wto2 = wt + 7 * 768;       // 768 vectors per k-step
-    if (PE_TERMS) {
-        auto swt = [&](const float* W, int ldw, int col0, int kreal, int nstep, const u32x4* out) {
-            hipLaunchKernelGGL(swizzle_terms_kernel, dim3(nstep), dim3(256), 0, st, W, ldw, col0, kreal, nstep, const_cast<u32x4*>(out));
-        };
-        swt(w->wd1, EC, 0, EC, 2, a.wtd1);
-        swt(w->wo0, ldo0, 2 * EC, EC, 2, a.wto0);
-        swt(w->wo0, ldo0, 3 * EC, 26, 1, a.wtdh);
-        swt(w->wo1, EC, 0, EC, 2, a.wto1);
-        swt(w->wo2, EC, 0, EC, 2, a.wto2);
-        ABOPT_LAUNCH_CHECK();
-    }
     a.atoms4 = pb.atoms4; a.aa_eff = pb.aa_eff; a.res_nb = pb.resnb; a.chain_nb = pb.chain; a.flags = pb.flags;
     a.t_aap = t_aap; a.t_rel = t_rel; a.sp = sp; a.freq = w->freq_bands;
     a.wd0 = wd0; a.bd0 = w->bd0; a.wd1 = wd1; a.bd1 = w->bd1; a.wo0 = wo0; a.bo0 = w->bo0; a.wo1 = wo1; a.bo1 = w->bo1; a.wo2 = wo2; a.bo2 = w->bo2;
     a.out = pair_feat; a.N = N; a.L = L; a.A = A; a.has_struct = in->structure_mask ? 1 : 0; a.acts = acts; a.gsave = gsave; a.tsave = tsave;
     const int jblocks = (L + 16 * PMT - 1) / (16 * PMT);
     const int64_t units = rows * jblocks;
-    size_t dyn_lds = 0;
-#if PE_TERMS
-    {   // developer experiment: ABOPT_PE_LDS=<bytes> of (unused) dynamic LDS per workgroup limits how many workgroups share a CU -- the SAME binary at
-        // one wave per SIMD (> 80 KB) against two
-        static const int e = getenv("ABOPT_PE_LDS") ? atoi(getenv("ABOPT_PE_LDS")) : 0;
-        dyn_lds = (size_t)e;
-        if (e > 0) ABOPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_embed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e));
-    }
-#endif
-    hipLaunchKernelGGL(pair_embed_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), dyn_lds, st, a);
+    hipLaunchKernelGGL(pair_embed_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, a);
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

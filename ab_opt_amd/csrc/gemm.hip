@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_xwT_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[i][j][r] + ((bias && col + r < N) ? bias[col + r] : 0.f);
-                if (RELU) v[r] = fmaxf(v[r], 0.f);
+                if (RELU) v[r] = relu_nan(v[r]);
             }
             float* yp = Y + (size_t)row * ldy + col;
             if (vec_ok && col + 3 < N) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -226,7 +226,7 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, int lda, 
             if (row >= M || col >= N) continue;
             f32x4 v = acc[i][j] * alpha;
             if (bias) { for (int r = 0; r < 4; ++r) if (col + r < N) v[r] += bias[col + r]; }       // y = x W^T + b (and ReLU) in the product's epilogue
-            if (relu) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+            if (relu) { for (int r = 0; r < 4; ++r) v[r] = relu_nan(v[r]); }
             float* cp = C + (int64_t)row * ldc + col;
             if (cvec && col + 3 < N) *reinterpret_cast<f32x4*>(cp) = v;
             else { for (int r = 0; r < 4; ++r) if (col + r < N) cp[r] = v[r]; }

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
             for (int i = 0; i < 4; ++i) {
                 const int o = wave * 32 + g * 8 + csub + i;
                 const float* wt = w1 + (int64_t)o * ld1 + HF;
-                v[i] = fmaxf(fmaf(a0[4 * g + i] + a1[4 * g + i], winv, b1[o] + (wt[0] * bt + (wt[1] * sb + wt[2] * cb))), 0.f);
+                v[i] = relu_nan(fmaf(a0[4 * g + i] + a1[4 * g + i], winv, b1[o] + (wt[0] * bt + (wt[1] * sb + wt[2] * cb))));
             }
             const int col = (wave & 3) * 32 + g * 8 + csub;
             put_terms2(dst, mrow * HP_ROW + col * 2, v[0], v[1]);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
             const int col = (wave & 3) * 32 + g * 8 + csub;
             float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(a0[4 * g + i] + a1[4 * g + i], winv, b2[col + i]), 0.f);
+            for (int i = 0; i < 4; ++i) v[i] = relu_nan(fmaf(a0[4 * g + i] + a1[4 * g + i], winv, b2[col + i]));
             put_terms2(dst, mrow * HP_ROW + col * 2, v[0], v[1]);
             put_terms2(dst, mrow * HP_ROW + col * 2 + 4, v[2], v[3]);
         }
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(HTH) void mixer_kernel(const float* __restrict__ re
             const int col = wave * 32 + g * 8 + csub;
             float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = ok ? fmaxf(fmaf(a0[4 * g + i] + a1[4 * g + i], winv, tr[col + i]), 0.f) : __builtin_nanf("");
+            for (int i = 0; i < 4; ++i) v[i] = ok ? relu_nan(fmaf(a0[4 * g + i] + a1[4 * g + i], winv, tr[col + i])) : __builtin_nanf("");
             put_terms2(sm.hp[0], mrow * HP_ROW + col * 2, v[0], v[1]);
             put_terms2(sm.hp[0], mrow * HP_ROW + col * 2 + 4, v[2], v[3]);
         }

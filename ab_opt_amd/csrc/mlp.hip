@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void fused_ln_mlp_kernel(const float* __restri
     for (int nt = 0; nt < 4; ++nt) {
         const int col = half * 64 + nt * 16 + kq * 4;
         const float4 bv = *reinterpret_cast<const float4*>(b0 + col);
-        *reinterpret_cast<float4*>(&ha[rg * 16 + fm][col]) = make_float4(fmaxf(acc[nt][0] + bv.x, 0.f), fmaxf(acc[nt][1] + bv.y, 0.f),
-                                                                          fmaxf(acc[nt][2] + bv.z, 0.f), fmaxf(acc[nt][3] + bv.w, 0.f));
+        *reinterpret_cast<float4*>(&ha[rg * 16 + fm][col]) = make_float4(relu_nan(acc[nt][0] + bv.x), relu_nan(acc[nt][1] + bv.y),
+                                                                          relu_nan(acc[nt][2] + bv.z), relu_nan(acc[nt][3] + bv.w));
     }
     __syncthreads();
     mlp_store_w(wl, wreg);
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void fused_ln_mlp_kernel(const float* __restri
     for (int nt = 0; nt < 4; ++nt) {
         const int col = half * 64 + nt * 16 + kq * 4;
         const float4 bv = *reinterpret_cast<const float4*>(b1 + col);
-        *reinterpret_cast<float4*>(&hb[rg * 16 + fm][col]) = make_float4(fmaxf(acc[nt][0] + bv.x, 0.f), fmaxf(acc[nt][1] + bv.y, 0.f),
-                                                                          fmaxf(acc[nt][2] + bv.z, 0.f), fmaxf(acc[nt][3] + bv.w, 0.f));
+        *reinterpret_cast<float4*>(&hb[rg * 16 + fm][col]) = make_float4(relu_nan(acc[nt][0] + bv.x), relu_nan(acc[nt][1] + bv.y),
+                                                                          relu_nan(acc[nt][2] + bv.z), relu_nan(acc[nt][3] + bv.w));
     }
     __syncthreads();
     mlp_store_w(wl, wreg);

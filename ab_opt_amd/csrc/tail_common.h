@@ -251,7 +251,7 @@ __device__ __forceinline__ void tail_p2_run(TailP2Pre<NW>& pre, GetU&& get_u, fl
             for (int rt = 0; rt < 2; ++rt) {
                 const int orow = rt * 16 + fm;
                 const f32x4 v = (f32x4){fmaf(o[rt][0], isc, bv[0]), fmaf(o[rt][1], isc, bv[1]), fmaf(o[rt][2], isc, bv[2]), fmaf(o[rt][3], isc, bv[3])};
-                const f32x4 hv = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                const f32x4 hv = (f32x4){relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
                 store_terms2h(dst, orow * AP_ROW + ocol * 2, hv[0], hv[1]);
                 store_terms2h(dst, orow * AP_ROW + ocol * 2 + 4, hv[2], hv[3]);
                 if (DUMP && row0 + orow < row_end) *reinterpret_cast<f32x4*>(dump + (2 + layer) * slab + (row0 + orow) * F + ocol) = hv;
