@@ -551,8 +551,9 @@ def main():
             'in-kernel launch spans (abopt_prof_spans: 100 MHz wall clock of the first workgroup in / last workgroup out of every launch) of ONE more '
             'replay of the timed graph, run right after the repeats (it took instrumented_ms_per_step); eager_events = the same K steps launched '
             'eagerly with HIP events around every launch, for comparison')
-        fused = bool(two_launch) and per_launch_ms > 1.08 * two_launch['ipa_core_avg_launch_ms']
-        kernel_name = ('ipa_core32_kernel<true>: IPA core + block tail (out_transform, LayerNorm, MLP, LayerNorm) as ONE kernel -- the survey\'s per-layer bytes are '
+        # in-kernel spans exist for the 32-row launches only, and the sampler's 32-row launch is the fused core + tail kernel unless ABOPT_FUSE_TAIL=0
+        fused = use_graph and instrumented is not None and os.environ.get('ABOPT_FUSE_TAIL') != '0' and hip.lib().abopt_pair_terms_used(N, L, 0) == 1
+        kernel_name = ('ipa_core32_kernel<true, *>: IPA core + block tail (out_transform, LayerNorm, MLP, LayerNorm) as ONE kernel -- the survey\'s per-layer bytes are '
                        'those of the whole block, so they apply unchanged' if fused else 'ipa_core')
         line = {
             'metric': 'denoising steps/sec (256-res complex, 100-step sampler)', 'value': round(world * N * K / dt, 2),
