@@ -78,8 +78,11 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     const int64_t M = (int64_t)N * L;
     int rc;
     // node projections q|k|v|qp|kp|vp, points to the global frame, MFMA fragment layout: one fused kernel when the packed weights are given
+    // the term forms (round 6) go together: fragments with q / k channel terms are written only for the kernels that read them, the 32-row block kernels
+    // handed pair terms -- every other core reads fp32 channel slots
+    if (!(pbc && pair_terms && !dbg && w->w_node_frag && ipa_core32_applies(N, L))) pair_terms = nullptr;
     if (w->w_node_frag) {
-        if ((rc = launch_node_frags(x, w->w_node_frag, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st))) return rc;
+        if ((rc = launch_node_frags(x, w->w_node_frag, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st, pair_terms ? 1 : 0))) return rc;
     } else {
         if ((rc = launch_linear(x, F, w->w_node, F, nullptr, s.proj, NP, (int)M, ABOPT_NODE_PROJ, F, false, st))) return rc;
         if ((rc = launch_ipa_frags(s.proj, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st))) return rc;
@@ -93,7 +96,7 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     }
     float* feat = (dbg && dbg->feat) ? dbg->feat : (feat_out ? feat_out : s.feat);
     if ((rc = launch_ipa_core(s.qf, s.kvf, z, mask, R, t, w->w_pair_bias, feat,
-                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, N, L, st, z_shared, s.split, s.split_floats, dbg ? nullptr : pair_terms))) return rc;
+                              dbg ? dbg->logits : nullptr, dbg ? dbg->alpha : nullptr, pbc, N, L, st, z_shared, s.split, s.split_floats, pair_terms))) return rc;
     // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
     if (w->w_out_frag && w->w_mlp_frag)
         return launch_out_ln_mlp(feat, w->w_out_frag, w->w_mlp_frag, x, w->b_out, mask, w->ln1_gamma, w->ln1_beta, w->b_mlp0, w->b_mlp1, w->b_mlp2,

@@ -1603,6 +1603,18 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
                     if (C32_ABL & 8) { acc0 = kf[hh & 1][0] * q0 + kf[hh & 1][1] * q1; acc1 = kf[hh & 1][2] * q2 + kf[hh & 1][3] * q3; }
                     else if (C32_ABL & 256) { acc0 = kf[hh & 1][0]; acc1 = q0; }
+                    else if constexpr (ZT) {
+                        // the 32 channels of q / sqrt(D) and k arrive as two fp16 terms each (node_frags, qk_terms: slot 0 = high, slot 1 = low terms): three 16-cycle
+                        // products, smallest first, instead of eight 32-cycle fp32 steps; the point part + norm step (squared distances of global coordinates
+                        // cancel there: 24 bits needed) stays on the fp32 chain
+                        const u32x4 kh = __builtin_bit_cast(u32x4, kf[hh & 1][0]), kl = __builtin_bit_cast(u32x4, kf[hh & 1][1]);
+                        const u32x4 qh = __builtin_bit_cast(u32x4, q0), ql = __builtin_bit_cast(u32x4, q1);
+                        acc0 = mfma_h(kl, qh, acc0); acc0 = mfma_h(kh, ql, acc0);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) { acc1 = mfma4(kf[hh & 1][2][s], q2[s], acc1); if (s == 1) acc0 = mfma_h(kh, qh, acc0); }
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) acc1 = mfma4(kf[hh & 1][3][s], q3[s], acc1);
+                    }
                     else {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) { acc0 = mfma4(kf[hh & 1][0][s], q0[s], acc0); acc1 = mfma4(kf[hh & 1][2][s], q2[s], acc1); }

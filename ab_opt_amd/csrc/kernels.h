@@ -41,7 +41,8 @@ int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float*
 // node_frags.hip: x [N*L,128] -> qfrag / kvfrag directly (projection GEMM + frame transform + fragment layout in one kernel)
 size_t node_wfrag_floats();
 int launch_node_frags(const float* x, const float* wfrag, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag,
-                      int N, int L, hipStream_t st);
+                      int N, int L, hipStream_t st,
+                      int qk_terms = 0 /* 1: the q / k channel slots as two fp16 terms each (high terms in slot 0, low terms in slot 1): what ipa_core32_kernel<*, true> reads */);
 
 // rows.hip ------------------------------------------------------------------------------------
 int launch_so3_exp(const float* w, float* R, int64_t n, hipStream_t st);

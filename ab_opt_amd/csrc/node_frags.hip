@@ -57,7 +57,7 @@ __device__ __forceinline__ float quad_bcast2(float v) { return __uint_as_float(_
 template <int HALF>
 __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4* wl, const float* __restrict__ R, const float* __restrict__ t,
                                         float* __restrict__ qfrag, float* __restrict__ kvfrag, int L, int nchunk, int total_tiles, int tile0, int h,
-                                        float ch_, float m2c, float winv, int lane, int fm, int kq) {
+                                        float ch_, float m2c, float winv, int lane, int fm, int kq, int qk_terms) {
     int64_t rowbase[2], row[2];
     int cbs[2];
 #pragma unroll
@@ -162,8 +162,16 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
         if (HALF == 0) {
             // ---- q, k: accumulator row 4 kq + r = channel, column fm = residue
             const float s = 0.17677669529663687f;                                // 1 / sqrt(D), ga.py:84
+            if (qk_terms) {
+                // round 6: the consumer (ipa_core32_kernel<*, true>) multiplies the 32 channels of q / sqrt(D) and k as two fp16 terms each -- slot 0 holds the high
+                // terms, slot 1 the low terms; K slot e of lane (residue fm, kq) is channel 4 kq + e (e < 4) or 16 + 4 kq + e - 4: the same map on both sides
+                const Split2 tq = split2(acc[rt][0] * s, acc[rt][1] * s), tk = split2(acc[rt][2], acc[rt][3]);
+                outq[0] = __builtin_bit_cast(f32x4, tq.h); outq[64] = __builtin_bit_cast(f32x4, tq.l);
+                outk[0] = __builtin_bit_cast(f32x4, tk.h); outk[64] = __builtin_bit_cast(f32x4, tk.l);
+            } else {
             outq[0] = acc[rt][0] * s; outq[64] = acc[rt][1] * s;
             outk[0] = acc[rt][2]; outk[64] = acc[rt][3];
+            }
             // ---- q_pts: point kq (tile A) and 4 + kq (tile B) of residue fm
             f32x4 ga = to_global(acc[rt][4]), gb = to_global(acc[rt][5]);
             const float nq = rows_sum(sq(ga) + sq(gb));                          // |q_pts|^2 over the head's 8 points
@@ -197,7 +205,7 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
 __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* __restrict__ x, const float* __restrict__ wfrag, const float* __restrict__ R,
                                                                    const float* __restrict__ t, const float* __restrict__ spatial_coef,
                                                                    float* __restrict__ qfrag, float* __restrict__ kvfrag, int L, int nchunk,
-                                                                   int total_tiles) {
+                                                                   int total_tiles, int qk_terms) {
     extern __shared__ __attribute__((aligned(16))) char nf_smem[];
     u32x4* wl = reinterpret_cast<u32x4*>(nf_smem);                             // [12 tiles][4 k-steps][2 terms][64]
     const int h = NF_SPLIT ? blockIdx.y >> 1 : blockIdx.y, tid = threadIdx.x, lane = tid & 63, fm = lane & 15, kq = lane >> 4;
@@ -232,8 +240,8 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
 #endif
     for (int task = t_lo + wave; task < t_hi; task += NF_WAVES) {
         const int tile0 = NF_SPLIT ? task * 2 : (task >> 1) * 2;
-        if (NF_SPLIT ? half : (task & 1)) nf_task<1>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq);
-        else          nf_task<0>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq);
+        if (NF_SPLIT ? half : (task & 1)) nf_task<1>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq, qk_terms);
+        else          nf_task<0>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq, qk_terms);
 #ifdef NF_TIMING
         if (ti < 3) te[ti++] = clock64() - c0;
 #endif
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
 size_t node_wfrag_floats() { return (size_t)H * NF_HEAD_VEC * 4 + 4; }      // + {S, 1 / S, 0, 0}
 
 int launch_node_frags(const float* x, const float* wfrag, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag,
-                      int N, int L, hipStream_t st) {
+                      int N, int L, hipStream_t st, int qk_terms) {
     if ((int64_t)N * L == 0) return ABOPT_OK;
     const int nchunk = (L + JC - 1) / JC, total = N * nchunk;
     int cus = 0, rc;
@@ -268,7 +276,7 @@ int launch_node_frags(const float* x, const float* wfrag, const float* R, const 
     const dim3 grid(groups, H);
 #endif
     hipLaunchKernelGGL(node_frags_kernel, grid, dim3(NF_WAVES * 64), NF_LDS_VEC * 16, st, x, wfrag, R, t, spatial_coef,
-                       qfrag, kvfrag, L, nchunk, total);
+                       qfrag, kvfrag, L, nchunk, total, qk_terms);
     ABOPT_LAUNCH_CHECK();
 #ifdef NF_TIMING
     {

@@ -276,6 +276,9 @@ def secondary_measurements(dev, L):
     # ---- the reference's own headline invocation (AbDock/README.md:61: dock_pdb.py -n 1000 -b 1000 with configs/test/dock_cdr.yml): 1000 poses of
     # ONE complex cropped to the CDR-H3 + 20 antigen residues (dock_single.yml:12-14 antigen_size 20, initial_patch_size 0) -> L ~ 30..48
     res.update(poses_measurement(dev, 1000, 48, 'poses1000'))
+    # ---- config 3 as BASELINE.json words it ("64 poses/complex"): 64 poses of ONE 256-residue complex, i.e. shared pair features (the number above
+    # gives every pose its own pair features, the conservative reading); with shared features z is cache-resident and the fp16 term forms of round 6 run
+    res.update(poses_measurement(dev, 64, L, 'config3_one_complex'))
     # ---- small batches at L=256 (latency-bound regime)
     res.update(poses_measurement(dev, 8, 256, 'n8_L256', abdesign=True))
     return res

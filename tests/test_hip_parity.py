@@ -1461,8 +1461,7 @@ def test_pair_aggregation_on_fp16_terms_vs_fp64(N, L, lengths, monkeypatch):
     (z and the probabilities as two fp16 terms each, packed along the key index; per-(row, channel) power-of-two scales).  Stated accuracy: that of the fp32
     statement.  Checked on the pair features of a block (feat[:, :, :768]) against an fp64 contraction of the kernel's own alpha with z, with z scaled over
     SIX orders of magnitude across channels and over four across query rows: per channel, the error of the term path is at most 3x the error of the fp32
-    path (+ 2e-7 of the channel's range); everything else the block computes (node / point features, block output) does not change by a bit or stays at
-    fp32 summation noise."""
+    path (+ 2e-7 of the channel's range); the other feature groups and the block output stay within 3x the fp32 path's error against the oracle in fp64."""
     from ab_opt_amd import hip
     monkeypatch.setenv('ABOPT_CORE32', '1')
     monkeypatch.setenv('ABOPT_CORE_NO_SPLIT', '1')
@@ -1481,17 +1480,57 @@ def test_pair_aggregation_on_fp16_terms_vs_fp64(N, L, lengths, monkeypatch):
     out16, feat16 = hip.ga_block_forward_cached(st, R, t, x, z, mask, pbc, terms, want_feat=True)
     fused = hip.ga_block_forward_cached(st, R, t, x, z, mask, pbc, terms)                     # core + tail in one launch: the same bits
     assert torch.isfinite(out16).all() and torch.equal(fused, out16)
-    assert torch.equal(feat16[..., 768:], feat32[..., 768:])                               # node features, points, distances, directions: untouched
-    _, parts = hip.ga_block_forward(st, R, t, x, z, mask, debug=True)
-    ref64 = torch.einsum('nijh,nijc->nihc', parts['alpha'].double(), z.double()).reshape(N, L, 768)
-    e16 = (feat16[..., :768].double() - ref64).abs().reshape(-1, 12, 64).amax(dim=(0, 1))
-    e32 = (feat32[..., :768].double() - ref64).abs().reshape(-1, 12, 64).amax(dim=(0, 1))
-    rng = ref64.abs().reshape(-1, 12, 64).amax(dim=(0, 1))
+    # the whole block in fp64 (the oracle's statements on double tensors)
+    from oracle import ipa as oipa
+    sd64 = {k: a.detach().cpu().double() for k, a in blk.state_dict().items()}
+    parts = {}
+    out64 = oipa.ga_block(sd64, '', R.cpu().double(), t.cpu().double(), x.cpu().double(), z.cpu().double(), mask.cpu(), mode='mm', parts=parts)
+    ref64 = parts['feat'].to(DEV)
+    valid = mask[:, :, None]
+    e16 = ((feat16.double() - ref64).abs() * valid)[..., :768].reshape(-1, 12, 64).amax(dim=(0, 1))
+    e32 = ((feat32.double() - ref64).abs() * valid)[..., :768].reshape(-1, 12, 64).amax(dim=(0, 1))
+    rng = (ref64.abs() * valid)[..., :768].reshape(-1, 12, 64).amax(dim=(0, 1))
     assert (e16 <= 3.0 * e32 + 2e-7 * rng).all(), (e16 / (e32 + 1e-30)).max().item()
     # per element, relative to what the row's column of z can produce at all
     zmax = z.abs().amax(dim=2)[:, :, None, :].expand(N, L, 12, 64).reshape(N, L, 768).double()
-    assert ((feat16[..., :768].double() - ref64).abs() <= 2e-6 * zmax + 1e-30).all()
-    assert max_abs(out16, out32) < 2e-5 * max(1.0, out32.abs().max().item())
+    assert (((feat16[..., :768].double() - ref64[..., :768]).abs() * valid) <= 2e-6 * zmax + 1e-30).all()
+    # node features, aggregated points, distances, directions: the logits' q . k part runs on fp16 terms too (22 bits against fp32's 24)
+    for lo, hi in ((768, 1152), (1152, 1440), (1440, 1536), (1536, 1824)):
+        f16, f32, f64 = [(a.double() * valid)[..., lo:hi] for a in (feat16, feat32, ref64)]
+        assert (f16 - f64).abs().max() <= 3.0 * (f32 - f64).abs().max() + 1e-6 * max(1.0, f64.abs().max().item()), (lo, hi)
+    assert max_abs(out16.cpu().double(), out64) <= 3.0 * max_abs(out32.cpu().double(), out64) + 2e-6
+
+
+@pytest.mark.parametrize('xscale', [1.0, 0.05, 6.0])
+def test_attention_logits_on_fp16_terms_vs_fp64(xscale, monkeypatch):
+    """Round 6: handed pair terms, the 32-row block kernels also multiply the 32 channels of q / sqrt(D) and k as two fp16 terms each (three 16-cycle products
+    per (head, row tile, chunk) instead of eight fp32 steps; the point part of the logit stays on fp32).  The logits themselves never leave the chip, so
+    the check is on what they produce: every group of IPA features (pair | node | points | distances | directions) against the oracle's statements in
+    fp64, with node features x scaled so that |q . k| is tiny, ordinary and large (sharply peaked softmax): the term path's error is at most 3x the fp32
+    path's (+ 1e-6 of the group's range)."""
+    from ab_opt_amd import hip
+    from oracle import ipa as oipa
+    monkeypatch.setenv('ABOPT_CORE32', '1')
+    monkeypatch.setenv('ABOPT_CORE_NO_SPLIT', '1')
+    N, L = 4, 112
+    blk = _block_on_device(seed=29)
+    R, t, x, z, mask = [dev(a) for a in cases.ipa_inputs(N, L, [112, 97, 50, 16], salt=8300)]
+    x = x * xscale
+    _, st = blk.packed()
+    pbc = hip.pair_bias_cache((hip.GaWeights * 1)(st), 1, z)
+    terms = hip.pair_terms(z)
+    out32, feat32 = hip.ga_block_forward_cached(st, R, t, x, z, mask, pbc, None, want_feat=True)
+    out16, feat16 = hip.ga_block_forward_cached(st, R, t, x, z, mask, pbc, terms, want_feat=True)
+    assert torch.equal(hip.ga_block_forward_cached(st, R, t, x, z, mask, pbc, terms), out16) and not torch.equal(feat16, feat32)
+    sd64 = {k: a.detach().cpu().double() for k, a in blk.state_dict().items()}
+    parts = {}
+    out64 = oipa.ga_block(sd64, '', R.cpu().double(), t.cpu().double(), x.cpu().double(), z.cpu().double(), mask.cpu(), mode='mm', parts=parts)
+    ref64 = parts['feat'].to(DEV)
+    valid = mask[:, :, None]
+    for lo, hi in ((0, 768), (768, 1152), (1152, 1440), (1440, 1536), (1536, 1824)):
+        f16, f32, f64 = [(a.double() * valid)[..., lo:hi] for a in (feat16, feat32, ref64)]
+        assert (f16 - f64).abs().max() <= 3.0 * (f32 - f64).abs().max() + 1e-6 * max(1.0, f64.abs().max().item()), (xscale, lo, hi)
+    assert max_abs(out16.cpu().double(), out64) <= 3.0 * max_abs(out32.cpu().double(), out64) + 2e-6
 
 
 @pytest.mark.parametrize('flavour', ['abdesign', 'abdock'])
