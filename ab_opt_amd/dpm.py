@@ -161,10 +161,9 @@ class FullDPM(nn.Module):
         e = os.environ.get('ABOPT_PAIR_TERMS')
         if e == '0' or dev.type != 'cuda' or L > 2048:
             return False
-        # Measured (profiles/r06_b_pair_terms_ab.txt): with DISTINCT pair features per sample the block kernel is bound by its 742 MB of streams and the
-        # cheaper aggregation buys nothing (0 +- 1 % on two boxes, and the terms cost 0.25 ms per call to build); with pair features SHARED by the samples of
-        # a complex (the reference's own batches: one crop replicated N times) z comes from the caches and the term path is 2-4 % faster -> default there only
-        if e != '1' and (n_pair == N or not hip.pair_terms_used(N, L, N // n_pair)):
+        # Measured (profiles/r06_b_pair_terms_ab.txt): the complete term path (pair aggregation + the logits' q . k part) is 8-11 % of a step faster with shared
+        # pair features and 7-9 % with distinct ones (the pair aggregation alone bought nothing there: the block kernel then sat on its streams)
+        if e != '1' and not hip.pair_terms_used(N, L, N // n_pair if n_pair != N else 0):
             return False
         free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
         return hip.pair_terms_bytes(n_pair, L) <= free // 2

@@ -399,7 +399,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         beta = dpm.trans_pos.var_sched.betas[T].expand([N]).contiguous()
         first = hip.eps_net_forward(dpm.eps_net.packed(), state[0], state[1] / 10.0, state[2], res_feat, pair_feat, beta, gen, mres, False, 0, False,
-                                    pair_bias_cache=hip.pair_bias_cache(dpm.eps_net.encoder.packed_array(), NUM_LAYERS, pair_feat))
+                                    pair_bias_cache=hip.pair_bias_cache(dpm.eps_net.encoder.packed_array(), NUM_LAYERS, pair_feat),
+                                    pair_terms=hip.pair_terms(pair_feat) if dpm._pair_terms_wanted(N, L, N, dev) else None)     # (what the timed loop runs)
         first = {k: (v.clone() if v is not None else None) for k, v in first.items()}
     if W > 0:
         run(W)
@@ -570,9 +571,11 @@ def main():
                        'samples_per_gpu': N, 'residues': L, 'sampler_steps': T, 'parallelism': f'independent samples x{world}',
                        'launch': ('hipGraph replay of the K-step loop (captured once, before the timed region; Philox position from device memory)'
                                   if use_graph else 'eager launches'),
-                       'arithmetic': 'fp32 storage and accumulation everywhere; attention logits / softmax / aggregations on the fp32 matrix instructions; the dense layers '
-                                     '(node projections, out_transform + MLP, heads, mixer) multiply fp32 operands as two fp16 terms each, three products, fp32-accurate '
-                                     '(tests/test_hip_parity.py::test_two_term_fp16_products_are_fp32_accurate)',
+                       'arithmetic': 'fp32 storage and accumulation everywhere.  fp32 x fp32 products as two fp16 terms per operand (three products, 22 significant bits, '
+                                     'power-of-two scales) on the fp16 matrix instructions in the dense layers (node projections, out_transform + MLP, heads, mixer: '
+                                     'tests/test_hip_parity.py::test_two_term_fp16_products_are_fp32_accurate) and, since round 6 (pair_terms: ' + str(bool(dpm.last_run_info.get('pair_terms'))) + '), in the pair '
+                                     'aggregation sum_j alpha z (z pre-split once per call) and the q . k channel part of the attention logits '
+                                     '(test_pair_aggregation_on_fp16_terms_vs_fp64, test_attention_logits_on_fp16_terms_vs_fp64); point distances, softmax, value / point aggregation on the fp32 matrix instructions',
                        'backend': backend, 'ranks_per_device': (world + ndev - 1) // ndev if world > 1 else 1,
                        'ranks': ranks_seen, 'ranks_note': None if ranks_seen is None else 'gathered through the process group: device and OWN median ms_per_step of every rank (the line\'s ms_per_step is the max over ranks per repeat)'},
             'roofline': {'bound': 'hbm', 'kernel': kernel_name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
