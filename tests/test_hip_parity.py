@@ -1533,6 +1533,39 @@ def test_attention_logits_on_fp16_terms_vs_fp64(xscale, monkeypatch):
     assert max_abs(out16.cpu().double(), out64) <= 3.0 * max_abs(out32.cpu().double(), out64) + 2e-6
 
 
+@pytest.mark.parametrize('fscale', [1e-3, 1e-4, 1e-6])
+def test_two_term_fp16_products_with_small_activations(fscale):
+    """activations are split WITHOUT a scale, so the low fp16 term of a value below 2^-3 is a subnormal and every activation carries an
+    ABSOLUTE rounding floor of 2^-25 (the rounding of an fp32 number of size 0.5) instead of fp32's relative 2^-24.  Here EVERY aggregated feature is
+    small (1e-3 ... 1e-6, no large column to hide behind).  Stated and checked: (i) u = feat . W_out^T formed from the two terms is off the fp64 product by
+    at most that floor times the row's sum of |W_out| -- relative to u itself the term path is WORSE than an fp32 GEMM on such inputs: the accuracy claim
+    of DESIGN.md section 3.2 is for activations of O(0.1 ... 1e4); (ii) what the block returns -- LayerNorm(x + u) and the layers behind it with node
+    features x of ordinary size -- stays within 3x the error of the fp32 statement."""
+    from ab_opt_amd import hip
+    import plain_statement
+    N, L = 3, 70
+    blk = _block_on_device(seed=19)
+    _, _, x, _, mask = [dev(a) for a in cases.ipa_inputs(N, L, [70, 33, 1], salt=4300)]
+    feat = dev(synth.hash_tensor((N, L, 1824), 4301, scale=1.0)) * fscale
+    t_ = blk.packed()[0]
+    out = hip.block_tail_forward(feat.reshape(-1, 1824), t_['w_out_frag'], t_['w_mlp_frag'], x.reshape(-1, 128), t_['b_out'], mask.reshape(-1), t_['ln1_gamma'],
+                                 t_['ln1_beta'], t_['b_mlp0'], t_['b_mlp1'], t_['b_mlp2'], t_['ln2_gamma'], t_['ln2_beta']).reshape(N, L, 128)
+    with torch.no_grad():
+        ref32 = plain_statement.block_tail(blk, x, feat, mask)
+        W = blk.out_transform.weight.detach()
+        # (i) the product itself, from the terms the kernel forms: h = fp16(f), l = fp16(f - h) -- the same roundings, the sums in fp64
+        h = feat.half().double()
+        l = (feat.double() - h).float().half().double()
+        u_terms = (h + l) @ W.double().t()
+        u64 = feat.double() @ W.double().t()
+        floor = 2.0 ** -25 * W.abs().sum(dim=1).double()                      # per output column
+        assert ((u_terms - u64).abs() <= floor + 1e-300).all()
+        blk.double()
+        ref64 = plain_statement.block_tail(blk, x.double(), feat.double(), mask)
+    e_hip, e_f32 = max_abs(out, ref64), max_abs(ref32, ref64)
+    assert torch.isfinite(out).all() and e_hip <= 3.0 * e_f32 + 2e-7 * ref64.abs().max().item(), (fscale, e_hip, e_f32)
+
+
 @pytest.mark.parametrize('flavour', ['abdesign', 'abdock'])
 def test_fused_heads_match_gemm_path(flavour, monkeypatch):
     """heads.hip (the three denoiser heads as one kernel, time features as an affine term; the mixer as one kernel with the sequence
