@@ -231,7 +231,7 @@ def secondary_measurements(dev, L):
                              'tflops': round(tb_flops / (best * 1e-3) / 1e12, 2), 'flop_frac': round(tb_flops / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                              'bound': ('fp32 matrix / vector pipes' if tb_flops / (FP32_PEAK_TFLOPS * 1e12) > tb_bytes / (HBM_PEAK_GBS * 1e9) else 'hbm') +
                                       ' (%.2f ms of HBM time against %.2f ms of fp32 FLOPs at peak)' % (tb_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, tb_flops / (FP32_PEAK_TFLOPS * 1e12) * 1e3),
-                             'kernel_share': 'profiles/r05_r_train_steady_step_kernel_stats.txt: steady-state share of GPU time in abopt:: kernels (94 %)'}
+                             'kernel_share': 'profiles/r06_e_train_steady_step_kernel_stats.txt: steady-state share of GPU time in abopt:: kernels (95 %)'}
     model.zero_grad(set_to_none=True)
     model.eval()
     del adam, tb
