@@ -908,12 +908,6 @@ __device__ unsigned long long g_c32_count[8];
 #ifndef C32_ABL
 #define C32_ABL 0        // developer ablations (timing only, results wrong): 1 no z / bias loads in the loop | 32 z / bias loads all from one L1-resident address | 64 no softmax arithmetic in rows 1..7 (P = S) | 128 no pair MFMAs | 256 / 512 no A / C MFMAs (nothing instead) | 2 no fragment loads in the loop | 4 / 8 / 16 pair / A / C MFMAs off | 1024 no accumulator rescale (pair and C waves) | 2048 no v_exp_f32 in rows 1..7
 #endif
-#ifndef ZT_LAYOUT
-#define ZT_LAYOUT 0       // developer A/B of the pair terms' layout: 0 [chunk][tile][lane] (1 KB per request) | 1 [chunk][key group][tile][fm] (the fp32 stream's addresses)
-#endif
-#ifndef ZT_DEV
-#define ZT_DEV 0          // developer timing switches of the term path (results wrong): 1 no per-channel factors in the epilogue | 2 no 2^14 on the probabilities
-#endif
 #ifndef C32_ZAUX
 #define C32_ZAUX 2       // cache policy bits of the z / bias stream's buffer loads (2 = nt)
 #endif
@@ -1172,7 +1166,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
 #define P2_KOFF(CH)                                                                                                      \
     {                                                                                                                    \
         const int ch_ = (C32_ABL & 32) ? 0 : min((CH), nchunk - 1);             /* past the end: harmless re-read */      \
-        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) koff_[r_] = ZT ? (ZT_LAYOUT ? (unsigned)(ch_ * (JC * C * 4) + kq * 1024 + r_ * 256 + fm * 16) : (unsigned)(ch_ * (JC * C * 4) + r_ * 1024 + lane * 16)) : (unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b; \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) koff_[r_] = ZT ? (unsigned)(ch_ * (JC * C * 4) + r_ * 1024 + lane * 16) : (unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b; \
     }
 #define P2_BOFF(CH) boff_ = (unsigned)((C32_ABL & 32) ? 0 : min((CH), nchunk - 1)) * (unsigned)(H * JC * 4) + pb_lane;
 #ifdef C32_OLDLOAD
@@ -1316,7 +1310,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         // the lane's four probabilities times 2^14 (exact; their low fp16 terms are then normal numbers down to P = 2^-28) -> {P_h(k0, k1), P_h(k2, k3), P_l(..), P_l(..)}
 #define P2H_SPLIT()                                                                                                      \
         { unsigned h01_, l01_, h23_, l23_;                                                                               \
-          split_pair2(pvn_[0] * ((ZT_DEV & 2) ? 1.f : 16384.f), pvn_[1] * ((ZT_DEV & 2) ? 1.f : 16384.f), h01_, l01_); split_pair2(pvn_[2] * ((ZT_DEV & 2) ? 1.f : 16384.f), pvn_[3] * ((ZT_DEV & 2) ? 1.f : 16384.f), h23_, l23_); \
+          split_pair2(pvn_[0] * 16384.f, pvn_[1] * 16384.f, h01_, l01_); split_pair2(pvn_[2] * 16384.f, pvn_[3] * 16384.f, h23_, l23_); \
           pkn_ = (u32x4){h01_, h23_, l01_, l23_}; }
 #define P2H_SM(II, BUF)                                                                                                   \
     {                                                                                                                    \
@@ -1547,7 +1541,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
                     if (fm < H) {
 #pragma unroll
                         for (int ii = 0; ii < RPW2; ++ii) {
-                            if constexpr (ZT && !(ZT_DEV & 1)) {            // 1 / S_ic of channels 16 kq + 4 c .. + 3 of row ii (powers of two: the products with rinv are exact)
+                            if constexpr (ZT) {                                         // 1 / S_ic of channels 16 kq + 4 c .. + 3 of row ii (powers of two: the products with rinv are exact)
                                 const f32x4 zs = *reinterpret_cast<const f32x4*>(zsc + (zbase + min(i0 + il0 + ii, L - 1)) * C + kq * 16 + c * 4);
                                 stage_put4(buf, il0 + ii, fm * 16 + kq * 4, mul_rn(accP[ii][0][c], rinv[ii] * zs[0]), mul_rn(accP[ii][1][c], rinv[ii] * zs[1]),
                                            mul_rn(accP[ii][2][c], rinv[ii] * zs[2]), mul_rn(accP[ii][3][c], rinv[ii] * zs[3]));
@@ -1914,7 +1908,6 @@ __global__ __launch_bounds__(256) void pair_terms_kernel(const float* __restrict
             unsigned h01, l01, h23, l23;
             split_pair2(zn[0][mt] * S[mt], zn[1][mt] * S[mt], h01, l01);
             split_pair2(zn[2][mt] * S[mt], zn[3][mt] * S[mt], h23, l23);
-            if (ZT_LAYOUT) out[ch * 256 + kq * 64 + mt * 16 + fm - lane] = (u32x4){h01, h23, l01, l23}; else
             out[(ch * 4 + mt) * 64] = (u32x4){h01, h23, l01, l23};
         }
     }
