@@ -2781,6 +2781,51 @@ def test_gemm_tn_grouped_vs_fp64():
 
 
 @pytest.mark.gpu
+def test_wgrad_group_check_detects_a_second_use_of_a_parameter():
+    """WgradGroup hands autograd an UNFILLED tensor as a leaf's gradient and fills it at the flush -- correct only if nothing else contributes to
+    that leaf in the same pass.  ABOPT_WGRAD_CHECK (WgradGroup.check) verifies it after every pass: with the package's own loss every queued leaf ends the pass
+    holding the very tensor the group computed; a regulariser written with plain torch operations on a queued weight makes the engine add to / clone the
+    unfinished tensor, and the check raises instead of returning a wrong gradient.  Non-contiguous or hooked parameters are never queued (they run at once)."""
+    from ab_opt_amd import training
+    N, L = 2, 64
+    d = standalone_abdesign_dpm(100, 2).to(DEV).train()
+    v, p, s, res_feat, pair_feat, _, gen, mres = synth.eps_inputs(N, L, [64, 50], [(25, 33), (51, 57)], salt=951)
+    s = s.clamp(max=19)
+    t = dev(torch.tensor([3, 77]))
+    w = d.eps_net.encoder.blocks[0].out_transform.weight
+
+    def run(extra):
+        d.zero_grad(set_to_none=True)
+        torch.manual_seed(5)
+        loss = sum(d(dev(v), dev(p) * 10, dev(s), dev(res_feat), dev(pair_feat), dev(gen), dev(mres), True, True, t=t).values())
+        if extra:
+            loss = loss + 1e-3 * (w * w).sum()                              # a second, plain-torch use of a weight whose gradient is queued
+        loss.backward()
+        torch.cuda.synchronize()
+        return w.grad.detach().clone()
+    was_on, was_check = training.WgradGroup.enabled, training.WgradGroup.check
+    try:
+        training.WgradGroup.enabled, training.WgradGroup.check = False, False
+        ref, ref_extra = run(False), run(True)
+        training.WgradGroup.enabled, training.WgradGroup.check = True, True
+        got = run(False)                                                    # the package's own pass: the check is silent
+        assert (got - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
+        with pytest.raises(RuntimeError, match='WgradGroup'):
+            run(True)
+        training.WgradGroup.sync()
+        # a hook on the parameter: its products run at once, the second use is then summed by the engine as usual
+        h = w.register_hook(lambda g: g)
+        try:
+            got_extra = run(True)
+        finally:
+            h.remove()
+        assert (got_extra - ref_extra).abs().max().item() <= 3e-4 * ref_extra.abs().max().item()
+    finally:
+        training.WgradGroup.sync()
+        training.WgradGroup.enabled, training.WgradGroup.check = was_on, was_check
+        d.zero_grad(set_to_none=True)
+
+
 def test_wgrad_group_matches_ungrouped_backward():
     """training.WgradGroup: the weight-gradient products of a backward pass queue and run as grouped launches (about one per GABlock + one
     when the engine finishes the pass).  Against the one-product-per-launch form: every gradient within fp32 summation-order distance
