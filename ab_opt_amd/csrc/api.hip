@@ -59,7 +59,7 @@ struct Carver {
 constexpr int F = 128, FI = F + 4;
 constexpr int OUT_KSPLIT = 2;     // out_transform (K = 1824, N = 128) has only M/64 * 2 tiles: split K so it fills the chip
 
-struct GaScratch { float *proj, *feat, *u, *kvf, *qf, *split; size_t split_floats; };
+struct GaScratch { float *proj, *feat, *u, *kvf, *qf, *split; size_t split_floats; float* xt[2]; };
 static GaScratch carve_ga(Carver& cv, int64_t M, int N, int L) {
     GaScratch s;
     s.proj = cv.f((size_t)M * NP);
@@ -69,12 +69,14 @@ static GaScratch carve_ga(Carver& cv, int64_t M, int N, int L) {
     s.qf = cv.f(ipa_qfrag_floats(N, L));
     s.split_floats = ipa_split_ws_floats(N, L);
     s.split = s.split_floats ? cv.f(s.split_floats) : nullptr;
+    s.xt[0] = cv.f((size_t)M * F);          // node features as two fp16 terms, ping-pong between blocks (written by the tail / mixer, read by node_frags)
+    s.xt[1] = cv.f((size_t)M * F);
     return s;
 }
 
 static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, const float* x, const float* z, const uint8_t* mask,
                     float* x_out, int N, int L, const abopt_ga_debug* dbg, const GaScratch& s, hipStream_t st, const float* pbc = nullptr, int z_shared = 0,
-                    const float* pair_terms = nullptr, float* feat_out = nullptr) {
+                    const float* pair_terms = nullptr, float* feat_out = nullptr, const float* x_terms = nullptr, float* xt_out = nullptr) {
     const int64_t M = (int64_t)N * L;
     int rc;
     // node projections q|k|v|qp|kp|vp, points to the global frame, MFMA fragment layout: one fused kernel when the packed weights are given
@@ -82,7 +84,7 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     // handed pair terms -- every other core reads fp32 channel slots
     if (!(pbc && pair_terms && !dbg && w->w_node_frag && ipa_core32_applies(N, L))) pair_terms = nullptr;
     if (w->w_node_frag) {
-        if ((rc = launch_node_frags(x, w->w_node_frag, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st, pair_terms ? 1 : 0))) return rc;
+        if ((rc = launch_node_frags(x, w->w_node_frag, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st, pair_terms ? 1 : 0, x_terms))) return rc;
     } else {
         if ((rc = launch_linear(x, F, w->w_node, F, nullptr, s.proj, NP, (int)M, ABOPT_NODE_PROJ, F, false, st))) return rc;
         if ((rc = launch_ipa_frags(s.proj, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st))) return rc;
@@ -91,7 +93,7 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
         // core + tail as one kernel (feat stays on the chip) wherever the 32-row core is the one to run; bit-identical to the two launches below
         int fused = 0;
         if ((rc = launch_ipa_block_fused(s.qf, s.kvf, z, mask, R, t, pbc, N, L, st, z_shared, w->w_out_terms, w->w_mlp_frag, x, w->b_out, w->ln1_gamma,
-                                         w->ln1_beta, w->b_mlp0, w->b_mlp1, w->b_mlp2, w->ln2_gamma, w->ln2_beta, x_out, &fused, pair_terms))) return rc;
+                                         w->ln1_beta, w->b_mlp0, w->b_mlp1, w->b_mlp2, w->ln2_gamma, w->ln2_beta, x_out, &fused, pair_terms, xt_out))) return rc;
         if (fused) return ABOPT_OK;
     }
     float* feat = (dbg && dbg->feat) ? dbg->feat : (feat_out ? feat_out : s.feat);
@@ -100,7 +102,7 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     // out_transform -> mask -> +x -> LN1 -> MLP -> +res -> LN2
     if (w->w_out_frag && w->w_mlp_frag)
         return launch_out_ln_mlp(feat, w->w_out_frag, w->w_mlp_frag, x, w->b_out, mask, w->ln1_gamma, w->ln1_beta, w->b_mlp0, w->b_mlp1, w->b_mlp2,
-                                 w->ln2_gamma, w->ln2_beta, x_out, nullptr, M, st);
+                                 w->ln2_gamma, w->ln2_beta, x_out, nullptr, M, st, xt_out);
     if ((rc = launch_linear(feat, ABOPT_IPA_FEAT, w->w_out, ABOPT_IPA_FEAT, nullptr, s.u, F, (int)M, F, ABOPT_IPA_FEAT, false, st,
                             OUT_KSPLIT, M * F))) return rc;
     if ((rc = launch_fused_ln_mlp(x, s.u, OUT_KSPLIT, M * F, w->b_out, mask, w->ln1_gamma, w->ln1_beta, w->w_mlp0, w->b_mlp0, w->w_mlp1, w->b_mlp1,
@@ -401,15 +403,24 @@ extern "C" int abopt_ga_block_forward_cached(const abopt_ga_weights* w, const fl
 
 static int ga_encoder(const abopt_ga_weights* blocks, int num_layers, const float* R, const float* t, const float* x, const float* z,
                       const uint8_t* mask, float* x_out, int N, int L, const GaScratch& s, float* pong, hipStream_t st,
-                      const float* pair_bias_cache = nullptr, int z_shared = 0, const float* pair_terms = nullptr) {
+                      const float* pair_bias_cache = nullptr, int z_shared = 0, const float* pair_terms = nullptr, const float* x_terms = nullptr) {
     // ga.py:190-193: the same R, t, z feed every block.  Ping-pong so the last block writes x_out.
     const float* cur = x;
+    // x as fp16 terms travels with x from block to block (round 6): block i reads the terms its producer wrote (the mixer for block 0, `x_terms`; the tail of block
+    // i - 1 afterwards) and has its own tail write block i + 1's -- where the packed weights put node_frags and the term-writing tails on the path; ABOPT_X_TERMS=0: never
+    const bool xt_off = getenv("ABOPT_X_TERMS") && getenv("ABOPT_X_TERMS")[0] == '0';
+    const float* xt_cur = xt_off ? nullptr : x_terms;
     for (int i = 0; i < num_layers; ++i) {
         float* dst = ((num_layers - 1 - i) % 2 == 0) ? x_out : pong;
-        int rc = ga_block(&blocks[i], R, t, cur, z, mask, dst, N, L, nullptr, s, st,
-                          pair_bias_cache ? pair_bias_cache + (size_t)i * pair_bias_layer_floats(z_shared ? N / z_shared : N, L) : nullptr, z_shared, pair_bias_cache ? pair_terms : nullptr);
+        const abopt_ga_weights* w = &blocks[i];
+        const bool writes = !xt_off && i + 1 < num_layers && w->w_out_frag && w->w_mlp_frag && blocks[i + 1].w_node_frag;
+        float* xt_dst = writes ? s.xt[i & 1] : nullptr;
+        int rc = ga_block(w, R, t, cur, z, mask, dst, N, L, nullptr, s, st,
+                          pair_bias_cache ? pair_bias_cache + (size_t)i * pair_bias_layer_floats(z_shared ? N / z_shared : N, L) : nullptr, z_shared, pair_bias_cache ? pair_terms : nullptr,
+                          nullptr, xt_cur, xt_dst);
         if (rc) return rc;
         cur = dst;
+        xt_cur = xt_dst;
     }
     if (num_layers == 0) ABOPT_HIP(hipMemcpyAsync(x_out, x, (size_t)N * L * F * sizeof(float), hipMemcpyDeviceToDevice, st));
     return ABOPT_OK;
@@ -530,8 +541,11 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
     if (!cv.ok) { set_error("eps_net_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, abopt_eps_workspace_bytes(N, L, Fd, Cd)); return ABOPT_EWORKSPACE; }
 
     // dpm_full.py:86  R = exp(v_t)   and   dpm_full.py:89  res_feat_mixer([res_feat | Embedding(s_t)])
+    float* x0_terms = nullptr;
     if (w->w_mix_frag && w->mix_table) {
-        if ((rc = launch_mixer(res_feat, s_t, w->w_mix_frag, w->mix_table, w->b_mix1, e.cat, M, st, v_t, e.R))) return rc;       // one launch for both
+        const bool xt0 = w->num_layers > 0 && w->blocks[0].w_node_frag && !(getenv("ABOPT_X_TERMS") && getenv("ABOPT_X_TERMS")[0] == '0');
+        x0_terms = xt0 ? e.ga.xt[1] : nullptr;                                 // (block 0 writes xt[0], block 1 xt[1], ...: the mixer's copy is read before it is overwritten)
+        if ((rc = launch_mixer(res_feat, s_t, w->w_mix_frag, w->mix_table, w->b_mix1, e.cat, M, st, v_t, e.R, x0_terms))) return rc;       // one launch for both
     } else {
         if ((rc = launch_so3_exp(v_t, e.R, M, st))) return rc;
         if ((rc = launch_embed_concat(res_feat, s_t, w->seq_embed, e.cat, M, st))) return rc;
@@ -539,7 +553,7 @@ extern "C" int abopt_eps_net_forward(const abopt_eps_weights* w, const float* v_
         if ((rc = launch_linear(e.x0, F, w->w_mix1, F, w->b_mix1, e.cat, F, (int)M, F, F, false, st))) return rc;   // reuse cat[:, :F] as x (ld = F)
     }
     // dpm_full.py:90  encoder
-    if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st, pair_bias_cache, zg, pair_terms))) return rc;
+    if ((rc = ga_encoder(w->blocks, w->num_layers, e.R, p_t, e.cat, pair_feat, mask_res, e.xe, N, L, e.ga, e.pong, st, pair_bias_cache, zg, pair_terms, x0_terms))) return rc;
     bool heads_fused = false;
     if (w->w_heads_frag) {
         // dpm_full.py:92-101: time features + the three heads in one launch (heads.hip)

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(HTH) void heads_mlp_kernel(const float* __restrict_
 // products on the same path as the heads.  Waves 0..3 own the four 32-column blocks of each layer.
 __global__ __launch_bounds__(HTH) void mixer_kernel(const float* __restrict__ res_feat, const int64_t* __restrict__ s_t, const float* __restrict__ wfrag,
                                                     const float* __restrict__ table, const float* __restrict__ b1, float* __restrict__ x_out,
-                                                    int64_t rows, const float* __restrict__ v_t, float* __restrict__ R_out) {
+                                                    int64_t rows, const float* __restrict__ v_t, float* __restrict__ R_out, unsigned* __restrict__ xt_out) {
     extern __shared__ __attribute__((aligned(16))) char hd_raw[];
     HeadsSmem& sm = *reinterpret_cast<HeadsSmem*>(hd_raw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -189,20 +189,26 @@ __global__ __launch_bounds__(HTH) void mixer_kernel(const float* __restrict__ re
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int col = wave * 32 + g * 8 + csub;
-                *reinterpret_cast<f32x4*>(x_out + (row0 + mrow) * HF + col) =
-                    (f32x4){fmaf(a0[4 * g] + a1[4 * g], winv, b1[col]), fmaf(a0[4 * g + 1] + a1[4 * g + 1], winv, b1[col + 1]),
-                            fmaf(a0[4 * g + 2] + a1[4 * g + 2], winv, b1[col + 2]), fmaf(a0[4 * g + 3] + a1[4 * g + 3], winv, b1[col + 3])};
+                const f32x4 o = (f32x4){fmaf(a0[4 * g] + a1[4 * g], winv, b1[col]), fmaf(a0[4 * g + 1] + a1[4 * g + 1], winv, b1[col + 1]),
+                                        fmaf(a0[4 * g + 2] + a1[4 * g + 2], winv, b1[col + 2]), fmaf(a0[4 * g + 3] + a1[4 * g + 3], winv, b1[col + 3])};
+                *reinterpret_cast<f32x4*>(x_out + (row0 + mrow) * HF + col) = o;
+                if (xt_out) {                                                  // the first block's node_frags reads x as terms (tail_common.h: tail_p2_run writes the same layout)
+                    unsigned h0_, l0_, h1_, l1_;
+                    split_pair2(o[0], o[1], h0_, l0_); split_pair2(o[2], o[3], h1_, l1_);
+                    unsigned* d = xt_out + (row0 + mrow) * HF + col / 2;
+                    *reinterpret_cast<uint2*>(d) = make_uint2(h0_, h1_); *reinterpret_cast<uint2*>(d + 64) = make_uint2(l0_, l1_);
+                }
             }
         }
     }
 }
 
 int launch_mixer(const float* res_feat, const int64_t* s_t, const float* wfrag, const float* table, const float* b1, float* x_out, int64_t rows,
-                 hipStream_t st, const float* v_t, float* R_out) {
+                 hipStream_t st, const float* v_t, float* R_out, float* xt_out) {
     if (rows == 0) return ABOPT_OK;
     static LdsConfig lds_cfg;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(mixer_kernel), sizeof(HeadsSmem), lds_cfg)) return rc;
-    hipLaunchKernelGGL(mixer_kernel, dim3((unsigned)((rows + HR - 1) / HR)), dim3(HTH), sizeof(HeadsSmem), st, res_feat, s_t, wfrag, table, b1, x_out, rows, v_t, R_out);
+    hipLaunchKernelGGL(mixer_kernel, dim3((unsigned)((rows + HR - 1) / HR)), dim3(HTH), sizeof(HeadsSmem), st, res_feat, s_t, wfrag, table, b1, x_out, rows, v_t, R_out, reinterpret_cast<unsigned*>(xt_out));
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }

@@ -959,6 +959,7 @@ __device__ long long g_c32f_timing[8][16];
 struct TailArgs {
     const float *wot, *wmf, *x, *ubias, *g1, *be1, *b0, *b1, *b2, *g2, *be2;
     float* out;
+    unsigned* xt;           // optional: the output rows as two fp16 terms as well (tail_common.h: tail_p2_run)
 };
 constexpr int C32_LOOP_LDS_FLOATS = 3 * 32 * SROW + 2 * 32 * SCLD + 32 * SCLD + 32 * 32;      // sp | scl | lsum | mlr (then the key mask)
 constexpr int C32F_PTS_OFF = ((C32_LOOP_LDS_FLOATS * 4 + 2048 + 255) / 256) * 256;               // aggregated points [32][12][24] fp32, behind the key mask of L <= 2048
@@ -1771,7 +1772,7 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         const float (*us)[XLD] = reinterpret_cast<const float (*)[XLD]>(smem_raw + C32F_U_OFF);
         auto get_u = [&](int rl) { return *reinterpret_cast<const float2*>(&us[rl][2 * lane]); };
         tail_p2_run<NTH2 / 64, false>(pre, get_u, reinterpret_cast<float (*)[XLD]>(smem_raw + C32F_YS_OFF), bias, smem_raw + C32F_APA_OFF,
-                                      smem_raw + C32F_PTS_OFF, ta.wmf, ta.g2, ta.be2, ta.out, nullptr, 0, row0, row_end, wave, lane);
+                                      smem_raw + C32F_PTS_OFF, ta.wmf, ta.g2, ta.be2, ta.out, nullptr, 0, row0, row_end, wave, lane, ta.xt);
         C32F_STAMP(15)
     }
     if (blockIdx.x == 0 && tid == 0) { g_clock_probe[0] = clock64() - probe_c0; g_clock_probe[1] = wall_clock64() - probe_w0; }
@@ -2038,7 +2039,7 @@ bool ipa_core32_applies(int N, int L) {
 int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                            const float* pair_bias_cache, int N, int L, hipStream_t st, int z_shared, const float* wot, const float* wmf, const float* x,
                            const float* ubias, const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2,
-                           const float* be2, float* out, int* fused, const float* pair_terms) {
+                           const float* be2, float* out, int* fused, const float* pair_terms, float* xt_out) {
     *fused = 0;
     const char* e = getenv("ABOPT_FUSE_TAIL");
     if (!pair_bias_cache || !wot || !wmf || (e && e[0] == '0') || CORE_ABL || C32_ABL) return ABOPT_OK;
@@ -2047,7 +2048,7 @@ int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float*
     if (!use_core32(N, L, cus)) return ABOPT_OK;
     const int nib2 = (L + BI2 - 1) / BI2;
     static LdsConfig lds_cfg, lds_cfg_t;
-    TailArgs ta{wot, wmf, x, ubias, g1, be1, b0, b1, b2, g2, be2, out};
+    TailArgs ta{wot, wmf, x, ubias, g1, be1, b0, b1, b2, g2, be2, out, reinterpret_cast<unsigned*>(xt_out)};
     const float* zsc = pair_terms ? pair_terms + pair_terms_floats(z_shared ? N / z_shared : N, L) : nullptr;
     if (pair_terms) {
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_core32_kernel<true, true>), C32F_LDS_BYTES, lds_cfg_t)) return rc;

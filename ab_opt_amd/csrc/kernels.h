@@ -36,13 +36,14 @@ int launch_ipa_core(const float* qfrag, const float* kvfrag, const float* z, con
 int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                            const float* pair_bias_cache, int N, int L, hipStream_t st, int z_shared, const float* wot /* W_out as bf16 terms */, const float* wmf, const float* x,
                            const float* ubias, const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2,
-                           const float* be2, float* out, int* fused, const float* pair_terms = nullptr);
+                           const float* be2, float* out, int* fused, const float* pair_terms = nullptr, float* xt_out = nullptr);
 
 // node_frags.hip: x [N*L,128] -> qfrag / kvfrag directly (projection GEMM + frame transform + fragment layout in one kernel)
 size_t node_wfrag_floats();
 int launch_node_frags(const float* x, const float* wfrag, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag,
                       int N, int L, hipStream_t st,
-                      int qk_terms = 0 /* 1: the q / k channel slots as two fp16 terms each (high terms in slot 0, low terms in slot 1): what ipa_core32_kernel<*, true> reads */);
+                      int qk_terms = 0 /* 1: the q / k channel slots as two fp16 terms each (high terms in slot 0, low terms in slot 1): what ipa_core32_kernel<*, true> reads */,
+                      const float* x_terms = nullptr /* optional: x as two fp16 terms per value, written by the kernel that produced x (tail / mixer): no split here */);
 
 // rows.hip ------------------------------------------------------------------------------------
 int launch_so3_exp(const float* w, float* R, int64_t n, hipStream_t st);
@@ -55,12 +56,12 @@ int launch_fused_ln_mlp(const float* x, const float* u, int nslab, int64_t slab_
 // dump (optional, training): five [rows,128] slabs for launch_tail_backward
 int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, const float* x, const float* ubias, const uint8_t* mask,
                       const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2, const float* be2,
-                      float* out, float* dump, int64_t rows, hipStream_t st);
+                      float* out, float* dump, int64_t rows, hipStream_t st, float* xt_out = nullptr /* optional [rows, 128]: the output rows as two fp16 terms for the next block's node_frags */);
 // heads.hip: the three denoiser heads (first layers fused, time features as an affine term) -> out3 [rows,32]
 size_t heads_wfrag_floats();
 size_t mixer_wfrag_floats();
 int launch_mixer(const float* res_feat, const int64_t* s_t, const float* wfrag, const float* table, const float* b1, float* x_out, int64_t rows,
-                 hipStream_t st, const float* v_t = nullptr, float* R_out = nullptr /* optional: R = exp(v_t) of the same rows, fused */);
+                 hipStream_t st, const float* v_t = nullptr, float* R_out = nullptr /* optional: R = exp(v_t) of the same rows, fused */, float* xt_out = nullptr);
 // arguments of the heads' geometric epilogue (launch_heads_epilogue) when it runs as the tail of launch_heads_mlp
 struct HeadsEpilogue { const float *R = nullptr, *v_t = nullptr; const uint8_t* mask_generate = nullptr; float *v_next = nullptr, *R_next = nullptr, *eps_pos = nullptr, *c_den = nullptr; int grad_mode = 0; unsigned* nonfinite = nullptr; };
 // rows.hip: the device word the heads' epilogue raises on a non-finite output (abopt_nonfinite_flag)

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
                                                            const float* __restrict__ g1, const float* __restrict__ be1,
                                                            const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2,
                                                            const float* __restrict__ g2, const float* __restrict__ be2,
-                                                           float* __restrict__ out, float* __restrict__ dump, int64_t rows) {
+                                                           float* __restrict__ out, float* __restrict__ dump, int64_t rows, unsigned* __restrict__ xt_out) {
     extern __shared__ __attribute__((aligned(16))) char ot_raw[];
     OtSmem& sm = *reinterpret_cast<OtSmem*>(ot_raw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(OT_TH) void out_ln_mlp_kernel(const float* __restri
         const float2 u2 = *reinterpret_cast<const float2*>(&sm.part[2][rl][2 * lane]), u3 = *reinterpret_cast<const float2*>(&sm.part[3][rl][2 * lane]);
         return make_float2((u0.x + u1.x) + (u2.x + u3.x), (u0.y + u1.y) + (u2.y + u3.y));
     };
-    tail_p2_run<OT_NW, DUMP>(pre, get_u, sm.ys, sm.bias, apA, apB, wmf, g2, be2, out, dump, slab, row0, rows, wave, lane);
+    tail_p2_run<OT_NW, DUMP>(pre, get_u, sm.ys, sm.bias, apA, apB, wmf, g2, be2, out, dump, slab, row0, rows, wave, lane, xt_out);
 #ifdef OT_TIMING
     if (blockIdx.x == 17 && lane == 0) { long long* o = g_ot_timing[wave]; o[0] = tc1 - tc0; o[1] = tc2 - tc1; o[2] = clock64() - tc2; o[3] = 0; o[4] = 0; o[5] = 0; }
 #endif
@@ -347,21 +347,21 @@ size_t mlp_wfrag_floats() { return (size_t)3 * F * F * 3 / 2; }
 template <bool DUMP>
 static int launch_out_ln_mlp_t(const float* feat, const float* wof, const float* wmf, const float* x, const float* ubias, const uint8_t* mask,
                                const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2, const float* be2,
-                               float* out, float* dump, int64_t rows, hipStream_t st) {
+                               float* out, float* dump, int64_t rows, hipStream_t st, float* xt_out) {
     static LdsConfig lds_cfg;                                               // per instantiation
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(out_ln_mlp_kernel<DUMP>), sizeof(OtSmem), lds_cfg)) return rc;
     hipLaunchKernelGGL(out_ln_mlp_kernel<DUMP>, dim3((unsigned)((rows + MR - 1) / MR)), dim3(OT_TH), sizeof(OtSmem), st, feat, wof, wmf, x, ubias, mask,
-                       g1, be1, b0, b1, b2, g2, be2, out, dump, rows);
+                       g1, be1, b0, b1, b2, g2, be2, out, dump, rows, reinterpret_cast<unsigned*>(xt_out));
     ABOPT_LAUNCH_CHECK();
     return ABOPT_OK;
 }
 
 int launch_out_ln_mlp(const float* feat, const float* wof, const float* wmf, const float* x, const float* ubias, const uint8_t* mask,
                       const float* g1, const float* be1, const float* b0, const float* b1, const float* b2, const float* g2, const float* be2,
-                      float* out, float* dump, int64_t rows, hipStream_t st) {
+                      float* out, float* dump, int64_t rows, hipStream_t st, float* xt_out) {
     if (rows == 0) return ABOPT_OK;
-    const int rc = dump ? launch_out_ln_mlp_t<true>(feat, wof, wmf, x, ubias, mask, g1, be1, b0, b1, b2, g2, be2, out, dump, rows, st)
-                        : launch_out_ln_mlp_t<false>(feat, wof, wmf, x, ubias, mask, g1, be1, b0, b1, b2, g2, be2, out, dump, rows, st);
+    const int rc = dump ? launch_out_ln_mlp_t<true>(feat, wof, wmf, x, ubias, mask, g1, be1, b0, b1, b2, g2, be2, out, dump, rows, st, xt_out)
+                        : launch_out_ln_mlp_t<false>(feat, wof, wmf, x, ubias, mask, g1, be1, b0, b1, b2, g2, be2, out, dump, rows, st, xt_out);
 #ifdef OT_TIMING
     {
         long long hh[16][8];

@@ -55,7 +55,7 @@ __device__ __forceinline__ float quad_bcast2(float v) { return __uint_as_float(_
 
 // One task: tiles [HALF * 6, HALF * 6 + 6) of head h for the row tiles tile0, tile0 + 1.
 template <int HALF>
-__device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4* wl, const float* __restrict__ R, const float* __restrict__ t,
+__device__ __forceinline__ void nf_task(const float* __restrict__ x, const unsigned* __restrict__ xt, const u32x4* wl, const float* __restrict__ R, const float* __restrict__ t,
                                         float* __restrict__ qfrag, float* __restrict__ kvfrag, int L, int nchunk, int total_tiles, int tile0, int h,
                                         float ch_, float m2c, float winv, int lane, int fm, int kq, int qk_terms) {
     int64_t rowbase[2], row[2];
@@ -68,12 +68,19 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
         rowbase[rt] = (int64_t)n * L;
         row[rt] = rowbase[rt] + min(cbs[rt] * JC + fm, L - 1);                   // rows past the end: clamped copies (finite; the core never stores them)
     }
-    // lane (row fm, kq) holds k = 32 s + 8 kq + i of its row for k-step s
+    // lane (row fm, kq) holds k = 32 s + 8 kq + i of its row for k-step s -- as fp32 (split here) or, when the kernel that produced x also wrote its terms
+    // (xt: [row][64 words of high terms | 64 words of low terms]), as the two 16-byte term vectors themselves
     f32x4 xa[2][2];
+    Split2 xn[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-        xa[rt][0] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + kq * 8);
-        xa[rt][1] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + kq * 8 + 4);
+        if (xt) {
+            xn[rt].h = *reinterpret_cast<const u32x4*>(xt + row[rt] * NF_F + kq * 4);
+            xn[rt].l = *reinterpret_cast<const u32x4*>(xt + row[rt] * NF_F + 64 + kq * 4);
+        } else {
+            xa[rt][0] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + kq * 8);
+            xa[rt][1] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + kq * 8 + 4);
+        }
     }
     f32x4 acc[2][NF_HT];
 #pragma unroll
@@ -90,22 +97,18 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
     for (int g = 0; g < NF_KS * NF_HT; ++g) {
         const int s = g / NF_HT, T = g % NF_HT;
         if (T == 0) {
-            // developer build -DNF_ABL=<mask>: 16 splits only at s == 0 (loads kept) | 32 loads only at s == 0 (splits kept) | 4 no epilogue | 8 no LDS reads after the first
-#if defined(NF_ABL) && (NF_ABL & 16)
-            for (int rt = 0; rt < 2; ++rt) { asm volatile("" ::"v"(xa[rt][0]), "v"(xa[rt][1])); }
-            if (s == 0)
-#endif
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) xs[rt] = split2(xa[rt][0], xa[rt][1]);
-#if defined(NF_ABL) && (NF_ABL & 32)
-            if (false) {
-#else
+            for (int rt = 0; rt < 2; ++rt) xs[rt] = xt ? xn[rt] : split2(xa[rt][0], xa[rt][1]);
             if (s + 1 < NF_KS) {
-#endif
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    xa[rt][0] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + (s + 1) * 32 + kq * 8);
-                    xa[rt][1] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + (s + 1) * 32 + kq * 8 + 4);
+                    if (xt) {
+                        xn[rt].h = *reinterpret_cast<const u32x4*>(xt + row[rt] * NF_F + (s + 1) * 16 + kq * 4);
+                        xn[rt].l = *reinterpret_cast<const u32x4*>(xt + row[rt] * NF_F + 64 + (s + 1) * 16 + kq * 4);
+                    } else {
+                        xa[rt][0] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + (s + 1) * 32 + kq * 8);
+                        xa[rt][1] = *reinterpret_cast<const f32x4*>(x + row[rt] * NF_F + (s + 1) * 32 + kq * 8 + 4);
+                    }
                 }
             }
         }
@@ -202,7 +205,7 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const u32x4
     }
 }
 
-__global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* __restrict__ x, const float* __restrict__ wfrag, const float* __restrict__ R,
+__global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* __restrict__ x, const unsigned* __restrict__ xt, const float* __restrict__ wfrag, const float* __restrict__ R,
                                                                    const float* __restrict__ t, const float* __restrict__ spatial_coef,
                                                                    float* __restrict__ qfrag, float* __restrict__ kvfrag, int L, int nchunk,
                                                                    int total_tiles, int qk_terms) {
@@ -240,8 +243,8 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
 #endif
     for (int task = t_lo + wave; task < t_hi; task += NF_WAVES) {
         const int tile0 = NF_SPLIT ? task * 2 : (task >> 1) * 2;
-        if (NF_SPLIT ? half : (task & 1)) nf_task<1>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq, qk_terms);
-        else          nf_task<0>(x, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq, qk_terms);
+        if (NF_SPLIT ? half : (task & 1)) nf_task<1>(x, xt, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq, qk_terms);
+        else          nf_task<0>(x, xt, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq, qk_terms);
 #ifdef NF_TIMING
         if (ti < 3) te[ti++] = clock64() - c0;
 #endif
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
 size_t node_wfrag_floats() { return (size_t)H * NF_HEAD_VEC * 4 + 4; }      // + {S, 1 / S, 0, 0}
 
 int launch_node_frags(const float* x, const float* wfrag, const float* R, const float* t, const float* spatial_coef, float* qfrag, float* kvfrag,
-                      int N, int L, hipStream_t st, int qk_terms) {
+                      int N, int L, hipStream_t st, int qk_terms, const float* x_terms) {
     if ((int64_t)N * L == 0) return ABOPT_OK;
     const int nchunk = (L + JC - 1) / JC, total = N * nchunk;
     int cus = 0, rc;
@@ -275,7 +278,7 @@ int launch_node_frags(const float* x, const float* wfrag, const float* R, const 
     const int groups = max(1, min(cus / H, (ntask + NF_WAVES - 1) / NF_WAVES));          // one workgroup per CU: 96 KB of LDS each
     const dim3 grid(groups, H);
 #endif
-    hipLaunchKernelGGL(node_frags_kernel, grid, dim3(NF_WAVES * 64), NF_LDS_VEC * 16, st, x, wfrag, R, t, spatial_coef,
+    hipLaunchKernelGGL(node_frags_kernel, grid, dim3(NF_WAVES * 64), NF_LDS_VEC * 16, st, x, reinterpret_cast<const unsigned*>(x_terms), wfrag, R, t, spatial_coef,
                        qfrag, kvfrag, L, nchunk, total, qk_terms);
     ABOPT_LAUNCH_CHECK();
 #ifdef NF_TIMING

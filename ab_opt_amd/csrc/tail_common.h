@@ -201,7 +201,7 @@ template <int NW, bool DUMP, class GetU>
 __device__ __forceinline__ void tail_p2_run(TailP2Pre<NW>& pre, GetU&& get_u, float (*ys)[XLD], float (*bias)[F], char* apA, char* apB,
                                             const float* __restrict__ wmf, const float* __restrict__ g2, const float* __restrict__ be2,
                                             float* __restrict__ out, float* __restrict__ dump, int64_t slab, int64_t row0, int64_t row_end,
-                                            int wave, int lane) {
+                                            int wave, int lane, unsigned* __restrict__ xt_out = nullptr) {
     constexpr int RW = MR / NW;
     const int fm = lane & 15, kq = lane >> 4;
     const bool mlpw = wave < 8;                                                                          // waves 0..7 own the eight 16-column tiles
@@ -287,7 +287,13 @@ __device__ __forceinline__ void tail_p2_run(TailP2Pre<NW>& pre, GetU&& get_u, fl
         for (int rr = 0; rr < RW; ++rr) {
             const int64_t row = row0 + wave * RW + rr;
             const float sd = sqrtf(var[rr] + 1e-10f);
-            if (row < row_end) reinterpret_cast<float2*>(out + row * F)[lane] = make_float2(v[rr].x / sd * g.x + bt.x, v[rr].y / sd * g.y + bt.y);
+            if (row < row_end) {
+                const float o0 = v[rr].x / sd * g.x + bt.x, o1 = v[rr].y / sd * g.y + bt.y;
+                reinterpret_cast<float2*>(out + row * F)[lane] = make_float2(o0, o1);
+                // round 6: the same row as two fp16 terms ([64 words of high terms | 64 words of low terms], split_pair2) for the NEXT block's node_frags, whose 24
+                // (head, half) workgroups would otherwise each split these values again
+                if (xt_out) { unsigned h_, l_; split_pair2(o0, o1, h_, l_); xt_out[row * F + lane] = h_; xt_out[row * F + 64 + lane] = l_; }
+            }
         }
     }
 }

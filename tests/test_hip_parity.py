@@ -1410,6 +1410,32 @@ def test_fp16_range_guard_falls_back_to_fp32_layers():
         d.sample(v, p * 10, s, rf, pf, gen, mres, seed=5)
 
 
+@pytest.mark.parametrize('flavour,N,L', [('abdesign', 3, 70), ('abdock', 32, 256), ('abdock', 40, 48)])
+def test_node_feature_terms_travel_with_x_bit_identically(flavour, N, L, monkeypatch):
+    """Round 6: the kernel that produces a block's node features x (the mixer for the first block, the previous block's tail afterwards) also writes them as two
+    fp16 terms, and node_frags reads those instead of splitting x again in each of its 24 (head, half) workgroups.  The split is the same function on the same
+    values, so nothing may change by a bit: EpsilonNet with ABOPT_X_TERMS=0 (every node_frags splits for itself) against the default, 16-row and 32-row kernels,
+    fused and two-launch tails, ragged lengths."""
+    from ab_opt_amd import hip
+    d = standalone_abdesign_dpm(100, 2).to(DEV) if flavour == 'abdesign' else build_model(100, 2, device=DEV).diffusion
+    lens = [L - (5 * i) % max(1, L // 3) for i in range(N)]
+    v, p, s, rf, pf, gen, mres = _rand_eps_inputs(N, L, lens, 9100 + N, [(5, 14), (22, 30)])
+    beta = d.trans_pos.var_sched.betas[37].expand([N]).contiguous()
+    arr, ew = d.eps_net.encoder.packed_array(), d.eps_net.packed()
+    pbc = hip.pair_bias_cache(arr, 6, pf)
+    terms = hip.pair_terms(pf) if hip.pair_terms_used(N, L) else None
+    outs = []
+    for xt in ('0', '1'):
+        monkeypatch.setenv('ABOPT_X_TERMS', xt)
+        for fuse in ('0', '1'):
+            monkeypatch.setenv('ABOPT_FUSE_TAIL', fuse)
+            o = hip.eps_net_forward(ew, v, p, s, rf, pf, beta, gen, mres, d.abdock, d.num_bins, False, pair_bias_cache=pbc, pair_terms=terms)
+            outs.append({k: a.clone() for k, a in o.items() if a is not None})
+    for o in outs[1:]:
+        for k in outs[0]:
+            assert torch.isfinite(o[k]).all() and torch.equal(o[k], outs[0][k]), k
+
+
 def _pair_terms_statement(z, L):
     """torch statement of abopt_pair_terms (include/abopt.h): per (row, channel) power-of-two scale, two fp16 terms, K-packed layout."""
     N = z.shape[0]
