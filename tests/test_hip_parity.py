@@ -2536,8 +2536,11 @@ def test_training_step_config5_vs_oracle_at_full_size():
             exempt.append((n, e_all, e_rest))
     print('config 5 at full size vs the float64 oracle -- tensors with a row above 3e-4 (name, worst row, third-worst row):', exempt)
     print('worst tensors (all rows but the two worst | worst row | oracle fp32 | name):', ' ; '.join('%.1e | %.1e | %.1e | %s' % w for w in sorted(rows)[-4:]))
-    assert all(a <= 3e-4 and b <= 5e-3 for a, b, c, n in rows), [w for w in rows if w[0] > 3e-4 or w[1] > 5e-3][:6]
-    assert len(exempt) <= 6, exempt
+    # ... and only where a ReLU follows the layer (the flipped unit is a row of THAT layer's weight / bias gradient): every other tensor holds 3e-4 on all of its rows
+    # (the exemption was a blanket over all 145 tensors; measured in round 6: no tensor needs it, worst row of any tensor 4.5e-5)
+    relu_fed = lambda n: any(k in n for k in ('mlp_transition.0.', 'mlp_transition.2.', 'res_feat_mixer.0.', '_net.0.', '_net.2.'))
+    assert all(a <= 3e-4 and b <= (5e-3 if relu_fed(n) else 3e-4) for a, b, c, n in rows), [w for w in rows if w[0] > 3e-4 or w[1] > (5e-3 if relu_fed(w[3]) else 3e-4)][:6]
+    assert len(exempt) <= 2, exempt
     block0 = [w for w in rows if 'blocks.0.' in w[3] or 'mixer' in w[3]]
     assert len(block0) > 20 and max(w[1] for w in block0) <= 3e-4, sorted(block0)[-3:]
 
