@@ -47,6 +47,9 @@ __device__ long long g_core_timing[3][8];
 #endif
 #endif
 
+#ifndef PBC_CHUNK_MAJOR
+#define PBC_CHUNK_MAJOR 1 // layout of a layer's slab of the pair-bias cache: 1 [chunk][row of the batch][12 x 16] (the same argument as ZT_CHUNK_MAJOR below) | 0 [row][chunk][12 x 16]
+#endif
 namespace abopt {
 
 constexpr int NPW = 8, RPW = BI / NPW;          // pair waves, query rows per pair wave
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         const char* pbrow[RPW];                                          // wave-uniform row bases (SGPRs) + one per-lane byte offset
 #pragma unroll
         for (int ii = 0; ii < RPW; ++ii)
-            pbrow[ii] = CACHED ? reinterpret_cast<const char*>(pbc + ((zbase + min(i0 + il0 + ii, L - 1)) * (int64_t)nchunk) * (H * JC)) : nullptr;
+            pbrow[ii] = CACHED ? reinterpret_cast<const char*>(pbc + ((zbase + min(i0 + il0 + ii, L - 1)) * (int64_t)(PBC_CHUNK_MAJOR ? 1 : nchunk)) * (H * JC)) : nullptr;
+        const unsigned pb_chunk = PBC_CHUNK_MAJOR ? (unsigned)((N / (z_shared ? z_shared : 1)) * L) * (unsigned)(H * JC * 4) : (unsigned)(H * JC * 4);      // bytes from a row's chunk to its next one
         const unsigned pb_lane = (unsigned)(min(fm, H - 1) * JC + kq * 4) * 4u;
         // the dump goes out through a buffer descriptor: base = this sample's [12,L,L] slab (SGPRs), one lane-constant byte offset
         // (head, key group) and a wave-uniform row/chunk offset -- no 64-bit per-lane addresses in the hot loop
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_kernel(const float* __restrict__
         const int ch_ = chunk_of(min((CH), ncl - 1));                          /* past the end: harmless re-read */      \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                \
             ring[SLOT][r_] = ZLOAD(reinterpret_cast<const f32x4*>(zrow[II] + ((unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b))); \
-        if (CACHED && !(CORE_ABL & 64)) ringb[SLOT] = ZLOAD(reinterpret_cast<const f32x4*>(pbrow[II] + ((unsigned)ch_ * (unsigned)(H * JC * 4) + pb_lane))); \
+        if (CACHED && !(CORE_ABL & 64)) ringb[SLOT] = ZLOAD(reinterpret_cast<const f32x4*>(pbrow[II] + ((unsigned)ch_ * pb_chunk + pb_lane))); \
     }
 // z and its bias cache are read once per launch: non-temporal loads (measured 182 -> 174 us per launch at N=32, L=256)
 #ifdef CORE_NO_NT
@@ -570,12 +574,13 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
         const unsigned lane_b = (unsigned)fm * 16u;
         const unsigned pb_lane = (unsigned)(min(fm, H - 1) * JC + kq * 4) * 4u;
         const char *zrow[RPW], *pbrow[RPW], *zrow_n[RPW], *pbrow_n[RPW];     // wave-uniform row bases of the current and the next block
+        const unsigned pb_chunk = PBC_CHUNK_MAJOR ? (unsigned)(((total_blocks / nib) / (z_shared ? z_shared : 1)) * L) * (unsigned)(H * JC * 4) : (unsigned)(H * JC * 4);
         auto rows_of = [&](const PBlk& b, const char** zr, const char** pr) {
 #pragma unroll
             for (int ii = 0; ii < RPW; ++ii) {
                 const int64_t row = b.zbase + min(b.i0 + il0 + ii, L - 1);
                 zr[ii] = reinterpret_cast<const char*>(z + (row * (int64_t)L) * C);
-                pr[ii] = reinterpret_cast<const char*>(pbc + (row * (int64_t)nchunk) * (H * JC));
+                pr[ii] = reinterpret_cast<const char*>(pbc + (row * (int64_t)(PBC_CHUNK_MAJOR ? 1 : nchunk)) * (H * JC));
             }
         };
         f32x4 ring[3][4], ringb[3];
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(NTH) void ipa_core_persist_kernel(const float* __re
         const char* pr_ = (nx_ && has_next) ? pbrow_n[II] : pbrow[II];                                                   \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                \
             ring[SLOT][r_] = ZLOAD(reinterpret_cast<const f32x4*>(zr_ + ((unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b))); \
-        ringb[SLOT] = ZLOAD(reinterpret_cast<const f32x4*>(pr_ + ((unsigned)ch_ * (unsigned)(H * JC * 4) + pb_lane)));   \
+        ringb[SLOT] = ZLOAD(reinterpret_cast<const f32x4*>(pr_ + ((unsigned)ch_ * pb_chunk + pb_lane)));   \
     }
         PBlk bk = blk(0);
         rows_of(bk, zrow, pbrow);
@@ -908,6 +913,10 @@ __device__ unsigned long long g_c32_count[8];
 #ifndef C32_ABL
 #define C32_ABL 0        // developer ablations (timing only, results wrong): 1 no z / bias loads in the loop | 32 z / bias loads all from one L1-resident address | 64 no softmax arithmetic in rows 1..7 (P = S) | 128 no pair MFMAs | 256 / 512 no A / C MFMAs (nothing instead) | 2 no fragment loads in the loop | 4 / 8 / 16 pair / A / C MFMAs off | 1024 no accumulator rescale (pair and C waves) | 2048 no v_exp_f32 in rows 1..7
 #endif
+#ifndef ZT_CHUNK_MAJOR
+#define ZT_CHUNK_MAJOR 2  // layout of the pair terms: 2 [chunk][row of the batch][4 KB] -- every workgroup of a launch reads the SAME chunk of its rows at the same time, so the live
+                          // set of a chunk interval is ONE dense plane (33 MB at the bench shape) instead of 4 KB out of every 64 KB row | 1 chunk-major inside a sample's slab | 0 [row][chunk][4 KB]
+#endif
 #ifndef C32_ZAUX
 #define C32_ZAUX 2       // cache policy bits of the z / bias stream's buffer loads (2 = nt)
 #endif
@@ -1148,15 +1157,18 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
         // z and the bias cache are read through buffer descriptors of this sample's slabs: a request is ONE instruction -- descriptor (SGPRs),
         // the row's byte offset (an SGPR, added by the hardware) and the lane's offset inside a row (a VGPR that lives for a whole chunk)
         // (ZT: the same bytes per row-chunk, 4 KB, in the term layout [chunk][channel tile][lane]: every request is 1 KB contiguous, chunks past L are zero-padded)
-        const __amdgpu_buffer_rsrc_t zrs = ZT ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zt + zbase * (int64_t)nchunk * (JC * C)), 0, L * nchunk * (JC * C * 4), 0x00020000)
+        const int rows_tot_ = ((int)gridDim.x / nib2 / (z_shared ? z_shared : 1)) * L;          // rows of the terms buffer (distinct samples x L): ZT_CHUNK_MAJOR == 2
+        const __amdgpu_buffer_rsrc_t zrs = ZT ? (ZT_CHUNK_MAJOR == 2 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zt), 0, (unsigned)rows_tot_ * (unsigned)nchunk * (JC * C * 4), 0x00020000)
+                                                                     : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zt + zbase * (int64_t)nchunk * (JC * C)), 0, L * nchunk * (JC * C * 4), 0x00020000))
                                               : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(z + zbase * (int64_t)L * C), 0, L * L * C * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pbc + zbase * (int64_t)nchunk * (H * JC)), 0, L * nchunk * (H * JC) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t brs = PBC_CHUNK_MAJOR ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pbc), 0, (unsigned)rows_tot_ * (unsigned)nchunk * (H * JC * 4), 0x00020000)
+                                                           : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pbc + zbase * (int64_t)nchunk * (H * JC)), 0, L * nchunk * (H * JC) * 4, 0x00020000);
         int zrow[RPW2], pbrow[RPW2];
 #pragma unroll
         for (int ii = 0; ii < RPW2; ++ii) {
             const int row = min(i0 + il0 + ii, L - 1);
-            zrow[ii] = ZT ? row * nchunk * (JC * C * 4) : row * L * (C * 4);
-            pbrow[ii] = row * nchunk * (H * JC * 4);
+            zrow[ii] = ZT ? (ZT_CHUNK_MAJOR == 2 ? ((int)zbase + row) * (JC * C * 4) : (ZT_CHUNK_MAJOR ? row * (JC * C * 4) : row * nchunk * (JC * C * 4))) : row * L * (C * 4);
+            pbrow[ii] = PBC_CHUNK_MAJOR ? ((int)zbase + row) * (H * JC * 4) : row * nchunk * (H * JC * 4);
         }
         const unsigned lane_b = (unsigned)fm * 16u;
         const unsigned pb_lane = (unsigned)(min(fm, H - 1) * JC + kq * 4) * 4u;
@@ -1167,12 +1179,12 @@ __global__ __launch_bounds__(NTH2) void ipa_core32_kernel(const float* __restric
 #define P2_KOFF(CH)                                                                                                      \
     {                                                                                                                    \
         const int ch_ = (C32_ABL & 32) ? 0 : min((CH), nchunk - 1);             /* past the end: harmless re-read */      \
-        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) koff_[r_] = ZT ? (unsigned)(ch_ * (JC * C * 4) + r_ * 1024 + lane * 16) : (unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b; \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) koff_[r_] = ZT ? ((unsigned)ch_ * (unsigned)(ZT_CHUNK_MAJOR == 2 ? rows_tot_ * (JC * C * 4) : (ZT_CHUNK_MAJOR ? L * (JC * C * 4) : (JC * C * 4))) + (unsigned)(r_ * 1024 + lane * 16)) : (unsigned)min(ch_ * JC + kq * 4 + r_, L - 1) * (unsigned)(C * 4) + lane_b; \
     }
-#define P2_BOFF(CH) boff_ = (unsigned)((C32_ABL & 32) ? 0 : min((CH), nchunk - 1)) * (unsigned)(H * JC * 4) + pb_lane;
+#define P2_BOFF(CH) boff_ = (unsigned)((C32_ABL & 32) ? 0 : min((CH), nchunk - 1)) * (PBC_CHUNK_MAJOR ? (unsigned)rows_tot_ * (unsigned)(H * JC * 4) : (unsigned)(H * JC * 4)) + pb_lane;
 #ifdef C32_OLDLOAD
         const char* zslab = reinterpret_cast<const char*>(z + zbase * (int64_t)L * C);
-        const char* bslab = reinterpret_cast<const char*>(pbc + zbase * (int64_t)nchunk * (H * JC));
+        const char* bslab = reinterpret_cast<const char*>(pbc + (PBC_CHUNK_MAJOR ? 0 : zbase * (int64_t)nchunk * (H * JC)));
 #define P2_ISSUE_Z(SLOT, II)                                                                                            \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                                \
             ring[SLOT][r_] = ZLOAD(reinterpret_cast<const f32x4*>(zslab + zrow[II] + koff_[r_]));
@@ -1818,7 +1830,7 @@ __global__ __launch_bounds__(256) void pair_bias_cache_kernel(const float* __res
         f32x4 za[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) za[q] = *reinterpret_cast<const f32x4*>(&zst[wave][fm][kq * 16 + q * 4]);
-        const int64_t u = row * nchunk + ch;
+        const int64_t u = PBC_CHUNK_MAJOR ? (int64_t)ch * rows + row : row * nchunk + ch;
         auto layer = [&](int l, const f32x4 (&w4)[4]) {
             f32x4 acc4[4];
 #pragma unroll
@@ -1900,7 +1912,8 @@ __global__ __launch_bounds__(256) void pair_terms_kernel(const float* __restrict
         S[e] = __uint_as_float((unsigned)(267 - ex) << 23);
         if (wave == 0 && kq == 0) zsc[row * C + fm * 4 + e] = __uint_as_float((unsigned)(ex - 27) << 23);     // 2^-14 / S: the consumer's probabilities carry 2^14
     }
-    u32x4* out = reinterpret_cast<u32x4*>(terms) + row * (int64_t)nchunk * 256 + lane;
+    const int64_t smp = row / L, ri = row % L;                               // (ZT_CHUNK_MAJOR: [sample][chunk][row of the sample], 256 vectors per (row, chunk))
+    u32x4* out = reinterpret_cast<u32x4*>(terms) + (ZT_CHUNK_MAJOR == 2 ? row * 256 : (ZT_CHUNK_MAJOR ? smp * (int64_t)L * nchunk * 256 + ri * 256 : row * (int64_t)nchunk * 256)) + lane;
     for (int ch = wave; ch < nchunk; ch += 4) {
         f32x4 zn[4];
         load(ch, zn);
@@ -1909,13 +1922,15 @@ __global__ __launch_bounds__(256) void pair_terms_kernel(const float* __restrict
             unsigned h01, l01, h23, l23;
             split_pair2(zn[0][mt] * S[mt], zn[1][mt] * S[mt], h01, l01);
             split_pair2(zn[2][mt] * S[mt], zn[3][mt] * S[mt], h23, l23);
-            out[(ch * 4 + mt) * 64] = (u32x4){h01, h23, l01, l23};
+            out[(ZT_CHUNK_MAJOR == 2 ? (int64_t)ch * gridDim.x * 256 : (ZT_CHUNK_MAJOR ? (int64_t)ch * L * 256 : (int64_t)ch * 256)) + mt * 64] = (u32x4){h01, h23, l01, l23};
         }
     }
 }
 
 int launch_pair_terms(const float* z, float* blob, int Nz, int L, hipStream_t st) {
     if ((int64_t)Nz * L == 0) return ABOPT_OK;
+    ABOPT_CHECK_ARG(pair_terms_floats(Nz, L) * sizeof(float) < ((size_t)1 << 32), "pair_terms: %d x %d x %d values exceed the 4 GB a 32-bit buffer offset reaches (the consuming kernels address the whole "
+                    "batch's terms chunk-major through one descriptor)", Nz, L, L);
     const int nchunk = (L + JC - 1) / JC;
     hipLaunchKernelGGL(pair_terms_kernel, dim3((unsigned)((int64_t)Nz * L)), dim3(256), 0, st, z, blob, blob + pair_terms_floats(Nz, L), L, nchunk);
     ABOPT_LAUNCH_CHECK();

@@ -159,7 +159,7 @@ class FullDPM(nn.Module):
         """The fp16 pair terms pay where the library's launch geometry takes the 32-row block kernels (abopt_pair_terms_used) and their
         n_pair * L^2 * 256 B fit next to everything else; ABOPT_PAIR_TERMS=0 / 1 overrides (0: the fp32 stream everywhere)."""
         e = os.environ.get('ABOPT_PAIR_TERMS')
-        if e == '0' or dev.type != 'cuda' or L > 2048:
+        if e == '0' or dev.type != 'cuda' or L > 2048 or hip.pair_terms_bytes(n_pair, L) >= (1 << 32):       # (one buffer descriptor addresses the batch's terms)
             return False
         # Measured (profiles/r06_b_pair_terms_ab.txt): the complete term path (pair aggregation + the logits' q . k part) is 8-11 % of a step faster with shared
         # pair features and 7-9 % with distinct ones (the pair aggregation alone bought nothing there: the block kernel then sat on its streams)

@@ -1449,8 +1449,8 @@ def _pair_terms_statement(z, L):
     zs = zp * S[:, :, None, :]
     h = zs.half()
     l = (zs - h.float()).half()
-    # [n, i, ch, kq, e, fm, mt] -> [n, i, ch, mt, kq, fm, term, e]
-    t = torch.stack([h.view(N, L, nch, 4, 4, 16, 4), l.view(N, L, nch, 4, 4, 16, 4)], dim=-1).permute(0, 1, 2, 6, 3, 5, 7, 4).contiguous()
+    # [n, i, ch, kq, e, fm, mt] -> [ch, n, i, mt, kq, fm, term, e]: chunk-major over the whole batch (every workgroup of a launch reads the same chunk of its rows at the same time)
+    t = torch.stack([h.view(N, L, nch, 4, 4, 16, 4), l.view(N, L, nch, 4, 4, 16, 4)], dim=-1).permute(2, 0, 1, 6, 3, 5, 7, 4).contiguous()
     return t, invS, S
 
 
@@ -1469,13 +1469,13 @@ def test_pair_terms_layout_and_scales():
         assert blob.numel() == nt + N * L * 64 == hip.pair_terms_bytes(N, L) // 4
         t, invS, S = _pair_terms_statement(z, L)
         assert torch.equal(blob[nt:].view(N, L, 64), invS)
-        assert torch.equal(blob[:nt].view(torch.float16).view(N, L, nch, 4, 4, 16, 2, 4), t)
+        assert torch.equal(blob[:nt].view(torch.float16).view(nch, N, L, 4, 4, 16, 2, 4), t)
         am = z.abs().amax(dim=2)
         nz = am > 0
         assert ((am * S)[nz] >= 2.0 ** 13).all() and ((am * S)[nz] < 2.0 ** 14).all() and torch.equal((S * invS), torch.full_like(S, 2.0 ** -14))
         # the terms carry 22 bits of every value within 2^-17 of its column's largest
-        rec = (t[..., 0, :].float() + t[..., 1, :].float())                # [n, i, ch, mt, kq, fm, e]
-        zr = rec.permute(0, 1, 2, 4, 6, 5, 3).reshape(N, L, nch * 16, 64)[:, :, :L] * (invS * 2.0 ** 14)[:, :, None, :]
+        rec = (t[..., 0, :].float() + t[..., 1, :].float())                # [ch, n, i, mt, kq, fm, e]
+        zr = rec.permute(1, 2, 0, 4, 6, 5, 3).reshape(N, L, nch * 16, 64)[:, :, :L] * (invS * 2.0 ** 14)[:, :, None, :]
         big = z.abs() >= am[:, :, None, :] * 2.0 ** -17
         assert ((zr - z).abs()[big] <= z.abs()[big] * 2.0 ** -21).all()
         assert ((zr - z).abs() <= am[:, :, None, :] * 2.0 ** -37).logical_or(big).all()
