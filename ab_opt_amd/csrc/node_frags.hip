@@ -54,7 +54,7 @@ __device__ __forceinline__ float quad_bcast1(float v) { return __uint_as_float(_
 __device__ __forceinline__ float quad_bcast2(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xAA, 0xf, 0xf, false)); }
 
 // One task: tiles [HALF * 6, HALF * 6 + 6) of head h for the row tiles tile0, tile0 + 1.
-template <int HALF>
+template <int HALF, bool XT>
 __device__ __forceinline__ void nf_task(const float* __restrict__ x, const unsigned* __restrict__ xt, const u32x4* wl, const float* __restrict__ R, const float* __restrict__ t,
                                         float* __restrict__ qfrag, float* __restrict__ kvfrag, int L, int nchunk, int total_tiles, int tile0, int h,
                                         float ch_, float m2c, float winv, int lane, int fm, int kq, int qk_terms) {
@@ -74,7 +74,7 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const unsig
     Split2 xn[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-        if (xt) {
+        if constexpr (XT) {
             xn[rt].h = *reinterpret_cast<const u32x4*>(xt + row[rt] * NF_F + kq * 4);
             xn[rt].l = *reinterpret_cast<const u32x4*>(xt + row[rt] * NF_F + 64 + kq * 4);
         } else {
@@ -98,11 +98,14 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const unsig
         const int s = g / NF_HT, T = g % NF_HT;
         if (T == 0) {
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) xs[rt] = xt ? xn[rt] : split2(xa[rt][0], xa[rt][1]);
+            for (int rt = 0; rt < 2; ++rt) {
+                if constexpr (XT) xs[rt] = xn[rt];
+                else xs[rt] = split2(xa[rt][0], xa[rt][1]);
+            }
             if (s + 1 < NF_KS) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    if (xt) {
+                    if constexpr (XT) {
                         xn[rt].h = *reinterpret_cast<const u32x4*>(xt + row[rt] * NF_F + (s + 1) * 16 + kq * 4);
                         xn[rt].l = *reinterpret_cast<const u32x4*>(xt + row[rt] * NF_F + 64 + (s + 1) * 16 + kq * 4);
                     } else {
@@ -205,6 +208,9 @@ __device__ __forceinline__ void nf_task(const float* __restrict__ x, const unsig
     }
 }
 
+// XT: x arrives as fp16 terms (xt) -- its own instantiation, so that neither path carries the other's registers (one kernel with a run-time switch: 172 instead of
+// 144 registers, two waves per SIMD instead of three, 24.4 -> 30.7 us at the bench shape)
+template <bool XT>
 __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* __restrict__ x, const unsigned* __restrict__ xt, const float* __restrict__ wfrag, const float* __restrict__ R,
                                                                    const float* __restrict__ t, const float* __restrict__ spatial_coef,
                                                                    float* __restrict__ qfrag, float* __restrict__ kvfrag, int L, int nchunk,
@@ -243,8 +249,8 @@ __global__ __launch_bounds__(NF_WAVES * 64) void node_frags_kernel(const float* 
 #endif
     for (int task = t_lo + wave; task < t_hi; task += NF_WAVES) {
         const int tile0 = NF_SPLIT ? task * 2 : (task >> 1) * 2;
-        if (NF_SPLIT ? half : (task & 1)) nf_task<1>(x, xt, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq, qk_terms);
-        else          nf_task<0>(x, xt, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq, qk_terms);
+        if (NF_SPLIT ? half : (task & 1)) nf_task<1, XT>(x, xt, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq, qk_terms);
+        else          nf_task<0, XT>(x, xt, wl, R, t, qfrag, kvfrag, L, nchunk, total_tiles, tile0, h, ch_, m2c, winv, lane, fm, kq, qk_terms);
 #ifdef NF_TIMING
         if (ti < 3) te[ti++] = clock64() - c0;
 #endif
@@ -265,8 +271,11 @@ int launch_node_frags(const float* x, const float* wfrag, const float* R, const 
     const int nchunk = (L + JC - 1) / JC, total = N * nchunk;
     int cus = 0, rc;
     if ((rc = device_cu_count(&cus))) return rc;
-    static LdsConfig lds_cfg;
-    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(node_frags_kernel), NF_LDS_VEC * 16, lds_cfg))) return rc;
+    static LdsConfig lds_cfg[2];
+    const bool xt = x_terms != nullptr;
+    if ((rc = ensure_dynamic_lds(xt ? reinterpret_cast<const void*>(node_frags_kernel<true>) : reinterpret_cast<const void*>(node_frags_kernel<false>), NF_LDS_VEC * 16,
+                                 lds_cfg[xt])))
+        return rc;
 #if NF_SPLIT
     // 24 (head, half) columns of workgroups x `groups` shares of the row-tile pairs; 48 KB of LDS each: NF_WGPC = 3 per CU.  At the bench shape
     // (256 pairs, 256 CUs): 32 groups of 8 pairs, two tasks for each of the four waves -- every wave of the chip does the same amount of work.
@@ -278,8 +287,12 @@ int launch_node_frags(const float* x, const float* wfrag, const float* R, const 
     const int groups = max(1, min(cus / H, (ntask + NF_WAVES - 1) / NF_WAVES));          // one workgroup per CU: 96 KB of LDS each
     const dim3 grid(groups, H);
 #endif
-    hipLaunchKernelGGL(node_frags_kernel, grid, dim3(NF_WAVES * 64), NF_LDS_VEC * 16, st, x, reinterpret_cast<const unsigned*>(x_terms), wfrag, R, t, spatial_coef,
-                       qfrag, kvfrag, L, nchunk, total, qk_terms);
+    if (xt)
+        hipLaunchKernelGGL(node_frags_kernel<true>, grid, dim3(NF_WAVES * 64), NF_LDS_VEC * 16, st, x, reinterpret_cast<const unsigned*>(x_terms), wfrag, R, t,
+                           spatial_coef, qfrag, kvfrag, L, nchunk, total, qk_terms);
+    else
+        hipLaunchKernelGGL(node_frags_kernel<false>, grid, dim3(NF_WAVES * 64), NF_LDS_VEC * 16, st, x, nullptr, wfrag, R, t, spatial_coef, qfrag, kvfrag, L, nchunk,
+                           total, qk_terms);
     ABOPT_LAUNCH_CHECK();
 #ifdef NF_TIMING
     {
