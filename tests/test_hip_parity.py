@@ -302,6 +302,32 @@ def test_encode_L256_training_gradients_vs_reference():
     print('encode_L256: worst relative gradient error', worst)
 
 
+@pytest.mark.gpu
+def test_pair_embedding_repeats_beside_a_second_process():
+    """The pair embedding while a second process runs this library's denoiser on the same GPU (its waves share SIMDs with the embedding's): every one
+    of a few thousand launches of a 64-workgroup embedding must equal the first bit for bit.  Round 6: with the literal dihedral arithmetic (IEEE
+    divisions, libm acosf: chains of v_cmp -> lane mask -> v_cndmask) 1-3 % of these launches returned a 16-pair tile computed from a wrong angle in
+    lanes 48-63 of one wave -- never in a process that had the GPU to itself; csrc/embed.hip: dihedral_from_four_points, tools/r06/pe_share.py."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, 'tools', 'r06', 'pe_share.py')
+    env = dict(os.environ, ABOPT_CORE32='1')
+    partner = subprocess.Popen([sys.executable, tool, 'partner', '--kind', 'eps', '--seconds', '14'], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        out = subprocess.run([sys.executable, tool, 'victim', '--n', '1', '--layout', '128', '--reps', '0', '--seconds', '6', '--burst', '10'],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300).stdout
+    finally:
+        pout = partner.communicate(timeout=300)[0]
+    import re
+    m_ = re.search(r'victim N=1 L=128: (\d+) of (\d+) launches differ', out)
+    assert m_, out[-2000:]
+    assert int(m_.group(2)) >= 2000, out[-500:]
+    p_ = re.search(r'partner eps: (\d+) iterations', pout)
+    assert p_ and int(p_.group(1)) >= 50, pout[-2000:]                 # the partner really ran beside the launches
+    assert int(m_.group(1)) == 0, out[-2000:]
+
+
 @pytest.mark.parametrize('resolution', ['full', 'backbone+CB'])
 def test_pair_embedding_repeats_bit_for_bit(resolution):
     """Race detector for the pair-embedding kernels (round 4 saw run-to-run different 16-pair tiles in an experimental bf16-term build of
