@@ -53,8 +53,9 @@ __device__ __forceinline__ float gauss_exp(float c, float dd) { return __builtin
 // hipcc emits for the divisions, sqrtf and acosf is a chain of v_cmp -> SGPR lane mask -> v_cndmask / v_div_fmas at the minimum distances of its gfx940
 // hazard table with transcendental instructions in between; idle wait states elsewhere, s_waitcnt 0 after every instruction and one wave per SIMD do not
 // remove the failures, removing this arithmetic does.  Not root-caused to one instruction pair (no assembler-level control from HIP source); the form
-// below needs no lane mask: raw v_rsq_f32 / v_sqrt_f32, the sign through v_bfi_b32, acos as one polynomial (Abramowitz & Stegun 4.4.46, |error| <= 2e-8
-// on [0, 1]) reflected arithmetically.  Against the literal form: <= 3e-7 rad away from the clamp, the same sensitivity d acos / dc <= 707 at it.
+// below needs no lane mask: one raw v_rsq_f32 of the product of the squared norms, raw v_sqrt_f32, the sign through v_bfi_b32, acos as one polynomial (Abramowitz & Stegun 4.4.46, |error| <= 2e-8
+// on [0, 1]) reflected arithmetically.  Accuracy against float64 on random backbones (numpy emulation): mean 4.2e-7 rad against the literal form's 2.4e-7, the same
+// sensitivity d acos / dc <= 707 at the clamp.  (A Newton step behind v_rsq_f32 brought the failures back, 48 of 28.5 k launches: the schedule matters, not only the masks.)
 #ifndef DIH_MODE
 #define DIH_MODE 2
 #endif
@@ -73,8 +74,7 @@ __device__ __forceinline__ float dihedral_from_four_points(V3 p0, V3 p1, V3 p2, 
 #else
     // a zero normal (coincident or masked atoms: 0 x inf = NaN) leaves the clamp as -0.999999 (v_max_f32 / v_min_f32 return the other operand), and
     // sd = 0 whenever a normal is zero, so the result is 0 as in the literal form (NaN -> 0)
-    const float i1 = __builtin_amdgcn_rsqf(dot3(u1, u1)), i2 = __builtin_amdgcn_rsqf(dot3(u2, u2));
-    float c = dot3(u1 * i1, u2 * i2);
+    float c = dot3(u1, u2) * __builtin_amdgcn_rsqf(dot3(u1, u1) * dot3(u2, u2));    // |u|^2 <= 1e3 for bonded backbone atoms: the product stays normal
     c = fminf(fmaxf(c, -0.999999f), 0.999999f);
     const float a = fabsf(c);
     float p = -0.0012624911f;

@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--burst', type=int, default=10)
     ap.add_argument('--tag', default='')
     ap.add_argument('--resolution', default='full')
+    ap.add_argument('--ready-file', default='', help='partner: created when the load starts (a shell can wait for it)')
     ap.add_argument('--acts', action='store_true', help='victim: the training form of the launch (per-layer activation dump); the first wrong layer of a bad tile is reported')
     a = ap.parse_args()
     from conftest import build_model
@@ -72,6 +73,9 @@ def main():
             feat = torch.randn(S * 128, 1824, device=dev)
         x = torch.randn(4096, 4096, device=dev)
         big = torch.randn(64 << 20, device=dev)
+        if a.ready_file:
+            open(a.ready_file, 'w').write('ready')
+        t0 = time.time()
         while time.time() - t0 < a.seconds:
             it += 1
             if a.kind == 'sampler':
