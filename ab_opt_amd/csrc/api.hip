@@ -82,7 +82,7 @@ static int ga_block(const abopt_ga_weights* w, const float* R, const float* t, c
     // node projections q|k|v|qp|kp|vp, points to the global frame, MFMA fragment layout: one fused kernel when the packed weights are given
     // the term forms (round 6) go together: fragments with q / k channel terms are written only for the kernels that read them, the 32-row block kernels
     // handed pair terms -- every other core reads fp32 channel slots
-    if (!(pbc && pair_terms && !dbg && w->w_node_frag && ipa_core32_applies(N, L))) pair_terms = nullptr;
+    if (!(pbc && pair_terms && !dbg && w->w_node_frag && ipa_core32_applies(N, L, z_shared))) pair_terms = nullptr;
     if (w->w_node_frag) {
         if ((rc = launch_node_frags(x, w->w_node_frag, R, t, w->spatial_coef, s.qf, s.kvf, N, L, st, pair_terms ? 1 : 0, x_terms))) return rc;
     } else {
@@ -457,9 +457,8 @@ extern "C" int abopt_nonfinite_flag(int reset, abopt_stream stream) {
 extern "C" size_t abopt_pair_terms_bytes(int N, int L) { return pair_terms_blob_floats(N, L) * sizeof(float); }
 
 extern "C" int abopt_pair_terms_used(int N, int L, int pair_feat_shared) {
-    (void)pair_feat_shared;
     if (N <= 0 || L <= 0) return 0;
-    return ipa_core32_applies(N, L) ? 1 : 0;
+    return ipa_core32_applies(N, L, pair_feat_shared) ? 1 : 0;
 }
 
 extern "C" int abopt_pair_terms(const float* pair_feat, float* terms, int N, int L, int Cd, abopt_stream stream) {

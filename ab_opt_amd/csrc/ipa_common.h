@@ -151,7 +151,7 @@ int prof_spans_read(int nslots, int* launches, double* total_ms);
 int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float* z, const uint8_t* mask, const float* R, const float* t,
                            const float* w_pair_bias, float* feat, float* dump, float* dump_stats, const float* pair_bias_cache, int N, int L,
                            hipStream_t st, int z_shared, float* split_ws = nullptr, size_t split_ws_floats = 0, const float* pair_terms = nullptr);
-bool ipa_core32_applies(int N, int L);           // the launch geometry takes the 32-row kernels (with a bias cache)
+bool ipa_core32_applies(int N, int L, int z_shared = 0);           // the launch geometry takes the 32-row kernels (with a bias cache)
 size_t pair_terms_floats(int Nz, int L);
 size_t pair_terms_blob_floats(int Nz, int L);
 int launch_pair_terms(const float* z, float* blob, int Nz, int L, hipStream_t st);

@@ -1874,7 +1874,7 @@ int launch_pair_bias_cache(const float* z, const float* const* wb, int num_layer
 // its (row, channel) column keeps a NORMAL low term, i.e. 22 significant bits, whatever the magnitudes of other channels or rows; pass B writes, per chunk of
 // 16 keys and channel tile mt, lane (fm, kq)'s 16 bytes
 //     {h(k0), h(k1) | h(k2), h(k3) | l(k0), l(k1) | l(k2), l(k3)},  k_e = key 16 ch + 4 kq + e, of channel c = 4 fm + mt;  h = fp16(S z), l = fp16(S z - h)
-// at float offset ((row nchunk + ch) 4 + mt) 256 + 4 lane (keys past L: zeros), and the 64 factors 2^-14 / S_ic of every row (the consumer multiplies its probabilities by 2^14) behind the terms.  Same bytes as z (+ 1.6 %).
+// at float offset ((ch ROWS + row) 4 + mt) 256 + 4 lane with ROWS = N L rows of the whole batch (chunk-major: ZT_CHUNK_MAJOR; keys past L: zeros), and the 64 factors 2^-14 / S_ic of every row (the consumer multiplies its probabilities by 2^14) behind the terms.  Same bytes as z (+ 1.6 %).
 size_t pair_terms_floats(int Nz, int L) { return (size_t)Nz * L * ((L + JC - 1) / JC) * (JC * C); }
 size_t pair_terms_blob_floats(int Nz, int L) { return pair_terms_floats(Nz, L) + (size_t)Nz * L * C; }
 
@@ -2027,9 +2027,11 @@ static int core32_remap(int N, int z_shared) {
     if (z_shared > 1 && z_shared < N && N % z_shared == 0 && (N / z_shared) % 8 == 0) return 2;
     return (N % 8 == 0) ? 1 : 0;
 }
-static bool use_core32(int N, int L, int cus) {
+static bool use_core32(int N, int L, int cus, int z_shared) {
     const char* e = getenv("ABOPT_CORE32");
     if (L > 2048) return false;                                 // its buffer descriptors address a sample's z slab (L^2 * 256 bytes) with 32-bit offsets
+    // ... and ONE descriptor addresses a block's whole chunk-major slab of the bias cache (distinct samples x L rows x chunks x 768 bytes): 1365 distinct samples at L = 256
+    if ((int64_t)(z_shared > 1 ? N / z_shared : N) * L * ((L + JC - 1) / JC) * (H * JC * 4) >= (1ll << 32)) return false;
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return L > BI;
     if (cus < 8) return false;
@@ -2042,10 +2044,10 @@ static bool use_core32(int N, int L, int cus) {
     return total * 100 >= rounds * cus * 95;
 }
 
-bool ipa_core32_applies(int N, int L) {
+bool ipa_core32_applies(int N, int L, int z_shared) {
     int cus = 0;
     if (device_cu_count(&cus)) return false;
-    return !CORE_ABL && use_core32(N, L, cus);
+    return !CORE_ABL && use_core32(N, L, cus, z_shared);
 }
 
 // The whole block behind the projections in ONE launch (ipa_core32_kernel<true, ZT>: core + tail) where the 32-row kernel is the core of
@@ -2060,7 +2062,7 @@ int launch_ipa_block_fused(const float* qfrag, const float* kvfrag, const float*
     if (!pair_bias_cache || !wot || !wmf || (e && e[0] == '0') || CORE_ABL || C32_ABL) return ABOPT_OK;
     int cus = 0;
     if (int rc = device_cu_count(&cus)) return rc;
-    if (!use_core32(N, L, cus)) return ABOPT_OK;
+    if (!use_core32(N, L, cus, z_shared)) return ABOPT_OK;
     const int nib2 = (L + BI2 - 1) / BI2;
     static LdsConfig lds_cfg, lds_cfg_t;
     TailArgs ta{wot, wmf, x, ubias, g1, be1, b0, b1, b2, g2, be2, out, reinterpret_cast<unsigned*>(xt_out)};
@@ -2126,7 +2128,7 @@ int launch_ipa_core_kernel(const float* qfrag, const float* kvfrag, const float*
     ABOPT_CHECK_ARG(!dump || (int64_t)H * L * L * 4 < (1ll << 31), "ipa_core: L=%d too long for the logits dump", L);
     int cus32 = 0;
     if (pair_bias_cache && !dump && !CORE_ABL) { if (int rc = device_cu_count(&cus32)) return rc; }
-    if (pair_bias_cache && !dump && !CORE_ABL && use_core32(N, L, cus32)) {
+    if (pair_bias_cache && !dump && !CORE_ABL && use_core32(N, L, cus32, z_shared)) {
         const int nib2 = (L + BI2 - 1) / BI2, nchunk = (L + JC - 1) / JC;
         const size_t lds = sizeof(float) * (3 * BI2 * SROW + 2 * BI2 * SCLD + BI2 * SCLD + BI2 * 32) + (size_t)nchunk * JC;
         ABOPT_CHECK_ARG(lds <= 160 * 1024, "ipa_core: L=%d needs %zu bytes of LDS for the key mask (max 163840)", L, lds);

@@ -171,7 +171,8 @@ size_t abopt_eps_workspace_bytes(int N, int L, int F, int C);
 /* Per-call pair-bias cache: proj_pair_bias(z) of EVERY block (ga.py:88-90) in one pass over pair_feat.  pair_feat and
  * the weights are constant over the steps of FullDPM.sample / optimize (dpm_full.py:274-283), so the sampler builds the
  * cache once per call and passes it to every abopt_eps_net_forward; the per-step kernel then skips that contraction
- * (bit-identical results).  cache: abopt_pair_bias_cache_bytes(N, L, num_layers) bytes, caller-owned. */
+ * (bit-identical results).  cache: abopt_pair_bias_cache_bytes(N, L, num_layers) bytes, caller-owned.  The cache is an opaque operand of this library for exactly the
+ * (N, L) batch it was built from (per block: chunk of 16 keys outermost, then the rows of the whole batch): it cannot be sliced per sample. */
 size_t abopt_pair_bias_cache_bytes(int N, int L, int num_layers);
 int abopt_pair_bias_cache(const abopt_ga_weights* blocks, int num_layers, const float* pair_feat, float* cache,
                           int N, int L, int C, abopt_stream stream);
@@ -191,7 +192,8 @@ int abopt_nonfinite_flag(int reset, abopt_stream stream);
  * v_mfma_f32_16x16x32_f16, the factors 2^-14 / S_ic follow them (the consuming kernel multiplies its probabilities by 2^14 before their split).
  * With the terms the 32-row block kernels run that aggregation on the fp16 matrix instructions (products exact, fp32 accumulation; error against the fp32
  * statement: that of fp32 accumulation itself, tests/test_hip_parity.py::test_pair_aggregation_on_fp16_terms_vs_fp64); without them (NULL) on the fp32 ones.
- * terms: abopt_pair_terms_bytes(N, L) bytes, caller-owned; N = number of DISTINCT pair_feat entries (as for the bias cache); L <= 2048. */
+ * terms: abopt_pair_terms_bytes(N, L) bytes (< 4 GB), caller-owned; N = number of DISTINCT pair_feat entries (as for the bias cache); L <= 2048.  Opaque like the cache and
+ * laid out over the whole batch ([chunk of 16 keys][row of the batch][4 KB]): not sliceable per sample. */
 size_t abopt_pair_terms_bytes(int N, int L);
 int abopt_pair_terms(const float* pair_feat, float* terms, int N, int L, int C, abopt_stream stream);
 /* 1 if abopt_eps_net_forward(N samples, L residues, a bias cache, pair_feat_shared) would launch the kernels that read the terms on the current device
