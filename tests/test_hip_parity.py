@@ -1193,6 +1193,8 @@ def test_config4_rank_leg_grouped_launch(monkeypatch):
     grouped = {k: (a.clone() if a is not None else None) for k, a in grouped.items()}
     # the same launch with the fp16 pair terms the sampler builds at this shape (one set of terms per complex, shared like the bias cache)
     assert hip.pair_terms_used(N, L, S)
+    # one buffer descriptor addresses a block's chunk-major cache slab (distinct samples x L x L/16 x 768 bytes): beyond 4 GB the 16-row kernels take the launch
+    assert hip.pair_terms_used(1360, 256, 0) and not hip.pair_terms_used(1400, 256, 0) and hip.pair_terms_used(1400, 256, 100)
     grouped_t = hip.eps_net_forward(ew, v, p, s, rf.repeat_interleave(S, 0), pf, beta, gen, mres, d.abdock, d.num_bins, False,
                                     pair_bias_cache=hip.pair_bias_cache(arr, 6, pf), pair_feat_shared=S, pair_terms=hip.pair_terms(pf))
     grouped_t = {k: (a.clone() if a is not None else None) for k, a in grouped_t.items()}
