@@ -42,51 +42,21 @@ __device__ __forceinline__ V3 xyz(f32x4 a) { return v3(a[0], a[1], a[2]); }
 __device__ __forceinline__ float gauss_d2(float dx, float dy, float dz) { return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * 0.01f; }
 __device__ __forceinline__ float gauss_exp(float c, float dd) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * c * dd); }
 
-// geometry.py:336-362: signed dihedral of p0-p1-p2-p3, NaN -> 0.
-// DIH_MODE 2 (shipped): no lane mask anywhere in the function -- see the note below.  DIH_MODE 0: the literal form (IEEE divisions by the norms, libm's
-// acosf, selects for the sign and for NaN -> 0), kept for A/B runs of tools/r06/pe_share.py.
-//
-// Why: under a second process on the same GPU (its waves share the SIMDs of this kernel's waves; tools/r06/pe_share.py, partner = this library's denoiser)
-// the literal form returned, in about 1-3 % of the launches of a 64-workgroup pair embedding, a wrong phi-like angle in lanes 48-63 of one wave (a whole
-// 16-pair tile of pair_feat off by O(1 %)): found by the per-layer activation dump (only feature 12 of the dihedral block differs, the one feature the
-// last quarter-wave derives from that angle) and by the developer builds (no sin / cos: still there; angle replaced by a coordinate: gone).  The code
-// hipcc emits for the divisions, sqrtf and acosf is a chain of v_cmp -> SGPR lane mask -> v_cndmask / v_div_fmas at the minimum distances of its gfx940
-// hazard table with transcendental instructions in between; idle wait states elsewhere, s_waitcnt 0 after every instruction and one wave per SIMD do not
-// remove the failures, removing this arithmetic does.  Not root-caused to one instruction pair (no assembler-level control from HIP source); the form
-// below needs no lane mask: one raw v_rsq_f32 of the product of the squared norms, raw v_sqrt_f32, the sign through v_bfi_b32, acos as one polynomial (Abramowitz & Stegun 4.4.46, |error| <= 2e-8
-// on [0, 1]) reflected arithmetically.  Accuracy against float64 on random backbones (numpy emulation): mean 4.2e-7 rad against the literal form's 2.4e-7, the same
-// sensitivity d acos / dc <= 707 at the clamp.  (A Newton step behind v_rsq_f32 brought the failures back, 48 of 28.5 k launches: the schedule matters, not only the masks.)
-#ifndef DIH_MODE
-#define DIH_MODE 2
-#endif
+// geometry.py:336-362: signed dihedral of p0-p1-p2-p3, NaN -> 0 -- the reference's arithmetic op for op (IEEE divisions by the norms, acos, sign).
+// Round 6: hipcc turned parts of this into v_pk_*_f32 instructions, and those return wrong lanes 48-63 while another wave of the SIMD runs 16x16x32 f16 / bf16 MFMAs (the
+// pair embedding beside this library's denoiser in a second process: 1-3 % of its small launches wrong) -- the library is built without packed-FP32 instructions since
+// (csrc/Makefile: NOPK; tests: test_pair_embedding_repeats_beside_a_second_process, test_no_packed_fp32_instructions_in_the_library).
 __device__ __forceinline__ float dihedral_from_four_points(V3 p0, V3 p1, V3 p2, V3 p3) {
     const V3 v0 = p2 - p1, v1 = p0 - p1, v2 = p3 - p2;
     const V3 u1 = cross3(v0, v1), u2 = cross3(v0, v2);
-    const float sd = dot3(cross3(v1, v2), v0);
-#if DIH_MODE == 0
     const float l1 = norm3(u1), l2 = norm3(u2);
     const V3 n1 = v3(u1.x / l1, u1.y / l1, u1.z / l1), n2 = v3(u2.x / l2, u2.y / l2, u2.z / l2);
+    const float sd = dot3(cross3(v1, v2), v0);
     const float sgn = (sd > 0.f) ? 1.f : ((sd < 0.f) ? -1.f : 0.f);
     float c = dot3(n1, n2);
     c = fminf(fmaxf(c, -0.999999f), 0.999999f);
     const float d = sgn * acosf(c);
     return (d != d) ? 0.f : d;
-#else
-    // a zero normal (coincident or masked atoms: 0 x inf = NaN) leaves the clamp as -0.999999 (v_max_f32 / v_min_f32 return the other operand), and
-    // sd = 0 whenever a normal is zero, so the result is 0 as in the literal form (NaN -> 0)
-    float c = dot3(u1, u2) * __builtin_amdgcn_rsqf(dot3(u1, u1) * dot3(u2, u2));    // |u|^2 <= 1e3 for bonded backbone atoms: the product stays normal
-    c = fminf(fmaxf(c, -0.999999f), 0.999999f);
-    const float a = fabsf(c);
-    float p = -0.0012624911f;
-    p = __builtin_fmaf(p, a, 0.0066700901f); p = __builtin_fmaf(p, a, -0.0170881256f); p = __builtin_fmaf(p, a, 0.0308918810f);
-    p = __builtin_fmaf(p, a, -0.0501743046f); p = __builtin_fmaf(p, a, 0.0889789874f); p = __builtin_fmaf(p, a, -0.2145988016f);
-    p = __builtin_fmaf(p, a, 1.5707963050f);
-    const float r = __builtin_amdgcn_sqrtf(1.f - a) * p;                        // acos(|c|); 1 - |c| >= 1e-6: no subnormal reaches v_sqrt_f32
-    const float s = __builtin_copysignf(1.f, c);
-    const float ac = __builtin_fmaf(s, r, (1.f - s) * 1.5707963267948966f);    // c < 0: pi - acos(|c|)
-    const float on = fminf(fabsf(sd) * 3.0e38f, 1.f);                          // sign(0) = 0 (geometry.py:357 torch.sign)
-    return __builtin_copysignf(ac * on, sd);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------ per-residue pack
