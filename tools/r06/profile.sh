@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-6 evidence set on ONE box:  gpurun --timeout 2400 -- 'bash tools/r06/profile.sh gpurun_out/r06_h'
+# Round-6 evidence set on ONE box:  gpurun --timeout 2400 -- 'bash tools/r06/profile.sh gpurun_out/r06_j'
 # 1. the driver's bench command (full line)   2. rocprofv3 --kernel-trace --stats of the SAME command   3. PMC passes (one group per run,
 # --kernel-trace only) on a short eager run, digested for the block's kernels   4. HBM read traffic of the dominant kernel by source (FETCH_SIZE
 # passes of developer builds with one stream removed: W_out terms / key-value fragments / z + bias cache)   5. steady-state training step   6. other shapes
-cd "$(dirname "$0")/../.." && ROOT=$(pwd) && OUT=$ROOT/${1:-gpurun_out/r06_h} && mkdir -p $OUT && TAG=$(basename $OUT)
+cd "$(dirname "$0")/../.." && ROOT=$(pwd) && OUT=$ROOT/${1:-gpurun_out/r06_j} && mkdir -p $OUT && TAG=$(basename $OUT)
 export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 5 > $OUT/bench_full.log 2> $OUT/bench_full.err
 cd /tmp
