@@ -119,11 +119,13 @@ class FullDPM(nn.Module):
                                    ppl_masked, noise, seed, rng_offset, pbar, stop_after, optimize_mode, use_bias_cache)
         N, L = mask_res.shape
         shared = pair_feat.shape[0] != N
-        if use_bias_cache is None:
-            use_bias_cache = shared or self._bias_cache_fits(pair_feat.shape[0], L, res_feat.device, graph=True)
         self.eps_net.packed()
-        key = (res_feat.device.index, N, L, t_start, stop_after, bool(sample_structure), bool(sample_sequence), bool(ppl_masked),
-               bool(optimize_mode), tuple(res_feat.shape), tuple(pair_feat.shape), bool(use_bias_cache), id(self.eps_net._pack))
+        mk = lambda cache: (res_feat.device.index, N, L, t_start, stop_after, bool(sample_structure), bool(sample_sequence), bool(ppl_masked),
+                            bool(optimize_mode), tuple(res_feat.shape), tuple(pair_feat.shape), bool(cache), id(self.eps_net._pack))
+        if use_bias_cache is None:
+            # a captured loop with the cache owns its memory already: no need to ask the allocator again (torch.cuda.memory_stats is 0.1 ms of host time per call)
+            use_bias_cache = shared or mk(True) in self._graphs or self._bias_cache_fits(pair_feat.shape[0], L, res_feat.device, graph=True)
+        key = mk(use_bias_cache)
         g = self._graphs.get(key)
         if g is None:
             if graph == 'auto' and key not in self._graph_seen:         # a one-off call should not pay for a capture

@@ -219,13 +219,17 @@ class EpsilonNet(nn.Module):
         return d
 
     def _sources(self):
-        ps = [p for n, p in self.named_parameters() if not n.startswith('encoder.')]
-        return ps
+        # every parameter outside the encoder (whose blocks fingerprint their own), in named_parameters() order, without walking the encoder's modules
+        ps = list(self._parameters.values())
+        for name, mod in self.named_children():
+            if name != 'encoder':
+                ps += list(mod.parameters())
+        return [p for p in ps if p is not None]
 
     @torch.no_grad()
     def packed(self):
         arr = self.encoder.packed_array()
-        snap = _snapshot(self._sources()) + tuple(_snapshot(b._sources()) for b in self.encoder.blocks)
+        snap = _snapshot(self._sources()) + tuple(b._pack[0] for b in self.encoder.blocks)        # (packed_array() has just verified / rebuilt every block's own fingerprint)
         if self._pack is not None and self._pack[0] == snap:
             return self._pack[2]
         f = lambda p: p.detach().float().contiguous()
